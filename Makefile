@@ -1,0 +1,55 @@
+# Build everything in-tree (built .so/.o are git-ignored but travel to the GPU box with gpurun).
+#   make            -> oracle + tools + product library + CLIs
+#   make oracle     -> oracle/liboracle.so   (CPU checker; test infrastructure only)
+#   make product    -> unicore_amd/libunicore_cluster.so, bin/unicore, bin/foldseek (shim)
+HIPCC   ?= /opt/rocm/bin/hipcc
+CC      ?= gcc
+CXX     ?= g++
+ARCH    ?= gfx950
+OPT     ?= -O3
+
+.PHONY: all oracle tools product clean
+all: oracle tools product
+
+# ---------------------------------------------------------------- oracle (plain C, OpenMP)
+oracle: oracle/liboracle.so
+oracle/liboracle.so: oracle/uc_oracle.c oracle/uc_oracle.h
+	$(CC) -std=c11 $(OPT) -fopenmp -fPIC -shared -Wall -Wextra -o $@ oracle/uc_oracle.c -lm
+
+# ---------------------------------------------------------------- tools
+tools: bin/gen_synth
+bin/gen_synth: tools/gen_synth.c
+	@mkdir -p bin
+	$(CC) -std=c11 -O2 -Wall -o $@ $< -lm
+
+# ---------------------------------------------------------------- product (C++17 host + HIP kernels, gfx950 only)
+CSRC    := unicore_amd/csrc
+HOSTSRC := $(wildcard $(CSRC)/*.cpp)
+HIPSRC  := $(wildcard $(CSRC)/*.hip)
+HOSTOBJ := $(HOSTSRC:.cpp=.o)
+HIPOBJ  := $(HIPSRC:.hip=.o)
+HDRS    := $(wildcard $(CSRC)/*.h $(CSRC)/*.hpp include/*.h)
+CXXFLAGS := -std=c++17 $(OPT) -fPIC -Wall -Wextra -Iinclude -I$(CSRC) -pthread
+HIPFLAGS := --offload-arch=$(ARCH) -std=c++17 $(OPT) -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-parameter
+
+product: unicore_amd/libunicore_cluster.so bin/unicore bin/foldseek
+
+$(CSRC)/%.o: $(CSRC)/%.cpp $(HDRS)
+	$(HIPCC) -x c++ -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include $(CXXFLAGS) -c $< -o $@
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+unicore_amd/libunicore_cluster.so: $(HOSTOBJ) $(HIPOBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -pthread
+
+bin/unicore: $(CSRC)/cli/unicore_main.cpp unicore_amd/libunicore_cluster.so $(HDRS)
+	@mkdir -p bin
+	$(CXX) -std=c++17 $(OPT) -Iinclude -I$(CSRC) -o $@ $< -Lunicore_amd -lunicore_cluster -Wl,-rpath,'$$ORIGIN/../unicore_amd' -pthread
+
+bin/foldseek: $(CSRC)/cli/foldseek_shim.cpp unicore_amd/libunicore_cluster.so $(HDRS)
+	@mkdir -p bin
+	$(CXX) -std=c++17 $(OPT) -Iinclude -I$(CSRC) -o $@ $< -Lunicore_amd -lunicore_cluster -Wl,-rpath,'$$ORIGIN/../unicore_amd' -pthread
+
+clean:
+	rm -f oracle/*.so $(CSRC)/*.o unicore_amd/*.so bin/unicore bin/foldseek bin/gen_synth

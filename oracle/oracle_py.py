@@ -1,0 +1,216 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+Importers allowed: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.  The product package
+(unicore_amd) never imports this module.  See oracle/uc_oracle.h for the frozen spec UC-1 and the
+"parity unpinned" statement.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+A = 21
+K = 6
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("S3", C.c_int8 * (A * A)), ("SA", C.c_int8 * (A * A)), ("pattern", C.c_char * 33),
+        ("kmer_thr", C.c_int), ("min_diag_hits", C.c_int), ("min_ungapped", C.c_int), ("max_seqs", C.c_int),
+        ("gap_open", C.c_int), ("gap_ext", C.c_int), ("rev_correction", C.c_int),
+        ("evalue", C.c_double), ("lambda_", C.c_double), ("K", C.c_double),
+        ("cov", C.c_float), ("cov_mode", C.c_int), ("min_seq_id", C.c_float),
+    ]
+
+
+class Db(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("off", C.POINTER(C.c_uint64)), ("s3", C.POINTER(C.c_uint8)),
+                ("sa", C.POINTER(C.c_uint8)), ("names", C.POINTER(C.c_char_p))]
+
+
+class Index(C.Structure):
+    _fields_ = [("koff", C.POINTER(C.c_uint32)), ("ent_seq", C.POINTER(C.c_uint32)),
+                ("ent_pos", C.POINTER(C.c_uint16)), ("n_entries", C.c_uint64)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("t", C.c_uint32), ("score", C.c_int32), ("diag", C.c_int32)]
+
+
+class Aln(C.Structure):
+    _fields_ = [("score", C.c_int32), ("score_rev", C.c_int32), ("corrected", C.c_int32),
+                ("qstart", C.c_int32), ("qend", C.c_int32), ("tstart", C.c_int32), ("tend", C.c_int32),
+                ("aln_len", C.c_int32), ("idents", C.c_int32), ("pass_evalue", C.c_int32), ("accepted", C.c_int32)]
+
+
+class Counts(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_sim_kmers", "n_kmer_hits", "n_candidates", "n_prefilter_hits",
+                                          "n_alignments", "n_edges", "n_clusters", "cells_fwd", "cells_rev", "cells_start")]
+
+
+HIT_DTYPE = np.dtype([("t", "<u4"), ("score", "<i4"), ("diag", "<i4")])
+ALN_DTYPE = np.dtype([(n, "<i4") for n in ("score", "score_rev", "corrected", "qstart", "qend", "tstart", "tend",
+                                            "aln_len", "idents", "pass_evalue", "accepted")])
+
+_lib = None
+
+
+def lib():
+    """Load (building if necessary — gcc is part of the image) oracle/liboracle.so."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "uc_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _ROOT, "oracle"], stdout=subprocess.DEVNULL)
+    L = C.CDLL(so)
+    L.uco_letter_code.argtypes = [C.c_char]
+    L.uco_params_default.argtypes = [C.POINTER(Params)]
+    L.uco_load_matrix.argtypes = [C.c_char_p, C.POINTER(C.c_int8)]
+    L.uco_db_read.argtypes = [C.c_char_p, C.POINTER(Db)]
+    L.uco_db_free.argtypes = [C.POINTER(Db)]
+    L.uco_index_build.argtypes = [C.POINTER(Db), C.c_uint32, C.c_uint32, C.POINTER(Params), C.POINTER(Index)]
+    L.uco_index_free.argtypes = [C.POINTER(Index)]
+    L.uco_similar_kmers.argtypes = [C.POINTER(C.c_int8), C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_uint32), C.c_size_t]
+    L.uco_similar_kmers.restype = C.c_size_t
+    L.uco_ungapped.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int8)]
+    L.uco_ungapped.restype = C.c_int32
+    L.uco_prefilter_query.argtypes = [C.POINTER(Db), C.POINTER(Index), C.c_uint32, C.POINTER(Params), C.c_void_p, C.POINTER(Counts)]
+    L.uco_sw.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                         C.POINTER(Params), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.uco_min_score.argtypes = [C.POINTER(Params), C.c_int, C.c_uint64]
+    L.uco_min_score.restype = C.c_int32
+    L.uco_align_pair.argtypes = [C.POINTER(Db), C.c_uint32, C.c_uint32, C.POINTER(Params), C.c_int32, C.POINTER(Aln)]
+    L.uco_setcover.argtypes = [C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.uco_cluster.argtypes = [C.POINTER(Db), C.POINTER(Params), C.c_int, C.c_void_p, C.POINTER(Counts), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.uco_write_tsv.argtypes = [C.c_char_p, C.POINTER(Db), C.c_void_p]
+    _lib = L
+    return L
+
+
+def data_path(name):
+    return os.path.join(_ROOT, "unicore_amd", "data", name)
+
+
+def default_params(**over):
+    p = Params()
+    lib().uco_params_default(C.byref(p))
+    assert lib().uco_load_matrix(data_path("mat3di_synthetic.out").encode(), p.S3) == 0
+    assert lib().uco_load_matrix(data_path("blosum62.out").encode(), p.SA) == 0
+    for k, v in over.items():
+        if k == "pattern":
+            v = v.encode() if isinstance(v, str) else v
+        setattr(p, "lambda_" if k == "lambda" else k, v)
+    return p
+
+
+def encode(seq):
+    """letters -> uint8 codes (same table as uco_letter_code)."""
+    lut = np.full(256, 20, np.uint8)
+    for i, c in enumerate("ACDEFGHIKLMNPQRSTVWY"):
+        lut[ord(c)] = i
+        lut[ord(c.lower())] = i
+    return lut[np.frombuffer(seq.encode() if isinstance(seq, str) else seq, np.uint8)]
+
+
+class OracleDb:
+    """In-memory DB for the oracle, either read from disk or built from code arrays."""
+
+    def __init__(self, prefix=None, s3=None, sa=None, names=None):
+        self.db = Db()
+        self._keep = []
+        if prefix is not None:
+            rc = lib().uco_db_read(prefix.encode(), C.byref(self.db))
+            if rc != 0:
+                raise IOError("uco_db_read(%s) failed: %d" % (prefix, rc))
+            self._owned = True
+        else:
+            n = len(s3)
+            lens = np.array([len(x) for x in s3], np.uint64)
+            off = np.zeros(n + 1, np.uint64)
+            off[1:] = np.cumsum(lens)
+            cat3 = np.concatenate([np.asarray(x, np.uint8) for x in s3] + [np.zeros(1, np.uint8)])
+            cata = np.concatenate([np.asarray(x, np.uint8) for x in sa] + [np.zeros(1, np.uint8)])
+            names = names or ["seq%d" % i for i in range(n)]
+            arr = (C.c_char_p * n)(*[x.encode() for x in names])
+            self._keep = [off, cat3, cata, arr]
+            self.db.n = n
+            self.db.off = off.ctypes.data_as(C.POINTER(C.c_uint64))
+            self.db.s3 = cat3.ctypes.data_as(C.POINTER(C.c_uint8))
+            self.db.sa = cata.ctypes.data_as(C.POINTER(C.c_uint8))
+            self.db.names = C.cast(arr, C.POINTER(C.c_char_p))
+            self._owned = False
+
+    @property
+    def n(self):
+        return int(self.db.n)
+
+    def offsets(self):
+        return np.ctypeslib.as_array(self.db.off, shape=(self.n + 1,)).copy()
+
+    def codes(self):
+        tot = int(self.offsets()[-1])
+        return (np.ctypeslib.as_array(self.db.s3, shape=(tot,)).copy(),
+                np.ctypeslib.as_array(self.db.sa, shape=(tot,)).copy())
+
+    def names(self):
+        return [self.db.names[i].decode() for i in range(self.n)]
+
+    def __del__(self):
+        if getattr(self, "_owned", False):
+            lib().uco_db_free(C.byref(self.db))
+
+
+def sw(q3, qa, t3, ta, p, rev_q=0, rev_t=0):
+    q3 = np.ascontiguousarray(q3, np.uint8); qa = np.ascontiguousarray(qa, np.uint8)
+    t3 = np.ascontiguousarray(t3, np.uint8); ta = np.ascontiguousarray(ta, np.uint8)
+    s, qe, te = C.c_int32(), C.c_int32(), C.c_int32()
+    lib().uco_sw(q3.ctypes.data, qa.ctypes.data, len(q3), rev_q, t3.ctypes.data, ta.ctypes.data, len(t3), rev_t,
+                 C.byref(p), C.byref(s), C.byref(qe), C.byref(te))
+    return s.value, qe.value, te.value
+
+
+def ungapped(q3, t3, diag, p):
+    q3 = np.ascontiguousarray(q3, np.uint8); t3 = np.ascontiguousarray(t3, np.uint8)
+    return int(lib().uco_ungapped(q3.ctypes.data, len(q3), t3.ctypes.data, len(t3), diag, p.S3))
+
+
+def similar_kmers(letters, thr, p):
+    c = (C.c_uint8 * K)(*letters)
+    n = lib().uco_similar_kmers(p.S3, c, thr, None, 0)
+    out = np.zeros(max(n, 1), np.uint32)
+    lib().uco_similar_kmers(p.S3, c, thr, out.ctypes.data_as(C.POINTER(C.c_uint32)), n)
+    return out[:n]
+
+
+def setcover(n, edges):
+    e = np.ascontiguousarray(edges, np.uint32).reshape(-1, 2)
+    assign = np.zeros(n, np.uint32)
+    lib().uco_setcover(n, e.ctypes.data, len(e), assign.ctypes.data)
+    return assign
+
+
+def cluster(odb, p, threads=0, dumps=True):
+    """Full pipeline.  Returns dict(assign, counts, hits, hit_cnt, aln)."""
+    n, M = odb.n, p.max_seqs
+    assign = np.zeros(n, np.uint32)
+    cnt = Counts()
+    hits = np.zeros((n, M), HIT_DTYPE) if dumps else None
+    hcnt = np.zeros(n, np.uint32) if dumps else None
+    aln = np.zeros((n, M), ALN_DTYPE) if dumps else None
+    rc = lib().uco_cluster(C.byref(odb.db), C.byref(p), threads, assign.ctypes.data, C.byref(cnt),
+                           hits.ctypes.data if dumps else None, hcnt.ctypes.data if dumps else None,
+                           aln.ctypes.data if dumps else None)
+    if rc != 0:
+        raise RuntimeError("uco_cluster failed: %d" % rc)
+    return dict(assign=assign, counts={f: getattr(cnt, f) for f, _ in Counts._fields_}, hits=hits, hit_cnt=hcnt, aln=aln)
+
+
+def write_tsv(path, odb, assign):
+    a = np.ascontiguousarray(assign, np.uint32)
+    if lib().uco_write_tsv(path.encode(), C.byref(odb.db), a.ctypes.data) != 0:
+        raise IOError(path)

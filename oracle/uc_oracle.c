@@ -1,0 +1,642 @@
+/* uc_oracle.c — CPU ORACLE (TEST INFRASTRUCTURE ONLY; see uc_oracle.h for the rules and spec UC-1).
+ *
+ * PARITY UNPINNED: restates the published Foldseek/MMseqs2 algorithm behind the three subprocess
+ * calls of /root/reference/src/modules/cluster.rs:45-76; no reference golden vector exists.
+ * Every function names the reference call site / published stage it stands for.
+ */
+#include "uc_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ alphabet / matrices */
+
+/* MMseqs2-style alphabetical letter table; X and everything unknown -> 20. */
+int uco_letter_code(char c) {
+    static const char LET[] = "ACDEFGHIKLMNPQRSTVWY";
+    if (c >= 'a' && c <= 'z') c = (char)(c - 'a' + 'A');
+    const char *p = c ? strchr(LET, c) : NULL;
+    return p ? (int)(p - LET) : 20;
+}
+
+void uco_params_default(uco_params *p) {
+    memset(p, 0, sizeof *p);
+    strcpy(p->pattern, "1101010011");
+    p->kmer_thr = 22;
+    p->min_diag_hits = 2;
+    p->min_ungapped = 15;
+    p->max_seqs = 300;
+    p->gap_open = 10;
+    p->gap_ext = 1;
+    p->rev_correction = 1;
+    p->evalue = 0.01;
+    p->lambda = 0.34657359027997264; /* ln2/2: half-bit units */
+    p->K = 0.1;
+    p->cov = 0.8f;
+    p->cov_mode = 0;
+    p->min_seq_id = 0.0f;
+}
+
+/* MMseqs-style matrix text: '#' comments, a header row of column letters, then "L v v v ..." rows.
+   Letters outside the 21-letter alphabet (B, Z, *) are ignored; missing X entries default to -1. */
+int uco_load_matrix(const char *path, int8_t out[UCO_A * UCO_A]) {
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    for (int i = 0; i < UCO_A * UCO_A; i++) out[i] = -1;
+    char line[4096];
+    int cols[64], ncols = 0, seen_rows = 0;
+    while (fgets(line, sizeof line, f)) {
+        char *s = line;
+        while (*s == ' ' || *s == '\t') s++;
+        if (*s == '#' || *s == '\n' || *s == 0) continue;
+        if (ncols == 0) { /* header */
+            for (char *tok = strtok(s, " \t\r\n"); tok && ncols < 64; tok = strtok(NULL, " \t\r\n")) {
+                int known = (strlen(tok) == 1) && (uco_letter_code(tok[0]) < 20 || tok[0] == 'X' || tok[0] == 'x');
+                cols[ncols++] = known ? uco_letter_code(tok[0]) : -1;
+            }
+            continue;
+        }
+        char *tok = strtok(s, " \t\r\n");
+        if (!tok || strlen(tok) != 1) continue;
+        int known = uco_letter_code(tok[0]) < 20 || tok[0] == 'X' || tok[0] == 'x';
+        int row = known ? uco_letter_code(tok[0]) : -1;
+        for (int c = 0; c < ncols; c++) {
+            tok = strtok(NULL, " \t\r\n");
+            if (!tok) break;
+            if (row >= 0 && cols[c] >= 0) {
+                long v = strtol(tok, NULL, 10);
+                if (v < -127 || v > 127) { fclose(f); return -2; }
+                out[row * UCO_A + cols[c]] = (int8_t)v;
+            }
+        }
+        if (row >= 0) seen_rows++;
+    }
+    fclose(f);
+    return seen_rows >= 20 ? 0 : -3;
+}
+
+/* ------------------------------------------------------------------ DB reader
+ * Format witness: /root/reference/src/seq/create_gene_specific_fasta.rs:9-36 (entries "TEXT\n\0",
+ * three index-aligned files <db>, <db>_ss, <db>_h); index "key\toffset\tlength" (SURVEY.md App. B). */
+static char *read_file(const char *path, size_t *len) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return NULL;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    char *buf = (char *)malloc((size_t)n + 1);
+    if (n > 0 && fread(buf, 1, (size_t)n, f) != (size_t)n) { free(buf); fclose(f); return NULL; }
+    buf[n] = 0;
+    fclose(f);
+    *len = (size_t)n;
+    return buf;
+}
+typedef struct { uint64_t key, off, len; } idx_ent;
+static int cmp_idx(const void *a, const void *b) {
+    const idx_ent *x = (const idx_ent *)a, *y = (const idx_ent *)b;
+    return x->key < y->key ? -1 : x->key > y->key;
+}
+static idx_ent *read_index(const char *path, uint32_t *n) {
+    size_t len; char *txt = read_file(path, &len);
+    if (!txt) return NULL;
+    size_t cap = 1024, cnt = 0;
+    idx_ent *e = (idx_ent *)malloc(cap * sizeof *e);
+    char *s = txt;
+    while (*s) {
+        char *end;
+        uint64_t k = strtoull(s, &end, 10);
+        if (end == s) break;
+        uint64_t o = strtoull(end, &end, 10);
+        uint64_t l = strtoull(end, &end, 10);
+        if (cnt == cap) { cap *= 2; e = (idx_ent *)realloc(e, cap * sizeof *e); }
+        e[cnt].key = k; e[cnt].off = o; e[cnt].len = l; cnt++;
+        s = end;
+        while (*s == '\n' || *s == '\r' || *s == ' ' || *s == '\t') s++;
+    }
+    free(txt);
+    qsort(e, cnt, sizeof *e, cmp_idx);
+    *n = (uint32_t)cnt;
+    return e;
+}
+
+int uco_db_read(const char *prefix, uco_db *db) {
+    memset(db, 0, sizeof *db);
+    char path[4096];
+    uint32_t na = 0, ns = 0, nh = 0;
+    snprintf(path, sizeof path, "%s.index", prefix);     idx_ent *ia = read_index(path, &na);
+    snprintf(path, sizeof path, "%s_ss.index", prefix);  idx_ent *is = read_index(path, &ns);
+    snprintf(path, sizeof path, "%s_h.index", prefix);   idx_ent *ih = read_index(path, &nh);
+    if (!ia || !is || !ih || na != ns || na != nh) { free(ia); free(is); free(ih); return -1; }
+    size_t la, ls, lh;
+    snprintf(path, sizeof path, "%s", prefix);     char *da = read_file(path, &la);
+    snprintf(path, sizeof path, "%s_ss", prefix);  char *ds = read_file(path, &ls);
+    snprintf(path, sizeof path, "%s_h", prefix);   char *dh = read_file(path, &lh);
+    if (!da || !ds || !dh) { free(ia); free(is); free(ih); free(da); free(ds); free(dh); return -2; }
+    db->n = na;
+    db->off = (uint64_t *)malloc((na + 1) * sizeof(uint64_t));
+    db->names = (char **)calloc(na, sizeof(char *));
+    uint64_t tot = 0;
+    for (uint32_t i = 0; i < na; i++) {
+        if (ia[i].key != is[i].key || ia[i].key != ih[i].key) return -3;
+        uint64_t l = ia[i].len >= 2 ? ia[i].len - 2 : 0;
+        uint64_t l2 = is[i].len >= 2 ? is[i].len - 2 : 0;
+        if (l != l2 || ia[i].off + l > la || is[i].off + l > ls) return -4;
+        db->off[i] = tot; tot += l;
+    }
+    db->off[na] = tot;
+    db->s3 = (uint8_t *)malloc(tot + 1); db->sa = (uint8_t *)malloc(tot + 1);
+    for (uint32_t i = 0; i < na; i++) {
+        uint64_t l = db->off[i + 1] - db->off[i];
+        for (uint64_t k = 0; k < l; k++) {
+            db->sa[db->off[i] + k] = (uint8_t)uco_letter_code(da[ia[i].off + k]);
+            db->s3[db->off[i] + k] = (uint8_t)uco_letter_code(ds[is[i].off + k]);
+        }
+        const char *h = dh + ih[i].off;
+        size_t hl = 0;
+        while (ih[i].off + hl < lh && h[hl] && h[hl] != ' ' && h[hl] != '\t' && h[hl] != '\n') hl++;
+        db->names[i] = (char *)malloc(hl + 1);
+        memcpy(db->names[i], h, hl); db->names[i][hl] = 0;
+    }
+    free(ia); free(is); free(ih); free(da); free(ds); free(dh);
+    return 0;
+}
+
+void uco_db_free(uco_db *db) {
+    if (db->names) { for (uint32_t i = 0; i < db->n; i++) free(db->names[i]); free(db->names); }
+    free(db->off); free(db->s3); free(db->sa);
+    memset(db, 0, sizeof *db);
+}
+
+/* ------------------------------------------------------------------ E1: k-mer index */
+
+int uco_pattern_offsets(const char *pattern, int off[UCO_K]) {
+    int n = 0, span = (int)strlen(pattern);
+    if (span > UCO_MAXSPAN) return -1;
+    for (int i = 0; i < span; i++) {
+        if (pattern[i] == '1') { if (n == UCO_K) return -1; off[n++] = i; }
+        else if (pattern[i] != '0') return -1;
+    }
+    return n == UCO_K && pattern[0] == '1' && pattern[span - 1] == '1' ? span : -1;
+}
+
+#define KSPACE 64000000u /* 20^6 */
+
+static inline int kmer_at(const uint8_t *s, const int off[UCO_K], uint32_t *v) {
+    uint32_t x = 0, mul = 1;
+    for (int m = 0; m < UCO_K; m++) {
+        uint8_t c = s[off[m]];
+        if (c >= UCO_KA) return 0;
+        x += c * mul; mul *= UCO_KA;
+    }
+    *v = x;
+    return 1;
+}
+
+/* MMseqs2 prefilter index table: CSR k-mer -> (seq, pos), X-containing k-mers skipped. */
+int uco_index_build(const uco_db *db, uint32_t tbegin, uint32_t tend, const uco_params *p, uco_index *ix) {
+    int off[UCO_K];
+    int span = uco_pattern_offsets(p->pattern, off);
+    if (span < 0) return -1;
+    memset(ix, 0, sizeof *ix);
+    ix->koff = (uint32_t *)calloc((size_t)KSPACE + 1, sizeof(uint32_t));
+    if (!ix->koff) return -2;
+    for (uint32_t t = tbegin; t < tend; t++) {
+        const uint8_t *s = db->s3 + db->off[t];
+        int64_t l = (int64_t)(db->off[t + 1] - db->off[t]);
+        for (int64_t j = 0; j + span <= l && j <= 65535; j++) {
+            uint32_t v;
+            if (kmer_at(s + j, off, &v)) ix->koff[v + 1]++;
+        }
+    }
+    for (uint32_t v = 0; v < KSPACE; v++) ix->koff[v + 1] += ix->koff[v];
+    ix->n_entries = ix->koff[KSPACE];
+    ix->ent_seq = (uint32_t *)malloc((ix->n_entries + 1) * sizeof(uint32_t));
+    ix->ent_pos = (uint16_t *)malloc((ix->n_entries + 1) * sizeof(uint16_t));
+    uint32_t *cur = (uint32_t *)malloc((size_t)KSPACE * sizeof(uint32_t));
+    memcpy(cur, ix->koff, (size_t)KSPACE * sizeof(uint32_t));
+    for (uint32_t t = tbegin; t < tend; t++) {
+        const uint8_t *s = db->s3 + db->off[t];
+        int64_t l = (int64_t)(db->off[t + 1] - db->off[t]);
+        for (int64_t j = 0; j + span <= l && j <= 65535; j++) {
+            uint32_t v;
+            if (kmer_at(s + j, off, &v)) { uint32_t e = cur[v]++; ix->ent_seq[e] = t; ix->ent_pos[e] = (uint16_t)j; }
+        }
+    }
+    free(cur);
+    return 0;
+}
+
+void uco_index_free(uco_index *ix) { free(ix->koff); free(ix->ent_seq); free(ix->ent_pos); memset(ix, 0, sizeof *ix); }
+
+/* ------------------------------------------------------------------ E2: similar k-mers (MMseqs2 KmerGenerator) */
+
+typedef struct { uint32_t *v; size_t n, cap; int count_only; } kvec;
+static void kvec_push(kvec *k, uint32_t x) {
+    if (!k->count_only) {
+        if (k->n == k->cap) { k->cap = k->cap ? k->cap * 2 : 256; k->v = (uint32_t *)realloc(k->v, k->cap * sizeof(uint32_t)); }
+        k->v[k->n] = x;
+    }
+    k->n++;
+}
+static void sim_dfs(const int8_t *S3, const uint8_t *c, const int *restmax, int thr, int m, int partial,
+                    uint32_t val, uint32_t mul, kvec *out) {
+    if (m == UCO_K) { kvec_push(out, val); return; }
+    const int8_t *row = S3 + c[m] * UCO_A;
+    for (int b = 0; b < UCO_KA; b++) {
+        int s = partial + row[b];
+        if (s + restmax[m + 1] >= thr) sim_dfs(S3, c, restmax, thr, m + 1, s, val + (uint32_t)b * mul, mul * UCO_KA, out);
+    }
+}
+static void similar_kmers(const int8_t *S3, const uint8_t c[UCO_K], int thr, kvec *out) {
+    int restmax[UCO_K + 1];
+    restmax[UCO_K] = 0;
+    for (int m = UCO_K - 1; m >= 0; m--) {
+        int best = -128;
+        for (int b = 0; b < UCO_KA; b++) if (S3[c[m] * UCO_A + b] > best) best = S3[c[m] * UCO_A + b];
+        restmax[m] = restmax[m + 1] + best;
+    }
+    if (restmax[0] < thr) return;
+    sim_dfs(S3, c, restmax, thr, 0, 0, 0, 1, out);
+}
+size_t uco_similar_kmers(const int8_t S3[UCO_A * UCO_A], const uint8_t c[UCO_K], int thr, uint32_t *out, size_t cap) {
+    kvec k = {0};
+    k.count_only = (out == NULL);
+    similar_kmers(S3, c, thr, &k);
+    if (out) { memcpy(out, k.v, (k.n < cap ? k.n : cap) * sizeof(uint32_t)); free(k.v); }
+    return k.n;
+}
+
+/* ------------------------------------------------------------------ E3: ungapped diagonal score
+ * MMseqs2 UngappedAlignment on the 3Di track: Kadane along the whole diagonal,
+ * saturating at 255. */
+int32_t uco_ungapped(const uint8_t *q3, int lq, const uint8_t *t3, int lt, int diag, const int8_t S3[UCO_A * UCO_A]) {
+    int i0 = diag > 0 ? diag : 0;
+    int i1 = lq < lt + diag ? lq : lt + diag;
+    int run = 0, best = 0;
+    for (int i = i0; i < i1; i++) {
+        run += S3[q3[i] * UCO_A + t3[i - diag]];
+        if (run < 0) run = 0;
+        if (run > best) best = run;
+    }
+    return best > 255 ? 255 : best;
+}
+
+/* ------------------------------------------------------------------ E2+E3+E4 for one query */
+static int cmp_u64(const void *a, const void *b) {
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : x > y;
+}
+static int cmp_hit(const void *a, const void *b) {
+    const uco_hit *x = (const uco_hit *)a, *y = (const uco_hit *)b;
+    if (x->score != y->score) return x->score > y->score ? -1 : 1;
+    return x->t < y->t ? -1 : x->t > y->t;
+}
+
+int uco_prefilter_query(const uco_db *db, const uco_index *ix, uint32_t q, const uco_params *p,
+                        uco_hit *hits, uco_counts *cnt) {
+    int off[UCO_K];
+    int span = uco_pattern_offsets(p->pattern, off);
+    const uint8_t *q3 = db->s3 + db->off[q];
+    int lq = (int)(db->off[q + 1] - db->off[q]);
+    kvec sim = {0};
+    uint64_t *hk = NULL; size_t nh = 0, hcap = 0;
+    for (int i = 0; i + span <= lq && i <= 65535; i++) {
+        uint8_t c[UCO_K]; int ok = 1;
+        for (int m = 0; m < UCO_K; m++) { c[m] = q3[i + off[m]]; if (c[m] >= UCO_KA) ok = 0; }
+        if (!ok) continue;
+        sim.n = 0;
+        similar_kmers(p->S3, c, p->kmer_thr, &sim);
+        if (cnt) cnt->n_sim_kmers += sim.n;
+        for (size_t k = 0; k < sim.n; k++) {
+            uint32_t v = sim.v[k];
+            for (uint32_t e = ix->koff[v]; e < ix->koff[v + 1]; e++) {
+                if (nh == hcap) { hcap = hcap ? hcap * 2 : 4096; hk = (uint64_t *)realloc(hk, hcap * sizeof(uint64_t)); }
+                int d = i - (int)ix->ent_pos[e];
+                hk[nh++] = ((uint64_t)ix->ent_seq[e] << 32) | (uint32_t)(d + 65536);
+            }
+        }
+    }
+    free(sim.v);
+    if (cnt) cnt->n_kmer_hits += nh;
+    qsort(hk, nh, sizeof(uint64_t), cmp_u64);
+    /* per target: diagonal with most hits (tie: smallest diagonal); double-hit rule */
+    uco_hit *cand = NULL; size_t nc = 0, ccap = 0;
+    size_t a = 0;
+    while (a < nh) {
+        uint32_t t = (uint32_t)(hk[a] >> 32);
+        int best_cnt = 0, best_d = 0;
+        size_t b = a;
+        while (b < nh && (uint32_t)(hk[b] >> 32) == t) {
+            size_t e = b;
+            while (e < nh && hk[e] == hk[b]) e++;
+            int c = (int)(e - b);
+            if (c > best_cnt) { best_cnt = c; best_d = (int)(uint32_t)hk[b] - 65536; }
+            b = e;
+        }
+        if (best_cnt >= p->min_diag_hits) {
+            if (nc == ccap) { ccap = ccap ? ccap * 2 : 256; cand = (uco_hit *)realloc(cand, ccap * sizeof *cand); }
+            const uint8_t *t3 = db->s3 + db->off[t];
+            int lt = (int)(db->off[t + 1] - db->off[t]);
+            cand[nc].t = t; cand[nc].diag = best_d;
+            cand[nc].score = uco_ungapped(q3, lq, t3, lt, best_d, p->S3);
+            nc++;
+        }
+        a = b;
+    }
+    free(hk);
+    if (cnt) cnt->n_candidates += nc;
+    size_t kept = 0;
+    for (size_t k = 0; k < nc; k++) if (cand[k].score >= p->min_ungapped) cand[kept++] = cand[k];
+    qsort(cand, kept, sizeof *cand, cmp_hit);
+    if (kept > (size_t)p->max_seqs) kept = (size_t)p->max_seqs;
+    memcpy(hits, cand, kept * sizeof *cand);
+    free(cand);
+    if (cnt) cnt->n_prefilter_hits += kept;
+    return (int)kept;
+}
+
+/* ------------------------------------------------------------------ E5: gapped 3Di+AA Smith-Waterman
+ * Foldseek structurealign / SSW: affine local alignment on S3+SA, score + end with
+ * the frozen tie-break (smallest tEnd, then smallest qEnd).  rev_q/rev_t read the first lq/lt
+ * residues backwards (index l-1-k) — used for the reverse-query pass and the start-position pass. */
+void uco_sw(const uint8_t *q3, const uint8_t *qa, int lq, int rev_q,
+            const uint8_t *t3, const uint8_t *ta, int lt, int rev_t,
+            const uco_params *p, int32_t *score, int32_t *qend, int32_t *tend) {
+    const int open = p->gap_open, ext = p->gap_ext;
+    int32_t *H = (int32_t *)calloc((size_t)lq + 1, sizeof(int32_t));   /* column j-1, rows -1..lq-1 at [i+1] */
+    int32_t *E = (int32_t *)malloc(((size_t)lq + 1) * sizeof(int32_t));
+    for (int i = 0; i <= lq; i++) E[i] = -(1 << 28);
+    int32_t best = 0, bq = -1, bt = -1;
+    for (int j = 0; j < lt; j++) {
+        int tj = rev_t ? lt - 1 - j : j;
+        const int8_t *r3 = p->S3 + t3[tj];           /* column of S3 (symmetric use: S[q][t]) */
+        const int8_t *ra = p->SA + ta[tj];
+        int32_t hdiag = 0, f = -(1 << 28), hup = 0;
+        int32_t colbest = 0, colrow = -1;
+        for (int i = 0; i < lq; i++) {
+            int qi = rev_q ? lq - 1 - i : i;
+            int s = r3[q3[qi] * UCO_A] + ra[qa[qi] * UCO_A];
+            int32_t hleft = H[i + 1];
+            int32_t e = E[i + 1] - ext; if (hleft - open > e) e = hleft - open;
+            f = f - ext; if (hup - open > f) f = hup - open;
+            int32_t h = hdiag + s;
+            if (e > h) h = e;
+            if (f > h) h = f;
+            if (h < 0) h = 0;
+            hdiag = hleft;
+            H[i + 1] = h; E[i + 1] = e; hup = h;
+            if (h > colbest) { colbest = h; colrow = i; }
+        }
+        if (colbest > best) { best = colbest; bq = colrow; bt = j; }
+    }
+    free(H); free(E);
+    *score = best; *qend = bq; *tend = bt;
+}
+
+int32_t uco_min_score(const uco_params *p, int lq, uint64_t db_residues) {
+    double scale = p->K * (double)lq * (double)db_residues;
+    int32_t s = 1;
+    while (scale * exp(-p->lambda * (double)s) > p->evalue && s < (1 << 30)) s++;
+    return s;
+}
+
+/* traceback on the [qs..qe]x[ts..te] box (spec E6): returns aln_len and idents */
+static void traceback(const uco_db *db, uint32_t q, uint32_t t, const uco_params *p,
+                      int qs, int qe, int ts, int te, int32_t *aln_len, int32_t *idents) {
+    const uint8_t *q3 = db->s3 + db->off[q] + qs, *qa = db->sa + db->off[q] + qs;
+    const uint8_t *t3 = db->s3 + db->off[t] + ts, *ta = db->sa + db->off[t] + ts;
+    int lq = qe - qs + 1, lt = te - ts + 1;
+    const int open = p->gap_open, ext = p->gap_ext;
+    const int32_t NEG = -(1 << 28);
+    size_t W = (size_t)lt + 1;
+    int32_t *H = (int32_t *)calloc(((size_t)lq + 1) * W, sizeof(int32_t));
+    int32_t *E = (int32_t *)malloc(((size_t)lq + 1) * W * sizeof(int32_t));
+    int32_t *F = (int32_t *)malloc(((size_t)lq + 1) * W * sizeof(int32_t));
+    for (size_t k = 0; k < ((size_t)lq + 1) * W; k++) { E[k] = NEG; F[k] = NEG; }
+    for (int i = 1; i <= lq; i++)
+        for (int j = 1; j <= lt; j++) {
+            int s = p->S3[q3[i - 1] * UCO_A + t3[j - 1]] + p->SA[qa[i - 1] * UCO_A + ta[j - 1]];
+            int32_t e = E[i * W + j - 1] - ext; if (H[i * W + j - 1] - open > e) e = H[i * W + j - 1] - open;
+            int32_t f = F[(i - 1) * W + j] - ext; if (H[(i - 1) * W + j] - open > f) f = H[(i - 1) * W + j] - open;
+            int32_t h = H[(i - 1) * W + j - 1] + s;
+            if (e > h) h = e;
+            if (f > h) h = f;
+            if (h < 0) h = 0;
+            H[i * W + j] = h; E[i * W + j] = e; F[i * W + j] = f;
+        }
+    int i = lq, j = lt, state = 0, len = 0, id = 0;
+    while (i > 0 && j > 0) {
+        if (state == 0) {
+            int32_t h = H[i * W + j];
+            if (h == 0) break;
+            int s = p->S3[q3[i - 1] * UCO_A + t3[j - 1]] + p->SA[qa[i - 1] * UCO_A + ta[j - 1]];
+            if (h == H[(i - 1) * W + j - 1] + s) { len++; id += (qa[i - 1] == ta[j - 1]); i--; j--; }
+            else if (h == F[i * W + j]) state = 1;
+            else state = 2;
+        } else if (state == 1) { /* gap consuming query residue i */
+            len++;
+            if (F[i * W + j] == H[(i - 1) * W + j] - open) state = 0;
+            i--;
+        } else {                 /* gap consuming target residue j */
+            len++;
+            if (E[i * W + j] == H[i * W + j - 1] - open) state = 0;
+            j--;
+        }
+    }
+    free(H); free(E); free(F);
+    *aln_len = len; *idents = id;
+}
+
+/* Foldseek structurealign for one (query, target) pair (call site cluster.rs:45-49). */
+void uco_align_pair(const uco_db *db, uint32_t q, uint32_t t, const uco_params *p, int32_t min_score, uco_aln *o) {
+    memset(o, 0, sizeof *o);
+    const uint8_t *q3 = db->s3 + db->off[q], *qa = db->sa + db->off[q];
+    const uint8_t *t3 = db->s3 + db->off[t], *ta = db->sa + db->off[t];
+    int lq = (int)(db->off[q + 1] - db->off[q]), lt = (int)(db->off[t + 1] - db->off[t]);
+    int32_t qe, te, dq, dt;
+    uco_sw(q3, qa, lq, 0, t3, ta, lt, 0, p, &o->score, &qe, &te);
+    if (p->rev_correction) uco_sw(q3, qa, lq, 1, t3, ta, lt, 0, p, &o->score_rev, &dq, &dt);
+    o->corrected = o->score - o->score_rev;
+    o->qend = qe; o->tend = te; o->qstart = -1; o->tstart = -1;
+    o->pass_evalue = (o->score > 0 && o->corrected >= min_score);
+    if (!o->pass_evalue) return;
+    int32_t s2, qe2, te2;
+    uco_sw(q3, qa, qe + 1, 1, t3, ta, te + 1, 1, p, &s2, &qe2, &te2);
+    o->qstart = qe - qe2; o->tstart = te - te2;
+    float qcov = (float)(o->qend - o->qstart + 1) / (float)lq;
+    float tcov = (float)(o->tend - o->tstart + 1) / (float)lt;
+    int ok = p->cov_mode == 0 ? (qcov >= p->cov && tcov >= p->cov) : p->cov_mode == 1 ? (tcov >= p->cov) : (qcov >= p->cov);
+    if (ok && p->min_seq_id > 0.0f) {
+        traceback(db, q, t, p, o->qstart, o->qend, o->tstart, o->tend, &o->aln_len, &o->idents);
+        float sid = o->aln_len > 0 ? (float)o->idents / (float)o->aln_len : 0.0f;
+        ok = sid >= p->min_seq_id;
+    }
+    o->accepted = ok;
+}
+
+/* ------------------------------------------------------------------ E7: greedy set cover (MMseqs2 clust, cluster-mode 0) */
+typedef struct { uint32_t cnt, id; } hent;
+static int hless(hent a, hent b) { return a.cnt != b.cnt ? a.cnt > b.cnt : a.id < b.id; } /* a before b */
+typedef struct { hent *h; size_t n, cap; } heap_t;
+static void hpush(heap_t *hp, hent x) {
+    if (hp->n == hp->cap) { hp->cap = hp->cap ? hp->cap * 2 : 1024; hp->h = (hent *)realloc(hp->h, hp->cap * sizeof(hent)); }
+    size_t i = hp->n++;
+    while (i > 0) { size_t pa = (i - 1) / 2; if (hless(x, hp->h[pa])) { hp->h[i] = hp->h[pa]; i = pa; } else break; }
+    hp->h[i] = x;
+}
+static hent hpop(heap_t *hp) {
+    hent top = hp->h[0], x = hp->h[--hp->n];
+    size_t i = 0;
+    for (;;) {
+        size_t l = 2 * i + 1, r = l + 1, m = i; hent best = x;
+        if (l < hp->n && hless(hp->h[l], best)) { m = l; best = hp->h[l]; }
+        if (r < hp->n && hless(hp->h[r], best)) { m = r; best = hp->h[r]; }
+        if (m == i) break;
+        hp->h[i] = hp->h[m]; i = m;
+    }
+    if (hp->n) hp->h[i] = x;
+    return top;
+}
+
+int uco_setcover(uint32_t n, const uint32_t *edges, uint64_t n_edges, uint32_t *assign) {
+    /* symmetric, de-duplicated adjacency without self loops */
+    uint64_t *keys = (uint64_t *)malloc((2 * n_edges + 1) * sizeof(uint64_t));
+    uint64_t nk = 0;
+    for (uint64_t e = 0; e < n_edges; e++) {
+        uint32_t a = edges[2 * e], b = edges[2 * e + 1];
+        if (a == b || a >= n || b >= n) continue;
+        keys[nk++] = ((uint64_t)a << 32) | b;
+        keys[nk++] = ((uint64_t)b << 32) | a;
+    }
+    qsort(keys, nk, sizeof(uint64_t), cmp_u64);
+    uint64_t u = 0;
+    for (uint64_t k = 0; k < nk; k++) if (k == 0 || keys[k] != keys[k - 1]) keys[u++] = keys[k];
+    nk = u;
+    uint64_t *aoff = (uint64_t *)calloc((size_t)n + 1, sizeof(uint64_t));
+    for (uint64_t k = 0; k < nk; k++) aoff[(keys[k] >> 32) + 1]++;
+    for (uint32_t i = 0; i < n; i++) aoff[i + 1] += aoff[i];
+    uint32_t *cnt = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
+    heap_t hp = {0};
+    uint32_t *newly = NULL; size_t newly_cap = 0;
+    for (uint32_t i = 0; i < n; i++) { cnt[i] = (uint32_t)(aoff[i + 1] - aoff[i]) + 1; assign[i] = UINT32_MAX; hpush(&hp, (hent){cnt[i], i}); }
+    while (hp.n) {
+        hent top = hpop(&hp);
+        if (assign[top.id] != UINT32_MAX || top.cnt != cnt[top.id]) continue; /* stale */
+        uint32_t rep = top.id;
+        /* members: rep + its still-unassigned neighbours */
+        size_t nn = 0;
+        if (newly_cap < (size_t)(aoff[rep + 1] - aoff[rep]) + 1) {
+            newly_cap = (size_t)(aoff[rep + 1] - aoff[rep]) + 1;
+            newly = (uint32_t *)realloc(newly, newly_cap * sizeof(uint32_t));
+        }
+        assign[rep] = rep; newly[nn++] = rep;
+        for (uint64_t k = aoff[rep]; k < aoff[rep + 1]; k++) {
+            uint32_t v = (uint32_t)keys[k];
+            if (assign[v] == UINT32_MAX) { assign[v] = rep; newly[nn++] = v; }
+        }
+        /* every newly covered element leaves the sets of its still-unassigned neighbours */
+        for (size_t a = 0; a < nn; a++) {
+            uint32_t v = newly[a];
+            for (uint64_t m = aoff[v]; m < aoff[v + 1]; m++) {
+                uint32_t w = (uint32_t)keys[m];
+                if (assign[w] == UINT32_MAX) { cnt[w]--; hpush(&hp, (hent){cnt[w], w}); }
+            }
+        }
+    }
+    free(newly); free(hp.h); free(cnt); free(aoff); free(keys);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ full pipeline == `foldseek cluster` (cluster.rs:45-56) */
+int uco_cluster(const uco_db *db, const uco_params *p, int threads, uint32_t *assign, uco_counts *cnt,
+                uco_hit *hits_out, uint32_t *hit_cnt_out, uco_aln *aln_out) {
+    uco_index ix;
+    if (uco_index_build(db, 0, db->n, p, &ix) != 0) return -1;
+    const uint32_t n = db->n; const int M = p->max_seqs;
+    uco_hit *hits = hits_out ? hits_out : (uco_hit *)malloc((size_t)n * M * sizeof(uco_hit));
+    uint32_t *hcnt = hit_cnt_out ? hit_cnt_out : (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
+    uco_counts total; memset(&total, 0, sizeof total);
+    (void)threads;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel
+    {
+        uco_counts loc; memset(&loc, 0, sizeof loc);
+#pragma omp for schedule(dynamic, 8)
+        for (int64_t q = 0; q < (int64_t)n; q++)
+            hcnt[q] = (uint32_t)uco_prefilter_query(db, &ix, (uint32_t)q, p, hits + (size_t)q * M, &loc);
+#pragma omp critical
+        {
+            total.n_sim_kmers += loc.n_sim_kmers; total.n_kmer_hits += loc.n_kmer_hits;
+            total.n_candidates += loc.n_candidates; total.n_prefilter_hits += loc.n_prefilter_hits;
+        }
+    }
+    uco_index_free(&ix);
+    uint64_t npairs = 0;
+    uint64_t *poff = (uint64_t *)malloc(((size_t)n + 1) * sizeof(uint64_t));
+    for (uint32_t q = 0; q < n; q++) { poff[q] = npairs; npairs += hcnt[q]; }
+    poff[n] = npairs;
+    uint32_t *edges = (uint32_t *)malloc((2 * npairs + 2) * sizeof(uint32_t));
+    uint8_t *acc = (uint8_t *)calloc(npairs + 1, 1);
+    const uint64_t dbres = db->off[n];
+    uint64_t c_f = 0, c_r = 0, c_s = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : c_f, c_r, c_s)
+    for (int64_t q = 0; q < (int64_t)n; q++) {
+        int lq = (int)(db->off[q + 1] - db->off[q]);
+        int32_t ms = uco_min_score(p, lq, dbres);
+        for (uint32_t k = 0; k < hcnt[q]; k++) {
+            uco_aln a;
+            uint32_t t = hits[(size_t)q * M + k].t;
+            uco_align_pair(db, (uint32_t)q, t, p, ms, &a);
+            int lt = (int)(db->off[t + 1] - db->off[t]);
+            c_f += (uint64_t)lq * lt; if (p->rev_correction) c_r += (uint64_t)lq * lt;
+            if (a.pass_evalue) c_s += (uint64_t)(a.qend + 1) * (a.tend + 1);
+            acc[poff[q] + k] = (uint8_t)a.accepted;
+            if (aln_out) aln_out[(size_t)q * M + k] = a;
+        }
+    }
+    uint64_t ne = 0;
+    for (uint32_t q = 0; q < n; q++)
+        for (uint32_t k = 0; k < hcnt[q]; k++)
+            if (acc[poff[q] + k]) { edges[2 * ne] = q; edges[2 * ne + 1] = hits[(size_t)q * M + k].t; ne++; }
+    uco_setcover(n, edges, ne, assign);
+    uint64_t ncl = 0;
+    for (uint32_t i = 0; i < n; i++) ncl += (assign[i] == i);
+    total.n_alignments = npairs; total.n_edges = ne; total.n_clusters = ncl;
+    total.cells_fwd = c_f; total.cells_rev = c_r; total.cells_start = c_s;
+    if (cnt) *cnt = total;
+    free(edges); free(acc); free(poff);
+    if (!hits_out) free(hits);
+    if (!hit_cnt_out) free(hcnt);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ E9: `foldseek createtsv` (cluster.rs:59-64) */
+int uco_write_tsv(const char *path, const uco_db *db, const uint32_t *assign) {
+    FILE *f = fopen(path, "w");
+    if (!f) return -1;
+    const uint32_t n = db->n;
+    /* members of each representative in ascending id: counting sort by rep */
+    uint64_t *off = (uint64_t *)calloc((size_t)n + 1, sizeof(uint64_t));
+    for (uint32_t i = 0; i < n; i++) off[assign[i] + 1]++;
+    for (uint32_t i = 0; i < n; i++) off[i + 1] += off[i];
+    uint32_t *mem = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
+    uint64_t *cur = (uint64_t *)malloc(((size_t)n + 1) * sizeof(uint64_t));
+    memcpy(cur, off, ((size_t)n + 1) * sizeof(uint64_t));
+    for (uint32_t i = 0; i < n; i++) mem[cur[assign[i]]++] = i;
+    for (uint32_t r = 0; r < n; r++) {
+        if (off[r + 1] == off[r]) continue;
+        fprintf(f, "%s\t%s\n", db->names[r], db->names[r]);
+        for (uint64_t k = off[r]; k < off[r + 1]; k++)
+            if (mem[k] != r) fprintf(f, "%s\t%s\n", db->names[r], db->names[mem[k]]);
+    }
+    free(off); free(mem); free(cur);
+    fclose(f);
+    return 0;
+}
