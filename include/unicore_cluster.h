@@ -1,0 +1,144 @@
+/* unicore_cluster.h — C ABI of the MI355X-native `unicore cluster` engine (libunicore_cluster.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of steineggerlab/unicore: the three external
+ * `foldseek` invocations of /root/reference/src/modules/cluster.rs:45-76.  The reference has no
+ * in-process FFI for this path (its extension point is the binary registry path.cfg:2 +
+ * src/util/command.rs:4-24), so the entry points below are exactly what a Rust `unicore` would bind
+ * with `extern "C"` to replace those three spawns (INTEGRATION.md shows the binding), plus a staged
+ * engine API used by the multi-GPU driver, bench.py and the parity tests.
+ *
+ * Conventions: plain pointers and sizes, caller-owned memory unless stated, UTF-8 paths, no
+ * exceptions cross the boundary.  Every int-returning function returns 0 on success or an error class
+ * (exit status is the reference's only error channel: src/util/command.rs:10-14):
+ *     1 generic, 2 bad arguments / unknown flag, 3 I/O, 4 device (HIP) failure or no GPU.
+ * uc_last_error() gives the message (thread-local).  There is NO CPU fallback: without a working HIP
+ * device every compute entry point fails with class 4.
+ */
+#ifndef UNICORE_CLUSTER_H
+#define UNICORE_CLUSTER_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UC_OK 0
+#define UC_ERR_GENERIC 1
+#define UC_ERR_ARGS 2
+#define UC_ERR_IO 3
+#define UC_ERR_DEVICE 4
+
+/* Options.  `cluster_options` is the raw whitespace-split Foldseek-style flag string that
+ * src/modules/cluster.rs:35,49 forwards verbatim (default "-c 0.8", src/util/arg_parser.rs:238-239).
+ * Unknown flags are rejected (UC_ERR_ARGS), never ignored. */
+typedef struct uc_opts {
+    uint32_t struct_size;        /* = sizeof(uc_opts) */
+    int32_t threads;             /* host threads, >=1 (cluster.rs:46 "--threads") */
+    int32_t verbosity;           /* 0..3, Foldseek scale after the 4->3,3->2 mapping of cluster.rs:18 */
+    int32_t device;              /* HIP device ordinal, -1 = current */
+    const char *cluster_options; /* may be NULL == "" */
+    const char *data_dir;        /* directory holding mat3di*.out / blosum62.out; NULL = <lib dir>/data */
+} uc_opts;
+
+#define UC_NSTAGE 8
+enum { UC_ST_LOAD = 0, UC_ST_INDEX = 1, UC_ST_KMER = 2, UC_ST_UNGAPPED = 3, UC_ST_SELECT = 4,
+       UC_ST_GAPPED = 5, UC_ST_SETCOVER = 6, UC_ST_OUTPUT = 7 };
+
+typedef struct uc_stats {
+    uint64_t n_seqs, n_residues;
+    uint64_t n_index_entries, n_sim_kmers, n_kmer_hits, n_candidates, n_prefilter_hits;
+    uint64_t n_gapped_alignments;        /* (query,target) pairs handed to stage E5: the metric's unit */
+    uint64_t n_start_alignments;         /* pairs that also ran the start-position pass */
+    uint64_t n_edges, n_clusters;
+    uint64_t cells_fwd, cells_rev, cells_start;          /* DP cell updates per pass */
+    uint64_t algorithmic_bytes[UC_NSTAGE];               /* SURVEY.md 8(d) per-stage algorithmic bytes */
+    double stage_seconds[UC_NSTAGE];                     /* host wall per stage */
+    /* dominant kernel (gapped SW, all passes): HIP-event time on the engine stream */
+    double sw_kernel_ms;
+    uint64_t sw_kernel_launches;
+    uint64_t sw_algorithmic_bytes;                       /* sum over launches of 2*(Lq+Lt)+32 per alignment-pass */
+    double prefilter_kernel_ms;                          /* all prefilter kernels (HIP events) */
+} uc_stats;
+
+/* ---- the three calls of cluster.rs ------------------------------------------------------------ */
+/* == `foldseek cluster --threads T -v V <db> <out>_cluster <tmp> <opts...>`  (cluster.rs:45-56) */
+int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, const uc_opts *o, uc_stats *stats_out);
+/* == `foldseek createtsv --threads T -v V <db> <db> <out>_cluster <out>.tsv`   (cluster.rs:59-64) */
+int uc_createtsv(const char *db, const char *cluster_db, const char *out_tsv, const uc_opts *o);
+/* == `foldseek rmdb <out>_cluster -v V`                                         (cluster.rs:67-76) */
+int uc_rmdb(const char *db_prefix);
+
+const char *uc_last_error(void);
+const char *uc_version(void);
+/* validates a Foldseek-style option string without running anything (0 or UC_ERR_ARGS) */
+int uc_check_options(const char *cluster_options);
+
+/* ---- staged engine API (multi-GPU driver, bench, parity tests) -------------------------------- */
+typedef struct uc_engine uc_engine;
+
+typedef struct uc_hit {          /* one prefilter result (stage E4 output) */
+    uint32_t target;
+    int32_t score;               /* ungapped diagonal score, 0..255 */
+    int32_t diag;                /* query pos - target pos of the best diagonal */
+} uc_hit;
+
+typedef struct uc_aln {          /* one gapped alignment result (stage E5/E6 output) */
+    int32_t score, score_rev, corrected;
+    int32_t qstart, qend, tstart, tend;    /* valid iff pass_evalue */
+    int32_t aln_len, idents;               /* valid iff a seq-id threshold is active */
+    int32_t pass_evalue, accepted;
+} uc_aln;
+
+int uc_engine_create(const uc_opts *o, uc_engine **out);
+void uc_engine_destroy(uc_engine *e);
+/* load <db>, <db>_ss, <db>_h (+ .index) from disk and upload both tracks to HBM */
+int uc_engine_load_db(uc_engine *e, const char *db_prefix);
+/* or hand over encoded sequences directly: codes 0..20, off has n+1 entries (bytes), no padding */
+int uc_engine_set_db(uc_engine *e, uint32_t n, const uint64_t *off, const uint8_t *s3, const uint8_t *sa);
+uint32_t uc_engine_num_seqs(const uc_engine *e);
+
+/* E1-E4: index targets [tbegin,tend), match ALL queries against it, keep per-query top max_seqs */
+int uc_engine_prefilter(uc_engine *e, uint32_t tbegin, uint32_t tend);
+/* hit lists live in the engine: counts[n_seqs], hits flat, grouped by query in query order */
+int uc_engine_hits_size(const uc_engine *e, uint64_t *n_hits);
+int uc_engine_hits_get(const uc_engine *e, uint32_t *counts, uc_hit *hits);
+/* replace the engine's hit lists (counts[n_seqs] + flat hits grouped by query) */
+int uc_engine_hits_set(uc_engine *e, const uint32_t *counts, const uc_hit *hits);
+/* replace the engine's hit lists by the merge of n_parts shard lists (each: counts[n_seqs] + flat hits),
+ * keeping per query the top max_seqs under the frozen order (score desc, target asc) */
+int uc_engine_hits_merge(uc_engine *e, int n_parts, const uint32_t *const *counts, const uc_hit *const *hits);
+/* the same merge as a free host function (needs no device): the post-exchange step of the multi-GPU
+ * layout.  out_hits must hold out_capacity entries; *out_n receives the merged total. */
+int uc_hits_merge(uint32_t n_seqs, int32_t max_seqs, int n_parts, const uint32_t *const *counts,
+                  const uc_hit *const *hits, uint32_t *out_counts, uc_hit *out_hits, uint64_t out_capacity,
+                  uint64_t *out_n);
+
+/* E5-E6 for queries [qbegin,qend) of the engine's hit lists; results are kept per hit */
+int uc_engine_align(uc_engine *e, uint32_t qbegin, uint32_t qend);
+int uc_engine_alns_get(const uc_engine *e, uint32_t qbegin, uint32_t qend, uc_aln *out);   /* one per hit */
+int uc_engine_edges_size(const uc_engine *e, uint64_t *n_edges);
+int uc_engine_edges_get(const uc_engine *e, uint32_t *edges /* 2*n_edges: (query,target) */);
+
+int uc_engine_stats(const uc_engine *e, uc_stats *out);
+void uc_engine_reset_stats(uc_engine *e);
+
+/* E7 (host, as the north star prescribes): greedy set cover over (a,b) pairs; assign[i] = representative */
+int uc_setcover(uint32_t n, const uint32_t *edges, uint64_t n_edges, uint32_t *assign);
+/* E8/E9 outputs from an assignment: cluster DB (<prefix>, .index, .dbtype) */
+int uc_write_cluster_db(const char *out_cluster_db, uint32_t n, const uint32_t *assign);
+
+/* ---- kernel-level entry points (parity tests call the HIP kernels through these) -------------- */
+/* ungapped diagonal score (E3) for n candidates (q[i], t[i], diag[i]) of the engine's DB */
+int uc_engine_ungapped_batch(uc_engine *e, uint64_t n, const uint32_t *q, const uint32_t *t,
+                             const int32_t *diag, int32_t *score_out);
+/* gapped DP (E5) for n pairs.  mode 0: forward (score, qend, tend); mode 1: reversed query (score);
+ * mode 2: start pass on reverse(q[0..qend_in]) x reverse(t[0..tend_in]) (score, qend', tend').
+ * Pairs may be in any order (the engine groups them by query internally). */
+int uc_engine_sw_batch(uc_engine *e, int mode, uint64_t n, const uint32_t *q, const uint32_t *t,
+                       const int32_t *qend_in, const int32_t *tend_in,
+                       int32_t *score_out, int32_t *qend_out, int32_t *tend_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

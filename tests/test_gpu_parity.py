@@ -1,0 +1,158 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs — bit-exact (integer scores, positions, hit lists, cluster assignments, clust.tsv bytes)."""
+import os
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle_py
+    return oracle_py
+
+
+@pytest.fixture(scope="module")
+def small(O):
+    s3, sa = util.family_db(11, n_fam=14, members=6, extra=(700, 1100, 1500, 2040))
+    off, c3, ca = util.flat(s3, sa)
+    import unicore_amd as U
+    e = U.Engine("-c 0.8", verbosity=1)
+    e.set_db(off, c3, ca)
+    return dict(s3=s3, sa=sa, off=off, eng=e, odb=O.OracleDb(s3=s3, sa=sa))
+
+
+def test_ungapped_parity(O, small):
+    rng = np.random.default_rng(5)
+    n, N = 4000, len(small["s3"])
+    q, t = rng.integers(0, N, n), rng.integers(0, N, n)
+    q[:600] = (np.arange(600) // 6) % N          # related pairs (same family) too
+    t[:600] = np.minimum(q[:600] // 6 * 6 + rng.integers(0, 6, 600), N - 1)
+    lq = np.array([len(small["s3"][i]) for i in q]); lt = np.array([len(small["s3"][i]) for i in t])
+    diag = rng.integers(-(lt - 1), np.maximum(lq, 1))
+    diag[:600] = rng.integers(-3, 4, 600)
+    got = small["eng"].ungapped(q, t, diag)
+    p = O.default_params()
+    exp = np.array([O.ungapped(small["s3"][a], small["s3"][b], int(d), p) for a, b, d in zip(q, t, diag)])
+    assert np.array_equal(got, exp)
+    assert exp.max() > 50 and exp.min() == 0   # both regimes exercised
+
+
+def _pairs(small, n, seed):
+    rng = np.random.default_rng(seed)
+    N = len(small["s3"])
+    q, t = rng.integers(0, N, n), rng.integers(0, N, n)
+    k = n // 2
+    fam = rng.integers(0, 14, k)
+    q[:k] = fam * 6 + rng.integers(0, 6, k)
+    t[:k] = fam * 6 + rng.integers(0, 6, k)
+    q[k:k + 8] = np.arange(N - 8, N)             # long / tiny / all-X sequences as queries
+    t[k + 8:k + 16] = np.arange(N - 8, N)        # ... and as targets
+    q[k + 16:k + 24] = np.arange(N - 8, N); t[k + 16:k + 24] = np.arange(N - 8, N)   # self pairs
+    return q.astype(np.uint32), t.astype(np.uint32)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sw_forward_and_reverse_parity(O, small, mode):
+    q, t = _pairs(small, 1500, 21 + mode)
+    s, qe, te = small["eng"].sw(mode, q, t)
+    p = O.default_params()
+    for i in range(len(q)):
+        es, eq, et = O.sw(small["s3"][q[i]], small["sa"][q[i]], small["s3"][t[i]], small["sa"][t[i]], p, rev_q=mode)
+        assert s[i] == es, (i, q[i], t[i])
+        if mode == 0:
+            assert (qe[i], te[i]) == (eq, et), (i, q[i], t[i], s[i])
+
+
+def test_sw_start_pass_parity(O, small):
+    q, t = _pairs(small, 1200, 33)
+    s, qe, te = small["eng"].sw(0, q, t)
+    keep = s > 0
+    q, t, s, qe, te = q[keep], t[keep], s[keep], qe[keep], te[keep]
+    s2, q2, t2 = small["eng"].sw(2, q, t, qe, te)
+    p = O.default_params()
+    assert np.array_equal(s2, s)     # reversed prefixes reach the same optimum
+    for i in range(len(q)):
+        a3, aa = small["s3"][q[i]][: qe[i] + 1], small["sa"][q[i]][: qe[i] + 1]
+        b3, ba = small["s3"][t[i]][: te[i] + 1], small["sa"][t[i]][: te[i] + 1]
+        es, eq, et = O.sw(a3, aa, b3, ba, p, rev_q=1, rev_t=1)
+        assert (s2[i], q2[i], t2[i]) == (es, eq, et), (i, q[i], t[i])
+
+
+def test_sw_long_query_fallback(O):
+    """queries longer than the largest group class (2048 rows) take the generic kernel — same results"""
+    rng = np.random.default_rng(9)
+    base3, basea = rng.integers(0, 20, 2600, dtype=np.uint8), rng.integers(0, 20, 2600, dtype=np.uint8)
+    s3 = [base3, base3[100:2500].copy(), rng.integers(0, 20, 300, dtype=np.uint8), base3[:2100].copy()]
+    sa = [basea, basea[100:2500].copy(), rng.integers(0, 20, 300, dtype=np.uint8), basea[:2100].copy()]
+    s3[1][::17] = (s3[1][::17] + 3) % 20
+    off, c3, ca = util.flat(s3, sa)
+    import unicore_amd as U
+    e = U.Engine("-c 0.8", verbosity=1)
+    e.set_db(off, c3, ca)
+    q = np.array([0, 0, 0, 1, 3, 3, 2, 1], np.uint32); t = np.array([1, 2, 0, 0, 0, 2, 0, 3], np.uint32)
+    p = O.default_params()
+    s, qe, te = e.sw(0, q, t)
+    s1, _, _ = e.sw(1, q, t)
+    for i in range(len(q)):
+        assert (s[i], qe[i], te[i]) == O.sw(s3[q[i]], sa[q[i]], s3[t[i]], sa[t[i]], p), i
+        assert s1[i] == O.sw(s3[q[i]], sa[q[i]], s3[t[i]], sa[t[i]], p, rev_q=1)[0], i
+    keep = s > 0
+    s2, q2, t2 = e.sw(2, q[keep], t[keep], qe[keep], te[keep])
+    for k, i in enumerate(np.nonzero(keep)[0]):
+        exp = O.sw(s3[q[i]][: qe[i] + 1], sa[q[i]][: qe[i] + 1], s3[t[i]][: te[i] + 1], sa[t[i]][: te[i] + 1], p, rev_q=1, rev_t=1)
+        assert (s2[k], q2[k], t2[k]) == exp, i
+
+
+@pytest.mark.parametrize("opts", ["-c 0.8", "-c 0.5 -s 6 --max-seqs 5", "-c 0.8 --cov-mode 1 -e 1e-6 --rev-correction 0"])
+def test_pipeline_stage_parity(O, small, opts):
+    """prefilter hit lists, per-pair alignment records, edges and the set cover all equal the oracle's"""
+    import unicore_amd as U
+    e = U.Engine(opts, verbosity=1)
+    e.set_db(small["off"], *util.flat(small["s3"], small["sa"])[1:])
+    p = util.oracle_params(O, opts)
+    ref = O.cluster(small["odb"], p, threads=8)
+    e.prefilter()
+    cnt, hits = e.hits()
+    assert np.array_equal(cnt, ref["hit_cnt"])
+    rh = np.concatenate([ref["hits"][i, : cnt[i]] for i in range(len(cnt))])
+    assert np.array_equal(hits["target"], rh["t"]) and np.array_equal(hits["score"], rh["score"]) and np.array_equal(hits["diag"], rh["diag"])
+    e.align()
+    al = e.alns()
+    ra = np.concatenate([ref["aln"][i, : cnt[i]] for i in range(len(cnt))])
+    for f in ("score", "score_rev", "corrected", "pass_evalue", "accepted"):
+        assert np.array_equal(al[f], ra[f]), f
+    pe = al["pass_evalue"] == 1
+    for f in ("qstart", "qend", "tstart", "tend"):
+        assert np.array_equal(al[f][pe], ra[f][pe]), f
+    st = e.stats()
+    c = ref["counts"]
+    for a, b in (("n_sim_kmers", "n_sim_kmers"), ("n_kmer_hits", "n_kmer_hits"), ("n_candidates", "n_candidates"),
+                 ("n_prefilter_hits", "n_prefilter_hits"), ("n_gapped_alignments", "n_alignments"), ("n_edges", "n_edges"),
+                 ("cells_fwd", "cells_fwd"), ("cells_start", "cells_start")):
+        assert st[a] == c[b], (a, st[a], c[b])
+    assign = U.setcover(e.n, e.edges())
+    assert np.array_equal(assign, ref["assign"])
+    assert len(set(assign.tolist())) < e.n   # something actually clustered
+
+
+def test_cluster_end_to_end_tsv_bytes(O, tmp_path):
+    """uc_cluster + uc_createtsv + uc_rmdb on DB files == oracle clust.tsv, byte for byte"""
+    import unicore_amd as U
+    db = util.gen_synth_db(str(tmp_path / "db"), 6, 0x5EED0001, 48, 0.6)
+    out = str(tmp_path / "clu" / "clust")
+    os.makedirs(os.path.dirname(out))
+    st = U.cluster(db, out + "_cluster", str(tmp_path / "tmp"), "-c 0.8", threads=4)
+    U.createtsv(db, out + "_cluster", out + ".tsv")
+    odb = O.OracleDb(db)
+    ref = O.cluster(odb, util.oracle_params(O, "-c 0.8"), threads=8, dumps=False)
+    O.write_tsv(str(tmp_path / "ref.tsv"), odb, ref["assign"])
+    assert open(out + ".tsv", "rb").read() == open(str(tmp_path / "ref.tsv"), "rb").read()
+    util.tsv_invariants(out + ".tsv", odb.names())
+    assert st["n_clusters"] == ref["counts"]["n_clusters"] and st["n_gapped_alignments"] == ref["counts"]["n_alignments"]
+    U.rmdb(out + "_cluster")
+    assert not os.path.exists(out + "_cluster") and not os.path.exists(out + "_cluster.index")

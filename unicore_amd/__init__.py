@@ -1,0 +1,257 @@
+"""unicore_amd — ctypes binding of libunicore_cluster.so (the MI355X-native `unicore cluster` engine).
+
+The library is the product; this module only mirrors its C ABI (include/unicore_cluster.h) for Python
+callers (tests, bench.py, the multi-GPU driver in unicore_amd.dist).  There is no Python or CPU
+fallback: if the HIP library cannot be loaded, importing `lib()` raises, and on a machine without a
+GPU every compute call returns UC_ERR_DEVICE.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunicore_cluster.so")
+
+UC_OK, UC_ERR_GENERIC, UC_ERR_ARGS, UC_ERR_IO, UC_ERR_DEVICE = 0, 1, 2, 3, 4
+NSTAGE = 8
+STAGES = ("load", "index", "kmer", "ungapped", "select", "gapped", "setcover", "output")
+
+
+class UcOpts(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("threads", C.c_int32), ("verbosity", C.c_int32), ("device", C.c_int32),
+                ("cluster_options", C.c_char_p), ("data_dir", C.c_char_p)]
+
+
+class UcStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "n_seqs", "n_residues", "n_index_entries", "n_sim_kmers", "n_kmer_hits", "n_candidates", "n_prefilter_hits",
+        "n_gapped_alignments", "n_start_alignments", "n_edges", "n_clusters", "cells_fwd", "cells_rev", "cells_start")] + [
+        ("algorithmic_bytes", C.c_uint64 * NSTAGE), ("stage_seconds", C.c_double * NSTAGE),
+        ("sw_kernel_ms", C.c_double), ("sw_kernel_launches", C.c_uint64), ("sw_algorithmic_bytes", C.c_uint64),
+        ("prefilter_kernel_ms", C.c_double)]
+
+    def as_dict(self):
+        d = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            d[name] = list(v) if hasattr(v, "__len__") else v
+        return d
+
+
+HIT_DTYPE = np.dtype([("target", "<u4"), ("score", "<i4"), ("diag", "<i4")])
+ALN_DTYPE = np.dtype([(n, "<i4") for n in ("score", "score_rev", "corrected", "qstart", "qend", "tstart", "tend",
+                                            "aln_len", "idents", "pass_evalue", "accepted")])
+
+# every symbol include/unicore_cluster.h declares (tests check the library exports all of them)
+SYMBOLS = (
+    "uc_cluster", "uc_createtsv", "uc_rmdb", "uc_last_error", "uc_version", "uc_check_options",
+    "uc_engine_create", "uc_engine_destroy", "uc_engine_load_db", "uc_engine_set_db", "uc_engine_num_seqs",
+    "uc_engine_prefilter", "uc_engine_hits_size", "uc_engine_hits_get", "uc_engine_hits_set", "uc_engine_hits_merge",
+    "uc_hits_merge", "uc_engine_align", "uc_engine_alns_get", "uc_engine_edges_size", "uc_engine_edges_get",
+    "uc_engine_stats", "uc_engine_reset_stats", "uc_setcover", "uc_write_cluster_db",
+    "uc_engine_ungapped_batch", "uc_engine_sw_batch",
+)
+
+_lib = None
+
+
+class UcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("unicore_cluster error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing — run `make product` (or __graft_entry__.build()); there is no fallback path" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+    L.uc_last_error.restype = C.c_char_p
+    L.uc_version.restype = C.c_char_p
+    L.uc_check_options.argtypes = [C.c_char_p]
+    L.uc_cluster.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(UcOpts), C.POINTER(UcStats)]
+    L.uc_createtsv.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(UcOpts)]
+    L.uc_rmdb.argtypes = [C.c_char_p]
+    L.uc_engine_create.argtypes = [C.POINTER(UcOpts), C.POINTER(vp)]
+    L.uc_engine_destroy.argtypes = [vp]
+    L.uc_engine_destroy.restype = None
+    L.uc_engine_load_db.argtypes = [vp, C.c_char_p]
+    L.uc_engine_set_db.argtypes = [vp, u32, vp, vp, vp]
+    L.uc_engine_num_seqs.argtypes = [vp]
+    L.uc_engine_num_seqs.restype = u32
+    L.uc_engine_prefilter.argtypes = [vp, u32, u32]
+    L.uc_engine_hits_size.argtypes = [vp, C.POINTER(u64)]
+    L.uc_engine_hits_get.argtypes = [vp, vp, vp]
+    L.uc_engine_hits_set.argtypes = [vp, vp, vp]
+    L.uc_engine_hits_merge.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]
+    L.uc_hits_merge.argtypes = [u32, i32, C.c_int, C.POINTER(vp), C.POINTER(vp), vp, vp, u64, C.POINTER(u64)]
+    L.uc_engine_align.argtypes = [vp, u32, u32]
+    L.uc_engine_alns_get.argtypes = [vp, u32, u32, vp]
+    L.uc_engine_edges_size.argtypes = [vp, C.POINTER(u64)]
+    L.uc_engine_edges_get.argtypes = [vp, vp]
+    L.uc_engine_stats.argtypes = [vp, C.POINTER(UcStats)]
+    L.uc_engine_reset_stats.argtypes = [vp]
+    L.uc_engine_reset_stats.restype = None
+    L.uc_setcover.argtypes = [u32, vp, u64, vp]
+    L.uc_write_cluster_db.argtypes = [C.c_char_p, u32, vp]
+    L.uc_engine_ungapped_batch.argtypes = [vp, u64, vp, vp, vp, vp]
+    L.uc_engine_sw_batch.argtypes = [vp, C.c_int, u64, vp, vp, vp, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise UcError(rc, lib().uc_last_error().decode(errors="replace"))
+
+
+def make_opts(cluster_options="", threads=1, verbosity=1, device=-1, data_dir=None):
+    o = UcOpts()
+    o.struct_size = C.sizeof(UcOpts)
+    o.threads = threads
+    o.verbosity = verbosity
+    o.device = device
+    o.cluster_options = cluster_options.encode()
+    o.data_dir = data_dir.encode() if data_dir else None
+    return o
+
+
+def version():
+    return lib().uc_version().decode()
+
+
+def check_options(s):
+    return lib().uc_check_options(s.encode())
+
+
+def cluster(db, out_cluster_db, tmp, cluster_options="-c 0.8", threads=1, verbosity=1, device=-1):
+    """== `foldseek cluster` (cluster.rs:45-56).  Returns the stats dict."""
+    o, st = make_opts(cluster_options, threads, verbosity, device), UcStats()
+    _check(lib().uc_cluster(db.encode(), out_cluster_db.encode(), tmp.encode(), C.byref(o), C.byref(st)))
+    return st.as_dict()
+
+
+def createtsv(db, cluster_db, out_tsv, verbosity=1):
+    o = make_opts("", 1, verbosity)
+    _check(lib().uc_createtsv(db.encode(), cluster_db.encode(), out_tsv.encode(), C.byref(o)))
+
+
+def rmdb(prefix):
+    _check(lib().uc_rmdb(prefix.encode()))
+
+
+def setcover(n, edges):
+    e = np.ascontiguousarray(edges, np.uint32).reshape(-1, 2)
+    assign = np.zeros(n, np.uint32)
+    _check(lib().uc_setcover(n, e.ctypes.data, len(e), assign.ctypes.data))
+    return assign
+
+
+def hits_merge(n_seqs, max_seqs, parts):
+    """parts: list of (counts u32[n_seqs], hits HIT_DTYPE[...]).  Host-only (no device needed)."""
+    k = len(parts)
+    cs = [np.ascontiguousarray(c, np.uint32) for c, _ in parts]
+    hs = [np.ascontiguousarray(h, HIT_DTYPE) for _, h in parts]
+    cp = (C.c_void_p * k)(*[c.ctypes.data for c in cs])
+    hp = (C.c_void_p * k)(*[h.ctypes.data for h in hs])
+    cap = int(sum(len(h) for h in hs))
+    oc, oh, on = np.zeros(n_seqs, np.uint32), np.zeros(max(cap, 1), HIT_DTYPE), C.c_uint64()
+    _check(lib().uc_hits_merge(n_seqs, max_seqs, k, cp, hp, oc.ctypes.data, oh.ctypes.data, cap, C.byref(on)))
+    return oc, oh[: on.value].copy()
+
+
+class Engine:
+    """One engine = one HIP device with the sequence DB resident in HBM (uc_engine_* of the C ABI)."""
+
+    def __init__(self, cluster_options="-c 0.8", threads=1, verbosity=1, device=-1, data_dir=None):
+        self._h = C.c_void_p()
+        o = make_opts(cluster_options, threads, verbosity, device, data_dir)
+        _check(lib().uc_engine_create(C.byref(o), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().uc_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_db(self, prefix):
+        _check(lib().uc_engine_load_db(self._h, prefix.encode()))
+
+    def set_db(self, off, s3, sa):
+        off = np.ascontiguousarray(off, np.uint64)
+        s3 = np.ascontiguousarray(s3, np.uint8)
+        sa = np.ascontiguousarray(sa, np.uint8)
+        _check(lib().uc_engine_set_db(self._h, len(off) - 1, off.ctypes.data, s3.ctypes.data, sa.ctypes.data))
+
+    @property
+    def n(self):
+        return int(lib().uc_engine_num_seqs(self._h))
+
+    def prefilter(self, tbegin=0, tend=None):
+        _check(lib().uc_engine_prefilter(self._h, tbegin, self.n if tend is None else tend))
+
+    def hits(self):
+        nh = C.c_uint64()
+        _check(lib().uc_engine_hits_size(self._h, C.byref(nh)))
+        counts = np.zeros(self.n, np.uint32)
+        hits = np.zeros(max(nh.value, 1), HIT_DTYPE)
+        _check(lib().uc_engine_hits_get(self._h, counts.ctypes.data, hits.ctypes.data))
+        return counts, hits[: nh.value]
+
+    def set_hits(self, counts, hits):
+        counts = np.ascontiguousarray(counts, np.uint32)
+        hits = np.ascontiguousarray(hits, HIT_DTYPE)
+        _check(lib().uc_engine_hits_set(self._h, counts.ctypes.data, hits.ctypes.data))
+
+    def align(self, qbegin=0, qend=None):
+        _check(lib().uc_engine_align(self._h, qbegin, self.n if qend is None else qend))
+
+    def alns(self, qbegin=0, qend=None):
+        qend = self.n if qend is None else qend
+        counts, _ = self.hits()
+        n = int(counts[qbegin:qend].sum())
+        out = np.zeros(max(n, 1), ALN_DTYPE)
+        _check(lib().uc_engine_alns_get(self._h, qbegin, qend, out.ctypes.data))
+        return out[:n]
+
+    def edges(self):
+        ne = C.c_uint64()
+        _check(lib().uc_engine_edges_size(self._h, C.byref(ne)))
+        e = np.zeros((max(ne.value, 1), 2), np.uint32)
+        _check(lib().uc_engine_edges_get(self._h, e.ctypes.data))
+        return e[: ne.value]
+
+    def stats(self):
+        st = UcStats()
+        _check(lib().uc_engine_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def reset_stats(self):
+        lib().uc_engine_reset_stats(self._h)
+
+    def ungapped(self, q, t, diag):
+        q = np.ascontiguousarray(q, np.uint32); t = np.ascontiguousarray(t, np.uint32)
+        diag = np.ascontiguousarray(diag, np.int32)
+        out = np.zeros(len(q), np.int32)
+        _check(lib().uc_engine_ungapped_batch(self._h, len(q), q.ctypes.data, t.ctypes.data, diag.ctypes.data, out.ctypes.data))
+        return out
+
+    def sw(self, mode, q, t, qend=None, tend=None):
+        q = np.ascontiguousarray(q, np.uint32); t = np.ascontiguousarray(t, np.uint32)
+        n = len(q)
+        qe = np.ascontiguousarray(qend, np.int32) if qend is not None else None
+        te = np.ascontiguousarray(tend, np.int32) if tend is not None else None
+        s, oq, ot = np.zeros(n, np.int32), np.full(n, -1, np.int32), np.full(n, -1, np.int32)
+        _check(lib().uc_engine_sw_batch(self._h, mode, n, q.ctypes.data, t.ctypes.data,
+                                        qe.ctypes.data if qe is not None else None, te.ctypes.data if te is not None else None,
+                                        s.ctypes.data, oq.ctypes.data, ot.ctypes.data))
+        return s, oq, ot

@@ -1,0 +1,68 @@
+// foldseek_shim.cpp — `foldseek`-argv-compatible executable for the sub-commands the reference's cluster
+// path spawns, so that an UNMODIFIED Rust `unicore` can be pointed at this engine through path.cfg
+// (`foldseek=<path>`, /root/reference/path.cfg:2; accepted by `unicore config --set-foldseek` because
+// `<bin> version` exits 0, src/modules/config.rs:49-66).
+//   cluster   --threads T -v V <db> <out>_cluster <tmp> <opts...>     cluster.rs:45-49
+//   createtsv --threads T -v V <db> <db> <out>_cluster <out>.tsv      cluster.rs:59-62
+//   rmdb      <out>_cluster -v V                                       cluster.rs:67-73
+//   version
+// Exit status is the only error channel (src/util/command.rs:10-14): 0 ok, non-zero + stderr text otherwise.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "unicore_cluster.h"
+
+static int die(int rc) {
+    fprintf(stderr, "Error: %s\n", uc_last_error());
+    return rc ? rc : 1;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) { fprintf(stderr, "usage: foldseek <cluster|createtsv|rmdb|version> ...\n"); return 2; }
+    const std::string cmd = argv[1];
+    if (cmd == "version") { puts(uc_version()); return 0; }
+    // flags may appear anywhere; --threads / -v are consumed here, everything else that starts with '-'
+    // (plus its value, validated by the engine) is forwarded as the cluster option string
+    std::vector<std::string> pos;
+    std::string opts;
+    int threads = 1, verbosity = 3;
+    for (int i = 2; i < argc; i++) {
+        std::string a = argv[i];
+        if (a == "--threads" && i + 1 < argc) threads = atoi(argv[++i]);
+        else if (a == "-v" && i + 1 < argc) verbosity = atoi(argv[++i]);
+        else if (a.size() > 1 && a[0] == '-' && !(a[1] >= '0' && a[1] <= '9')) {
+            opts += (opts.empty() ? "" : " ") + a;
+            // a following token that is not itself a flag is this flag's value
+            if (i + 1 < argc && !(argv[i + 1][0] == '-' && !(argv[i + 1][1] >= '0' && argv[i + 1][1] <= '9')) && pos.size() >= (cmd == "cluster" ? 3u : 99u))
+                opts += std::string(" ") + argv[++i];
+        } else if (cmd == "cluster" && pos.size() >= 3) opts += (opts.empty() ? "" : " ") + a;
+        else pos.push_back(a);
+    }
+    uc_opts o;
+    memset(&o, 0, sizeof o);
+    o.struct_size = sizeof o;
+    o.threads = threads > 0 ? threads : 1;
+    o.verbosity = verbosity;
+    o.device = -1;
+    o.cluster_options = opts.c_str();
+    if (cmd == "cluster") {
+        if (pos.size() != 3) { fprintf(stderr, "Error: cluster expects <db> <out_cluster_db> <tmp>\n"); return 2; }
+        int rc = uc_cluster(pos[0].c_str(), pos[1].c_str(), pos[2].c_str(), &o, nullptr);
+        return rc ? die(rc) : 0;
+    }
+    if (cmd == "createtsv") {
+        if (pos.size() != 4) { fprintf(stderr, "Error: createtsv expects <db> <db> <cluster_db> <out.tsv>\n"); return 2; }
+        int rc = uc_createtsv(pos[0].c_str(), pos[2].c_str(), pos[3].c_str(), &o);
+        return rc ? die(rc) : 0;
+    }
+    if (cmd == "rmdb") {
+        if (pos.size() != 1) { fprintf(stderr, "Error: rmdb expects <db>\n"); return 2; }
+        int rc = uc_rmdb(pos[0].c_str());
+        return rc ? die(rc) : 0;
+    }
+    fprintf(stderr, "Error: sub-command '%s' is not provided by this engine (cluster, createtsv, rmdb, version)\n", cmd.c_str());
+    return 2;
+}

@@ -1,0 +1,137 @@
+// unicore_main.cpp — C++ host mirror of the reference's `unicore cluster` module surface.
+// (The reference host is Rust; no Rust toolchain exists in this image — SURVEY.md 0.2/D3 — so the host
+// above the C ABI is C++ with the same names, argument meaning and error behaviour.)
+//   CLI surface      /root/reference/src/util/arg_parser.rs:225-246  (Commands::Cluster)
+//   module body      /root/reference/src/modules/cluster.rs:9-84     (modules::cluster::run)
+//   checkpoint       /root/reference/src/util/checkpoint.rs:2-5
+//   error/exit codes /root/reference/src/envs/error_handler.rs:5-45
+//   messages         /root/reference/src/util/message.rs:4-22
+// The three `foldseek` spawns of cluster.rs:45-76 become three in-process calls through the C ABI.
+#include <sys/stat.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "unicore_cluster.h"
+
+namespace {
+
+constexpr int ERR_GENERAL = 0x01, ERR_ARGPARSE = 0x40;   // error_handler.rs:6,13
+int g_verbosity = 3;                                       // variables.rs:146
+
+void print_message(const std::string &m, int level) { if (level <= g_verbosity) { fputs(m.c_str(), stdout); fflush(stdout); } }
+void println_message(const std::string &m, int level) { if (level <= g_verbosity) { puts(m.c_str()); } }
+[[noreturn]] void error(int code, const std::string &object) {   // error_handler.rs:42-45
+    if (1 <= g_verbosity) fprintf(stderr, "%s%s\n", code == ERR_ARGPARSE ? "Argument parsing error: " : "Error: ", object.c_str());
+    exit(code);
+}
+
+void write_checkpoint(const std::string &file, const char *content) {   // checkpoint.rs:2-5 (no newline)
+    std::ofstream f(file, std::ios::binary | std::ios::trunc);
+    if (!f) error(ERR_GENERAL, "Could not write checkpoint " + file);
+    f << content;
+}
+
+void create_dir_all(const std::string &path) {
+    std::string cur;
+    for (size_t i = 0; i <= path.size(); i++) {
+        if ((i == path.size() || path[i] == '/') && !cur.empty() && cur != "/") {
+            struct stat st;
+            if (stat(cur.c_str(), &st) != 0 && mkdir(cur.c_str(), 0777) != 0) error(ERR_GENERAL, "Could not create directory " + cur);
+        }
+        if (i < path.size()) cur.push_back(path[i]);
+    }
+}
+
+void usage() {
+    puts("Usage: unicore cluster [OPTIONS] <INPUT> <OUTPUT> <TMP>\n\n"
+         "Arguments:\n"
+         "  <INPUT>   Input database (createdb output)\n"
+         "  <OUTPUT>  Output prefix; the result will be saved as OUTPUT.tsv\n"
+         "  <TMP>     Temp directory\n\n"
+         "Options:\n"
+         "  -k, --keep-cluster-db            Keep intermediate cluster database\n"
+         "  -c, --cluster-options <STRING>   Arguments for foldseek-style options in string e.g. -c \"-c 0.8\" [default: \"-c 0.8\"]\n"
+         "      --threads <THREADS>          Number of threads to use; 0 to use all [default: 0]\n"
+         "  -v, --verbosity <VERBOSITY>      Verbosity (0: quiet, 1: +errors, 2: +warnings, 3: +info, 4: +debug) [default: 3]\n"
+         "  -h, --help                       Print help");
+}
+
+// modules::cluster::run (cluster.rs:9-84)
+int cluster_run(const std::string &input, const std::string &output, const std::string &tmp, bool keep_cluster_db,
+                const std::string &cluster_options, int threads) {
+    const int engine_verbosity = g_verbosity == 4 ? 3 : g_verbosity == 3 ? 2 : g_verbosity;   // cluster.rs:18
+    // parent directory of the output (cluster.rs:21-29).  Deviation: an OUTPUT without a directory
+    // component yields "" in the reference (checkpoint lands in "/cluster.chk"); "." is the intent.
+    size_t slash = output.find_last_of('/');
+    std::string parent = slash == std::string::npos ? "." : (slash == 0 ? "/" : output.substr(0, slash));
+    create_dir_all(parent);
+    write_checkpoint(parent + "/cluster.chk", "0");   // cluster.rs:32
+
+    const std::string output_cluster_db = output + "_cluster", output_tsv = output + ".tsv";   // cluster.rs:43-44
+    uc_opts o;
+    memset(&o, 0, sizeof o);
+    o.struct_size = sizeof o;
+    o.threads = threads;
+    o.verbosity = engine_verbosity;
+    o.device = -1;
+    o.cluster_options = cluster_options.c_str();
+
+    print_message("Running cluster on the MI355X engine...", 3);   // cluster.rs:52
+    if (g_verbosity >= 3) putchar('\n');
+    int rc = uc_cluster(input.c_str(), output_cluster_db.c_str(), tmp.c_str(), &o, nullptr);   // cluster.rs:45-55
+    if (rc != 0) error(ERR_GENERAL, std::string("cluster engine failed with code ") + std::to_string(rc) + "\n" + uc_last_error());   // command.rs:10-14
+    println_message(" Done", 3);                                    // cluster.rs:56
+    rc = uc_createtsv(input.c_str(), output_cluster_db.c_str(), output_tsv.c_str(), &o);           // cluster.rs:59-64
+    if (rc != 0) error(ERR_GENERAL, std::string("createtsv failed with code ") + std::to_string(rc) + "\n" + uc_last_error());
+    if (!keep_cluster_db) {                                         // cluster.rs:67-76
+        rc = uc_rmdb(output_cluster_db.c_str());
+        if (rc != 0) error(ERR_GENERAL, std::string("rmdb failed with code ") + std::to_string(rc) + "\n" + uc_last_error());
+    }
+    write_checkpoint(parent + "/cluster.chk", "1");   // cluster.rs:81
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc < 2 || !strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) { usage(); return argc < 2 ? 2 : 0; }
+    if (!strcmp(argv[1], "version") || !strcmp(argv[1], "--version")) { puts(uc_version()); return 0; }
+    if (strcmp(argv[1], "cluster") != 0) error(0x30 /* ERR_MODULE_NOT_IMPLEMENTED */, argv[1]);
+    std::vector<std::string> pos;
+    bool keep = false;
+    std::string copts = "-c 0.8";   // arg_parser.rs:238-239
+    int threads = 0, verbosity = 3;
+    for (int i = 2; i < argc; i++) {
+        std::string a = argv[i];
+        auto value = [&]() -> std::string {
+            if (i + 1 >= argc) error(ERR_ARGPARSE, "cluster - missing value for " + a);
+            return argv[++i];
+        };
+        if (a == "-k" || a == "--keep-cluster-db") keep = true;
+        else if (a == "-c" || a == "--cluster-options") copts = value();
+        else if (a.rfind("--cluster-options=", 0) == 0) copts = a.substr(18);
+        else if (a == "--threads") threads = atoi(value().c_str());
+        else if (a == "-v" || a == "--verbosity") verbosity = atoi(value().c_str());
+        else if (a == "-h" || a == "--help") { usage(); return 0; }
+        else if (a.size() > 1 && a[0] == '-') error(ERR_ARGPARSE, "cluster - unexpected argument " + a);
+        else pos.push_back(a);
+    }
+    if (pos.size() != 3) { usage(); error(ERR_ARGPARSE, "cluster - expected <INPUT> <OUTPUT> <TMP>"); }
+    if (verbosity < 0 || verbosity > 4) error(ERR_ARGPARSE, "cluster - verbosity");
+    g_verbosity = verbosity;
+    // set_threads (variables.rs:155-166): 0 -> all CPUs, clamp to the CPU count
+    int cpus = (int)std::thread::hardware_concurrency();
+    if (cpus < 1) cpus = 1;
+    if (threads > cpus) {
+        if (g_verbosity >= 2) fprintf(stderr, "Warning: the given number of threads is greater than the number of system CPUs; adjusting to %d\n", cpus);
+        threads = cpus;
+    }
+    if (threads <= 0) threads = cpus;
+    return cluster_run(pos[0], pos[1], pos[2], keep, copts, threads);
+}

@@ -1,0 +1,294 @@
+// uc_capi.cpp — extern "C" boundary (include/unicore_cluster.h).  No exception crosses it: every entry
+// point converts failures into the status classes of the header and records uc_last_error().
+#include <sys/stat.h>
+
+#include <cstring>
+#include <memory>
+
+#include "uc_engine.h"
+
+using namespace uc;
+
+struct uc_engine {
+    std::unique_ptr<Engine> e;
+};
+
+namespace {
+
+template <typename F>
+int guard(F &&f) {
+    try {
+        f();
+        return UC_OK;
+    } catch (const Error &e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        set_last_error("out of host memory");
+        return UC_ERR_GENERIC;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        return UC_ERR_GENERIC;
+    }
+}
+
+Params params_from(const uc_opts *o) {
+    Params p;
+    if (o) {
+        if (o->struct_size != sizeof(uc_opts)) fail(UC_ERR_ARGS, "uc_opts.struct_size mismatch (%u != %zu)", o->struct_size, sizeof(uc_opts));
+        p.threads = o->threads > 0 ? o->threads : 1;
+        p.verbosity = o->verbosity;
+        if (o->cluster_options) parse_cluster_options(o->cluster_options, p);
+    }
+    g_verbosity = p.verbosity;
+    finalize_params(p, o && o->data_dir ? o->data_dir : "");
+    return p;
+}
+
+void mkdir_p(const std::string &path) {
+    std::string cur;
+    for (size_t i = 0; i <= path.size(); i++) {
+        if (i == path.size() || path[i] == '/') {
+            if (!cur.empty() && cur != "/") {
+                struct stat st;
+                if (stat(cur.c_str(), &st) != 0 && mkdir(cur.c_str(), 0777) != 0) fail(UC_ERR_IO, "cannot create directory %s", cur.c_str());
+            }
+        }
+        if (i < path.size()) cur.push_back(path[i]);
+    }
+}
+
+void require(const void *p, const char *what) {
+    if (!p) fail(UC_ERR_ARGS, "%s must not be NULL", what);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *uc_last_error(void) { return last_error_cstr(); }
+const char *uc_version(void) { return "unicore-cluster-mi355x 0.1.0 (spec UC-1, gfx950)"; }
+
+int uc_check_options(const char *cluster_options) {
+    return guard([&] { Params p; parse_cluster_options(cluster_options ? cluster_options : "", p); });
+}
+
+int uc_engine_create(const uc_opts *o, uc_engine **out) {
+    return guard([&] {
+        require(out, "out");
+        *out = nullptr;
+        Params p = params_from(o);
+        auto h = std::make_unique<uc_engine>();
+        h->e = std::make_unique<Engine>(p, o ? o->device : -1);
+        *out = h.release();
+    });
+}
+
+void uc_engine_destroy(uc_engine *e) { delete e; }
+
+int uc_engine_load_db(uc_engine *e, const char *db_prefix) {
+    return guard([&] {
+        require(e, "engine"); require(db_prefix, "db_prefix");
+        Timer tm;
+        read_seq_db(db_prefix, e->e->hdb, true);
+        e->e->stats.stage_seconds[UC_ST_LOAD] += tm.seconds();
+        e->e->upload_db();
+    });
+}
+
+int uc_engine_set_db(uc_engine *e, uint32_t n, const uint64_t *off, const uint8_t *s3, const uint8_t *sa) {
+    return guard([&] {
+        require(e, "engine"); require(off, "off");
+        if (n >= (1u << 24)) fail(UC_ERR_ARGS, "this build supports < 2^24 sequences");
+        HostDb &d = e->e->hdb;
+        d = HostDb();
+        d.n = n;
+        d.off.assign(off, off + n + 1);
+        if (d.off[0] != 0) fail(UC_ERR_ARGS, "off[0] must be 0");
+        for (uint32_t i = 0; i < n; i++) {
+            if (d.off[i + 1] < d.off[i]) fail(UC_ERR_ARGS, "offsets must be non-decreasing");
+            if (d.off[i + 1] - d.off[i] > 65535) fail(UC_ERR_ARGS, "sequence %u longer than 65535", i);
+        }
+        const uint64_t tot = d.off[n];
+        if (tot) { require(s3, "s3"); require(sa, "sa"); }
+        d.s3.assign(s3, s3 + tot);
+        d.sa.assign(sa, sa + tot);
+        for (uint64_t k = 0; k < tot; k++)
+            if (d.s3[k] > 20 || d.sa[k] > 20) fail(UC_ERR_ARGS, "sequence codes must be in 0..20");
+        d.keys.resize(n);
+        for (uint32_t i = 0; i < n; i++) d.keys[i] = i;
+        e->e->upload_db();
+    });
+}
+
+uint32_t uc_engine_num_seqs(const uc_engine *e) { return e && e->e ? e->e->hdb.n : 0; }
+
+int uc_engine_prefilter(uc_engine *e, uint32_t tbegin, uint32_t tend) {
+    return guard([&] { require(e, "engine"); e->e->prefilter(tbegin, tend); });
+}
+
+int uc_engine_hits_size(const uc_engine *e, uint64_t *n_hits) {
+    return guard([&] { require(e, "engine"); require(n_hits, "n_hits"); *n_hits = e->e->hits.size(); });
+}
+
+int uc_engine_hits_get(const uc_engine *e, uint32_t *counts, uc_hit *hits) {
+    return guard([&] {
+        require(e, "engine");
+        const Engine &E = *e->e;
+        if (counts && E.hdb.n) memcpy(counts, E.hit_cnt.data(), (size_t)E.hdb.n * 4);
+        if (hits && !E.hits.empty()) memcpy(hits, E.hits.data(), E.hits.size() * sizeof(uc_hit));
+    });
+}
+
+int uc_hits_merge(uint32_t n_seqs, int32_t max_seqs, int n_parts, const uint32_t *const *counts, const uc_hit *const *hits,
+                  uint32_t *out_counts, uc_hit *out_hits, uint64_t out_capacity, uint64_t *out_n) {
+    return guard([&] {
+        require(counts, "counts"); require(hits, "hits"); require(out_counts, "out_counts"); require(out_n, "out_n");
+        if (n_parts < 1 || max_seqs < 1) fail(UC_ERR_ARGS, "n_parts and max_seqs must be >= 1");
+        std::vector<uint32_t> c;
+        std::vector<uc_hit> h;
+        merge_hits(n_seqs, max_seqs, n_parts, counts, hits, c, h);
+        *out_n = h.size();
+        if (h.size() > out_capacity) fail(UC_ERR_ARGS, "uc_hits_merge: output capacity %llu < %zu", (unsigned long long)out_capacity, h.size());
+        if (n_seqs) memcpy(out_counts, c.data(), (size_t)n_seqs * 4);
+        if (!h.empty()) { require(out_hits, "out_hits"); memcpy(out_hits, h.data(), h.size() * sizeof(uc_hit)); }
+    });
+}
+
+int uc_engine_hits_set(uc_engine *e, const uint32_t *counts, const uc_hit *hits) {
+    return guard([&] { require(e, "engine"); require(counts, "counts"); e->e->set_hits(counts, hits); });
+}
+
+int uc_engine_hits_merge(uc_engine *e, int n_parts, const uint32_t *const *counts, const uc_hit *const *hits) {
+    return guard([&] {
+        require(e, "engine"); require(counts, "counts"); require(hits, "hits");
+        std::vector<uint32_t> c;
+        std::vector<uc_hit> h;
+        merge_hits(e->e->hdb.n, e->e->p.max_seqs, n_parts, counts, hits, c, h);
+        e->e->set_hits(c.data(), h.data());
+    });
+}
+
+int uc_engine_align(uc_engine *e, uint32_t qbegin, uint32_t qend) {
+    return guard([&] { require(e, "engine"); e->e->align(qbegin, qend); });
+}
+
+int uc_engine_alns_get(const uc_engine *e, uint32_t qbegin, uint32_t qend, uc_aln *out) {
+    return guard([&] {
+        require(e, "engine");
+        const Engine &E = *e->e;
+        if (qbegin > qend || qend > E.hdb.n) fail(UC_ERR_ARGS, "alns_get: bad query range");
+        const uint64_t b = E.hit_off[qbegin], n = E.hit_off[qend] - b;
+        if (n) { require(out, "out"); memcpy(out, E.alns.data() + b, n * sizeof(uc_aln)); }
+    });
+}
+
+int uc_engine_edges_size(const uc_engine *e, uint64_t *n_edges) {
+    return guard([&] { require(e, "engine"); require(n_edges, "n_edges"); *n_edges = e->e->edges.size() / 2; });
+}
+
+int uc_engine_edges_get(const uc_engine *e, uint32_t *edges) {
+    return guard([&] {
+        require(e, "engine");
+        if (!e->e->edges.empty()) { require(edges, "edges"); memcpy(edges, e->e->edges.data(), e->e->edges.size() * 4); }
+    });
+}
+
+int uc_engine_stats(const uc_engine *e, uc_stats *out) {
+    return guard([&] { require(e, "engine"); require(out, "out"); *out = e->e->stats; });
+}
+
+void uc_engine_reset_stats(uc_engine *e) {
+    if (!e || !e->e) return;
+    uc_stats &s = e->e->stats;
+    const uint64_t ns = s.n_seqs, nr = s.n_residues;
+    memset(&s, 0, sizeof s);
+    s.n_seqs = ns; s.n_residues = nr;
+}
+
+int uc_setcover(uint32_t n, const uint32_t *edges, uint64_t n_edges, uint32_t *assign) {
+    return guard([&] {
+        if (n) require(assign, "assign");
+        if (n_edges) require(edges, "edges");
+        set_cover(n, edges, n_edges, assign);
+    });
+}
+
+int uc_write_cluster_db(const char *out_cluster_db, uint32_t n, const uint32_t *assign) {
+    return guard([&] {
+        require(out_cluster_db, "out_cluster_db");
+        std::vector<uint64_t> keys(n);
+        for (uint32_t i = 0; i < n; i++) keys[i] = i;
+        write_cluster_db(out_cluster_db, keys, assign, n);
+    });
+}
+
+int uc_engine_ungapped_batch(uc_engine *e, uint64_t n, const uint32_t *q, const uint32_t *t, const int32_t *diag, int32_t *score_out) {
+    return guard([&] {
+        require(e, "engine");
+        if (n) { require(q, "q"); require(t, "t"); require(diag, "diag"); require(score_out, "score_out"); }
+        e->e->ungapped_batch(n, q, t, diag, score_out);
+    });
+}
+
+int uc_engine_sw_batch(uc_engine *e, int mode, uint64_t n, const uint32_t *q, const uint32_t *t, const int32_t *qend_in,
+                       const int32_t *tend_in, int32_t *score_out, int32_t *qend_out, int32_t *tend_out) {
+    return guard([&] {
+        require(e, "engine");
+        if (mode < 0 || mode > 2) fail(UC_ERR_ARGS, "sw_batch: mode must be 0, 1 or 2");
+        if (!n) return;
+        require(q, "q"); require(t, "t"); require(score_out, "score_out");
+        if (mode == 2) { require(qend_in, "qend_in"); require(tend_in, "tend_in"); }
+        std::vector<PairIn> pairs(n);
+        for (uint64_t i = 0; i < n; i++) pairs[i] = {q[i], t[i], mode == 2 ? qend_in[i] : 0, mode == 2 ? tend_in[i] : 0};
+        e->e->sw_batch(mode, pairs, score_out, qend_out, tend_out);
+    });
+}
+
+// ---- the three calls of /root/reference/src/modules/cluster.rs:45-76 ----------------------------
+
+int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, const uc_opts *o, uc_stats *stats_out) {
+    return guard([&] {
+        require(db, "db"); require(out_cluster_db, "out_cluster_db");
+        Params p = params_from(o);
+        if (tmp && *tmp) mkdir_p(tmp);   // callee owns <tmp>; nothing is spilled there yet
+        Engine E(p, o ? o->device : -1);
+        Timer tl;
+        logf(3, "unicore-cluster: reading %s\n", db);
+        read_seq_db(db, E.hdb, false);
+        E.stats.stage_seconds[UC_ST_LOAD] += tl.seconds();
+        E.upload_db();
+        logf(3, "unicore-cluster: %u sequences, %llu residues on device %d\n", E.hdb.n, (unsigned long long)E.hdb.residues(), E.device);
+        E.prefilter(0, E.hdb.n);
+        logf(3, "unicore-cluster: prefilter kept %zu pairs (k-score %d, max-seqs %d)\n", E.hits.size(), p.kmer_thr, p.max_seqs);
+        E.align(0, E.hdb.n);
+        logf(3, "unicore-cluster: %llu alignments, %llu accepted\n", (unsigned long long)E.stats.n_gapped_alignments, (unsigned long long)E.stats.n_edges);
+        Timer tc;
+        std::vector<uint32_t> assign(E.hdb.n);
+        set_cover(E.hdb.n, E.edges.data(), E.edges.size() / 2, assign.data());
+        uint64_t ncl = 0;
+        for (uint32_t i = 0; i < E.hdb.n; i++) ncl += assign[i] == i;
+        E.stats.n_clusters = ncl;
+        E.stats.algorithmic_bytes[UC_ST_SETCOVER] = 8ull * (E.edges.size() / 2) + 4ull * E.hdb.n;
+        E.stats.stage_seconds[UC_ST_SETCOVER] += tc.seconds();
+        Timer to;
+        write_cluster_db(out_cluster_db, E.hdb.keys, assign.data(), E.hdb.n);
+        E.stats.stage_seconds[UC_ST_OUTPUT] += to.seconds();
+        logf(3, "unicore-cluster: %llu clusters -> %s\n", (unsigned long long)ncl, out_cluster_db);
+        if (stats_out) *stats_out = E.stats;
+    });
+}
+
+int uc_createtsv(const char *db, const char *cluster_db, const char *out_tsv, const uc_opts *o) {
+    return guard([&] {
+        require(db, "db"); require(cluster_db, "cluster_db"); require(out_tsv, "out_tsv");
+        if (o) g_verbosity = o->verbosity;
+        create_tsv(db, cluster_db, out_tsv);
+    });
+}
+
+int uc_rmdb(const char *db_prefix) {
+    return guard([&] { require(db_prefix, "db_prefix"); remove_db(db_prefix); });
+}
+
+}  // extern "C"

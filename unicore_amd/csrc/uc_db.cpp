@@ -1,0 +1,186 @@
+// uc_db.cpp — DB reader / cluster-DB writer / createtsv / rmdb (host side of the boundary).
+#include "uc_db.h"
+
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <unordered_map>
+
+#include "uc_common.h"
+#include "uc_options.h"
+
+namespace uc {
+
+std::string read_whole_file(const std::string &path) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) fail(UC_ERR_IO, "cannot open %s", path.c_str());
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::string s;
+    s.resize((size_t)n);
+    if (n > 0 && fread(&s[0], 1, (size_t)n, f) != (size_t)n) { fclose(f); fail(UC_ERR_IO, "short read on %s", path.c_str()); }
+    fclose(f);
+    return s;
+}
+
+std::vector<IndexEntry> read_index(const std::string &path) {
+    std::string txt = read_whole_file(path);
+    std::vector<IndexEntry> v;
+    const char *s = txt.c_str(), *end = s + txt.size();
+    auto num = [&](uint64_t &out) -> bool {
+        while (s < end && (*s == ' ' || *s == '\t' || *s == '\r' || *s == '\n')) s++;
+        if (s >= end || *s < '0' || *s > '9') return false;
+        uint64_t x = 0;
+        while (s < end && *s >= '0' && *s <= '9') x = x * 10 + (uint64_t)(*s++ - '0');
+        out = x;
+        return true;
+    };
+    for (;;) {
+        IndexEntry e;
+        if (!num(e.key)) break;
+        if (!num(e.off) || !num(e.len)) fail(UC_ERR_IO, "malformed index line in %s", path.c_str());
+        v.push_back(e);
+    }
+    std::sort(v.begin(), v.end(), [](const IndexEntry &a, const IndexEntry &b) { return a.key < b.key; });
+    return v;
+}
+
+void read_seq_db(const std::string &prefix, HostDb &db, bool with_headers) {
+    std::vector<IndexEntry> ia = read_index(prefix + ".index");
+    std::vector<IndexEntry> is = read_index(prefix + "_ss.index");
+    if (ia.size() != is.size()) fail(UC_ERR_IO, "%s and %s_ss have different entry counts", prefix.c_str(), prefix.c_str());
+    if (ia.size() >= (1u << 24)) fail(UC_ERR_ARGS, "database has %zu sequences; this build supports < 2^24", ia.size());
+    std::string da = read_whole_file(prefix), ds = read_whole_file(prefix + "_ss");
+    db.n = (uint32_t)ia.size();
+    db.keys.resize(db.n);
+    db.off.assign((size_t)db.n + 1, 0);
+    uint64_t tot = 0;
+    for (uint32_t i = 0; i < db.n; i++) {
+        if (ia[i].key != is[i].key) fail(UC_ERR_IO, "key mismatch between AA and 3Di index at entry %u", i);
+        uint64_t l = ia[i].len >= 2 ? ia[i].len - 2 : 0, l2 = is[i].len >= 2 ? is[i].len - 2 : 0;
+        if (l != l2) fail(UC_ERR_IO, "AA/3Di length mismatch for key %llu", (unsigned long long)ia[i].key);
+        if (ia[i].off + l > da.size() || is[i].off + l > ds.size()) fail(UC_ERR_IO, "index entry beyond data file (key %llu)", (unsigned long long)ia[i].key);
+        if (l > 65535) fail(UC_ERR_ARGS, "sequence key %llu longer than 65535 (max-seq-len)", (unsigned long long)ia[i].key);
+        db.keys[i] = ia[i].key;
+        db.off[i] = tot;
+        tot += l;
+    }
+    db.off[db.n] = tot;
+    db.s3.resize(tot);
+    db.sa.resize(tot);
+    for (uint32_t i = 0; i < db.n; i++) {
+        uint64_t l = db.off[i + 1] - db.off[i];
+        const char *pa = da.data() + ia[i].off, *ps = ds.data() + is[i].off;
+        uint8_t *oa = db.sa.data() + db.off[i], *os = db.s3.data() + db.off[i];
+        for (uint64_t k = 0; k < l; k++) { oa[k] = (uint8_t)letter_code(pa[k]); os[k] = (uint8_t)letter_code(ps[k]); }
+    }
+    db.names.clear();
+    if (with_headers) {
+        std::vector<IndexEntry> ih = read_index(prefix + "_h.index");
+        if (ih.size() != ia.size()) fail(UC_ERR_IO, "%s_h has a different entry count", prefix.c_str());
+        std::string dh = read_whole_file(prefix + "_h");
+        db.names.resize(db.n);
+        for (uint32_t i = 0; i < db.n; i++) {
+            if (ih[i].key != ia[i].key) fail(UC_ERR_IO, "key mismatch between header and sequence index at entry %u", i);
+            size_t b = ih[i].off, e = b;
+            while (e < dh.size() && dh[e] && dh[e] != ' ' && dh[e] != '\t' && dh[e] != '\n') e++;
+            db.names[i] = dh.substr(b, e - b);
+        }
+    }
+}
+
+static void write_dbtype(const std::string &path, int32_t t) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) fail(UC_ERR_IO, "cannot write %s", path.c_str());
+    fwrite(&t, 4, 1, f);
+    fclose(f);
+}
+
+void write_cluster_db(const std::string &prefix, const std::vector<uint64_t> &keys, const uint32_t *assign, uint32_t n) {
+    std::vector<uint64_t> cnt((size_t)n + 1, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        if (assign[i] >= n) fail(UC_ERR_GENERIC, "invalid cluster assignment for sequence %u", i);
+        cnt[assign[i] + 1]++;
+    }
+    for (uint32_t i = 0; i < n; i++) cnt[i + 1] += cnt[i];
+    std::vector<uint32_t> mem(n);
+    std::vector<uint64_t> cur(cnt.begin(), cnt.end() - 1);
+    for (uint32_t i = 0; i < n; i++) mem[cur[assign[i]]++] = i;   // ascending id within each cluster
+    std::string tmpd = prefix + ".tmp_data", tmpi = prefix + ".tmp_index";
+    FILE *fd = fopen(tmpd.c_str(), "wb"), *fi = fopen(tmpi.c_str(), "wb");
+    if (!fd || !fi) { if (fd) fclose(fd); if (fi) fclose(fi); fail(UC_ERR_IO, "cannot write cluster DB %s", prefix.c_str()); }
+    uint64_t off = 0;
+    char buf[32];
+    for (uint32_t r = 0; r < n; r++) {
+        if (cnt[r + 1] == cnt[r]) continue;
+        if (assign[r] != r) fail(UC_ERR_GENERIC, "cluster %u has members but is not its own representative", r);
+        uint64_t len = 0;
+        int k = snprintf(buf, sizeof buf, "%llu\n", (unsigned long long)keys[r]);
+        fwrite(buf, 1, (size_t)k, fd); len += (uint64_t)k;
+        for (uint64_t m = cnt[r]; m < cnt[r + 1]; m++) {
+            if (mem[m] == r) continue;
+            k = snprintf(buf, sizeof buf, "%llu\n", (unsigned long long)keys[mem[m]]);
+            fwrite(buf, 1, (size_t)k, fd); len += (uint64_t)k;
+        }
+        fputc(0, fd); len += 1;
+        fprintf(fi, "%llu\t%llu\t%llu\n", (unsigned long long)keys[r], (unsigned long long)off, (unsigned long long)len);
+        off += len;
+    }
+    bool bad = ferror(fd) || ferror(fi);
+    bad |= fclose(fd) != 0;
+    bad |= fclose(fi) != 0;
+    if (bad) fail(UC_ERR_IO, "write error on cluster DB %s", prefix.c_str());
+    // never leave a partial result behind with exit 0 (SURVEY.md 8b "errors")
+    if (rename(tmpd.c_str(), prefix.c_str()) != 0 || rename(tmpi.c_str(), (prefix + ".index").c_str()) != 0)
+        fail(UC_ERR_IO, "cannot finalize cluster DB %s", prefix.c_str());
+    write_dbtype(prefix + ".dbtype", 6);
+}
+
+void create_tsv(const std::string &db_prefix, const std::string &cluster_db, const std::string &out_tsv) {
+    // names: first whitespace-delimited token of each header entry (for Unicore DBs exactly
+    // "unicore_<10 hex>", createdb.rs:104-106)
+    std::vector<IndexEntry> ih = read_index(db_prefix + "_h.index");
+    std::string dh = read_whole_file(db_prefix + "_h");
+    std::unordered_map<uint64_t, std::string> name;
+    name.reserve(ih.size() * 2);
+    for (const IndexEntry &e : ih) {
+        size_t b = e.off, x = b;
+        while (x < dh.size() && dh[x] && dh[x] != ' ' && dh[x] != '\t' && dh[x] != '\n') x++;
+        name[e.key] = dh.substr(b, x - b);
+    }
+    std::vector<IndexEntry> ic = read_index(cluster_db + ".index");
+    std::string dc = read_whole_file(cluster_db);
+    std::string tmp = out_tsv + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) fail(UC_ERR_IO, "cannot write %s", out_tsv.c_str());
+    for (const IndexEntry &e : ic) {
+        auto rit = name.find(e.key);
+        if (rit == name.end()) { fclose(f); fail(UC_ERR_IO, "cluster representative key %llu not in %s_h", (unsigned long long)e.key, db_prefix.c_str()); }
+        size_t p = e.off, end = std::min<size_t>(e.off + e.len, dc.size());
+        while (p < end && dc[p]) {
+            uint64_t k = 0; bool any = false;
+            while (p < end && dc[p] >= '0' && dc[p] <= '9') { k = k * 10 + (uint64_t)(dc[p++] - '0'); any = true; }
+            while (p < end && dc[p] && dc[p] != '\n') p++;   // ignore extra columns
+            if (p < end && dc[p] == '\n') p++;
+            if (!any) continue;
+            auto mit = name.find(k);
+            if (mit == name.end()) { fclose(f); fail(UC_ERR_IO, "cluster member key %llu not in %s_h", (unsigned long long)k, db_prefix.c_str()); }
+            fputs(rit->second.c_str(), f); fputc('\t', f); fputs(mit->second.c_str(), f); fputc('\n', f);
+        }
+    }
+    bool bad = ferror(f);
+    bad |= fclose(f) != 0;
+    if (bad || rename(tmp.c_str(), out_tsv.c_str()) != 0) fail(UC_ERR_IO, "write error on %s", out_tsv.c_str());
+}
+
+void remove_db(const std::string &prefix) {
+    static const char *sfx[] = {"", ".index", ".dbtype", ".lookup", ".source", "_h", "_h.index", "_h.dbtype", ".tmp_data", ".tmp_index"};
+    for (const char *s : sfx) unlink((prefix + s).c_str());
+}
+
+}  // namespace uc

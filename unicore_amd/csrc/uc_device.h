@@ -1,0 +1,43 @@
+// uc_device.h — device-side data layout shared by the HIP translation units.
+//
+// HBM layout of the sequence DB (both tracks resident for the whole run; 2 bytes/residue, C4 = 3.6 GB
+// of 288 GB):  s3[] / sa[] hold letter codes 0..20, every sequence starts on a 16-byte boundary and is
+// followed by >= 16 pad bytes (code 20), so per-lane dword/dwordx4 reads never straddle into unmapped
+// memory;  off[i] = byte offset of sequence i (u32: < 4 GiB of padded residues), len[i] = its length.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace uc {
+
+struct DeviceDb {
+    uint32_t n = 0;
+    const uint8_t *s3 = nullptr, *sa = nullptr;
+    const uint32_t *off = nullptr;   // n+1
+    const uint32_t *len = nullptr;   // n
+    const int8_t *S3 = nullptr, *SA = nullptr;   // 21x21 each
+};
+
+// one workgroup of the gapped kernel = one query + a contiguous run of its pairs
+struct SwTask { uint32_t q, begin, count; };
+
+struct SwArgs {
+    DeviceDb db;
+    const SwTask *tasks;
+    const uint32_t *pt;        // target id per pair
+    const int32_t *pqe, *pte;  // mode 2 only: forward end positions (define the reversed prefixes)
+    int32_t *oscore, *oqe, *ote;
+    int open, ext;
+};
+
+constexpr int SW_MAX_ROWS = 2048;   // largest single-strip class (G=64, R=32)
+
+// host launchers (uc_sw.hip / uc_prefilter.hip)
+void launch_sw_class(int G, int R, int mode, const SwArgs &a, uint32_t n_tasks, hipStream_t s);
+void launch_sw_generic(int mode, const SwArgs &a, uint32_t n_pairs, const uint32_t *pq, int32_t *work, uint32_t max_lq, hipStream_t s);
+void launch_ungapped(const DeviceDb &db, uint64_t n, const uint32_t *q, const uint32_t *t, const int32_t *diag,
+                     int32_t *score, hipStream_t s);
+bool sw_class_for(int lq, int *G, int *R);
+
+}  // namespace uc

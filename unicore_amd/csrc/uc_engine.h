@@ -1,0 +1,85 @@
+// uc_engine.h — the per-GPU engine: sequence DB resident in HBM + the staged pipeline E1..E6.
+// One engine = one HIP device = one process rank in the multi-GPU layout.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "uc_common.h"
+#include "uc_db.h"
+#include "uc_device.h"
+#include "uc_options.h"
+#include "unicore_cluster.h"
+
+namespace uc {
+
+template <typename T>
+struct DevBuf {   // plain owning device allocation (hipMalloc), grows geometrically
+    T *p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void reserve(size_t n) {
+        if (n <= cap) return;
+        release();
+        size_t want = n + n / 8 + 64;
+        UC_HIP(hipMalloc((void **)&p, want * sizeof(T)));
+        cap = want;
+    }
+};
+
+struct PairIn { uint32_t q, t; int32_t qe, te; };
+
+struct Engine {
+    Params p;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // host view of the DB
+    HostDb hdb;
+    bool have_db = false;
+    std::vector<uint32_t> h_poff;   // padded device offsets (n+1)
+    std::vector<uint32_t> h_len;
+
+    // device DB
+    DevBuf<uint8_t> d_s3, d_sa;
+    DevBuf<uint32_t> d_off, d_len;
+    DevBuf<int8_t> d_S3, d_SA;
+    DeviceDb ddb;
+
+    // stage outputs
+    std::vector<uint32_t> hit_cnt;     // per query
+    std::vector<uint64_t> hit_off;     // n+1
+    std::vector<uc_hit> hits;
+    std::vector<uc_aln> alns;          // parallel to hits
+    std::vector<uint8_t> aln_done;     // per query: aligned?
+    std::vector<uint32_t> edges;
+
+    uc_stats stats{};
+
+    explicit Engine(const Params &pp, int dev);
+    ~Engine();
+    void upload_db();
+    void prefilter(uint32_t tbegin, uint32_t tend);                       // uc_prefilter.hip
+    void set_hits(const uint32_t *counts, const uc_hit *h);
+    void align(uint32_t qbegin, uint32_t qend);
+    // kernel-level
+    void ungapped_batch(uint64_t n, const uint32_t *q, const uint32_t *t, const int32_t *diag, int32_t *out);
+    void sw_batch(int mode, const std::vector<PairIn> &pairs, int32_t *score, int32_t *qe, int32_t *te);
+
+    double timed_ms_begin();   // records ev0 on the stream
+    double timed_ms_end();     // records ev1, syncs, returns elapsed ms
+};
+
+void set_cover(uint32_t n, const uint32_t *edges, uint64_t n_edges, uint32_t *assign);
+void merge_hits(uint32_t n, int max_seqs, int n_parts, const uint32_t *const *counts, const uc_hit *const *hits,
+                std::vector<uint32_t> &out_cnt, std::vector<uc_hit> &out_hits);
+const char *last_error_cstr();
+
+}  // namespace uc

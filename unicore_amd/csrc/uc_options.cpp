@@ -1,0 +1,169 @@
+// uc_options.cpp — Foldseek-style option parsing, matrix loading, derived parameters.
+#include "uc_options.h"
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "uc_common.h"
+
+namespace uc {
+
+int g_verbosity = 3;
+static thread_local std::string t_last_error;
+void set_last_error(const std::string &m) { t_last_error = m; }
+const char *last_error_cstr() { return t_last_error.c_str(); }
+
+int letter_code(char c) {
+    switch (c >= 'a' && c <= 'z' ? c - 32 : c) {
+        case 'A': return 0;  case 'C': return 1;  case 'D': return 2;  case 'E': return 3;  case 'F': return 4;
+        case 'G': return 5;  case 'H': return 6;  case 'I': return 7;  case 'K': return 8;  case 'L': return 9;
+        case 'M': return 10; case 'N': return 11; case 'P': return 12; case 'Q': return 13; case 'R': return 14;
+        case 'S': return 15; case 'T': return 16; case 'V': return 17; case 'W': return 18; case 'Y': return 19;
+        default: return 20;
+    }
+}
+
+static bool is_matrix_letter(const std::string &tok) {
+    return tok.size() == 1 && (letter_code(tok[0]) < 20 || tok[0] == 'X' || tok[0] == 'x');
+}
+
+void load_matrix(const std::string &path, int8_t out[A * A]) {
+    std::ifstream f(path);
+    if (!f) fail(UC_ERR_IO, "cannot open substitution matrix %s", path.c_str());
+    for (int i = 0; i < A * A; i++) out[i] = -1;
+    std::string line;
+    std::vector<int> cols;
+    int rows = 0;
+    while (std::getline(f, line)) {
+        std::istringstream ss(line);
+        std::string tok;
+        if (!(ss >> tok) || tok[0] == '#') continue;
+        if (cols.empty()) {
+            do cols.push_back(is_matrix_letter(tok) ? letter_code(tok[0]) : -1);
+            while (ss >> tok);
+            continue;
+        }
+        if (tok.size() != 1) continue;
+        int row = is_matrix_letter(tok) ? letter_code(tok[0]) : -1;
+        for (size_t c = 0; c < cols.size(); c++) {
+            long v;
+            if (!(ss >> v)) break;
+            if (row < 0 || cols[c] < 0) continue;
+            // 48 keeps (S3 + SA + gap_open) inside the biased-byte query profile of the DP kernel
+            if (v < -48 || v > 48) fail(UC_ERR_ARGS, "matrix %s: value %ld outside [-48,48]", path.c_str(), v);
+            out[row * A + cols[c]] = (int8_t)v;
+        }
+        if (row >= 0) rows++;
+    }
+    if (rows < 20) fail(UC_ERR_ARGS, "matrix %s: expected 20 letter rows, found %d", path.c_str(), rows);
+}
+
+static double to_double(const std::string &flag, const std::string &v) {
+    char *end = nullptr;
+    double d = std::strtod(v.c_str(), &end);
+    if (end == v.c_str() || *end) fail(UC_ERR_ARGS, "option %s: '%s' is not a number", flag.c_str(), v.c_str());
+    return d;
+}
+static int to_int(const std::string &flag, const std::string &v) {
+    char *end = nullptr;
+    long d = std::strtol(v.c_str(), &end, 10);
+    if (end == v.c_str() || *end) fail(UC_ERR_ARGS, "option %s: '%s' is not an integer", flag.c_str(), v.c_str());
+    return (int)d;
+}
+
+void parse_cluster_options(const std::string &opts, Params &p) {
+    std::istringstream ss(opts);
+    std::vector<std::string> tok;
+    for (std::string t; ss >> t;) tok.push_back(t);
+    for (size_t i = 0; i < tok.size(); i++) {
+        const std::string &f = tok[i];
+        auto value = [&]() -> const std::string & {
+            if (i + 1 >= tok.size()) fail(UC_ERR_ARGS, "option %s needs a value", f.c_str());
+            return tok[++i];
+        };
+        auto opt_bool = [&]() -> bool {  // MMseqs-style switches accept an optional 0/1
+            if (i + 1 < tok.size() && (tok[i + 1] == "0" || tok[i + 1] == "1")) return tok[++i] == "1";
+            return true;
+        };
+        if (f == "-c") { p.cov = (float)to_double(f, value()); if (p.cov < 0.f || p.cov > 1.f) fail(UC_ERR_ARGS, "-c must be in [0,1]"); }
+        else if (f == "--cov-mode") { p.cov_mode = to_int(f, value()); if (p.cov_mode < 0 || p.cov_mode > 2) fail(UC_ERR_ARGS, "--cov-mode %d unsupported (0,1,2)", p.cov_mode); }
+        else if (f == "--min-seq-id") { p.min_seq_id = (float)to_double(f, value()); if (p.min_seq_id < 0.f || p.min_seq_id > 1.f) fail(UC_ERR_ARGS, "--min-seq-id must be in [0,1]"); }
+        else if (f == "-e") { p.evalue = to_double(f, value()); if (!(p.evalue > 0)) fail(UC_ERR_ARGS, "-e must be > 0"); }
+        else if (f == "-s") { p.sensitivity = (float)to_double(f, value()); }
+        else if (f == "--max-seqs") { p.max_seqs = to_int(f, value()); if (p.max_seqs < 1 || p.max_seqs > 65535) fail(UC_ERR_ARGS, "--max-seqs must be in [1,65535]"); }
+        else if (f == "--k-score") { p.kmer_thr = to_int(f, value()); }
+        else if (f == "--min-ungapped-score") { p.min_ungapped = to_int(f, value()); }
+        else if (f == "--min-diag-hits") { p.min_diag_hits = to_int(f, value()); if (p.min_diag_hits < 1) fail(UC_ERR_ARGS, "--min-diag-hits must be >= 1"); }
+        else if (f == "--gap-open") { p.gap_open = to_int(f, value()); if (p.gap_open < 1 || p.gap_open > 31) fail(UC_ERR_ARGS, "--gap-open must be in [1,31]"); }
+        else if (f == "--gap-extend") { p.gap_ext = to_int(f, value()); if (p.gap_ext < 0 || p.gap_ext > 31) fail(UC_ERR_ARGS, "--gap-extend must be in [0,31]"); }
+        else if (f == "--spaced-kmer-pattern") { p.pattern = value(); }
+        else if (f == "--rev-correction") { p.rev_correction = to_int(f, value()) != 0; }
+        else if (f == "--evalue-lambda") { p.lambda = to_double(f, value()); }
+        else if (f == "--evalue-k") { p.Kconst = to_double(f, value()); }
+        else if (f == "--mat3di") { p.mat3di_path = value(); }
+        else if (f == "--mat-aa") { p.mataa_path = value(); }
+        else if (f == "--cluster-mode") { p.cluster_mode = to_int(f, value()); if (p.cluster_mode != 0) fail(UC_ERR_ARGS, "--cluster-mode %d unsupported (only 0 = greedy set cover)", p.cluster_mode); }
+        else if (f == "--single-step-clustering") { p.single_step = opt_bool(); }
+        else if (f == "--cluster-steps") { p.cluster_steps = to_int(f, value()); }
+        else if (f == "--alignment-type") { int v = to_int(f, value()); if (v != 2) fail(UC_ERR_ARGS, "--alignment-type %d unsupported (only 2 = 3Di+AA)", v); }
+        else if (f == "--alignment-mode") { int v = to_int(f, value()); if (v < 0 || v > 3) fail(UC_ERR_ARGS, "--alignment-mode %d unsupported", v); }
+        else if (f == "--threads") { p.threads = to_int(f, value()); }
+        else if (f == "-v") { p.verbosity = to_int(f, value()); }
+        else if (f == "--remove-tmp-files" || f == "--db-load-mode" || f == "--compressed") { (void)value(); /* no effect on results */ }
+        else fail(UC_ERR_ARGS, "unknown or unsupported cluster option '%s'", f.c_str());
+    }
+}
+
+std::string default_data_dir() {
+    Dl_info info;
+    if (dladdr((void *)&default_data_dir, &info) && info.dli_fname) {
+        std::string p(info.dli_fname);
+        size_t s = p.find_last_of('/');
+        return (s == std::string::npos ? std::string(".") : p.substr(0, s)) + "/data";
+    }
+    return "data";
+}
+
+static bool exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+
+void finalize_params(Params &p, const std::string &data_dir_in) {
+    std::string dd = data_dir_in.empty() ? default_data_dir() : data_dir_in;
+    if (p.mat3di_path.empty()) p.mat3di_path = exists(dd + "/mat3di.out") ? dd + "/mat3di.out" : dd + "/mat3di_synthetic.out";
+    if (p.mataa_path.empty()) p.mataa_path = dd + "/blosum62.out";
+    load_matrix(p.mat3di_path, p.S3);
+    load_matrix(p.mataa_path, p.SA);
+    // pattern
+    int n = 0;
+    p.span = (int)p.pattern.size();
+    if (p.span < K || p.span > 32) fail(UC_ERR_ARGS, "--spaced-kmer-pattern: span must be in [6,32]");
+    for (int i = 0; i < p.span; i++) {
+        if (p.pattern[i] == '1') { if (n == K) fail(UC_ERR_ARGS, "--spaced-kmer-pattern needs exactly 6 ones"); p.koff[n++] = i; }
+        else if (p.pattern[i] != '0') fail(UC_ERR_ARGS, "--spaced-kmer-pattern must consist of 0/1");
+    }
+    if (n != K || p.pattern.front() != '1' || p.pattern.back() != '1') fail(UC_ERR_ARGS, "--spaced-kmer-pattern needs exactly 6 ones and 1 at both ends");
+    if (p.kmer_thr < 0) {
+        // sensitivity -> k-mer threshold: mean self score of a k-mer + 3 - 2*s  (data-driven stand-in for
+        // Foldseek's threshold table, SURVEY.md A.2 EXT-UNVERIFIED; --k-score overrides)
+        double diag = 0;
+        for (int a = 0; a < KA; a++) diag += p.S3[a * A + a];
+        p.kmer_thr = (int)std::lround(K * diag / KA + 3.0 - 2.0 * p.sensitivity);
+    }
+    if (!p.single_step || p.cluster_steps != 1)
+        logf(2, "Warning: cascaded clustering is not implemented; running single-step clustering\n");
+    if (p.threads < 1) p.threads = 1;
+}
+
+int32_t min_score_for(const Params &p, int lq, uint64_t db_residues) {
+    double scale = p.Kconst * (double)lq * (double)db_residues;
+    int32_t s = 1;
+    while (scale * std::exp(-p.lambda * (double)s) > p.evalue && s < (1 << 30)) s++;
+    return s;
+}
+
+}  // namespace uc

@@ -1,0 +1,58 @@
+// uc_options.h — clustering parameters and the Foldseek-style flag parser.
+// The reference forwards `-c/--cluster-options` as an opaque whitespace-split string
+// (/root/reference/src/modules/cluster.rs:35,49; default "-c 0.8", src/util/arg_parser.rs:238-239);
+// this is the only channel for clustering parameters, so the engine parses Foldseek's flag names.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace uc {
+
+constexpr int A = 21;    // alphabet incl. X
+constexpr int KA = 20;   // k-mer alphabet
+constexpr int K = 6;     // k-mer size
+constexpr uint32_t KSPACE = 64000000u;  // 20^6
+
+struct Params {
+    // matrices (loaded from data files, used verbatim)
+    int8_t S3[A * A];
+    int8_t SA[A * A];
+    std::string mat3di_path, mataa_path;
+    // prefilter
+    std::string pattern = "1101010011";
+    int koff[K] = {0, 1, 3, 5, 8, 9};
+    int span = 10;
+    float sensitivity = 4.0f;
+    int kmer_thr = -1;          // -1: derive from sensitivity
+    int min_diag_hits = 2;
+    int min_ungapped = 15;
+    int max_seqs = 300;
+    // gapped alignment
+    int gap_open = 10, gap_ext = 1;
+    int rev_correction = 1;
+    double evalue = 0.01, lambda = 0.34657359027997264, Kconst = 0.1;
+    float cov = 0.8f;
+    int cov_mode = 0;
+    float min_seq_id = 0.0f;
+    // clustering
+    int cluster_mode = 0;
+    int cluster_steps = 1;
+    bool single_step = true;
+    // runtime
+    int threads = 1;
+    int verbosity = 3;
+};
+
+// letters ACDEFGHIKLMNPQRSTVWY -> 0..19, everything else -> 20
+int letter_code(char c);
+void load_matrix(const std::string &path, int8_t out[A * A]);
+// parse `opts` (Foldseek flag names) into p; throws Error(UC_ERR_ARGS) on unknown flags / bad values
+void parse_cluster_options(const std::string &opts, Params &p);
+// resolve data files + derived values (pattern offsets, kmer_thr from sensitivity); loads matrices
+void finalize_params(Params &p, const std::string &data_dir);
+std::string default_data_dir();
+// smallest integer score S with K * lq * db_residues * exp(-lambda*S) <= evalue
+int32_t min_score_for(const Params &p, int lq, uint64_t db_residues);
+
+}  // namespace uc

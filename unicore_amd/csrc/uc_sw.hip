@@ -1,0 +1,66 @@
+// uc_sw.hip — dispatch for the gapped DP kernel classes, the long-query fallback, and stage E3
+// (ungapped diagonal score).
+#include "uc_sw_impl.hpp"
+
+namespace uc {
+
+void launch_sw_class_m0(int G, int R, const SwArgs &a, uint32_t n_tasks, hipStream_t s);
+void launch_sw_class_m1(int G, int R, const SwArgs &a, uint32_t n_tasks, hipStream_t s);
+void launch_sw_class_m2(int G, int R, const SwArgs &a, uint32_t n_tasks, hipStream_t s);
+
+// smallest (G,R) class whose G*R rows hold the query; false if it needs the generic kernel
+bool sw_class_for(int lq, int *G, int *R) {
+    static const int cls[][2] = {{16, 4}, {16, 8}, {16, 12}, {16, 16}, {16, 20}, {16, 24}, {16, 28}, {16, 32},
+                                 {32, 20}, {32, 24}, {32, 28}, {32, 32}, {64, 20}, {64, 24}, {64, 28}, {64, 32}};
+    for (const auto &c : cls)
+        if (c[0] * c[1] >= lq) { *G = c[0]; *R = c[1]; return true; }
+    return false;
+}
+
+void launch_sw_class(int G, int R, int mode, const SwArgs &a, uint32_t n_tasks, hipStream_t s) {
+    if (n_tasks == 0) return;
+    if (mode == 0) launch_sw_class_m0(G, R, a, n_tasks, s);
+    else if (mode == 1) launch_sw_class_m1(G, R, a, n_tasks, s);
+    else launch_sw_class_m2(G, R, a, n_tasks, s);
+}
+
+void launch_sw_generic(int mode, const SwArgs &a, uint32_t n_pairs, const uint32_t *pq, int32_t *work,
+                       uint32_t max_lq, hipStream_t s) {
+    if (n_pairs == 0) return;
+    const dim3 grid((n_pairs + 63) / 64), block(64);
+    if (mode == 0) hipLaunchKernelGGL(sw_generic_kernel<0>, grid, block, 0, s, a, n_pairs, pq, work, max_lq);
+    else if (mode == 1) hipLaunchKernelGGL(sw_generic_kernel<1>, grid, block, 0, s, a, n_pairs, pq, work, max_lq);
+    else hipLaunchKernelGGL(sw_generic_kernel<2>, grid, block, 0, s, a, n_pairs, pq, work, max_lq);
+}
+
+// ---- stage E3: ungapped diagonal score (MMseqs2 UngappedAlignment on the 3Di track) ----
+// One lane per candidate (q, t, diag): Kadane along the whole diagonal, saturating at 255.  The 21x21
+// 3Di matrix sits in LDS; candidates arrive sorted by (q, t) so neighbouring lanes share the query.
+__global__ void __launch_bounds__(256) ungapped_kernel(const DeviceDb db, uint64_t n, const uint32_t *q,
+                                                       const uint32_t *t, const int32_t *diag, int32_t *score) {
+    __shared__ int8_t S[21 * 21 + 3];
+    for (int i = threadIdx.x; i < 441; i += 256) S[i] = db.S3[i];
+    __syncthreads();
+    for (uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x; c < n; c += (uint64_t)gridDim.x * 256) {
+        const uint32_t qq = q[c], tt = t[c];
+        const int d = diag[c];
+        const int lq = (int)db.len[qq], lt = (int)db.len[tt];
+        const uint8_t *q3 = db.s3 + db.off[qq], *t3 = db.s3 + db.off[tt];
+        const int i0 = d > 0 ? d : 0, i1 = min(lq, lt + d);
+        int run = 0, best = 0;
+        for (int i = i0; i < i1; i++) {
+            run = max(run + S[q3[i] * 21 + t3[i - d]], 0);
+            best = max(best, run);
+        }
+        score[c] = min(best, 255);
+    }
+}
+
+void launch_ungapped(const DeviceDb &db, uint64_t n, const uint32_t *q, const uint32_t *t, const int32_t *diag,
+                     int32_t *score, hipStream_t s) {
+    if (n == 0) return;
+    const uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(ungapped_kernel, dim3((uint32_t)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, db, n, q, t, diag, score);
+}
+
+}  // namespace uc

@@ -1,0 +1,251 @@
+// uc_sw_impl.hpp — stage E5: gapped 3Di+AA Smith-Waterman as a wavefront-primitive anti-diagonal DP
+// kernel for gfx950 (wave64).  Replaces Foldseek's structurealign / SSW inside `foldseek cluster`
+// (call site /root/reference/src/modules/cluster.rs:45-56; algorithm SURVEY.md A.3; spec UC-1 E5).
+//
+// Design (integer VALU DP — no MFMA: this is not a contraction):
+//  * A group of G lanes (G = 16/32/64, 64/G alignments per wave) sweeps ONE alignment as a systolic
+//    anti-diagonal: lane g owns R consecutive query rows, at step st it computes its R cells of target
+//    column j = st - g.  Column results flow to lane g+1 through DPP row_shr:1 (G=16: one DPP row per
+//    alignment) or ds_bpermute (G=32/64); no DP state ever leaves registers.
+//  * The four alignments of a wave share one query: the workgroup stages a per-query PROFILE in LDS
+//    once (prof[track][letter][row] as biased bytes, 4 rows per dword, row blocks padded to an odd dword
+//    stride so the 16 lanes of a group hit 16 distinct banks) and then streams all of that query's
+//    targets through it, so the inner loop does R/4 ds_read_b32 per track per step, one packed add and
+//    one xor to form four signed (S3+SA+open) bytes, and v_dot4_i32_i8 to fold byte r into H(i-1,j-1).
+//  * DP state per row is (T = H - open, E>=0).  E and F live in the floored domain (max(.,0)), which
+//    is exact for local alignment and lets v_sub_u32 clamp + v_max3_i32 form H without a zero-compare.
+//  * End tracking (tie-break: smallest tEnd, then smallest qEnd) costs one v_lshl_or per cell: the
+//    row id rides in the low 5 bits of a keyed copy of H, the column comes from the step counter.
+//  * MODE 0 forward, MODE 1 reversed query (score only), MODE 2 start pass on the reversed prefixes
+//    (reversed query profile with the rows beyond qEnd masked to PAD, target read backwards from tEnd).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "uc_device.h"
+
+namespace uc {
+
+constexpr int SW_NLET = 22;            // 21 letters + PAD(21)
+constexpr uint32_t SW_PADPACK = 21u | (21u << 8);
+
+template <int G>
+__device__ __forceinline__ int shift_from_prev_lane(int v, int boundary, int g, int lane) {
+    if constexpr (G == 16) {
+        // DPP row_shr:1 — lane 0 of each 16-lane row keeps `old` (= boundary)
+        return __builtin_amdgcn_update_dpp(boundary, v, 0x111, 0xf, 0xf, false);
+    } else {
+        int r = __builtin_amdgcn_ds_bpermute((lane - 1) << 2, v);
+        return g == 0 ? boundary : r;
+    }
+}
+
+template <int G, int R, int MODE>
+__global__ void __launch_bounds__(256) sw_group_kernel(const SwArgs a) {
+    constexpr bool TRACK = MODE != 1, MASK = MODE == 2, REVQ = MODE != 0, REVT = MODE == 2;
+    constexpr int RW = R / 4, BW = RW | 1, RSW = G * BW, GPW = 64 / G;
+    static_assert(R % 4 == 0 && R <= 32, "R must be a multiple of 4, <= 32");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *P3 = lds, *PA = lds + SW_NLET * RSW;
+
+    const SwTask task = a.tasks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane % G, grp = lane / G;
+    const uint32_t qoff = a.db.off[task.q];
+    const int lq = (int)a.db.len[task.q];
+    const int open = a.open, ext = a.ext;
+
+    // ---- stage the query profile in LDS (biased bytes: b3 = S3+64, bA = SA+64+open; PAD = 0) ----
+    for (int idx = tid; idx < SW_NLET * G * RW; idx += 256) {
+        const int c = idx / (G * RW), rem = idx % (G * RW), gg = rem / RW, k = rem % RW;
+        uint32_t w3 = 0, wa = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int row = gg * R + 4 * k + b;
+            if (row < lq && c < 21) {
+                const int qi = REVQ ? lq - 1 - row : row;
+                const int q3 = a.db.s3[qoff + qi], qa = a.db.sa[qoff + qi];
+                w3 |= (uint32_t)(a.db.S3[q3 * 21 + c] + 64) << (8 * b);
+                wa |= (uint32_t)(a.db.SA[qa * 21 + c] + 64 + open) << (8 * b);
+            }
+        }
+        P3[c * RSW + gg * BW + k] = w3;
+        PA[c * RSW + gg * BW + k] = wa;
+    }
+    __syncthreads();
+
+    for (uint32_t pb = (uint32_t)wave * GPW; pb < task.count; pb += 4 * GPW) {
+        const bool pvalid = pb + grp < task.count;
+        const uint32_t gp = task.begin + (pvalid ? pb + grp : 0);
+        const uint32_t t = a.pt[gp];
+        const uint32_t toff = a.db.off[t];
+        int tlen = REVT ? a.pte[gp] + 1 : (int)a.db.len[t];
+        if (!pvalid) tlen = 0;
+        const int tlast = tlen - 1;
+        int rowoff = 0;
+        uint32_t msk[RW];
+        if constexpr (MASK) {
+            rowoff = lq - 1 - a.pqe[gp];
+#pragma unroll
+            for (int k = 0; k < RW; k++) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) m |= (g * R + 4 * k + b >= rowoff ? 0xFFu : 0u) << (8 * b);
+                msk[k] = m;
+            }
+        }
+        int maxlen = 0;
+#pragma unroll
+        for (int i = 0; i < GPW; i++) maxlen = max(maxlen, __builtin_amdgcn_readlane(tlen, i * G));
+        const int nsteps = maxlen > 0 ? maxlen + G - 1 : 0;
+
+        int T[R];
+        uint32_t E[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) { T[r] = -open; E[r] = 0; }
+        uint32_t best = 0;       // TRACK: keyed (score<<5 | 31-r); else plain score
+        int bestcol = -1;
+        int Tlast = -open, prevTup = -open;
+        uint32_t fout = 0, cpack = SW_PADPACK;
+
+        auto load_letter = [&](int st) -> uint32_t {
+            uint32_t c = SW_PADPACK;
+            if (g == 0 && st < tlen) {
+                const uint32_t p = toff + (uint32_t)(REVT ? tlast - st : st);
+                c = (uint32_t)a.db.s3[p] | ((uint32_t)a.db.sa[p] << 8);
+            }
+            return c;
+        };
+        uint32_t cA = load_letter(0), cB = load_letter(1);
+
+        for (int st = 0; st < nsteps; st++) {
+            const uint32_t cload = cA;
+            cA = cB;
+            cB = load_letter(st + 2);
+            const int Tup = shift_from_prev_lane<G>(Tlast, -open, g, lane);
+            const uint32_t fin = (uint32_t)shift_from_prev_lane<G>((int)fout, 0, g, lane);
+            const uint32_t cin = (uint32_t)shift_from_prev_lane<G>((int)cpack, (int)cload, g, lane);
+            const int c3 = cin & 0xff, ca = cin >> 8;
+            const uint32_t *p3 = P3 + c3 * RSW + g * BW, *pa = PA + ca * RSW + g * BW;
+            uint32_t ps[RW];
+#pragma unroll
+            for (int k = 0; k < RW; k++) {
+                uint32_t s = p3[k] + pa[k];
+                if constexpr (MASK) s &= msk[k];
+                ps[k] = s ^ 0x80808080u;
+            }
+            int diagT = prevTup;
+            uint32_t f = fin;
+            uint32_t colmax = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int x = __builtin_amdgcn_sdot4((int)ps[r >> 2], 1 << (8 * (r & 3)), diagT, false);
+                const int e = max((int)__builtin_elementwise_sub_sat(E[r], (uint32_t)ext), T[r]);
+                const int h = max(max(x, e), (int)f);
+                diagT = T[r];
+                T[r] = h - open;
+                E[r] = (uint32_t)e;
+                f = (uint32_t)max((int)__builtin_elementwise_sub_sat(f, (uint32_t)ext), T[r]);
+                if constexpr (TRACK) colmax = max(colmax, ((uint32_t)h << 5) | (uint32_t)(31 - r));
+                else colmax = max(colmax, (uint32_t)h);
+            }
+            if constexpr (TRACK) {
+                const bool upd = colmax > (best | 31u);
+                best = upd ? colmax : best;
+                bestcol = upd ? st - g : bestcol;
+            } else {
+                best = max(best, colmax);
+            }
+            Tlast = T[R - 1];
+            fout = f;
+            cpack = cin;
+            prevTup = Tup;
+        }
+
+        // ---- reduce over the G lanes of the group: (score desc, col asc, row asc) ----
+        int score = TRACK ? (int)(best >> 5) : (int)best;
+        int row = TRACK ? g * R + (31 - (int)(best & 31u)) : 0;
+        int col = bestcol;
+#pragma unroll
+        for (int m = 1; m < G; m <<= 1) {
+            const int os = __shfl_xor(score, m, 64), oc = __shfl_xor(col, m, 64), orow = __shfl_xor(row, m, 64);
+            const bool take = os > score || (os == score && (oc < col || (oc == col && orow < row)));
+            score = take ? os : score;
+            col = take ? oc : col;
+            row = take ? orow : row;
+        }
+        if (g == 0 && pvalid) {
+            a.oscore[gp] = score;
+            if constexpr (TRACK) {
+                a.oqe[gp] = score > 0 ? row - rowoff : -1;
+                a.ote[gp] = score > 0 ? col : -1;
+            }
+        }
+    }
+}
+
+// Fallback for queries longer than SW_MAX_ROWS: one lane per pair, column-major sweep with the H/E
+// column in a global workspace ([row][pair] so a wave's accesses coalesce).  Slow, rare, same spec.
+template <int MODE>
+__global__ void __launch_bounds__(64) sw_generic_kernel(const SwArgs a, uint32_t n_pairs, const uint32_t *pq,
+                                                        int32_t *work, uint32_t max_lq) {
+    constexpr bool TRACK = MODE != 1, REVQ = MODE != 0, REVT = MODE == 2;
+    const uint32_t p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint32_t q = pq[p], t = a.pt[p];
+    const uint32_t qoff = a.db.off[q], toff = a.db.off[t];
+    const int lq = REVT ? a.pqe[p] + 1 : (int)a.db.len[q];
+    const int lt = REVT ? a.pte[p] + 1 : (int)a.db.len[t];
+    const int qfull = (int)a.db.len[q];
+    const int open = a.open, ext = a.ext;
+    const size_t stride = (size_t)gridDim.x * 64;
+    int32_t *H = work + p, *E = work + (size_t)max_lq * stride + p;
+    for (int i = 0; i < lq; i++) { H[(size_t)i * stride] = 0; E[(size_t)i * stride] = 0; }
+    int best = 0, bq = -1, bt = -1;
+    for (int j = 0; j < lt; j++) {
+        const uint32_t tp = toff + (uint32_t)(REVT ? lt - 1 - j : j);
+        const int t3 = a.db.s3[tp], ta = a.db.sa[tp];
+        int hdiag = 0, hup = 0, f = 0, colbest = 0, colrow = -1;
+        for (int i = 0; i < lq; i++) {
+            // MODE 1 reverses the whole query; MODE 2 reads the prefix [0..qend] backwards
+            const int qi = MODE == 1 ? qfull - 1 - i : (MODE == 2 ? lq - 1 - i : i);
+            const int s = a.db.S3[a.db.s3[qoff + qi] * 21 + t3] + a.db.SA[a.db.sa[qoff + qi] * 21 + ta];
+            const int hleft = H[(size_t)i * stride];
+            const int e = max(max(E[(size_t)i * stride] - ext, hleft - open), 0);
+            f = max(max(f - ext, hup - open), 0);
+            const int h = max(max(hdiag + s, e), f);
+            hdiag = hleft;
+            H[(size_t)i * stride] = h;
+            E[(size_t)i * stride] = e;
+            hup = h;
+            if (h > colbest) { colbest = h; colrow = i; }
+        }
+        if (colbest > best) { best = colbest; bq = colrow; bt = j; }
+    }
+    (void)REVQ;
+    a.oscore[p] = best;
+    if constexpr (TRACK) { a.oqe[p] = bq; a.ote[p] = bt; }
+}
+
+template <int MODE>
+void launch_sw_class_mode(int G, int R, const SwArgs &a, uint32_t n_tasks, hipStream_t s) {
+#define UC_SW_CASE(GG, RR)                                                                              \
+    if (G == GG && R == RR) {                                                                           \
+        constexpr int BW = ((RR / 4) | 1);                                                              \
+        const size_t lds = (size_t)2 * SW_NLET * GG * BW * 4;                                           \
+        static bool attr_set = false;                                                                   \
+        if (!attr_set && lds > 64 * 1024) {                                                             \
+            (void)hipFuncSetAttribute((const void *)sw_group_kernel<GG, RR, MODE>,                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+            attr_set = true;                                                                            \
+        }                                                                                               \
+        hipLaunchKernelGGL((sw_group_kernel<GG, RR, MODE>), dim3(n_tasks), dim3(256), lds, s, a);       \
+        return;                                                                                         \
+    }
+    UC_SW_CASE(16, 4) UC_SW_CASE(16, 8) UC_SW_CASE(16, 12) UC_SW_CASE(16, 16)
+    UC_SW_CASE(16, 20) UC_SW_CASE(16, 24) UC_SW_CASE(16, 28) UC_SW_CASE(16, 32)
+    UC_SW_CASE(32, 20) UC_SW_CASE(32, 24) UC_SW_CASE(32, 28) UC_SW_CASE(32, 32)
+    UC_SW_CASE(64, 20) UC_SW_CASE(64, 24) UC_SW_CASE(64, 28) UC_SW_CASE(64, 32)
+#undef UC_SW_CASE
+}
+
+}  // namespace uc
