@@ -88,6 +88,8 @@ def lib():
     L.uco_setcover.argtypes = [C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
     L.uco_cluster.argtypes = [C.POINTER(Db), C.POINTER(Params), C.c_int, C.c_void_p, C.POINTER(Counts), C.c_void_p, C.c_void_p, C.c_void_p]
     L.uco_write_tsv.argtypes = [C.c_char_p, C.POINTER(Db), C.c_void_p]
+    L.uco_sample_run.argtypes = [C.POINTER(Db), C.POINTER(Index), C.POINTER(Params), C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
+    L.uco_sample_run.restype = C.c_uint64
     _lib = L
     return L
 
@@ -214,3 +216,23 @@ def write_tsv(path, odb, assign):
     a = np.ascontiguousarray(assign, np.uint32)
     if lib().uco_write_tsv(path.encode(), C.byref(odb.db), a.ctypes.data) != 0:
         raise IOError(path)
+
+
+def build_index(odb, p, tbegin=0, tend=None):
+    ix = Index()
+    rc = lib().uco_index_build(C.byref(odb.db), tbegin, odb.n if tend is None else tend, C.byref(p), C.byref(ix))
+    if rc != 0:
+        raise RuntimeError("uco_index_build failed: %d" % rc)
+    return ix
+
+
+def free_index(ix):
+    lib().uco_index_free(C.byref(ix))
+
+
+def sample_run(odb, ix, p, queries, threads=0):
+    """E2-E6 for `queries` on the CPU; returns (n_alignments, prefilter_seconds, align_seconds)."""
+    q = np.ascontiguousarray(queries, np.uint32)
+    sec = (C.c_double * 2)()
+    n = lib().uco_sample_run(C.byref(odb.db), C.byref(ix), C.byref(p), threads, q.ctypes.data, len(q), sec)
+    return int(n), sec[0], sec[1]

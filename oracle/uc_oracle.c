@@ -640,3 +640,39 @@ int uco_write_tsv(const char *path, const uco_db *db, const uint32_t *assign) {
     fclose(f);
     return 0;
 }
+
+/* ------------------------------------------------------------------ bench.py cpu_baseline leg */
+#include <time.h>
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+
+uint64_t uco_sample_run(const uco_db *db, const uco_index *ix, const uco_params *p, int threads,
+                        const uint32_t *queries, uint32_t n_queries, double seconds[2]) {
+    const int M = p->max_seqs;
+    uco_hit *hits = (uco_hit *)malloc((size_t)n_queries * M * sizeof(uco_hit));
+    uint32_t *hcnt = (uint32_t *)calloc(n_queries, sizeof(uint32_t));
+    (void)threads;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+    double t0 = now_s();
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t k = 0; k < (int64_t)n_queries; k++)
+        hcnt[k] = (uint32_t)uco_prefilter_query(db, ix, queries[k], p, hits + (size_t)k * M, NULL);
+    double t1 = now_s();
+    const uint64_t dbres = db->off[db->n];
+    uint64_t pairs = 0, acc = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : pairs, acc)
+    for (int64_t k = 0; k < (int64_t)n_queries; k++) {
+        const uint32_t q = queries[k];
+        const int32_t ms = uco_min_score(p, (int)(db->off[q + 1] - db->off[q]), dbres);
+        for (uint32_t h = 0; h < hcnt[k]; h++) {
+            uco_aln a;
+            uco_align_pair(db, q, hits[(size_t)k * M + h].t, p, ms, &a);
+            pairs++; acc += (uint64_t)a.accepted;
+        }
+    }
+    double t2 = now_s();
+    seconds[0] = t1 - t0; seconds[1] = t2 - t1;
+    free(hits); free(hcnt);
+    return pairs + 0 * acc;
+}

@@ -150,6 +150,11 @@ int  uco_cluster(const uco_db *db, const uco_params *p, int threads, uint32_t *a
 
 int  uco_write_tsv(const char *path, const uco_db *db, const uint32_t *assign);
 
+/* CPU-baseline helper (bench.py cpu_baseline leg): E2-E6 for the listed queries against a prebuilt index;
+   returns the number of gapped alignments done; seconds[0] = prefilter wall, seconds[1] = alignment wall */
+uint64_t uco_sample_run(const uco_db *db, const uco_index *ix, const uco_params *p, int threads,
+                        const uint32_t *queries, uint32_t n_queries, double seconds[2]);
+
 #ifdef __cplusplus
 }
 #endif

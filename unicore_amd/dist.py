@@ -1,0 +1,111 @@
+"""unicore_amd.dist — the multi-GPU layout of the cluster path, one process per GPU.
+
+    rank g:  index target shard g  ->  match ALL queries against it (E1-E4)  ->  per-shard hit lists
+    exchange: all-gather of the ragged hit lists (torch.distributed; backend "nccl" is RCCL over xGMI on
+              ROCm, "gloo" on CPU for the tests) — the ONE collective of the path
+    every rank: merge the shard lists per query under the frozen order (score desc, target asc), keep
+              max_seqs  ->  align its query range (E5/E6)  ->  accepted edges
+    gather:   edges to rank 0, which runs the host-side set cover (E7) and writes the result.
+
+The target DB is range-partitioned by residue count; per-shard truncation to max_seqs is lossless because
+the global top-M is contained in the union of the shard top-Ms, so the merged result is independent of the
+number of shards (tests/test_dist.py checks that with virtual shards and with 2 gloo ranks).
+torch is used for device buffers and the collective only.
+"""
+import numpy as np
+
+from . import HIT_DTYPE, hits_merge
+
+
+def shard_ranges(lens, world):
+    """Contiguous target ranges [b, e) with ~equal residue counts (range partition by key)."""
+    lens = np.asarray(lens, np.int64)
+    n = len(lens)
+    cum = np.concatenate([[0], np.cumsum(lens)])
+    total = int(cum[-1])
+    bounds = [0]
+    for g in range(1, world):
+        bounds.append(int(np.searchsorted(cum, total * g / world, side="left")))
+    bounds.append(n)
+    for i in range(1, len(bounds)):
+        bounds[i] = max(bounds[i], bounds[i - 1])
+    return [(bounds[g], bounds[g + 1]) for g in range(world)]
+
+
+def query_ranges(lens, counts, hits, world):
+    """Contiguous query ranges with ~equal gapped-DP work (cells = Lq * sum of target lengths)."""
+    lens = np.asarray(lens, np.int64)
+    counts = np.asarray(counts, np.int64)
+    n = len(lens)
+    tl = lens[np.asarray(hits["target"], np.int64)] if len(hits) else np.zeros(0, np.int64)
+    off = np.concatenate([[0], np.cumsum(counts)])
+    csum = np.concatenate([[0], np.cumsum(tl)])
+    work = lens * (csum[off[1:]] - csum[off[:-1]])
+    cum = np.concatenate([[0], np.cumsum(work)])
+    total = int(cum[-1])
+    bounds = [0]
+    for g in range(1, world):
+        bounds.append(int(np.searchsorted(cum, total * g / world, side="left")))
+    bounds.append(n)
+    for i in range(1, len(bounds)):
+        bounds[i] = max(bounds[i], bounds[i - 1])
+    return [(bounds[g], bounds[g + 1]) for g in range(world)]
+
+
+def _allgather_ragged(arr_u8, device, group=None):
+    """all-gather of one ragged byte buffer per rank -> list of np.uint8 arrays."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    n = torch.tensor([arr_u8.size], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(max(sizes), 1)
+    buf = torch.zeros(m, dtype=torch.uint8, device=device)
+    if arr_u8.size:
+        buf[: arr_u8.size] = torch.from_numpy(arr_u8).to(device)
+    outs = [torch.empty(m, dtype=torch.uint8, device=device) for _ in range(world)]
+    dist.all_gather(outs, buf, group=group)          # RCCL all-gather over xGMI when device is a GPU
+    return [o[:s].cpu().numpy() for o, s in zip(outs, sizes)]
+
+
+def exchange_hits(counts, hits, device="cpu", group=None):
+    """All-gather every rank's (counts, hits) -> list of per-shard (counts, hits)."""
+    c = _allgather_ragged(np.ascontiguousarray(counts, np.uint32).view(np.uint8), device, group)
+    h = _allgather_ragged(np.ascontiguousarray(hits, HIT_DTYPE).view(np.uint8), device, group)
+    return [(ci.view(np.uint32), hi.view(HIT_DTYPE)) for ci, hi in zip(c, h)]
+
+
+def gather_edges(edges, device="cpu", group=None):
+    parts = _allgather_ragged(np.ascontiguousarray(edges, np.uint32).reshape(-1).view(np.uint8), device, group)
+    return np.concatenate([p.view(np.uint32).reshape(-1, 2) for p in parts]) if parts else np.zeros((0, 2), np.uint32)
+
+
+def merged_hits(parts, n_seqs, max_seqs):
+    return hits_merge(n_seqs, max_seqs, parts)
+
+
+def cluster_step(engine, lens, rank, world, max_seqs, device="cpu", group=None, setcover=None):
+    """One pass of the sharded hot path on this rank.  Returns (assign or None, n_alignments_this_rank)."""
+    from . import setcover as host_setcover
+
+    n = len(lens)
+    tb, te = shard_ranges(lens, world)[rank]
+    engine.prefilter(tb, te)
+    counts, hits = engine.hits()
+    if world > 1:
+        parts = exchange_hits(counts, hits, device, group)
+        counts, hits = merged_hits(parts, n, max_seqs)
+        engine.set_hits(counts, hits)
+    qb, qe = query_ranges(lens, counts, hits, world)[rank]
+    engine.align(qb, qe)
+    edges = engine.edges()
+    n_aln = int(np.asarray(counts[qb:qe], np.int64).sum())
+    if world > 1:
+        edges = gather_edges(edges, device, group)
+    assign = None
+    if rank == 0:
+        assign = (setcover or host_setcover)(n, edges)
+    return assign, n_aln
