@@ -199,6 +199,11 @@ class Engine:
     def prefilter(self, tbegin=0, tend=None):
         _check(lib().uc_engine_prefilter(self._h, tbegin, self.n if tend is None else tend))
 
+    def hits_size(self):
+        nh = C.c_uint64()
+        _check(lib().uc_engine_hits_size(self._h, C.byref(nh)))
+        return int(nh.value)
+
     def hits(self):
         nh = C.c_uint64()
         _check(lib().uc_engine_hits_size(self._h, C.byref(nh)))

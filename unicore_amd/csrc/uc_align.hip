@@ -1,0 +1,433 @@
+// uc_align.hip — stage E5/E6 orchestration, device-resident.
+// The prefilter leaves its hit lists in HBM; everything between them and the accepted edge list stays on
+// the GPU: the planner sorts the pairs by (length class, query, target length), cuts them into workgroup
+// tasks and gathers the kernel inputs; the gates (E-value on the corrected score, coverage) are small
+// kernels with scan-based compaction.  The host only sees a handful of counters and, at the end, the
+// accepted edges (stands for Foldseek's structurealign result handling; spec UC-1 E5/E6).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "uc_engine.h"
+
+namespace uc {
+
+namespace {
+
+__device__ __constant__ int c_cls_cap[16] = {64, 128, 192, 256, 320, 384, 448, 512, 640, 768, 896, 1024, 1280, 1536, 1792, 2048};
+const int h_cls_g[16] = {16, 16, 16, 16, 16, 16, 16, 16, 32, 32, 32, 32, 64, 64, 64, 64};
+const int h_cls_r[16] = {4, 8, 12, 16, 20, 24, 28, 32, 20, 24, 28, 32, 20, 24, 28, 32};
+
+__device__ __forceinline__ int class_of(int lq) {
+    int c = 0;
+    while (c < 16 && c_cls_cap[c] < lq) c++;
+    return c;
+}
+// pairs per workgroup task: the long-query classes have few queries, so their pair lists are cut finer to
+// keep every CU busy (rebuilding the LDS profile per task is negligible against >= 16 long alignments)
+__device__ __forceinline__ uint32_t task_cap(int c) { return c < 8 ? 256u : (c < 12 ? 64u : 24u); }
+
+inline dim3 grid_for(uint64_t n, uint32_t cap = 16384) {
+    const uint64_t b = (n + 255) / 256;
+    return dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(b, cap)));
+}
+
+// key = [ class : 5 | query : 24 | 65535 - effective target length : 16 ]
+__global__ void __launch_bounds__(256) plan_key_kernel(uint32_t n, const uint32_t *q, const uint32_t *t, const int32_t *qe,
+                                                       const int32_t *te, const uint32_t *len, uint64_t *key, uint32_t *idx,
+                                                       unsigned long long *alg_bytes /* [0] bytes, [1] DP cells */) {
+    unsigned long long bytes = 0, cells = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t qq = q[i];
+        const uint32_t lq = len[qq];
+        const uint32_t tl = te ? (uint32_t)te[i] + 1 : len[t[i]];
+        const uint32_t ql = qe ? (uint32_t)qe[i] + 1 : lq;
+        key[i] = ((uint64_t)class_of((int)lq) << 40) | ((uint64_t)qq << 16) | (uint64_t)(65535u - tl);
+        idx[i] = i;
+        bytes += 2ull * (ql + tl) + 32;
+        cells += (unsigned long long)ql * tl;
+    }
+    for (int o = 32; o > 0; o >>= 1) { bytes += __shfl_down(bytes, o, 64); cells += __shfl_down(cells, o, 64); }
+    if ((threadIdx.x & 63) == 0 && bytes) { atomicAdd(alg_bytes, bytes); atomicAdd(alg_bytes + 1, cells); }
+}
+
+__global__ void __launch_bounds__(256) plan_gather_kernel(uint32_t n, const uint64_t *key, const uint32_t *idx, const uint32_t *t,
+                                                          const int32_t *qe, const int32_t *te, uint32_t *sq, uint32_t *st,
+                                                          int32_t *sqe, int32_t *ste, uint32_t *head) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint64_t k = key[i];
+        const uint32_t o = idx[i];
+        sq[i] = (uint32_t)(k >> 16) & 0xFFFFFFu;
+        st[i] = t[o];
+        if (qe) { sqe[i] = qe[o]; ste[i] = te[o]; }
+        head[i] = (i == 0 || (key[i - 1] >> 16) != (k >> 16)) ? i : 0u;
+    }
+}
+
+__global__ void __launch_bounds__(256) plan_taskflag_kernel(uint32_t n, const uint64_t *key, const uint32_t *segstart, uint32_t *flag) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        flag[i] = ((i - segstart[i]) % task_cap((int)(key[i] >> 40))) == 0 ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256) plan_taskfill_kernel(uint32_t n, const uint64_t *key, const uint32_t *flag, const uint32_t *tpos,
+                                                            SwTask *tasks, uint32_t *tcls) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        if (!flag[i]) continue;
+        const uint64_t k = key[i];
+        const uint32_t w = tpos[i];
+        tasks[w].q = (uint32_t)(k >> 16) & 0xFFFFFFu;
+        tasks[w].begin = i;
+        tcls[w] = (uint32_t)(k >> 40);
+    }
+}
+
+// count per task + an LPT sort key: [ class : 5 | ~work : 32 ], work = pairs x longest target of the task
+__global__ void __launch_bounds__(256) plan_taskcount_kernel(uint32_t ntasks, uint32_t n, SwTask *tasks, const uint32_t *tcls,
+                                                             const uint64_t *key, uint64_t *tkey, uint32_t *tidx) {
+    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < ntasks; k += gridDim.x * 256) {
+        const uint32_t b = tasks[k].begin;
+        const uint32_t cnt = (k + 1 < ntasks ? tasks[k + 1].begin : n) - b;
+        tasks[k].count = cnt;
+        const uint32_t work = cnt * (65535u - (uint32_t)(key[b] & 0xFFFF));
+        tkey[k] = ((uint64_t)tcls[k] << 32) | (uint64_t)(0xFFFFFFFFu - work);
+        tidx[k] = k;
+    }
+}
+
+__global__ void __launch_bounds__(256) plan_taskgather_kernel(uint32_t ntasks, const uint32_t *tidx, const SwTask *in, SwTask *out) {
+    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < ntasks; k += gridDim.x * 256) out[k] = in[tidx[k]];
+}
+
+// bounds[c] = first task of class >= c, bounds[18 + c] = first sorted pair of class >= c   (c = 0..17)
+__global__ void plan_bounds_kernel(uint32_t ntasks, const uint32_t *tcls, uint32_t n, const uint64_t *key, uint32_t *bounds) {
+    const uint32_t c = threadIdx.x;
+    if (c >= 18) return;
+    uint32_t lo = 0, hi = ntasks;
+    while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (tcls[m] < c) lo = m + 1; else hi = m; }
+    bounds[c] = lo;
+    lo = 0; hi = n;
+    while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if ((uint32_t)(key[m] >> 40) < c) lo = m + 1; else hi = m; }
+    bounds[18 + c] = lo;
+}
+
+__global__ void __launch_bounds__(256) scatter3_kernel(uint32_t n, const uint32_t *idx, const int32_t *a, const int32_t *b,
+                                                       const int32_t *c, int32_t *oa, int32_t *ob, int32_t *oc) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t o = idx[i];
+        oa[o] = a[i];
+        if (b) { ob[o] = b[i]; oc[o] = c[i]; }
+    }
+}
+
+// ---- gates --------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gate_kernel(uint32_t n, const uint32_t *sq, const int32_t *s0, const int32_t *s1,
+                                                   const int32_t *minscore, uint32_t qbase, uint32_t *flag) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int32_t rev = s1 ? s1[i] : 0;
+        flag[i] = (s0[i] > 0 && s0[i] - rev >= minscore[sq[i] - qbase]) ? 1u : 0u;
+    }
+}
+
+__global__ void __launch_bounds__(256) gate_scatter_kernel(uint32_t n, const uint32_t *flag, const uint32_t *pos, const uint32_t *sq,
+                                                           const uint32_t *st, const int32_t *qe, const int32_t *te, uint32_t *q2,
+                                                           uint32_t *t2, int32_t *qe2, int32_t *te2, uint32_t *link) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        if (!flag[i]) continue;
+        const uint32_t w = pos[i];
+        q2[w] = sq[i]; t2[w] = st[i]; qe2[w] = qe[i]; te2[w] = te[i]; link[w] = i;
+    }
+}
+
+__global__ void __launch_bounds__(256) aln_basic_kernel(uint32_t n, const uint32_t *idx, const int32_t *s0, const int32_t *s1,
+                                                        const int32_t *qe, const int32_t *te, const uint32_t *pass, uc_aln *out) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        uc_aln a;
+        a.score = s0[i]; a.score_rev = s1 ? s1[i] : 0; a.corrected = a.score - a.score_rev;
+        a.qstart = -1; a.qend = qe[i]; a.tstart = -1; a.tend = te[i];
+        a.aln_len = 0; a.idents = 0; a.pass_evalue = (int32_t)pass[i]; a.accepted = 0;
+        out[idx[i]] = a;
+    }
+}
+
+// over the start-pass results (sorted order of plan 2): start positions, coverage gate, edge flag
+__global__ void __launch_bounds__(256) finalize_kernel(uint32_t n2, const uint32_t *idx2, const uint32_t *link, const uint32_t *idx0,
+                                                       const uint32_t *sq2, const uint32_t *st2, const int32_t *s2, const int32_t *q2o,
+                                                       const int32_t *t2o, const uint32_t *len, float cov, int cov_mode, uc_aln *alns,
+                                                       uint32_t *eflag, uint32_t *mismatch) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
+        uc_aln &a = alns[idx0[link[idx2[i]]]];
+        if (s2[i] != a.score) atomicAdd(mismatch, 1u);
+        a.qstart = a.qend - q2o[i];
+        a.tstart = a.tend - t2o[i];
+        const float qcov = (float)(a.qend - a.qstart + 1) / (float)len[sq2[i]];
+        const float tcov = (float)(a.tend - a.tstart + 1) / (float)len[st2[i]];
+        const bool ok = cov_mode == 0 ? (qcov >= cov && tcov >= cov) : cov_mode == 1 ? (tcov >= cov) : (qcov >= cov);
+        a.accepted = ok;
+        eflag[i] = ok;
+    }
+}
+
+__global__ void __launch_bounds__(256) edge_scatter_kernel(uint32_t n2, const uint32_t *eflag, const uint32_t *epos, const uint32_t *sq2,
+                                                           const uint32_t *st2, uint32_t *edges) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
+        if (!eflag[i]) continue;
+        edges[2 * epos[i]] = sq2[i];
+        edges[2 * epos[i] + 1] = st2[i];
+    }
+}
+
+struct MaxU32 {
+    __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; }
+};
+
+}  // namespace
+
+// ---- planner -----------------------------------------------------------------------------------------
+struct SwPlan {
+    uint32_t n = 0, ntasks = 0;
+    DevBuf<uint64_t> key, key2;
+    DevBuf<uint32_t> idx_in, idx, sq, st, head, segstart, flag, tpos, tcls, bounds;
+    DevBuf<int32_t> sqe, ste;
+    DevBuf<SwTask> tasks, tasks_in;
+    DevBuf<uint64_t> tkey, tkey2;
+    DevBuf<uint32_t> tidx, tidx2;
+    DevBuf<unsigned long long> bytes;
+    uint32_t task_base[18] = {0}, pair_base[18] = {0};
+    uint64_t alg_bytes = 0, cells = 0;
+    bool has_ends = false;
+};
+
+static void scan_u32(Engine &E, DevBuf<char> &tmp, const uint32_t *in, uint32_t *out, uint32_t n, bool inclusive_max) {
+    size_t tb = 0;
+    if (inclusive_max) {
+        UC_HIP(rocprim::inclusive_scan(nullptr, tb, in, out, (size_t)n, MaxU32(), E.stream));
+        tmp.reserve(tb + 256);
+        UC_HIP(rocprim::inclusive_scan(tmp.p, tb, in, out, (size_t)n, MaxU32(), E.stream));
+    } else {
+        UC_HIP(rocprim::exclusive_scan(nullptr, tb, in, out, 0u, (size_t)n, rocprim::plus<uint32_t>(), E.stream));
+        tmp.reserve(tb + 256);
+        UC_HIP(rocprim::exclusive_scan(tmp.p, tb, in, out, 0u, (size_t)n, rocprim::plus<uint32_t>(), E.stream));
+    }
+}
+
+// total of a 0/1 flag array given its exclusive scan
+static uint32_t scan_total(Engine &E, const uint32_t *flag, const uint32_t *pos, uint32_t n) {
+    if (!n) return 0;
+    uint32_t a = 0, b = 0;
+    UC_HIP(hipMemcpyAsync(&a, pos + (n - 1), 4, hipMemcpyDeviceToHost, E.stream));
+    UC_HIP(hipMemcpyAsync(&b, flag + (n - 1), 4, hipMemcpyDeviceToHost, E.stream));
+    UC_HIP(hipStreamSynchronize(E.stream));
+    return a + b;
+}
+
+static void build_plan(Engine &E, SwPlan &P, DevBuf<char> &tmp, uint32_t n, const uint32_t *q, const uint32_t *t,
+                       const int32_t *qe, const int32_t *te) {
+    P.n = n; P.ntasks = 0; P.alg_bytes = 0; P.cells = 0; P.has_ends = qe != nullptr;
+    memset(P.task_base, 0, sizeof P.task_base);
+    memset(P.pair_base, 0, sizeof P.pair_base);
+    if (!n) return;
+    hipStream_t s = E.stream;
+    P.key.reserve(n); P.key2.reserve(n); P.idx_in.reserve(n); P.idx.reserve(n);
+    P.sq.reserve(n); P.st.reserve(n); P.head.reserve(n); P.segstart.reserve(n); P.flag.reserve(n); P.tpos.reserve(n);
+    if (qe) { P.sqe.reserve(n); P.ste.reserve(n); }
+    P.bytes.reserve(2); P.bounds.reserve(36);
+    UC_HIP(hipMemsetAsync(P.bytes.p, 0, 16, s));
+    hipLaunchKernelGGL(plan_key_kernel, grid_for(n), dim3(256), 0, s, n, q, t, qe, te, E.ddb.len, P.key.p, P.idx_in.p, P.bytes.p);
+    size_t tb = 0;
+    UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, P.key.p, P.key2.p, P.idx_in.p, P.idx.p, (size_t)n, 0u, 45u, s));
+    tmp.reserve(tb + 256);
+    UC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, P.key.p, P.key2.p, P.idx_in.p, P.idx.p, (size_t)n, 0u, 45u, s));
+    hipLaunchKernelGGL(plan_gather_kernel, grid_for(n), dim3(256), 0, s, n, P.key2.p, P.idx.p, t, qe, te, P.sq.p, P.st.p, P.sqe.p, P.ste.p, P.head.p);
+    scan_u32(E, tmp, P.head.p, P.segstart.p, n, true);
+    hipLaunchKernelGGL(plan_taskflag_kernel, grid_for(n), dim3(256), 0, s, n, P.key2.p, P.segstart.p, P.flag.p);
+    scan_u32(E, tmp, P.flag.p, P.tpos.p, n, false);
+    P.ntasks = scan_total(E, P.flag.p, P.tpos.p, n);
+    P.tasks.reserve(P.ntasks); P.tcls.reserve(P.ntasks);
+    hipLaunchKernelGGL(plan_taskfill_kernel, grid_for(n), dim3(256), 0, s, n, P.key2.p, P.flag.p, P.tpos.p, P.tasks.p, P.tcls.p);
+    // longest-processing-time-first inside each class: the big tasks start first, the small ones fill the tail
+    P.tasks_in.reserve(P.ntasks); P.tkey.reserve(P.ntasks); P.tkey2.reserve(P.ntasks); P.tidx.reserve(P.ntasks); P.tidx2.reserve(P.ntasks);
+    hipLaunchKernelGGL(plan_taskcount_kernel, grid_for(P.ntasks), dim3(256), 0, s, P.ntasks, n, P.tasks.p, P.tcls.p, P.key2.p, P.tkey.p, P.tidx.p);
+    UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, P.tkey.p, P.tkey2.p, P.tidx.p, P.tidx2.p, (size_t)P.ntasks, 0u, 37u, s));
+    tmp.reserve(tb + 256);
+    UC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, P.tkey.p, P.tkey2.p, P.tidx.p, P.tidx2.p, (size_t)P.ntasks, 0u, 37u, s));
+    UC_HIP(hipMemcpyAsync(P.tasks_in.p, P.tasks.p, (size_t)P.ntasks * sizeof(SwTask), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(plan_taskgather_kernel, grid_for(P.ntasks), dim3(256), 0, s, P.ntasks, P.tidx2.p, P.tasks_in.p, P.tasks.p);
+    hipLaunchKernelGGL(plan_bounds_kernel, dim3(1), dim3(64), 0, s, P.ntasks, P.tcls.p, n, P.key2.p, P.bounds.p);
+    uint32_t hb[36];
+    unsigned long long bytes[2] = {0, 0};
+    UC_HIP(hipMemcpyAsync(hb, P.bounds.p, sizeof hb, hipMemcpyDeviceToHost, s));
+    UC_HIP(hipMemcpyAsync(bytes, P.bytes.p, 16, hipMemcpyDeviceToHost, s));
+    UC_HIP(hipStreamSynchronize(s));
+    UC_HIP(hipGetLastError());
+    memcpy(P.task_base, hb, 18 * 4);
+    memcpy(P.pair_base, hb + 18, 18 * 4);
+    P.alg_bytes = bytes[0];
+    P.cells = bytes[1];
+}
+
+// one launch per populated class; outputs are in the plan's sorted order
+static void run_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t *oqe, int32_t *ote, DevBuf<int32_t> &work) {
+    if (!P.n) return;
+    SwArgs a;
+    a.db = E.ddb; a.tasks = P.tasks.p; a.pt = P.st.p; a.pqe = P.sqe.p; a.pte = P.ste.p;
+    a.oscore = os; a.oqe = oqe; a.ote = ote; a.open = E.p.gap_open; a.ext = E.p.gap_ext;
+    uint64_t launches = 0;
+    E.timed_ms_begin();
+    for (int c = 0; c < 16; c++) {
+        const uint32_t nt = P.task_base[c + 1] - P.task_base[c];
+        if (!nt) continue;
+        SwArgs ac = a;
+        ac.tasks = P.tasks.p + P.task_base[c];
+        launch_sw_class(h_cls_g[c], h_cls_r[c], mode, ac, nt, E.stream);
+        UC_HIP(hipGetLastError());
+        launches++;
+    }
+    const uint32_t gb = P.pair_base[16], ngen = P.n - gb;
+    if (ngen) {   // queries longer than the largest systolic class
+        const size_t lanes = (size_t)((ngen + 63) / 64) * 64;
+        work.reserve(2 * (size_t)E.max_len * lanes);
+        SwArgs ag = a;
+        ag.pt = P.st.p + gb;
+        ag.pqe = P.has_ends ? P.sqe.p + gb : nullptr;
+        ag.pte = P.has_ends ? P.ste.p + gb : nullptr;
+        ag.oscore = os + gb;
+        ag.oqe = oqe ? oqe + gb : nullptr;
+        ag.ote = ote ? ote + gb : nullptr;
+        launch_sw_generic(mode, ag, ngen, P.sq.p + gb, work.p, E.max_len, E.stream);
+        UC_HIP(hipGetLastError());
+        launches++;
+    }
+    E.stats.sw_kernel_ms += E.timed_ms_end();
+    E.stats.sw_kernel_launches += launches;
+    E.stats.sw_algorithmic_bytes += P.alg_bytes;
+}
+
+// ---- kernel-level entry point: arbitrary pair list from the host -----------------------------------
+void Engine::sw_batch(int mode, const std::vector<PairIn> &pairs, int32_t *score, int32_t *qe, int32_t *te) {
+    if (!have_db) fail(UC_ERR_ARGS, "no database loaded");
+    const size_t n = pairs.size();
+    if (n == 0) return;
+    if (n >= (1ull << 31)) fail(UC_ERR_ARGS, "sw_batch: too many pairs");
+    UC_HIP(hipSetDevice(device));
+    const bool track = mode != 1;
+    std::vector<uint32_t> hq(n), ht(n);
+    std::vector<int32_t> hqe, hte;
+    if (mode == 2) { hqe.resize(n); hte.resize(n); }
+    for (size_t i = 0; i < n; i++) {
+        const PairIn &x = pairs[i];
+        if (x.q >= hdb.n || x.t >= hdb.n) fail(UC_ERR_ARGS, "sw_batch: sequence id out of range");
+        if (mode == 2 && (x.qe < 0 || x.te < 0 || (uint32_t)x.qe >= h_len[x.q] || (uint32_t)x.te >= h_len[x.t]))
+            fail(UC_ERR_ARGS, "sw_batch: end position out of range");
+        hq[i] = x.q; ht[i] = x.t;
+        if (mode == 2) { hqe[i] = x.qe; hte[i] = x.te; }
+    }
+    DevBuf<uint32_t> dq, dt;
+    DevBuf<int32_t> dqe, dte, os, oq, ot, rs, rq, rt, work;
+    DevBuf<char> tmp;
+    dq.reserve(n); dt.reserve(n); os.reserve(n); rs.reserve(n);
+    UC_HIP(hipMemcpyAsync(dq.p, hq.data(), n * 4, hipMemcpyHostToDevice, stream));
+    UC_HIP(hipMemcpyAsync(dt.p, ht.data(), n * 4, hipMemcpyHostToDevice, stream));
+    if (mode == 2) {
+        dqe.reserve(n); dte.reserve(n);
+        UC_HIP(hipMemcpyAsync(dqe.p, hqe.data(), n * 4, hipMemcpyHostToDevice, stream));
+        UC_HIP(hipMemcpyAsync(dte.p, hte.data(), n * 4, hipMemcpyHostToDevice, stream));
+    }
+    if (track) { oq.reserve(n); ot.reserve(n); rq.reserve(n); rt.reserve(n); }
+    SwPlan P;
+    build_plan(*this, P, tmp, (uint32_t)n, dq.p, dt.p, dqe.p, dte.p);
+    run_plan(*this, P, mode, os.p, oq.p, ot.p, work);
+    hipLaunchKernelGGL(scatter3_kernel, grid_for(n), dim3(256), 0, stream, (uint32_t)n, P.idx.p, os.p, oq.p, ot.p, rs.p, rq.p, rt.p);
+    UC_HIP(hipMemcpyAsync(score, rs.p, n * 4, hipMemcpyDeviceToHost, stream));
+    if (track && qe) UC_HIP(hipMemcpyAsync(qe, rq.p, n * 4, hipMemcpyDeviceToHost, stream));
+    if (track && te) UC_HIP(hipMemcpyAsync(te, rt.p, n * 4, hipMemcpyDeviceToHost, stream));
+    UC_HIP(hipStreamSynchronize(stream));
+    UC_HIP(hipGetLastError());
+}
+
+// ---- stage E5 + E6 for queries [qbegin, qend) of the device-resident hit lists ----------------------
+void Engine::align(uint32_t qbegin, uint32_t qend) {
+    if (!have_db) fail(UC_ERR_ARGS, "no database loaded");
+    if (qbegin > qend || qend > hdb.n) fail(UC_ERR_ARGS, "align: bad query range");
+    if (p.min_seq_id > 0.0f)
+        fail(UC_ERR_ARGS, "--min-seq-id > 0 needs the traceback pass, which this build does not implement yet");
+    UC_HIP(hipSetDevice(device));
+    Timer tm;
+    hipStream_t s = stream;
+    const uint64_t dbres = hdb.residues();
+    if (d_alns.cap < std::max<uint64_t>(n_hits, 1)) {
+        d_alns.reserve(std::max<uint64_t>(n_hits, 1));
+        UC_HIP(hipMemsetAsync(d_alns.p, 0, n_hits * sizeof(uc_aln), s));
+    }
+    // E-value gate as an integer threshold per query length (host; exp() evaluated once per distinct length)
+    std::vector<int32_t> ms_by_len(65536, -1), h_ms(qend - qbegin);
+    for (uint32_t q = qbegin; q < qend; q++) {
+        int32_t &m = ms_by_len[h_len[q]];
+        if (m < 0) m = min_score_for(p, (int)h_len[q], dbres);
+        h_ms[q - qbegin] = m;
+    }
+    DevBuf<int32_t> d_ms, s0, qe0, te0, s1, qe2, te2, s2, q2o, t2o, work;
+    DevBuf<uint32_t> gflag, gpos, q2, t2, link, eflag, epos, mism, d_e;
+    DevBuf<char> tmp;
+    SwPlan P0, P2;
+    d_ms.reserve(std::max<size_t>(h_ms.size(), 1));
+    if (!h_ms.empty()) UC_HIP(hipMemcpyAsync(d_ms.p, h_ms.data(), h_ms.size() * 4, hipMemcpyHostToDevice, s));
+    mism.reserve(1);
+    UC_HIP(hipMemsetAsync(mism.p, 0, 4, s));
+
+    const uint64_t CHUNK = 64ull << 20;   // pairs per device batch
+    for (uint32_t qa = qbegin; qa < qend;) {
+        uint32_t qb = qa;
+        while (qb < qend && (qb == qa || hit_off[qb + 1] - hit_off[qa] <= CHUNK)) qb++;
+        const uint64_t b = hit_off[qa];
+        const uint32_t n = (uint32_t)(hit_off[qb] - b);
+        if (n) {
+            s0.reserve(n); qe0.reserve(n); te0.reserve(n); gflag.reserve(n); gpos.reserve(n);
+            build_plan(*this, P0, tmp, n, d_hq.p + b, d_ht.p + b, nullptr, nullptr);
+            run_plan(*this, P0, 0, s0.p, qe0.p, te0.p, work);
+            stats.cells_fwd += P0.cells;
+            if (p.rev_correction) { s1.reserve(n); run_plan(*this, P0, 1, s1.p, nullptr, nullptr, work); stats.cells_rev += P0.cells; }
+            const int32_t *s1p = p.rev_correction ? s1.p : nullptr;
+            hipLaunchKernelGGL(gate_kernel, grid_for(n), dim3(256), 0, s, n, P0.sq.p, s0.p, s1p, d_ms.p, qbegin, gflag.p);
+            scan_u32(*this, tmp, gflag.p, gpos.p, n, false);
+            const uint32_t n2 = scan_total(*this, gflag.p, gpos.p, n);
+            hipLaunchKernelGGL(aln_basic_kernel, grid_for(n), dim3(256), 0, s, n, P0.idx.p, s0.p, s1p, qe0.p, te0.p, gflag.p, d_alns.p + b);
+            if (n2) {
+                q2.reserve(n2); t2.reserve(n2); qe2.reserve(n2); te2.reserve(n2); link.reserve(n2);
+                s2.reserve(n2); q2o.reserve(n2); t2o.reserve(n2); eflag.reserve(n2); epos.reserve(n2);
+                hipLaunchKernelGGL(gate_scatter_kernel, grid_for(n), dim3(256), 0, s, n, gflag.p, gpos.p, P0.sq.p, P0.st.p, qe0.p, te0.p,
+                                   q2.p, t2.p, qe2.p, te2.p, link.p);
+                build_plan(*this, P2, tmp, n2, q2.p, t2.p, qe2.p, te2.p);
+                run_plan(*this, P2, 2, s2.p, q2o.p, t2o.p, work);
+                stats.cells_start += P2.cells;
+                hipLaunchKernelGGL(finalize_kernel, grid_for(n2), dim3(256), 0, s, n2, P2.idx.p, link.p, P0.idx.p, P2.sq.p, P2.st.p, s2.p,
+                                   q2o.p, t2o.p, ddb.len, p.cov, p.cov_mode, d_alns.p + b, eflag.p, mism.p);
+                scan_u32(*this, tmp, eflag.p, epos.p, n2, false);
+                const uint32_t ne = scan_total(*this, eflag.p, epos.p, n2);
+                if (ne) {
+                    d_e.reserve(2 * (size_t)ne);
+                    hipLaunchKernelGGL(edge_scatter_kernel, grid_for(n2), dim3(256), 0, s, n2, eflag.p, epos.p, P2.sq.p, P2.st.p, d_e.p);
+                    const size_t old = edges.size();
+                    edges.resize(old + 2 * (size_t)ne);
+                    UC_HIP(hipMemcpyAsync(edges.data() + old, d_e.p, 2 * (size_t)ne * 4, hipMemcpyDeviceToHost, s));
+                }
+            }
+            uint32_t bad = 0;
+            UC_HIP(hipMemcpyAsync(&bad, mism.p, 4, hipMemcpyDeviceToHost, s));
+            UC_HIP(hipStreamSynchronize(s));
+            UC_HIP(hipGetLastError());
+            if (bad) fail(UC_ERR_GENERIC, "start pass score differs from the forward score for %u pairs", bad);
+            stats.n_gapped_alignments += n;
+            stats.n_start_alignments += n2;
+        }
+        qa = qb;
+    }
+    alns_valid = true;
+    stats.n_edges = edges.size() / 2;
+    stats.algorithmic_bytes[UC_ST_GAPPED] = stats.sw_algorithmic_bytes;
+    stats.stage_seconds[UC_ST_GAPPED] += tm.seconds();
+}
+
+}  // namespace uc

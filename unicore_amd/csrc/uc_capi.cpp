@@ -128,7 +128,7 @@ int uc_engine_prefilter(uc_engine *e, uint32_t tbegin, uint32_t tend) {
 }
 
 int uc_engine_hits_size(const uc_engine *e, uint64_t *n_hits) {
-    return guard([&] { require(e, "engine"); require(n_hits, "n_hits"); *n_hits = e->e->hits.size(); });
+    return guard([&] { require(e, "engine"); require(n_hits, "n_hits"); *n_hits = e->e->n_hits; });
 }
 
 int uc_engine_hits_get(const uc_engine *e, uint32_t *counts, uc_hit *hits) {
@@ -136,7 +136,7 @@ int uc_engine_hits_get(const uc_engine *e, uint32_t *counts, uc_hit *hits) {
         require(e, "engine");
         const Engine &E = *e->e;
         if (counts && E.hdb.n) memcpy(counts, E.hit_cnt.data(), (size_t)E.hdb.n * 4);
-        if (hits && !E.hits.empty()) memcpy(hits, E.hits.data(), E.hits.size() * sizeof(uc_hit));
+        if (hits) E.get_hits(hits);
     });
 }
 
@@ -179,7 +179,7 @@ int uc_engine_alns_get(const uc_engine *e, uint32_t qbegin, uint32_t qend, uc_al
         const Engine &E = *e->e;
         if (qbegin > qend || qend > E.hdb.n) fail(UC_ERR_ARGS, "alns_get: bad query range");
         const uint64_t b = E.hit_off[qbegin], n = E.hit_off[qend] - b;
-        if (n) { require(out, "out"); memcpy(out, E.alns.data() + b, n * sizeof(uc_aln)); }
+        if (n) { require(out, "out"); E.get_alns(b, n, out); }
     });
 }
 
@@ -260,7 +260,7 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
         E.upload_db();
         logf(3, "unicore-cluster: %u sequences, %llu residues on device %d\n", E.hdb.n, (unsigned long long)E.hdb.residues(), E.device);
         E.prefilter(0, E.hdb.n);
-        logf(3, "unicore-cluster: prefilter kept %zu pairs (k-score %d, max-seqs %d)\n", E.hits.size(), p.kmer_thr, p.max_seqs);
+        logf(3, "unicore-cluster: prefilter kept %llu pairs (k-score %d, max-seqs %d)\n", (unsigned long long)E.n_hits, p.kmer_thr, p.max_seqs);
         E.align(0, E.hdb.n);
         logf(3, "unicore-cluster: %llu alignments, %llu accepted\n", (unsigned long long)E.stats.n_gapped_alignments, (unsigned long long)E.stats.n_edges);
         Timer tc;

@@ -76,8 +76,11 @@ void Engine::upload_db() {
     have_db = true;
     hit_cnt.assign(n, 0);
     hit_off.assign((size_t)n + 1, 0);
-    hits.clear(); alns.clear(); edges.clear();
-    aln_done.assign(n, 0);
+    n_hits = 0;
+    alns_valid = false;
+    edges.clear();
+    max_len = 1;
+    for (uint32_t i = 0; i < n; i++) max_len = std::max(max_len, h_len[i]);
     stats.n_seqs = n;
     stats.n_residues = hdb.residues();
     stats.algorithmic_bytes[UC_ST_LOAD] += 2 * hdb.residues() + 12ull * n;
@@ -96,238 +99,57 @@ void Engine::ungapped_batch(uint64_t n, const uint32_t *q, const uint32_t *t, co
     UC_HIP(hipMemcpyAsync(dq.p, q, n * 4, hipMemcpyHostToDevice, stream));
     UC_HIP(hipMemcpyAsync(dt.p, t, n * 4, hipMemcpyHostToDevice, stream));
     UC_HIP(hipMemcpyAsync(dd.p, diag, n * 4, hipMemcpyHostToDevice, stream));
-    launch_ungapped(ddb, n, dq.p, dt.p, dd.p, ds.p, stream);
+    launch_ungapped(ddb, n, dq.p, dt.p, dd.p, ds.p, nullptr, stream);
     UC_HIP(hipGetLastError());
     UC_HIP(hipMemcpyAsync(out, ds.p, n * 4, hipMemcpyDeviceToHost, stream));
     UC_HIP(hipStreamSynchronize(stream));
 }
 
-// Gapped DP for a list of pairs (any order).  Host side: group by query, pick the (G,R) class from the
-// query length, sort each query's targets by length so the alignments sharing a wave finish together,
-// cut into workgroup tasks; device side: one launch per class (uc_sw_impl.hpp).
-void Engine::sw_batch(int mode, const std::vector<PairIn> &pairs, int32_t *score, int32_t *qe, int32_t *te) {
-    if (!have_db) fail(UC_ERR_ARGS, "no database loaded");
-    const size_t n = pairs.size();
-    if (n == 0) return;
-    UC_HIP(hipSetDevice(device));
-    const bool track = mode != 1;
-    for (size_t i = 0; i < n; i++) {
-        const PairIn &x = pairs[i];
-        if (x.q >= hdb.n || x.t >= hdb.n) fail(UC_ERR_ARGS, "sw_batch: sequence id out of range");
-        if (mode == 2 && (x.qe < 0 || x.te < 0 || (uint32_t)x.qe >= h_len[x.q] || (uint32_t)x.te >= h_len[x.t]))
-            fail(UC_ERR_ARGS, "sw_batch: end position out of range");
-    }
-    // ---- order: by query (stable), then effective target length descending
-    std::vector<uint32_t> order(n);
-    std::iota(order.begin(), order.end(), 0u);
-    bool grouped = true;
-    for (size_t i = 1; i < n && grouped; i++) grouped = pairs[i].q >= pairs[i - 1].q;
-    auto tlen = [&](uint32_t i) { return mode == 2 ? (uint32_t)pairs[i].te + 1 : h_len[pairs[i].t]; };
-    if (!grouped) std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return pairs[a].q < pairs[b].q; });
-    struct Task { SwTask t; uint64_t work; };
-    constexpr int NCLS = 17;   // 16 group classes + generic
-    static const int cls_g[16] = {16, 16, 16, 16, 16, 16, 16, 16, 32, 32, 32, 32, 64, 64, 64, 64};
-    static const int cls_r[16] = {4, 8, 12, 16, 20, 24, 28, 32, 20, 24, 28, 32, 20, 24, 28, 32};
-    std::vector<std::vector<uint32_t>> cls_pairs(NCLS);   // sorted pair order per class
-    std::vector<std::vector<Task>> cls_tasks(NCLS);
-    uint64_t alg_bytes = 0;
-    for (size_t b = 0; b < n;) {
-        size_t e = b;
-        const uint32_t q = pairs[order[b]].q;
-        while (e < n && pairs[order[e]].q == q) e++;
-        std::sort(order.begin() + b, order.begin() + e, [&](uint32_t x, uint32_t y) {
-            uint32_t lx = tlen(x), ly = tlen(y);
-            return lx != ly ? lx > ly : x < y;
-        });
-        int G, R, c = 16;
-        if (sw_class_for((int)h_len[q], &G, &R))
-            for (c = 0; c < 16; c++) if (cls_g[c] == G && cls_r[c] == R) break;
-        std::vector<uint32_t> &cp = cls_pairs[c];
-        for (size_t k = b; k < e; k += 256) {
-            const size_t cnt = std::min<size_t>(256, e - k);
-            uint64_t work = 0;
-            for (size_t m = k; m < k + cnt; m++) work += tlen(order[m]);
-            cls_tasks[c].push_back({{q, (uint32_t)cp.size(), (uint32_t)cnt}, work});
-            for (size_t m = k; m < k + cnt; m++) {
-                cp.push_back(order[m]);
-                const uint32_t ql = mode == 2 ? (uint32_t)pairs[order[m]].qe + 1 : h_len[q];
-                alg_bytes += 2ull * (ql + tlen(order[m])) + 32;
-            }
-        }
-        b = e;
-    }
-    // ---- flatten: pairs of all classes back to back
-    std::vector<uint32_t> flat; flat.reserve(n);
-    std::vector<uint32_t> cls_base(NCLS + 1, 0);
-    for (int c = 0; c < NCLS; c++) { cls_base[c] = (uint32_t)flat.size(); flat.insert(flat.end(), cls_pairs[c].begin(), cls_pairs[c].end()); }
-    cls_base[NCLS] = (uint32_t)flat.size();
-    std::vector<uint32_t> h_pt(n), h_pq;
-    std::vector<int32_t> h_qe, h_te;
-    for (size_t i = 0; i < n; i++) h_pt[i] = pairs[flat[i]].t;
-    if (mode == 2) {
-        h_qe.resize(n); h_te.resize(n);
-        for (size_t i = 0; i < n; i++) { h_qe[i] = pairs[flat[i]].qe; h_te[i] = pairs[flat[i]].te; }
-    }
-    std::vector<SwTask> h_tasks;
-    std::vector<uint32_t> task_base(NCLS + 1, 0);
-    for (int c = 0; c < 16; c++) {
-        task_base[c] = (uint32_t)h_tasks.size();
-        std::vector<Task> &tv = cls_tasks[c];
-        std::stable_sort(tv.begin(), tv.end(), [](const Task &a, const Task &b) { return a.work > b.work; });   // big first
-        for (Task &t : tv) { t.t.begin += cls_base[c]; h_tasks.push_back(t.t); }
-    }
-    task_base[16] = task_base[NCLS] = (uint32_t)h_tasks.size();
-
-    DevBuf<uint32_t> d_pt, d_pq;
-    DevBuf<int32_t> d_qe, d_te, d_os, d_oq, d_ot, d_work;
-    DevBuf<SwTask> d_tasks;
-    d_pt.reserve(n); d_os.reserve(n);
-    UC_HIP(hipMemcpyAsync(d_pt.p, h_pt.data(), n * 4, hipMemcpyHostToDevice, stream));
-    if (mode == 2) {
-        d_qe.reserve(n); d_te.reserve(n);
-        UC_HIP(hipMemcpyAsync(d_qe.p, h_qe.data(), n * 4, hipMemcpyHostToDevice, stream));
-        UC_HIP(hipMemcpyAsync(d_te.p, h_te.data(), n * 4, hipMemcpyHostToDevice, stream));
-    }
-    if (track) { d_oq.reserve(n); d_ot.reserve(n); }
-    if (!h_tasks.empty()) {
-        d_tasks.reserve(h_tasks.size());
-        UC_HIP(hipMemcpyAsync(d_tasks.p, h_tasks.data(), h_tasks.size() * sizeof(SwTask), hipMemcpyHostToDevice, stream));
-    }
-    SwArgs a;
-    a.db = ddb; a.tasks = d_tasks.p; a.pt = d_pt.p; a.pqe = d_qe.p; a.pte = d_te.p;
-    a.oscore = d_os.p; a.oqe = d_oq.p; a.ote = d_ot.p; a.open = p.gap_open; a.ext = p.gap_ext;
-
-    uint64_t launches = 0;
-    timed_ms_begin();
-    for (int c = 0; c < 16; c++) {
-        const uint32_t nt = task_base[c + 1] - task_base[c];
-        if (!nt) continue;
-        SwArgs ac = a;
-        ac.tasks = d_tasks.p + task_base[c];
-        launch_sw_class(cls_g[c], cls_r[c], mode, ac, nt, stream);
-        UC_HIP(hipGetLastError());
-        launches++;
-    }
-    const uint32_t ngen = cls_base[17] - cls_base[16];
-    if (ngen) {   // long queries: generic one-lane-per-pair kernel
-        h_pq.resize(ngen);
-        uint32_t max_lq = 1;
-        for (uint32_t i = 0; i < ngen; i++) { h_pq[i] = pairs[flat[cls_base[16] + i]].q; max_lq = std::max(max_lq, h_len[h_pq[i]]); }
-        d_pq.reserve(ngen);
-        UC_HIP(hipMemcpyAsync(d_pq.p, h_pq.data(), (size_t)ngen * 4, hipMemcpyHostToDevice, stream));
-        const size_t lanes = (size_t)((ngen + 63) / 64) * 64;
-        d_work.reserve(2 * (size_t)max_lq * lanes);
-        SwArgs ag = a;
-        ag.pt = d_pt.p + cls_base[16];
-        ag.pqe = mode == 2 ? d_qe.p + cls_base[16] : nullptr;
-        ag.pte = mode == 2 ? d_te.p + cls_base[16] : nullptr;
-        ag.oscore = d_os.p + cls_base[16];
-        ag.oqe = track ? d_oq.p + cls_base[16] : nullptr;
-        ag.ote = track ? d_ot.p + cls_base[16] : nullptr;
-        launch_sw_generic(mode, ag, ngen, d_pq.p, d_work.p, max_lq, stream);
-        UC_HIP(hipGetLastError());
-        launches++;
-    }
-    const double ms = timed_ms_end();
-    stats.sw_kernel_ms += ms;
-    stats.sw_kernel_launches += launches;
-    stats.sw_algorithmic_bytes += alg_bytes;
-
-    std::vector<int32_t> r_s(n), r_q, r_t;
-    UC_HIP(hipMemcpyAsync(r_s.data(), d_os.p, n * 4, hipMemcpyDeviceToHost, stream));
-    if (track) {
-        r_q.resize(n); r_t.resize(n);
-        UC_HIP(hipMemcpyAsync(r_q.data(), d_oq.p, n * 4, hipMemcpyDeviceToHost, stream));
-        UC_HIP(hipMemcpyAsync(r_t.data(), d_ot.p, n * 4, hipMemcpyDeviceToHost, stream));
-    }
-    UC_HIP(hipStreamSynchronize(stream));
-    for (size_t i = 0; i < n; i++) {
-        score[flat[i]] = r_s[i];
-        if (track && qe) qe[flat[i]] = r_q[i];
-        if (track && te) te[flat[i]] = r_t[i];
-    }
-}
-
 void Engine::set_hits(const uint32_t *counts, const uc_hit *h) {
     const uint32_t n = hdb.n;
+    UC_HIP(hipSetDevice(device));
     hit_cnt.assign(counts, counts + n);
     hit_off.assign((size_t)n + 1, 0);
     for (uint32_t i = 0; i < n; i++) {
         if (counts[i] > (uint32_t)p.max_seqs) fail(UC_ERR_ARGS, "hit list of query %u longer than max_seqs", i);
         hit_off[i + 1] = hit_off[i] + counts[i];
     }
-    hits.assign(h, h + hit_off[n]);
-    for (const uc_hit &x : hits) if (x.target >= n) fail(UC_ERR_ARGS, "hit target out of range");
-    alns.assign(hits.size(), uc_aln{});
-    aln_done.assign(n, 0);
+    n_hits = hit_off[n];
+    std::vector<uint32_t> hq(n_hits), ht(n_hits);
+    std::vector<int32_t> hs(n_hits), hd(n_hits);
+    for (uint32_t q = 0; q < n; q++)
+        for (uint64_t k = hit_off[q]; k < hit_off[q + 1]; k++) {
+            if (h[k].target >= n) fail(UC_ERR_ARGS, "hit target out of range");
+            hq[k] = q; ht[k] = h[k].target; hs[k] = h[k].score; hd[k] = h[k].diag;
+        }
+    const size_t cap = std::max<uint64_t>(n_hits, 1);
+    d_hq.reserve(cap); d_ht.reserve(cap); d_hs.reserve(cap); d_hd.reserve(cap);
+    if (n_hits) {
+        UC_HIP(hipMemcpy(d_hq.p, hq.data(), n_hits * 4, hipMemcpyHostToDevice));
+        UC_HIP(hipMemcpy(d_ht.p, ht.data(), n_hits * 4, hipMemcpyHostToDevice));
+        UC_HIP(hipMemcpy(d_hs.p, hs.data(), n_hits * 4, hipMemcpyHostToDevice));
+        UC_HIP(hipMemcpy(d_hd.p, hd.data(), n_hits * 4, hipMemcpyHostToDevice));
+    }
+    alns_valid = false;
     edges.clear();
 }
 
-// Stage E5 + E6 for queries [qbegin, qend): forward pass (score + end), reversed-query pass, E-value
-// gate on the corrected score, start pass for the survivors, coverage gate -> edges.
-void Engine::align(uint32_t qbegin, uint32_t qend) {
-    if (!have_db) fail(UC_ERR_ARGS, "no database loaded");
-    if (qbegin > qend || qend > hdb.n) fail(UC_ERR_ARGS, "align: bad query range");
-    if (p.min_seq_id > 0.0f)
-        fail(UC_ERR_ARGS, "--min-seq-id > 0 needs the traceback pass, which this build does not implement yet");
-    Timer tm;
-    const uint64_t dbres = hdb.residues();
-    const size_t CHUNK = 8u << 20;   // pairs per device batch
-    for (uint32_t qa = qbegin; qa < qend;) {
-        uint32_t qb = qa;
-        while (qb < qend && (qb == qa || hit_off[qb + 1] - hit_off[qa] <= CHUNK)) qb++;
-        const uint64_t b = hit_off[qa], e = hit_off[qb];
-        const size_t n = (size_t)(e - b);
-        if (n) {
-            std::vector<PairIn> pairs(n);
-            for (uint32_t q = qa; q < qb; q++)
-                for (uint64_t k = hit_off[q]; k < hit_off[q + 1]; k++) pairs[k - b] = {q, hits[k].target, 0, 0};
-            std::vector<int32_t> s0(n), q0(n), t0(n), s1(n, 0);
-            sw_batch(0, pairs, s0.data(), q0.data(), t0.data());
-            if (p.rev_correction) sw_batch(1, pairs, s1.data(), nullptr, nullptr);
-            std::vector<PairIn> pass;
-            std::vector<size_t> pass_idx;
-            for (uint32_t q = qa; q < qb; q++) {
-                const int32_t ms = min_score_for(p, (int)h_len[q], dbres);
-                for (uint64_t k = hit_off[q]; k < hit_off[q + 1]; k++) {
-                    const size_t i = (size_t)(k - b);
-                    uc_aln &a = alns[k];
-                    a = uc_aln{};
-                    a.score = s0[i]; a.score_rev = s1[i]; a.corrected = s0[i] - s1[i];
-                    a.qend = q0[i]; a.tend = t0[i]; a.qstart = -1; a.tstart = -1;
-                    a.pass_evalue = (a.score > 0 && a.corrected >= ms);
-                    stats.cells_fwd += (uint64_t)h_len[q] * h_len[pairs[i].t];
-                    if (p.rev_correction) stats.cells_rev += (uint64_t)h_len[q] * h_len[pairs[i].t];
-                    if (a.pass_evalue) {
-                        pass.push_back({q, pairs[i].t, a.qend, a.tend});
-                        pass_idx.push_back((size_t)k);
-                        stats.cells_start += (uint64_t)(a.qend + 1) * (uint64_t)(a.tend + 1);
-                    }
-                }
-            }
-            std::vector<int32_t> s2(pass.size()), q2(pass.size()), t2(pass.size());
-            sw_batch(2, pass, s2.data(), q2.data(), t2.data());
-            for (size_t m = 0; m < pass.size(); m++) {
-                uc_aln &a = alns[pass_idx[m]];
-                if (s2[m] != a.score)
-                    fail(UC_ERR_GENERIC, "start pass score %d != forward score %d (query %u target %u)", s2[m], a.score, pass[m].q, pass[m].t);
-                a.qstart = a.qend - q2[m];
-                a.tstart = a.tend - t2[m];
-                const float qcov = (float)(a.qend - a.qstart + 1) / (float)h_len[pass[m].q];
-                const float tcov = (float)(a.tend - a.tstart + 1) / (float)h_len[pass[m].t];
-                const bool ok = p.cov_mode == 0 ? (qcov >= p.cov && tcov >= p.cov) : p.cov_mode == 1 ? (tcov >= p.cov) : (qcov >= p.cov);
-                a.accepted = ok;
-                if (ok) { edges.push_back(pass[m].q); edges.push_back(pass[m].t); }
-            }
-            stats.n_gapped_alignments += n;
-            stats.n_start_alignments += pass.size();
-        }
-        for (uint32_t q = qa; q < qb; q++) aln_done[q] = 1;
-        qa = qb;
-    }
-    stats.n_edges = edges.size() / 2;
-    stats.algorithmic_bytes[UC_ST_GAPPED] = stats.sw_algorithmic_bytes;
-    stats.stage_seconds[UC_ST_GAPPED] += tm.seconds();
+void Engine::get_hits(uc_hit *out) const {
+    if (!n_hits) return;
+    UC_HIP(hipSetDevice(device));
+    std::vector<uint32_t> ht(n_hits);
+    std::vector<int32_t> hs(n_hits), hd(n_hits);
+    UC_HIP(hipMemcpy(ht.data(), d_ht.p, n_hits * 4, hipMemcpyDeviceToHost));
+    UC_HIP(hipMemcpy(hs.data(), d_hs.p, n_hits * 4, hipMemcpyDeviceToHost));
+    UC_HIP(hipMemcpy(hd.data(), d_hd.p, n_hits * 4, hipMemcpyDeviceToHost));
+    for (uint64_t k = 0; k < n_hits; k++) { out[k].target = ht[k]; out[k].score = hs[k]; out[k].diag = hd[k]; }
+}
+
+void Engine::get_alns(uint64_t begin, uint64_t n, uc_aln *out) const {
+    if (!n) return;
+    if (!alns_valid) fail(UC_ERR_ARGS, "no alignment records: call align first");
+    UC_HIP(hipSetDevice(device));
+    UC_HIP(hipMemcpy(out, d_alns.p + begin, n * sizeof(uc_aln), hipMemcpyDeviceToHost));
 }
 
 // host merge of per-shard hit lists (multi-GPU exchange): per query keep the top

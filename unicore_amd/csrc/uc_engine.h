@@ -24,11 +24,21 @@ struct DevBuf {   // plain owning device allocation (hipMalloc), grows geometric
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-    void reserve(size_t n) {
+    void reserve(size_t n) {   // contents are NOT preserved
         if (n <= cap) return;
         release();
         size_t want = n + n / 8 + 64;
         UC_HIP(hipMalloc((void **)&p, want * sizeof(T)));
+        cap = want;
+    }
+    void grow_preserve(size_t n, size_t used) {   // keeps the first `used` elements
+        if (n <= cap) return;
+        size_t want = n + n / 2 + 64;
+        T *np = nullptr;
+        UC_HIP(hipMalloc((void **)&np, want * sizeof(T)));
+        if (used && p) UC_HIP(hipMemcpy(np, p, used * sizeof(T), hipMemcpyDeviceToDevice));
+        if (p) (void)hipFree(p);
+        p = np;
         cap = want;
     }
 };
@@ -53,12 +63,17 @@ struct Engine {
     DevBuf<int8_t> d_S3, d_SA;
     DeviceDb ddb;
 
-    // stage outputs
+    uint32_t max_len = 1;
+
+    // stage outputs.  Hit lists (E4) and alignment records (E5/E6) are device-resident, grouped by query
+    // in query order; the host keeps only the per-query counts/offsets and the accepted edges.
     std::vector<uint32_t> hit_cnt;     // per query
     std::vector<uint64_t> hit_off;     // n+1
-    std::vector<uc_hit> hits;
-    std::vector<uc_aln> alns;          // parallel to hits
-    std::vector<uint8_t> aln_done;     // per query: aligned?
+    uint64_t n_hits = 0;
+    DevBuf<uint32_t> d_hq, d_ht;       // query / target per hit
+    DevBuf<int32_t> d_hs, d_hd;        // ungapped score / diagonal per hit
+    DevBuf<uc_aln> d_alns;             // parallel to the hit arrays
+    bool alns_valid = false;
     std::vector<uint32_t> edges;
 
     uc_stats stats{};
@@ -68,6 +83,9 @@ struct Engine {
     void upload_db();
     void prefilter(uint32_t tbegin, uint32_t tend);                       // uc_prefilter.hip
     void set_hits(const uint32_t *counts, const uc_hit *h);
+    void get_hits(uc_hit *out) const;                        // D2H of the device hit arrays
+    void get_alns(uint64_t begin, uint64_t n, uc_aln *out) const;
+    void finish_hit_lists();                                  // counts/offsets from the device arrays
     void align(uint32_t qbegin, uint32_t qend);
     // kernel-level
     void ungapped_batch(uint64_t n, const uint32_t *q, const uint32_t *t, const int32_t *diag, int32_t *out);

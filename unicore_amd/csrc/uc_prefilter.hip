@@ -252,6 +252,41 @@ __global__ void __launch_bounds__(256) select_key_kernel(uint64_t n, const uint3
     if ((threadIdx.x & 63) == 0 && kept) atomicAdd(n_kept, kept);
 }
 
+// E4 truncation: entry i of the (query, score desc, target) sorted list survives iff its rank inside its
+// query's run is < max_seqs
+__global__ void __launch_bounds__(256) rank_flag_kernel(const uint64_t *skey, uint64_t n, uint32_t max_seqs, uint32_t *flag) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t qk = skey[i] & 0xFFFFFFFF00000000ull;
+        uint64_t lo = 0, hi = i;   // first index of this query's run
+        while (lo < hi) { const uint64_t m = (lo + hi) >> 1; if (skey[m] < qk) lo = m + 1; else hi = m; }
+        flag[i] = (i - lo) < max_seqs ? 1u : 0u;
+    }
+}
+
+__global__ void __launch_bounds__(256) hit_scatter_kernel(const uint64_t *skey, const int32_t *sdiag, uint64_t n, const uint32_t *flag,
+                                                          const uint64_t *pos, uint32_t *hq, uint32_t *ht, int32_t *hs, int32_t *hd) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        if (!flag[i]) continue;
+        const uint64_t k = skey[i], w = pos[i];
+        hq[w] = (uint32_t)(k >> 32);
+        ht[w] = (uint32_t)(k & 0xFFFFFFu);
+        hs[w] = 255 - (int32_t)((k >> 24) & 0xFF);
+        hd[w] = sdiag[i];
+    }
+}
+
+// per-query hit counts from the query-sorted hit array
+__global__ void __launch_bounds__(256) hit_count_kernel(const uint32_t *hq, uint64_t n_hits, uint32_t n, uint32_t *cnt) {
+    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < n; q += gridDim.x * 256) {
+        uint64_t lo = 0, hi = n_hits;
+        while (lo < hi) { const uint64_t m = (lo + hi) >> 1; if (hq[m] < q) lo = m + 1; else hi = m; }
+        const uint64_t b = lo;
+        hi = n_hits;
+        while (lo < hi) { const uint64_t m = (lo + hi) >> 1; if (hq[m] <= q) lo = m + 1; else hi = m; }
+        cnt[q] = (uint32_t)(lo - b);
+    }
+}
+
 static inline dim3 grid_for(uint64_t n, uint32_t cap = 16384) {
     const uint64_t b = (n + 255) / 256;
     return dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(b, cap)));
@@ -273,12 +308,13 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend) {
 
     hit_cnt.assign(n, 0);
     hit_off.assign((size_t)n + 1, 0);
-    hits.clear(); alns.clear(); edges.clear();
-    aln_done.assign(n, 0);
+    n_hits = 0;
+    alns_valid = false;
+    edges.clear();
 
-    DevBuf<unsigned long long> d_counters;   // [0] sim k-mers, [1] kept candidates
-    d_counters.reserve(2);
-    UC_HIP(hipMemsetAsync(d_counters.p, 0, 16, stream));
+    DevBuf<unsigned long long> d_counters;   // [0] sim k-mers, [1] kept candidates, [2] ungapped overlap residues
+    d_counters.reserve(3);
+    UC_HIP(hipMemsetAsync(d_counters.p, 0, 24, stream));
     DevBuf<char> d_temp;
     auto temp_reserve = [&](size_t bytes) { d_temp.reserve(bytes + 256); };
 
@@ -325,9 +361,7 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend) {
     DevBuf<uint32_t> d_cnt, d_flag, d_cq, d_ct;
     DevBuf<uint64_t> d_hoff, d_keys, d_keys2, d_pos, d_skey, d_skey2;
     DevBuf<int32_t> d_bestdiag, d_cd, d_cd2, d_score;
-    std::vector<uint64_t> h_skey;
-    std::vector<int32_t> h_sdiag;
-    uint64_t n_hits_total = 0, n_cand_total = 0, ungapped_bytes = 0;
+    uint64_t n_hits_total = 0, n_cand_total = 0;
     double t_kmer = 0, t_ung = 0, t_sel = 0;
 
     for (uint32_t qa = 0; qa < n;) {
@@ -410,7 +444,7 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend) {
             d_cq.reserve(n_cand); d_ct.reserve(n_cand); d_cd.reserve(n_cand); d_score.reserve(n_cand);
             hipLaunchKernelGGL(cand_scatter_kernel, grid_for(total_hits), dim3(256), 0, stream, d_keys2.p, total_hits, d_flag.p, d_pos.p,
                                d_bestdiag.p, qa, d_cq.p, d_ct.p, d_cd.p);
-            launch_ungapped(ddb, n_cand, d_cq.p, d_ct.p, d_cd.p, d_score.p, stream);
+            launch_ungapped(ddb, n_cand, d_cq.p, d_ct.p, d_cd.p, d_score.p, d_counters.p + 2, stream);
             UC_HIP(hipGetLastError());
             gpu_ms += timed_ms_end();
             t_ung += t_u.seconds();
@@ -427,47 +461,45 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend) {
             unsigned long long kept = 0;
             UC_HIP(hipMemcpyAsync(&kept, d_counters.p + 1, 8, hipMemcpyDeviceToHost, stream));
             UC_HIP(hipStreamSynchronize(stream));
-            h_skey.resize(kept); h_sdiag.resize(kept);
-            if (kept) {
-                UC_HIP(hipMemcpyAsync(h_skey.data(), d_skey2.p, kept * 8, hipMemcpyDeviceToHost, stream));
-                UC_HIP(hipMemcpyAsync(h_sdiag.data(), d_cd2.p, kept * 4, hipMemcpyDeviceToHost, stream));
+            if (kept) {   // rank inside each query's run, keep the first max_seqs, append to the device hit lists
+                d_flag.reserve(kept); d_pos.reserve(kept);
+                hipLaunchKernelGGL(rank_flag_kernel, grid_for(kept), dim3(256), 0, stream, d_skey2.p, (uint64_t)kept, (uint32_t)p.max_seqs, d_flag.p);
+                auto rin = rocprim::make_transform_iterator(d_flag.p, WidenU32());
+                UC_HIP(rocprim::exclusive_scan(nullptr, tb, rin, d_pos.p, (uint64_t)0, (size_t)kept, rocprim::plus<uint64_t>(), stream));
+                temp_reserve(tb);
+                UC_HIP(rocprim::exclusive_scan(d_temp.p, tb, rin, d_pos.p, (uint64_t)0, (size_t)kept, rocprim::plus<uint64_t>(), stream));
+                uint64_t lp = 0; uint32_t lf = 0;
+                UC_HIP(hipMemcpyAsync(&lp, d_pos.p + (kept - 1), 8, hipMemcpyDeviceToHost, stream));
+                UC_HIP(hipMemcpyAsync(&lf, d_flag.p + (kept - 1), 4, hipMemcpyDeviceToHost, stream));
+                UC_HIP(hipStreamSynchronize(stream));
+                const uint64_t add = lp + lf;
+                d_hq.grow_preserve(n_hits + add, n_hits); d_ht.grow_preserve(n_hits + add, n_hits);
+                d_hs.grow_preserve(n_hits + add, n_hits); d_hd.grow_preserve(n_hits + add, n_hits);
+                hipLaunchKernelGGL(hit_scatter_kernel, grid_for(kept), dim3(256), 0, stream, d_skey2.p, d_cd2.p, (uint64_t)kept, d_flag.p, d_pos.p,
+                                   d_hq.p + n_hits, d_ht.p + n_hits, d_hs.p + n_hits, d_hd.p + n_hits);
+                n_hits += add;
             }
+            UC_HIP(hipGetLastError());
             gpu_ms += timed_ms_end();
-            // host: linear truncation to max_seqs per query (keys are sorted by query, score desc, target asc)
-            for (size_t i = 0; i < kept;) {
-                const uint32_t q = (uint32_t)(h_skey[i] >> 32);
-                size_t e = i;
-                while (e < kept && (uint32_t)(h_skey[e] >> 32) == q) e++;
-                const size_t take = std::min<size_t>(e - i, (size_t)p.max_seqs);
-                hit_cnt[q] = (uint32_t)take;
-                for (size_t k = i; k < i + take; k++) {
-                    uc_hit h;
-                    h.target = (uint32_t)(h_skey[k] & 0xFFFFFFu);
-                    h.score = 255 - (int32_t)((h_skey[k] >> 24) & 0xFF);
-                    h.diag = h_sdiag[k];
-                    hits.push_back(h);
-                }
-                i = e;
-            }
-            // E3 algorithmic bytes: (overlap + 16) per candidate; overlap <= min(Lq, Lt) — counted exactly for kept hits only
-            ungapped_bytes += 16ull * n_cand;
             t_sel += t_s.seconds();
         }
         qa = qb;
     }
+    // per-query counts / offsets (the host only keeps these two small arrays)
+    if (n_hits) {
+        d_cnt.reserve(n);
+        hipLaunchKernelGGL(hit_count_kernel, grid_for(n), dim3(256), 0, stream, d_hq.p, n_hits, n, d_cnt.p);
+        UC_HIP(hipMemcpyAsync(hit_cnt.data(), d_cnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+        UC_HIP(hipStreamSynchronize(stream));
+    }
     for (uint32_t q = 0; q < n; q++) hit_off[q + 1] = hit_off[q] + hit_cnt[q];
-    if (hit_off[n] != hits.size()) fail(UC_ERR_GENERIC, "prefilter: hit list bookkeeping mismatch");
-    // exact overlap bytes for the ungapped stage are data-dependent; bound them by the kept hits' overlaps
-    for (uint32_t q = 0; q < n; q++)
-        for (uint64_t k = hit_off[q]; k < hit_off[q + 1]; k++) {
-            const int d = hits[k].diag, lq = (int)h_len[q], lt = (int)h_len[hits[k].target];
-            const int i0 = d > 0 ? d : 0, i1 = std::min(lq, lt + d);
-            ungapped_bytes += (uint64_t)std::max(0, i1 - i0);
-        }
-    alns.assign(hits.size(), uc_aln{});
+    if (hit_off[n] != n_hits) fail(UC_ERR_GENERIC, "prefilter: hit list bookkeeping mismatch");
+    unsigned long long ovl = 0;
+    UC_HIP(hipMemcpy(&ovl, d_counters.p + 2, 8, hipMemcpyDeviceToHost));
+    const uint64_t ungapped_bytes = ovl + 16ull * n_cand_total;   // (overlap + 16) B per candidate, SURVEY.md 8(d)
     stats.n_kmer_hits += n_hits_total;
     stats.n_candidates += n_cand_total;
-    stats.n_prefilter_hits += hits.size();
+    stats.n_prefilter_hits += n_hits;
     stats.algorithmic_bytes[UC_ST_KMER] += 8ull * stats.n_sim_kmers + 6ull * n_hits_total + 8ull * n_cand_total;
     stats.algorithmic_bytes[UC_ST_UNGAPPED] += ungapped_bytes;
     stats.algorithmic_bytes[UC_ST_SELECT] += 16ull * n_cand_total;

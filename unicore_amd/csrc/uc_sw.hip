@@ -37,8 +37,10 @@ void launch_sw_generic(int mode, const SwArgs &a, uint32_t n_pairs, const uint32
 // One lane per candidate (q, t, diag): Kadane along the whole diagonal, saturating at 255.  The 21x21
 // 3Di matrix sits in LDS; candidates arrive sorted by (q, t) so neighbouring lanes share the query.
 __global__ void __launch_bounds__(256) ungapped_kernel(const DeviceDb db, uint64_t n, const uint32_t *q,
-                                                       const uint32_t *t, const int32_t *diag, int32_t *score) {
+                                                       const uint32_t *t, const int32_t *diag, int32_t *score,
+                                                       unsigned long long *overlap_sum) {
     __shared__ int8_t S[21 * 21 + 3];
+    unsigned long long ovl = 0;
     for (int i = threadIdx.x; i < 441; i += 256) S[i] = db.S3[i];
     __syncthreads();
     for (uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x; c < n; c += (uint64_t)gridDim.x * 256) {
@@ -53,14 +55,19 @@ __global__ void __launch_bounds__(256) ungapped_kernel(const DeviceDb db, uint64
             best = max(best, run);
         }
         score[c] = min(best, 255);
+        ovl += (unsigned long long)max(i1 - i0, 0);
+    }
+    if (overlap_sum) {   // algorithmic-byte accounting of stage E3: one atomic per wave
+        for (int o = 32; o > 0; o >>= 1) ovl += __shfl_down(ovl, o, 64);
+        if ((threadIdx.x & 63) == 0 && ovl) atomicAdd(overlap_sum, ovl);
     }
 }
 
 void launch_ungapped(const DeviceDb &db, uint64_t n, const uint32_t *q, const uint32_t *t, const int32_t *diag,
-                     int32_t *score, hipStream_t s) {
+                     int32_t *score, unsigned long long *overlap_sum, hipStream_t s) {
     if (n == 0) return;
     const uint64_t blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(ungapped_kernel, dim3((uint32_t)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, db, n, q, t, diag, score);
+    hipLaunchKernelGGL(ungapped_kernel, dim3((uint32_t)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, db, n, q, t, diag, score, overlap_sum);
 }
 
 }  // namespace uc

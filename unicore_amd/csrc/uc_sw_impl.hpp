@@ -28,21 +28,28 @@ namespace uc {
 constexpr int SW_NLET = 22;            // 21 letters + PAD(21)
 constexpr uint32_t SW_PADPACK = 21u | (21u << 8);
 
+// waves per workgroup: every wave streams targets through the ONE LDS profile of the task's query, so the
+// classes with big profiles (1 or 2 workgroups per CU by LDS) use more waves to keep the SIMDs occupied
+constexpr int sw_waves_per_group(int G, int R) { return G < 64 ? 4 : (R > 28 ? 12 : 8); }
+
 template <int G>
-__device__ __forceinline__ int shift_from_prev_lane(int v, int boundary, int g, int lane) {
+__device__ __forceinline__ int shift_from_prev_lane(int v, int boundary, int g) {
     if constexpr (G == 16) {
         // DPP row_shr:1 — lane 0 of each 16-lane row keeps `old` (= boundary)
         return __builtin_amdgcn_update_dpp(boundary, v, 0x111, 0xf, 0xf, false);
     } else {
-        int r = __builtin_amdgcn_ds_bpermute((lane - 1) << 2, v);
-        return g == 0 ? boundary : r;
+        // DPP wave_shr:1 crosses the 16-lane rows; lane 0 of the wave keeps `old`, lane 32 of a
+        // G=32 group is patched with the boundary
+        const int r = __builtin_amdgcn_update_dpp(boundary, v, 0x138, 0xf, 0xf, false);
+        return (G == 64 || g != 0) ? r : boundary;
     }
 }
 
-template <int G, int R, int MODE>
-__global__ void __launch_bounds__(256) sw_group_kernel(const SwArgs a) {
+// NW = waves per workgroup: all of them stream targets through the one LDS profile of the task's query
+template <int G, int R, int MODE, int NW>
+__global__ void __launch_bounds__(NW * 64) sw_group_kernel(const SwArgs a) {
     constexpr bool TRACK = MODE != 1, MASK = MODE == 2, REVQ = MODE != 0, REVT = MODE == 2;
-    constexpr int RW = R / 4, BW = RW | 1, RSW = G * BW, GPW = 64 / G;
+    constexpr int RW = R / 4, BW = RW | 1, RSW = G * BW, GPW = 64 / G, NT = NW * 64;
     static_assert(R % 4 == 0 && R <= 32, "R must be a multiple of 4, <= 32");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *P3 = lds, *PA = lds + SW_NLET * RSW;
@@ -55,7 +62,7 @@ __global__ void __launch_bounds__(256) sw_group_kernel(const SwArgs a) {
     const int open = a.open, ext = a.ext;
 
     // ---- stage the query profile in LDS (biased bytes: b3 = S3+64, bA = SA+64+open; PAD = 0) ----
-    for (int idx = tid; idx < SW_NLET * G * RW; idx += 256) {
+    for (int idx = tid; idx < SW_NLET * G * RW; idx += NT) {
         const int c = idx / (G * RW), rem = idx % (G * RW), gg = rem / RW, k = rem % RW;
         uint32_t w3 = 0, wa = 0;
 #pragma unroll
@@ -73,7 +80,7 @@ __global__ void __launch_bounds__(256) sw_group_kernel(const SwArgs a) {
     }
     __syncthreads();
 
-    for (uint32_t pb = (uint32_t)wave * GPW; pb < task.count; pb += 4 * GPW) {
+    for (uint32_t pb = (uint32_t)wave * GPW; pb < task.count; pb += NW * GPW) {
         const bool pvalid = pb + grp < task.count;
         const uint32_t gp = task.begin + (pvalid ? pb + grp : 0);
         const uint32_t t = a.pt[gp];
@@ -105,7 +112,7 @@ __global__ void __launch_bounds__(256) sw_group_kernel(const SwArgs a) {
         uint32_t best = 0;       // TRACK: keyed (score<<5 | 31-r); else plain score
         int bestcol = -1;
         int Tlast = -open, prevTup = -open;
-        uint32_t fout = 0, cpack = SW_PADPACK;
+        uint32_t fout = 0;
 
         auto load_letter = [&](int st) -> uint32_t {
             uint32_t c = SW_PADPACK;
@@ -115,26 +122,39 @@ __global__ void __launch_bounds__(256) sw_group_kernel(const SwArgs a) {
             }
             return c;
         };
-        uint32_t cA = load_letter(0), cB = load_letter(1);
+        // letters are fetched three columns ahead, the profile words of a column one step ahead:
+        // neither the global nor the LDS latency sits on the step's dependency chain
+        uint32_t c1 = load_letter(1), c2 = load_letter(2);
+        uint32_t cin = (uint32_t)shift_from_prev_lane<G>((int)SW_PADPACK, (int)load_letter(0), g);
+        uint32_t n3[RW], na[RW];
+        {
+            const uint32_t *p3 = P3 + (cin & 0xff) * RSW + g * BW, *pa = PA + (cin >> 8) * RSW + g * BW;
+#pragma unroll
+            for (int k = 0; k < RW; k++) { n3[k] = p3[k]; na[k] = pa[k]; }
+        }
 
-        for (int st = 0; st < nsteps; st++) {
-            const uint32_t cload = cA;
-            cA = cB;
-            cB = load_letter(st + 2);
-            const int Tup = shift_from_prev_lane<G>(Tlast, -open, g, lane);
-            const uint32_t fin = (uint32_t)shift_from_prev_lane<G>((int)fout, 0, g, lane);
-            const uint32_t cin = (uint32_t)shift_from_prev_lane<G>((int)cpack, (int)cload, g, lane);
-            const int c3 = cin & 0xff, ca = cin >> 8;
-            const uint32_t *p3 = P3 + c3 * RSW + g * BW, *pa = PA + ca * RSW + g * BW;
+        // two steps per trip (an extra all-PAD step is harmless) so that the rotating (T, old T) register
+        // pairs need no copies at the back edge
+        auto do_step = [&](const int st) __attribute__((always_inline)) {
             uint32_t ps[RW];
 #pragma unroll
             for (int k = 0; k < RW; k++) {
-                uint32_t s = p3[k] + pa[k];
+                uint32_t s = n3[k] + na[k];
                 if constexpr (MASK) s &= msk[k];
                 ps[k] = s ^ 0x80808080u;
             }
+            // next column's letters and profile words
+            cin = (uint32_t)shift_from_prev_lane<G>((int)cin, (int)c1, g);
+            c1 = c2;
+            c2 = load_letter(st + 3);
+            {
+                const uint32_t *p3 = P3 + (cin & 0xff) * RSW + g * BW, *pa = PA + (cin >> 8) * RSW + g * BW;
+#pragma unroll
+                for (int k = 0; k < RW; k++) { n3[k] = p3[k]; na[k] = pa[k]; }
+            }
+            const int Tup = shift_from_prev_lane<G>(Tlast, -open, g);
+            uint32_t f = (uint32_t)shift_from_prev_lane<G>((int)fout, 0, g);
             int diagT = prevTup;
-            uint32_t f = fin;
             uint32_t colmax = 0;
 #pragma unroll
             for (int r = 0; r < R; r++) {
@@ -157,8 +177,11 @@ __global__ void __launch_bounds__(256) sw_group_kernel(const SwArgs a) {
             }
             Tlast = T[R - 1];
             fout = f;
-            cpack = cin;
             prevTup = Tup;
+        };
+        for (int st = 0; st < nsteps; st += 2) {
+            do_step(st);
+            do_step(st + 1);
         }
 
         // ---- reduce over the G lanes of the group: (score desc, col asc, row asc) ----
@@ -231,14 +254,15 @@ void launch_sw_class_mode(int G, int R, const SwArgs &a, uint32_t n_tasks, hipSt
 #define UC_SW_CASE(GG, RR)                                                                              \
     if (G == GG && R == RR) {                                                                           \
         constexpr int BW = ((RR / 4) | 1);                                                              \
+        constexpr int NW = sw_waves_per_group(GG, RR);                                                \
         const size_t lds = (size_t)2 * SW_NLET * GG * BW * 4;                                           \
         static bool attr_set = false;                                                                   \
         if (!attr_set && lds > 64 * 1024) {                                                             \
-            (void)hipFuncSetAttribute((const void *)sw_group_kernel<GG, RR, MODE>,                      \
+            (void)hipFuncSetAttribute((const void *)sw_group_kernel<GG, RR, MODE, NW>,                  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
             attr_set = true;                                                                            \
         }                                                                                               \
-        hipLaunchKernelGGL((sw_group_kernel<GG, RR, MODE>), dim3(n_tasks), dim3(256), lds, s, a);       \
+        hipLaunchKernelGGL((sw_group_kernel<GG, RR, MODE, NW>), dim3(n_tasks), dim3(NW * 64), lds, s, a); \
         return;                                                                                         \
     }
     UC_SW_CASE(16, 4) UC_SW_CASE(16, 8) UC_SW_CASE(16, 12) UC_SW_CASE(16, 16)

@@ -94,15 +94,18 @@ def cluster_step(engine, lens, rank, world, max_seqs, device="cpu", group=None, 
     n = len(lens)
     tb, te = shard_ranges(lens, world)[rank]
     engine.prefilter(tb, te)
-    counts, hits = engine.hits()
     if world > 1:
+        counts, hits = engine.hits()
         parts = exchange_hits(counts, hits, device, group)
         counts, hits = merged_hits(parts, n, max_seqs)
         engine.set_hits(counts, hits)
-    qb, qe = query_ranges(lens, counts, hits, world)[rank]
+        qb, qe = query_ranges(lens, counts, hits, world)[rank]
+        n_aln = int(np.asarray(counts[qb:qe], np.int64).sum())
+    else:   # single GPU: the hit lists never leave HBM
+        qb, qe = 0, n
+        n_aln = engine.hits_size()
     engine.align(qb, qe)
     edges = engine.edges()
-    n_aln = int(np.asarray(counts[qb:qe], np.int64).sum())
     if world > 1:
         edges = gather_edges(edges, device, group)
     assign = None
