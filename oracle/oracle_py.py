@@ -236,3 +236,15 @@ def sample_run(odb, ix, p, queries, threads=0):
     sec = (C.c_double * 2)()
     n = lib().uco_sample_run(C.byref(odb.db), C.byref(ix), C.byref(p), threads, q.ctypes.data, len(q), sec)
     return int(n), sec[0], sec[1]
+
+
+def prefilter_shard(odb, p, tbegin=0, tend=None):
+    """E1-E4 of every query against the k-mer index of targets [tbegin, tend) -> (counts, hits[n, max_seqs])."""
+    ix = build_index(odb, p, tbegin, tend)
+    n, M = odb.n, p.max_seqs
+    hits = np.zeros((n, M), HIT_DTYPE)
+    cnt = np.zeros(n, np.uint32)
+    for q in range(n):
+        cnt[q] = lib().uco_prefilter_query(C.byref(odb.db), C.byref(ix), q, C.byref(p), hits[q].ctypes.data, None)
+    free_index(ix)
+    return cnt, hits

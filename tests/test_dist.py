@@ -1,0 +1,95 @@
+"""The N>1 path on CPU: shard plan, ragged all-gather over torch.distributed (gloo, world_size 2), host merge.
+Per-shard hit lists come from the oracle here (no GPU in this container); the exchange + merge + partition
+code is exactly what bench.py runs with backend "nccl" (= RCCL) on the GPUs."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import util
+import unicore_amd as U
+from unicore_amd import dist as ucdist
+from oracle import oracle_py as O
+
+
+def test_shard_and_query_ranges_are_partitions():
+    rng = np.random.default_rng(0)
+    lens = rng.integers(1, 2000, 1000)
+    for w in (1, 2, 3, 4, 8):
+        r = ucdist.shard_ranges(lens, w)
+        assert r[0][0] == 0 and r[-1][1] == len(lens) and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+        res = [lens[b:e].sum() for b, e in r]
+        assert max(res) - min(res) <= 2 * lens.max()        # ~equal residues per shard
+    cnt = rng.integers(0, 20, 1000).astype(np.uint32)
+    hits = np.zeros(int(cnt.sum()), U.HIT_DTYPE)
+    hits["target"] = rng.integers(0, 1000, len(hits))
+    for w in (1, 2, 4, 8):
+        r = ucdist.query_ranges(lens, cnt, hits, w)
+        assert r[0][0] == 0 and r[-1][1] == len(lens) and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+
+
+def test_virtual_shards_merge_equals_unsharded_oracle():
+    """G virtual shards processed one after the other and merged == the G=1 list (determinism requirement)"""
+    s3, sa = util.family_db(17, n_fam=8, members=5, lmin=40, lmax=140)
+    odb = O.OracleDb(s3=s3, sa=sa)
+    p = util.oracle_params(O, "-c 0.8 --max-seqs 6")
+    lens = np.array([len(x) for x in s3])
+    cnt1, h1 = O.prefilter_shard(odb, p)
+    flat1 = np.concatenate([h1[q, : cnt1[q]] for q in range(odb.n)]).astype(U.HIT_DTYPE)
+    for g in (2, 4, 8):
+        parts = []
+        for tb, te in ucdist.shard_ranges(lens, g):
+            c, h = O.prefilter_shard(odb, p, tb, te)
+            parts.append((c, np.concatenate([h[q, : c[q]] for q in range(odb.n)]).astype(U.HIT_DTYPE)))
+        mc, mh = U.hits_merge(odb.n, p.max_seqs, parts)
+        assert np.array_equal(mc, cnt1)
+        assert np.array_equal(mh["target"], flat1["target"]) and np.array_equal(mh["score"], flat1["score"]) and np.array_equal(mh["diag"], flat1["diag"])
+
+
+def _rank_main(rank, world, port, tmpdir):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        s3, sa = util.family_db(23, n_fam=7, members=5, lmin=40, lmax=120)
+        odb = O.OracleDb(s3=s3, sa=sa)
+        p = util.oracle_params(O, "-c 0.8 --max-seqs 5")
+        lens = np.array([len(x) for x in s3])
+        tb, te = ucdist.shard_ranges(lens, world)[rank]
+        c, h = O.prefilter_shard(odb, p, tb, te)                      # this rank's shard (stands in for the HIP prefilter)
+        flat = np.concatenate([h[q, : c[q]] for q in range(odb.n)]).astype(U.HIT_DTYPE)
+        parts = ucdist.exchange_hits(c, flat, device="cpu")           # the collective
+        mc, mh = ucdist.merged_hits(parts, odb.n, p.max_seqs)
+        qb, qe = ucdist.query_ranges(lens, mc, mh, world)[rank]
+        # accepted edges of this rank's query range (oracle alignment as the stand-in for E5/E6)
+        import ctypes
+        off = np.concatenate([[0], np.cumsum(mc.astype(np.int64))])
+        edges = []
+        for q in range(qb, qe):
+            ms = O.lib().uco_min_score(p, int(lens[q]), int(lens.sum()))
+            for k in range(off[q], off[q + 1]):
+                a = O.Aln()
+                O.lib().uco_align_pair(ctypes.byref(odb.db), q, int(mh["target"][k]), ctypes.byref(p), ms, ctypes.byref(a))
+                if a.accepted:
+                    edges.append((q, int(mh["target"][k])))
+        alle = ucdist.gather_edges(np.array(edges, np.uint32).reshape(-1, 2), device="cpu")
+        np.save(os.path.join(tmpdir, "rank%d.npy" % rank), U.setcover(odb.n, alle) if rank == 0 else mc)
+        np.save(os.path.join(tmpdir, "hits%d.npy" % rank), mh)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_exchange_matches_single_rank(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    s3, sa = util.family_db(23, n_fam=7, members=5, lmin=40, lmax=120)
+    odb = O.OracleDb(s3=s3, sa=sa)
+    p = util.oracle_params(O, "-c 0.8 --max-seqs 5")
+    ref = O.cluster(odb, p, threads=2)
+    h0, h1 = np.load(tmp_path / "hits0.npy"), np.load(tmp_path / "hits1.npy")
+    assert np.array_equal(h0, h1)                                                         # every rank holds the same merged lists
+    flat = np.concatenate([ref["hits"][q, : ref["hit_cnt"][q]] for q in range(odb.n)])
+    assert np.array_equal(h0["target"], flat["t"]) and np.array_equal(h0["score"], flat["score"])
+    assert np.array_equal(np.load(tmp_path / "rank1.npy"), ref["hit_cnt"])
+    assert np.array_equal(np.load(tmp_path / "rank0.npy"), ref["assign"])                  # same clusters as 1 rank

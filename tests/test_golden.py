@@ -1,0 +1,66 @@
+"""Committed oracle-generated fixtures (tests/golden/, generator make_golden.py alongside).
+CPU: the oracle still reproduces them (pins the oracle against regressions) and the TSV satisfies the
+consumer contract of src/modules/profile.rs.  GPU: the HIP path reproduces them through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+import util
+
+GOLD = os.path.join(util.ROOT, "tests", "golden")
+CASES = ["default", "sensitive"]
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, "expected_%s.npz" % name))
+    return z, str(z["options"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_golden(name, tmp_path):
+    from oracle import oracle_py as O
+    z, opts = load(name)
+    odb = O.OracleDb(os.path.join(GOLD, "db"))
+    r = O.cluster(odb, util.oracle_params(O, opts), threads=4)
+    cnt = r["hit_cnt"]
+    assert np.array_equal(cnt, z["hit_cnt"]) and np.array_equal(r["assign"], z["assign"])
+    hits = np.concatenate([r["hits"][q, : cnt[q]] for q in range(odb.n)])
+    aln = np.concatenate([r["aln"][q, : cnt[q]] for q in range(odb.n)])
+    assert hits.tobytes() == z["hits"].tobytes() and aln.tobytes() == z["aln"].tobytes()
+    O.write_tsv(str(tmp_path / "c.tsv"), odb, r["assign"])
+    assert open(tmp_path / "c.tsv", "rb").read() == open(os.path.join(GOLD, "clust_%s.tsv" % name), "rb").read()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_tsv_satisfies_the_consumer_contract(name):
+    names = [l.split("\t")[1] for l in open(os.path.join(GOLD, "db.lookup"))]
+    rows = util.tsv_invariants(os.path.join(GOLD, "clust_%s.tsv" % name), names)
+    mapped = {l.split("\t")[0] for l in open(os.path.join(GOLD, "db.map"))}
+    assert {r[1] for r in rows} <= mapped          # names equal col 0 of <db>.map (profile.rs:22,79)
+    assert all(n.startswith("unicore_") and len(n) == 18 for n in names)   # createdb.rs:104-106
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_path_reproduces_golden(name, tmp_path):
+    import unicore_amd as U
+    z, opts = load(name)
+    e = U.Engine(opts, verbosity=1)
+    e.load_db(os.path.join(GOLD, "db"))
+    e.prefilter()
+    cnt, hits = e.hits()
+    assert np.array_equal(cnt, z["hit_cnt"])
+    assert np.array_equal(hits["target"], z["hits"]["t"]) and np.array_equal(hits["score"], z["hits"]["score"]) and np.array_equal(hits["diag"], z["hits"]["diag"])
+    e.align()
+    al = e.alns()
+    for f in ("score", "score_rev", "corrected", "pass_evalue", "accepted"):
+        assert np.array_equal(al[f], z["aln"][f]), f
+    pe = al["pass_evalue"] == 1
+    for f in ("qstart", "qend", "tstart", "tend"):
+        assert np.array_equal(al[f][pe], z["aln"][f][pe]), f
+    assert np.array_equal(U.setcover(e.n, e.edges()), z["assign"])
+    out = str(tmp_path / "clust")
+    U.cluster(os.path.join(GOLD, "db"), out + "_cluster", str(tmp_path / "tmp"), opts)
+    U.createtsv(os.path.join(GOLD, "db"), out + "_cluster", out + ".tsv")
+    assert open(out + ".tsv", "rb").read() == open(os.path.join(GOLD, "clust_%s.tsv" % name), "rb").read()

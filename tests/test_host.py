@@ -1,0 +1,181 @@
+"""CPU-side tests of the product's host logic and C-ABI surface (no compute calls — there is no GPU here)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import util
+import unicore_amd as U
+from oracle import oracle_py as O
+
+ROOT = util.ROOT
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = U.lib()
+    hdr = open(os.path.join(ROOT, "include", "unicore_cluster.h")).read()
+    declared = set(re.findall(r"\b(uc_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(U.SYMBOLS), declared ^ set(U.SYMBOLS)
+    for s in declared:
+        assert hasattr(L, s), s
+    assert "gfx950" in U.version()
+    assert os.path.exists(os.path.join(ROOT, "unicore_amd", "libunicore_cluster.so"))
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """the product path must fail loudly without the device: error class 4, never a CPU fallback"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(U.UcError) as ei:
+        U.Engine("-c 0.8")
+    assert ei.value.code == U.UC_ERR_DEVICE and "no CPU fallback" in str(ei.value)
+    with pytest.raises(U.UcError) as ei:
+        U.cluster("/nonexistent/db", "/tmp/x_cluster", "/tmp/x_tmp")
+    assert ei.value.code in (U.UC_ERR_DEVICE, U.UC_ERR_IO)
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under unicore_amd/ or include/ may reference it"""
+    bad = []
+    for base in ("unicore_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                    txt = open(os.path.join(dp, f), errors="replace").read()
+                    if re.search(r"uc_oracle|oracle_py|liboracle|from oracle|import oracle|uco_", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
+    out = subprocess.run(["ldd", U.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+@pytest.mark.parametrize("opts,ok", [
+    ("-c 0.8", True), ("", True), ("-c 0.8 --min-seq-id 0.3 -s 7.5 -e 0.001 --cov-mode 1 --max-seqs 100", True),
+    ("--single-step-clustering --cluster-mode 0 --alignment-type 2 --threads 4 -v 2", True),
+    ("--single-step-clustering 1 -c 0.5", True), ("--k-score 25 --min-ungapped-score 20 --gap-open 11 --gap-extend 1", True),
+    ("--bogus 1", False), ("-c", False), ("-c abc", False), ("-c 1.5", False), ("--cov-mode 5", False),
+    ("--cluster-mode 1", False), ("--alignment-type 1", False), ("--max-seqs 0", False), ("stray", False),
+])
+def test_foldseek_style_option_parser(opts, ok):
+    rc = U.check_options(opts)
+    assert (rc == 0) == ok
+    if not ok:
+        assert rc == U.UC_ERR_ARGS and len(U.lib().uc_last_error()) > 0
+
+
+def test_product_setcover_equals_oracle_on_random_graphs():
+    rng = np.random.default_rng(11)
+    for _ in range(80):
+        n = int(rng.integers(1, 300))
+        m = int(rng.integers(0, 4 * n))
+        e = rng.integers(0, n, (m, 2)).astype(np.uint32)
+        a, b = U.setcover(n, e), O.setcover(n, e)
+        assert np.array_equal(a, b)
+        assert (a[a] == a).all()
+    # clique-ish + hub structure at a larger size
+    n = 6000
+    fam = rng.integers(0, 150, n)
+    e = np.array([(i, j) for i in range(0, n, 7) for j in np.nonzero(fam == fam[i])[0][:20]], np.uint32)
+    assert np.array_equal(U.setcover(n, e), O.setcover(n, e))
+    with pytest.raises(U.UcError):
+        U.setcover(3, [(0, 5)])
+
+
+def _random_lists(rng, n, m, max_t):
+    cnt = rng.integers(0, m + 1, n).astype(np.uint32)
+    hits = np.zeros(int(cnt.sum()), U.HIT_DTYPE)
+    k = 0
+    for q in range(n):
+        t = rng.choice(max_t, cnt[q], replace=False)
+        sc = rng.integers(15, 256, cnt[q])
+        order = np.lexsort((t, -sc))
+        hits["target"][k:k + cnt[q]] = t[order]
+        hits["score"][k:k + cnt[q]] = sc[order]
+        hits["diag"][k:k + cnt[q]] = rng.integers(-50, 50, cnt[q])
+        k += cnt[q]
+    return cnt, hits
+
+
+def test_hits_merge_is_independent_of_the_sharding():
+    """split every query's list by target range into 1/2/4/8 'shards', truncate each to M, merge: the
+    result equals the top-M of the full list (per-shard truncation is lossless) — SURVEY.md 8(e)"""
+    rng = np.random.default_rng(2)
+    n, M, max_t = 200, 12, 500
+    cnt, hits = _random_lists(rng, n, 40, max_t)
+    off = np.concatenate([[0], np.cumsum(cnt.astype(np.int64))]).astype(np.int64)
+    expect_c, expect_h = U.hits_merge(n, M, [(cnt, hits)])
+    assert (expect_c == np.minimum(cnt, M)).all()
+    for shards in (2, 4, 8):
+        bounds = np.linspace(0, max_t, shards + 1).astype(int)
+        parts = []
+        for s in range(shards):
+            pc, ph = np.zeros(n, np.uint32), []
+            for q in range(n):
+                h = hits[off[q]:off[q + 1]]
+                h = h[(h["target"] >= bounds[s]) & (h["target"] < bounds[s + 1])][:M]
+                pc[q] = len(h)
+                ph.append(h)
+            parts.append((pc, np.concatenate(ph) if ph else np.zeros(0, U.HIT_DTYPE)))
+        c, h = U.hits_merge(n, M, parts)
+        assert np.array_equal(c, expect_c) and np.array_equal(h, expect_h)
+    # duplicated target across shards is a caller bug and must be rejected, not merged silently
+    with pytest.raises(U.UcError):
+        U.hits_merge(1, 5, [(np.array([1], np.uint32), hits[:1]), (np.array([1], np.uint32), hits[:1])])
+
+
+def test_cluster_db_createtsv_rmdb_roundtrip(tmp_path):
+    s3, sa = util.family_db(4, n_fam=6, members=4, with_x=False)
+    names = util.write_db(str(tmp_path / "db"), s3, sa)
+    n = len(s3)
+    rng = np.random.default_rng(0)
+    reps = np.sort(rng.choice(n, 7, replace=False))
+    assign = reps[rng.integers(0, len(reps), n)].astype(np.uint32)
+    assign[reps] = reps
+    cdb = str(tmp_path / "out" / "clust_cluster")
+    os.makedirs(os.path.dirname(cdb))
+    assert U.lib().uc_write_cluster_db(cdb.encode(), n, assign.ctypes.data) == 0
+    for sfx in ("", ".index", ".dbtype"):
+        assert os.path.exists(cdb + sfx)
+    assert int.from_bytes(open(cdb + ".dbtype", "rb").read(), "little") == 6
+    # cluster DB entry layout: member keys one per line, representative first, NUL-terminated
+    first = open(cdb, "rb").read().split(b"\0")[0].decode().split()
+    assert int(first[0]) == reps[0] and sorted(map(int, first[1:])) == list(map(int, first[1:]))
+    tsv = str(tmp_path / "out" / "clust.tsv")
+    U.createtsv(str(tmp_path / "db"), cdb, tsv)
+    rows = util.tsv_invariants(tsv, names)
+    assert [r[0] for r in rows] == [names[assign[i]] for i in np.lexsort((np.arange(n), np.arange(n) != assign, assign))]
+    # the oracle's writer produces the same bytes
+    odb = O.OracleDb(str(tmp_path / "db"))
+    O.write_tsv(str(tmp_path / "ref.tsv"), odb, assign)
+    assert open(tsv, "rb").read() == open(str(tmp_path / "ref.tsv"), "rb").read()
+    U.rmdb(cdb)
+    assert not any(os.path.exists(cdb + sfx) for sfx in ("", ".index", ".dbtype"))
+    bad = assign.copy(); bad[reps[0]] = reps[1]          # a cluster whose representative is not its own member
+    assert U.lib().uc_write_cluster_db(cdb.encode(), n, bad.ctypes.data) != 0
+
+
+def test_cli_surface_and_checkpoint_contract(tmp_path):
+    """`unicore cluster` mirrors src/util/arg_parser.rs:225-246 + src/modules/cluster.rs: arg errors exit 0x40,
+    the checkpoint is written as "0" before the engine runs, engine failure -> exit 1 with 'Error: ...'"""
+    exe = os.path.join(ROOT, "bin", "unicore")
+    r = subprocess.run([exe, "cluster"], capture_output=True, text=True)
+    assert r.returncode == 0x40 and "Argument parsing error" in r.stderr
+    r = subprocess.run([exe, "cluster", "a", "b", "c", "--nope"], capture_output=True, text=True)
+    assert r.returncode == 0x40
+    r = subprocess.run([exe, "version"], capture_output=True, text=True)
+    assert r.returncode == 0 and "unicore-cluster" in r.stdout
+    out = tmp_path / "res" / "clust"
+    r = subprocess.run([exe, "cluster", str(tmp_path / "missing_db"), str(out), str(tmp_path / "tmp"), "-c", "-c 0.8", "-v", "1"],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and r.stderr.startswith("Error: ")
+    assert open(tmp_path / "res" / "cluster.chk").read() == "0"      # started, never finished
+    r = subprocess.run([exe, "cluster", "db", str(out), "tmp", "-c", "--frobnicate 3"], capture_output=True, text=True)
+    assert r.returncode == 1 and "unknown or unsupported cluster option" in r.stderr
+    shim = os.path.join(ROOT, "bin", "foldseek")
+    assert subprocess.run([shim, "version"], capture_output=True).returncode == 0      # config.rs:49-66 handshake
+    assert subprocess.run([shim, "easy-search"], capture_output=True).returncode != 0
+    r = subprocess.run([shim, "rmdb", str(tmp_path / "nothing_cluster"), "-v", "2"], capture_output=True)
+    assert r.returncode == 0

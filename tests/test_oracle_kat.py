@@ -1,0 +1,276 @@
+"""Known-answer and property tests that PIN THE ORACLE (CPU only).
+
+The reference holds no golden vector for this path (parity unpinned, oracle/uc_oracle.h), so the oracle is
+pinned by (a) hand-computable cases, (b) an independent pure-Python restatement of every stage on small
+inputs, (c) the committed fixtures in tests/golden/ (test_golden.py).
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+import util
+from oracle import oracle_py as O
+
+LET = "ACDEFGHIKLMNPQRSTVWY"
+
+
+@pytest.fixture(scope="module")
+def p():
+    return O.default_params()
+
+
+def S3(p, a, b):
+    return p.S3[int(a) * 21 + int(b)]
+
+
+def SA(p, a, b):
+    return p.SA[int(a) * 21 + int(b)]
+
+
+def enc(s):
+    return O.encode(s)
+
+
+# ------------------------------------------------------------------ alphabet / matrices
+def test_letter_codes_and_matrix_values(p):
+    for i, c in enumerate(LET):
+        assert O.lib().uco_letter_code(c.encode()) == i and O.lib().uco_letter_code(c.lower().encode()) == i
+    for c in "XBZJOU*-":
+        assert O.lib().uco_letter_code(c.encode()) == 20
+    # BLOSUM62 spot values (Henikoff & Henikoff 1992)
+    idx = {c: i for i, c in enumerate(LET)}
+    for a, b, v in [("A", "A", 4), ("W", "W", 11), ("C", "C", 9), ("W", "C", -2), ("D", "E", 2), ("I", "V", 3), ("G", "I", -4), ("H", "Y", 2)]:
+        assert SA(p, idx[a], idx[b]) == v == SA(p, idx[b], idx[a])
+    assert SA(p, 20, 0) == 0 and SA(p, 20, 20) == -1          # X column of BLOSUM62
+    m3 = np.array(p.S3[:]).reshape(21, 21)
+    assert (m3 == m3.T).all() and (np.diag(m3)[:20] >= 4).all() and (m3[20] == -1).all()
+
+
+# ------------------------------------------------------------------ independent restatements (pure Python)
+def py_sw(q3, qa, t3, ta, p):
+    """textbook affine local alignment + the frozen tie-break (smallest tEnd, then smallest qEnd)"""
+    NEG = -10 ** 9
+    lq, lt = len(q3), len(t3)
+    H = [[0] * (lt + 1) for _ in range(lq + 1)]
+    E = [[NEG] * (lt + 1) for _ in range(lq + 1)]
+    F = [[NEG] * (lt + 1) for _ in range(lq + 1)]
+    for i in range(1, lq + 1):
+        for j in range(1, lt + 1):
+            s = S3(p, q3[i - 1], t3[j - 1]) + SA(p, qa[i - 1], ta[j - 1])
+            E[i][j] = max(E[i][j - 1] - p.gap_ext, H[i][j - 1] - p.gap_open)
+            F[i][j] = max(F[i - 1][j] - p.gap_ext, H[i - 1][j] - p.gap_open)
+            H[i][j] = max(0, H[i - 1][j - 1] + s, E[i][j], F[i][j])
+    best = max(max(r) for r in H)
+    if best == 0:
+        return 0, -1, -1
+    for j in range(1, lt + 1):
+        for i in range(1, lq + 1):
+            if H[i][j] == best:
+                return best, i - 1, j - 1
+
+
+def py_ungapped(q3, t3, d, p):
+    run = best = 0
+    for i in range(max(0, d), min(len(q3), len(t3) + d)):
+        run = max(0, run + S3(p, q3[i], t3[i - d]))
+        best = max(best, run)
+    return min(best, 255)
+
+
+def test_sw_identity_known_answer(p):
+    s = enc("ACDE")
+    # (4+4) + (4+9) + (5+6) + (8+5) from the two matrices
+    expect = sum(S3(p, c, c) + SA(p, c, c) for c in s)
+    assert expect == 45
+    assert O.sw(s, s, s, s, p) == (45, 3, 3)
+    assert O.sw(s, s, s, s, p, rev_q=1, rev_t=1) == (45, 3, 3)
+
+
+def test_sw_gap_known_answer(p):
+    left, right = enc("WCHWCH"), enc("MFYMFY")
+    q = np.concatenate([left, right])
+    junk = enc("GG")
+    t = np.concatenate([left, junk, right])
+    full = sum(S3(p, c, c) + SA(p, c, c) for c in q)
+    expect = full - (p.gap_open + (len(junk) - 1) * p.gap_ext)      # one gap of length 2: open + ext
+    assert expect > full // 2 + 20
+    assert O.sw(q, q, t, t, p) == (expect, len(q) - 1, len(t) - 1)
+    assert O.sw(t, t, q, q, p) == (expect, len(t) - 1, len(q) - 1)   # gap on the other side
+
+
+def test_sw_tiebreak_smallest_tend_then_qend(p):
+    s = enc("WCHMFY")
+    junk = enc("GGGG")
+    twice = np.concatenate([s, junk, s])
+    score = sum(S3(p, c, c) + SA(p, c, c) for c in s)
+    # the same optimum ends in two target columns -> the first one
+    assert O.sw(s, s, twice, twice, p) == (score, len(s) - 1, len(s) - 1)
+    # ... and in two query rows of the same column -> the smaller row
+    assert O.sw(twice, twice, s, s, p) == (score, len(s) - 1, len(s) - 1)
+
+
+def test_sw_no_alignment(p):
+    a, b = enc("DDDD"), enc("FFFF")     # S3[D][F] = -10, SA[D][F] = -3
+    assert O.sw(a, a, b, b, p) == (0, -1, -1)
+
+
+def test_sw_matches_pure_python_on_random_small_cases(p):
+    rng = np.random.default_rng(7)
+    for it in range(300):
+        lq, lt = int(rng.integers(1, 24)), int(rng.integers(1, 24))
+        q3, qa = rng.integers(0, 21, lq, dtype=np.uint8), rng.integers(0, 21, lq, dtype=np.uint8)
+        if it % 3 == 0:   # related pair: makes gaps and ties likely
+            keep = rng.random(lq) > 0.15
+            t3, ta = q3[keep].copy(), qa[keep].copy()
+            if len(t3) == 0:
+                t3, ta = q3[:1].copy(), qa[:1].copy()
+        else:
+            t3, ta = rng.integers(0, 21, lt, dtype=np.uint8), rng.integers(0, 21, lt, dtype=np.uint8)
+        assert O.sw(q3, qa, t3, ta, p) == py_sw(q3, qa, t3, ta, p)
+        assert O.sw(q3, qa, t3, ta, p, rev_q=1) == py_sw(q3[::-1], qa[::-1], t3, ta, p)
+        assert O.sw(q3, qa, t3, ta, p, rev_q=1, rev_t=1) == py_sw(q3[::-1], qa[::-1], t3[::-1], ta[::-1], p)
+
+
+def test_ungapped_known_answers_and_python(p):
+    s = enc("ACDEFGHIKL")
+    self_score = sum(S3(p, c, c) for c in s)
+    assert O.ungapped(s, s, 0, p) == self_score == 55
+    assert O.ungapped(s, s, 100, p) == 0 and O.ungapped(s, s, -100, p) == 0    # no overlap
+    long = np.tile(s, 10)
+    assert O.ungapped(long, long, 0, p) == 255                                   # saturates like MMseqs2's uint8
+    # Kadane reset: a strongly negative stretch must not leak into the second block
+    q = np.concatenate([enc("EEEE"), enc("DDDD"), enc("MMMM")])
+    t = np.concatenate([enc("EEEE"), enc("FFFF"), enc("MMMM")])
+    assert O.ungapped(q, t, 0, p) == 4 * S3(p, 3, 3) == 32
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        a, b = rng.integers(0, 21, int(rng.integers(1, 40)), dtype=np.uint8), rng.integers(0, 21, int(rng.integers(1, 40)), dtype=np.uint8)
+        d = int(rng.integers(-45, 45))
+        assert O.ungapped(a, b, d, p) == py_ungapped(a, b, d, p)
+
+
+# ------------------------------------------------------------------ similar k-mers
+def count_by_convolution(p, letters, thr):
+    """number of 6-tuples with score sum >= thr via convolution of the per-position score histograms"""
+    hist = {0: 1}
+    for c in letters:
+        nxt = {}
+        for s, n in hist.items():
+            for b in range(20):
+                k = s + S3(p, c, b)
+                nxt[k] = nxt.get(k, 0) + n
+        hist = nxt
+    return sum(n for s, n in hist.items() if s >= thr)
+
+
+def test_similar_kmers_exact_set(p):
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        letters = [int(x) for x in rng.integers(0, 20, 6)]
+        self_score = sum(S3(p, c, c) for c in letters)
+        for thr in (self_score + 1, self_score, self_score - 3, 24):
+            got = O.similar_kmers(letters, thr, p)
+            assert len(got) == len(set(got.tolist())) == count_by_convolution(p, letters, thr)
+            for v in got[:200]:
+                dec = [(int(v) // 20 ** m) % 20 for m in range(6)]
+                assert sum(S3(p, letters[m], dec[m]) for m in range(6)) >= thr
+        val = sum(c * 20 ** m for m, c in enumerate(letters))
+        assert val in set(O.similar_kmers(letters, self_score, p).tolist())       # the k-mer itself
+        assert len(O.similar_kmers(letters, self_score + 1, p)) == 0 or max(p.S3[c * 21 + b] for c in letters for b in range(20)) > 0
+
+
+# ------------------------------------------------------------------ set cover
+def py_setcover(n, edges):
+    adj = [set() for _ in range(n)]
+    for a, b in edges:
+        if a != b:
+            adj[a].add(b); adj[b].add(a)
+    assign = [-1] * n
+    while -1 in assign:
+        best, bu = -1, -1
+        for u in range(n):
+            if assign[u] == -1:
+                c = 1 + sum(1 for v in adj[u] if assign[v] == -1)
+                if c > best:
+                    best, bu = c, u
+        assign[bu] = bu
+        for v in adj[bu]:
+            if assign[v] == -1:
+                assign[v] = bu
+    return assign
+
+
+def test_setcover_known_answers():
+    # star: centre 3 covers everything
+    assert O.setcover(5, [(3, 0), (3, 1), (3, 2), (3, 4)]).tolist() == [3, 3, 3, 3, 3]
+    # path 0-1-2-3-4: nodes 1,2,3 cover 3 each -> smallest id 1 first, then 3 covers {3,4}... (2 is taken by 1)
+    assert O.setcover(5, [(0, 1), (1, 2), (2, 3), (3, 4)]).tolist() == [1, 1, 1, 3, 3]
+    # no edges: singletons; duplicates / self loops / both directions are harmless
+    assert O.setcover(3, np.zeros((0, 2), np.uint32)).tolist() == [0, 1, 2]
+    assert O.setcover(3, [(0, 1), (1, 0), (0, 1), (2, 2)]).tolist() == [0, 0, 2]
+    # two triangles joined by a bridge: tie on size 4 between 2 and 3 -> 2 first
+    e = [(0, 1), (0, 2), (1, 2), (2, 3), (3, 4), (3, 5), (4, 5)]
+    assert O.setcover(6, e).tolist() == [2, 2, 2, 2, 4, 4]
+
+
+def test_setcover_matches_pure_python_random():
+    rng = np.random.default_rng(5)
+    for _ in range(60):
+        n = int(rng.integers(1, 40))
+        m = int(rng.integers(0, 3 * n))
+        e = rng.integers(0, n, (m, 2))
+        assert O.setcover(n, e).tolist() == py_setcover(n, e.tolist())
+
+
+# ------------------------------------------------------------------ E-value gate, full pair, pipeline invariants
+def test_min_score_is_the_smallest_passing_integer(p):
+    import math
+    for lq, res in [(50, 10 ** 4), (300, 45 * 10 ** 6), (2000, 18 * 10 ** 8)]:
+        s = O.lib().uco_min_score(p, lq, res)
+        ev = lambda x: p.K * lq * res * math.exp(-p.lambda_ * x)
+        assert ev(s) <= p.evalue < ev(s - 1)
+
+
+def test_align_pair_start_positions_and_coverage(p):
+    core = enc("WCHMFYWCHMFYWCHMFYWCHMFY")                      # 24 strongly scoring residues
+    q = np.concatenate([enc("DDD"), core, enc("DD")])            # core at 3..26 of 29; flanks mismatch hard (S3[D][F] = -10)
+    t = np.concatenate([enc("FFFFF"), core])                     # core at 5..28 of 29
+    odb = O.OracleDb(s3=[q, t], sa=[q, t])
+    a = O.Aln()
+    import ctypes
+    O.lib().uco_align_pair(ctypes.byref(odb.db), 0, 1, ctypes.byref(p), 1, ctypes.byref(a))
+    assert (a.qstart, a.qend, a.tstart, a.tend) == (3, 26, 5, 28)
+    assert a.score == sum(S3(p, c, c) + SA(p, c, c) for c in core)
+    assert a.pass_evalue == 1 and a.accepted == 1                 # 24/29 = 0.83 >= 0.8 on both sides
+    p2 = O.default_params(cov=0.9)
+    O.lib().uco_align_pair(ctypes.byref(odb.db), 0, 1, ctypes.byref(p2), 1, ctypes.byref(a))
+    assert a.accepted == 0
+    p3 = O.default_params(min_seq_id=0.5)                          # traceback path: all 24 columns identical
+    O.lib().uco_align_pair(ctypes.byref(odb.db), 0, 1, ctypes.byref(p3), 1, ctypes.byref(a))
+    assert (a.aln_len, a.idents, a.accepted) == (24, 24, 1)
+
+
+def test_pipeline_on_family_db_recovers_families_and_tsv_invariants(tmp_path):
+    s3, sa = util.family_db(21, n_fam=10, members=5, lmin=60, lmax=160, with_x=False)
+    names = util.write_db(str(tmp_path / "db"), s3, sa)
+    odb = O.OracleDb(str(tmp_path / "db"))
+    assert odb.names() == names and odb.n == len(s3)
+    got3, gota = odb.codes()
+    assert np.array_equal(got3, np.concatenate(s3)) and np.array_equal(gota, np.concatenate(sa))
+    p = util.oracle_params(O, "-c 0.8")
+    r = O.cluster(odb, p, threads=4)
+    a = r["assign"]
+    for f in range(10):   # the 4 full-length members of every family share one representative
+        assert len(set(a[f * 5: f * 5 + 4].tolist())) == 1
+    assert len(set(a[:50].tolist())) >= 10
+    assert (a[a] == a).all()          # representatives represent themselves
+    O.write_tsv(str(tmp_path / "c.tsv"), odb, a)
+    util.tsv_invariants(str(tmp_path / "c.tsv"), names)
+    # every prefilter list is sorted by (score desc, target asc), holds the query itself when it has k-mers
+    for q in range(odb.n):
+        h = r["hits"][q, : r["hit_cnt"][q]]
+        key = list(zip((-h["score"]).tolist(), h["t"].tolist()))
+        assert key == sorted(key) and len(h) <= p.max_seqs
+        if len(s3[q]) >= 30 and (s3[q] < 20).all():
+            assert q in h["t"].tolist()
