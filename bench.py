@@ -26,7 +26,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_LANE_OPS = 78.6e12     # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (int32 VALU)
+VALU_PEAK_LANE_OPS = 39.3e12     # int32 VALU: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz — measured: every int32 VALU
+                                 # instruction of the SW kernel occupies its SIMD for 4 cycles (profiles/r1b_pmc_sw.txt)
+VALU_OPS_PER_CELL = {"fwd": 9.7, "rev": 8.7, "start": 9.95}   # static ISA counts of sw_group_kernel's step loop
+
+
+def pmc_traffic_per_launch():
+    """HBM bytes per SW launch from the committed rocprofv3 PMC passes (bench.py cannot read PMCs itself)."""
+    f = os.path.join(ROOT, "profiles", "sw_traffic.json")
+    if not os.path.exists(f):
+        return None
+    d = json.load(open(f))
+    return (d["fetch_size_kib"] + d["write_size_kib"]) * 1024.0 / d["sw_launches"]
 
 
 def gen_db(workdir, proteomes, families, scale, seed):
@@ -55,7 +66,7 @@ def cpu_baseline(prefix, opts, n_seqs, target_seconds=15.0):
     from oracle import oracle_py as O
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import util
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     p = util.oracle_params(O, opts)
     odb = O.OracleDb(prefix)
     t0 = time.time()
@@ -63,7 +74,7 @@ def cpu_baseline(prefix, opts, n_seqs, target_seconds=15.0):
     t_index = time.time() - t0
     rng = np.random.default_rng(12345)
     order = rng.permutation(n_seqs).astype(np.uint32)
-    n1 = min(n_seqs, max(64, 32 * cores))
+    n1 = min(n_seqs, max(64, 4 * cores))
     a1, tp1, ta1 = O.sample_run(odb, ix, p, order[:n1], threads=cores)
     rate = (tp1 + ta1) / max(n1, 1)
     n2 = int(min(n_seqs - n1, max(0, (target_seconds - (tp1 + ta1)) / max(rate, 1e-9))))
@@ -170,13 +181,15 @@ def main():
                        "parallelism": "target-shard x%d + RCCL hit all-gather" % world if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "sw_group_kernel (gapped 3Di+AA SW, all passes)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": pmc_traffic_per_launch(),
                          "algorithmic_bytes_per_launch": st["sw_algorithmic_bytes"] / max(st["sw_kernel_launches"], 1),
                          "avg_launch_ms": st["sw_kernel_ms"] / max(st["sw_kernel_launches"], 1),
                          "launches": st["sw_kernel_launches"],
                          "note": "integer-VALU-bound by design (SURVEY.md 8d): see valu_*",
                          "valu_gcups": cells / sw_s / 1e9 if sw_s > 0 else 0.0,
-                         "valu_peak_lane_ops": VALU_PEAK_LANE_OPS},
+                         "valu_peak_lane_ops": VALU_PEAK_LANE_OPS,
+                         "valu_frac": ((st["cells_fwd"] * VALU_OPS_PER_CELL["fwd"] + st["cells_rev"] * VALU_OPS_PER_CELL["rev"]
+                                        + st["cells_start"] * VALU_OPS_PER_CELL["start"]) / sw_s / VALU_PEAK_LANE_OPS) if sw_s > 0 else 0.0},
             "stages_s_per_step": {k: v / steps for k, v in zip(U.STAGES, st["stage_seconds"])},
             "prefilter_kernel_ms_per_step": st["prefilter_kernel_ms"] / steps,
             "sw_kernel_ms_per_step": st["sw_kernel_ms"] / steps,

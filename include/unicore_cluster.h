@@ -49,6 +49,7 @@ typedef struct uc_stats {
     uint64_t n_index_entries, n_sim_kmers, n_kmer_hits, n_candidates, n_prefilter_hits;
     uint64_t n_gapped_alignments;        /* (query,target) pairs handed to stage E5: the metric's unit */
     uint64_t n_start_alignments;         /* pairs that also ran the start-position pass */
+    uint64_t n_pk_reruns;                /* alignment-passes of the packed 16-bit kernel re-run in int32 */
     uint64_t n_edges, n_clusters;
     uint64_t cells_fwd, cells_rev, cells_start;          /* DP cell updates per pass */
     uint64_t algorithmic_bytes[UC_NSTAGE];               /* SURVEY.md 8(d) per-stage algorithmic bytes */

@@ -368,9 +368,17 @@ void uco_sw(const uint8_t *q3, const uint8_t *qa, int lq, int rev_q,
             const uint8_t *t3, const uint8_t *ta, int lt, int rev_t,
             const uco_params *p, int32_t *score, int32_t *qend, int32_t *tend) {
     const int open = p->gap_open, ext = p->gap_ext;
-    int32_t *H = (int32_t *)calloc((size_t)lq + 1, sizeof(int32_t));   /* column j-1, rows -1..lq-1 at [i+1] */
-    int32_t *E = (int32_t *)malloc(((size_t)lq + 1) * sizeof(int32_t));
-    for (int i = 0; i <= lq; i++) E[i] = -(1 << 28);
+    /* per-thread scratch (the cpu_baseline leg calls this millions of times from many threads) */
+    static __thread int32_t *scratch = NULL;
+    static __thread size_t scratch_cap = 0;
+    if (scratch_cap < 2 * ((size_t)lq + 1)) {
+        free(scratch);
+        scratch_cap = 2 * ((size_t)lq + 1) + 256;
+        scratch = (int32_t *)malloc(scratch_cap * sizeof(int32_t));
+    }
+    int32_t *H = scratch;                    /* column j-1, rows -1..lq-1 at [i+1] */
+    int32_t *E = scratch + (size_t)lq + 1;
+    for (int i = 0; i <= lq; i++) { H[i] = 0; E[i] = -(1 << 28); }
     int32_t best = 0, bq = -1, bt = -1;
     for (int j = 0; j < lt; j++) {
         int tj = rev_t ? lt - 1 - j : j;
@@ -394,7 +402,6 @@ void uco_sw(const uint8_t *q3, const uint8_t *qa, int lq, int rev_q,
         }
         if (colbest > best) { best = colbest; bq = colrow; bt = j; }
     }
-    free(H); free(E);
     *score = best; *qend = bq; *tend = bt;
 }
 

@@ -16,12 +16,13 @@ def O():
     return oracle_py
 
 
-@pytest.fixture(scope="module")
-def small(O):
+@pytest.fixture(scope="module", params=["pk16", "i32"])
+def small(O, request):
+    """both gapped-kernel variants: packed 16-bit (default; int32 re-run of flagged pairs) and pure int32"""
     s3, sa = util.family_db(11, n_fam=14, members=6, extra=(700, 1100, 1500, 2040))
     off, c3, ca = util.flat(s3, sa)
     import unicore_amd as U
-    e = U.Engine("-c 0.8", verbosity=1)
+    e = U.Engine("-c 0.8 --sw-kernel " + request.param, verbosity=1)
     e.set_db(off, c3, ca)
     return dict(s3=s3, sa=sa, off=off, eng=e, odb=O.OracleDb(s3=s3, sa=sa))
 
@@ -138,6 +139,12 @@ def test_pipeline_stage_parity(O, small, opts):
     assign = U.setcover(e.n, e.edges())
     assert np.array_equal(assign, ref["assign"])
     assert len(set(assign.tolist())) < e.n   # something actually clustered
+    # the int32-only kernel path gives the same records
+    e2 = U.Engine(opts + " --sw-kernel i32", verbosity=1)
+    e2.set_db(small["off"], *util.flat(small["s3"], small["sa"])[1:])
+    e2.set_hits(cnt, hits)
+    e2.align()
+    assert e2.alns().tobytes() == al.tobytes()
 
 
 def test_cluster_end_to_end_tsv_bytes(O, tmp_path):

@@ -26,7 +26,7 @@ class UcOpts(C.Structure):
 class UcStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "n_seqs", "n_residues", "n_index_entries", "n_sim_kmers", "n_kmer_hits", "n_candidates", "n_prefilter_hits",
-        "n_gapped_alignments", "n_start_alignments", "n_edges", "n_clusters", "cells_fwd", "cells_rev", "cells_start")] + [
+        "n_gapped_alignments", "n_start_alignments", "n_pk_reruns", "n_edges", "n_clusters", "cells_fwd", "cells_rev", "cells_start")] + [
         ("algorithmic_bytes", C.c_uint64 * NSTAGE), ("stage_seconds", C.c_double * NSTAGE),
         ("sw_kernel_ms", C.c_double), ("sw_kernel_launches", C.c_uint64), ("sw_algorithmic_bytes", C.c_uint64),
         ("prefilter_kernel_ms", C.c_double)]

@@ -15,20 +15,42 @@
 
 namespace uc {
 
+constexpr int SW_PK_OVF_HOST = 65535 - 256;   // == SW_PK_OVF of uc_sw_pk_impl.hpp
+
 namespace {
 
-__device__ __constant__ int c_cls_cap[16] = {64, 128, 192, 256, 320, 384, 448, 512, 640, 768, 896, 1024, 1280, 1536, 1792, 2048};
-const int h_cls_g[16] = {16, 16, 16, 16, 16, 16, 16, 16, 32, 32, 32, 32, 64, 64, 64, 64};
-const int h_cls_r[16] = {4, 8, 12, 16, 20, 24, 28, 32, 20, 24, 28, 32, 20, 24, 28, 32};
+// Length classes.  Table 0: int32 kernel for everything (16 systolic classes + generic).  Table 1: the packed
+// 16-bit kernel for queries <= 1024 rows (its 4R+ registers per lane limit R to 16), int32 classes above.
+constexpr int MAXCLS = 20;
+struct ClassTable {
+    int n;                 // systolic classes; index n = generic fallback (queries > cap[n-1])
+    int cap[MAXCLS], G[MAXCLS], R[MAXCLS], pk[MAXCLS];
+    uint32_t tcap[MAXCLS]; // pairs per workgroup task
+};
+// pairs per task: the long-query classes have few queries, so their pair lists are cut finer to keep every
+// CU busy (rebuilding the LDS profile per task is negligible against >= 16 long alignments)
+const ClassTable h_tab[2] = {
+    {16,
+     {64, 128, 192, 256, 320, 384, 448, 512, 640, 768, 896, 1024, 1280, 1536, 1792, 2048},
+     {16, 16, 16, 16, 16, 16, 16, 16, 32, 32, 32, 32, 64, 64, 64, 64},
+     {4, 8, 12, 16, 20, 24, 28, 32, 20, 24, 28, 32, 20, 24, 28, 32},
+     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+     {256, 256, 256, 256, 256, 256, 256, 256, 64, 64, 64, 64, 24, 24, 24, 24}},
+    {14,
+     {64, 128, 192, 256, 320, 384, 512, 640, 768, 1024, 1280, 1536, 1792, 2048},
+     {16, 16, 16, 16, 16, 16, 32, 32, 32, 64, 64, 64, 64, 64},
+     {4, 8, 12, 16, 20, 24, 16, 20, 24, 16, 20, 24, 28, 32},
+     {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0},
+     {64, 64, 64, 64, 64, 64, 64, 64, 64, 48, 48, 48, 24, 24}},
+};
+__device__ __constant__ ClassTable c_tab[2];
 
-__device__ __forceinline__ int class_of(int lq) {
+__device__ __forceinline__ int class_of(int lq, int tab) {
     int c = 0;
-    while (c < 16 && c_cls_cap[c] < lq) c++;
+    while (c < c_tab[tab].n && c_tab[tab].cap[c] < lq) c++;
     return c;
 }
-// pairs per workgroup task: the long-query classes have few queries, so their pair lists are cut finer to
-// keep every CU busy (rebuilding the LDS profile per task is negligible against >= 16 long alignments)
-__device__ __forceinline__ uint32_t task_cap(int c) { return c < 8 ? 256u : (c < 12 ? 64u : 24u); }
+__device__ __forceinline__ uint32_t task_cap(int c, int tab) { return c < c_tab[tab].n ? c_tab[tab].tcap[c] : 256u; }
 
 inline dim3 grid_for(uint64_t n, uint32_t cap = 16384) {
     const uint64_t b = (n + 255) / 256;
@@ -37,7 +59,7 @@ inline dim3 grid_for(uint64_t n, uint32_t cap = 16384) {
 
 // key = [ class : 5 | query : 24 | 65535 - effective target length : 16 ]
 __global__ void __launch_bounds__(256) plan_key_kernel(uint32_t n, const uint32_t *q, const uint32_t *t, const int32_t *qe,
-                                                       const int32_t *te, const uint32_t *len, uint64_t *key, uint32_t *idx,
+                                                       const int32_t *te, const uint32_t *len, int tab, uint64_t *key, uint32_t *idx,
                                                        unsigned long long *alg_bytes /* [0] bytes, [1] DP cells */) {
     unsigned long long bytes = 0, cells = 0;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
@@ -45,7 +67,7 @@ __global__ void __launch_bounds__(256) plan_key_kernel(uint32_t n, const uint32_
         const uint32_t lq = len[qq];
         const uint32_t tl = te ? (uint32_t)te[i] + 1 : len[t[i]];
         const uint32_t ql = qe ? (uint32_t)qe[i] + 1 : lq;
-        key[i] = ((uint64_t)class_of((int)lq) << 40) | ((uint64_t)qq << 16) | (uint64_t)(65535u - tl);
+        key[i] = ((uint64_t)class_of((int)lq, tab) << 40) | ((uint64_t)qq << 16) | (uint64_t)(65535u - tl);
         idx[i] = i;
         bytes += 2ull * (ql + tl) + 32;
         cells += (unsigned long long)ql * tl;
@@ -67,9 +89,9 @@ __global__ void __launch_bounds__(256) plan_gather_kernel(uint32_t n, const uint
     }
 }
 
-__global__ void __launch_bounds__(256) plan_taskflag_kernel(uint32_t n, const uint64_t *key, const uint32_t *segstart, uint32_t *flag) {
+__global__ void __launch_bounds__(256) plan_taskflag_kernel(uint32_t n, const uint64_t *key, const uint32_t *segstart, int tab, uint32_t *flag) {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
-        flag[i] = ((i - segstart[i]) % task_cap((int)(key[i] >> 40))) == 0 ? 1u : 0u;
+        flag[i] = ((i - segstart[i]) % task_cap((int)(key[i] >> 40), tab)) == 0 ? 1u : 0u;
 }
 
 __global__ void __launch_bounds__(256) plan_taskfill_kernel(uint32_t n, const uint64_t *key, const uint32_t *flag, const uint32_t *tpos,
@@ -101,16 +123,17 @@ __global__ void __launch_bounds__(256) plan_taskgather_kernel(uint32_t ntasks, c
     for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < ntasks; k += gridDim.x * 256) out[k] = in[tidx[k]];
 }
 
-// bounds[c] = first task of class >= c, bounds[18 + c] = first sorted pair of class >= c   (c = 0..17)
+// bounds[c] = first task of class >= c, bounds[NB + c] = first sorted pair of class >= c   (c = 0..NB-1)
+constexpr int NB = MAXCLS + 2;
 __global__ void plan_bounds_kernel(uint32_t ntasks, const uint32_t *tcls, uint32_t n, const uint64_t *key, uint32_t *bounds) {
     const uint32_t c = threadIdx.x;
-    if (c >= 18) return;
+    if (c >= NB) return;
     uint32_t lo = 0, hi = ntasks;
     while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (tcls[m] < c) lo = m + 1; else hi = m; }
     bounds[c] = lo;
     lo = 0; hi = n;
     while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if ((uint32_t)(key[m] >> 40) < c) lo = m + 1; else hi = m; }
-    bounds[18 + c] = lo;
+    bounds[NB + c] = lo;
 }
 
 __global__ void __launch_bounds__(256) scatter3_kernel(uint32_t n, const uint32_t *idx, const int32_t *a, const int32_t *b,
@@ -146,7 +169,8 @@ __global__ void __launch_bounds__(256) aln_basic_kernel(uint32_t n, const uint32
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         uc_aln a;
         a.score = s0[i]; a.score_rev = s1 ? s1[i] : 0; a.corrected = a.score - a.score_rev;
-        a.qstart = -1; a.qend = qe[i]; a.tstart = -1; a.tend = te[i];
+        // positions are only defined (and only exact) for pairs that pass the E-value gate
+        a.qstart = -1; a.qend = pass[i] ? qe[i] : -1; a.tstart = -1; a.tend = pass[i] ? te[i] : -1;
         a.aln_len = 0; a.idents = 0; a.pass_evalue = (int32_t)pass[i]; a.accepted = 0;
         out[idx[i]] = a;
     }
@@ -195,9 +219,10 @@ struct SwPlan {
     DevBuf<uint64_t> tkey, tkey2;
     DevBuf<uint32_t> tidx, tidx2;
     DevBuf<unsigned long long> bytes;
-    uint32_t task_base[18] = {0}, pair_base[18] = {0};
+    uint32_t task_base[NB] = {0}, pair_base[NB] = {0};
     uint64_t alg_bytes = 0, cells = 0;
     bool has_ends = false;
+    int tab = 0;
 };
 
 static void scan_u32(Engine &E, DevBuf<char> &tmp, const uint32_t *in, uint32_t *out, uint32_t n, bool inclusive_max) {
@@ -224,8 +249,10 @@ static uint32_t scan_total(Engine &E, const uint32_t *flag, const uint32_t *pos,
 }
 
 static void build_plan(Engine &E, SwPlan &P, DevBuf<char> &tmp, uint32_t n, const uint32_t *q, const uint32_t *t,
-                       const int32_t *qe, const int32_t *te) {
-    P.n = n; P.ntasks = 0; P.alg_bytes = 0; P.cells = 0; P.has_ends = qe != nullptr;
+                       const int32_t *qe, const int32_t *te, int tab) {
+    static bool tables_uploaded = false;
+    if (!tables_uploaded) { UC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), h_tab, sizeof h_tab)); tables_uploaded = true; }
+    P.n = n; P.ntasks = 0; P.alg_bytes = 0; P.cells = 0; P.has_ends = qe != nullptr; P.tab = tab;
     memset(P.task_base, 0, sizeof P.task_base);
     memset(P.pair_base, 0, sizeof P.pair_base);
     if (!n) return;
@@ -233,16 +260,16 @@ static void build_plan(Engine &E, SwPlan &P, DevBuf<char> &tmp, uint32_t n, cons
     P.key.reserve(n); P.key2.reserve(n); P.idx_in.reserve(n); P.idx.reserve(n);
     P.sq.reserve(n); P.st.reserve(n); P.head.reserve(n); P.segstart.reserve(n); P.flag.reserve(n); P.tpos.reserve(n);
     if (qe) { P.sqe.reserve(n); P.ste.reserve(n); }
-    P.bytes.reserve(2); P.bounds.reserve(36);
+    P.bytes.reserve(2); P.bounds.reserve(2 * NB);
     UC_HIP(hipMemsetAsync(P.bytes.p, 0, 16, s));
-    hipLaunchKernelGGL(plan_key_kernel, grid_for(n), dim3(256), 0, s, n, q, t, qe, te, E.ddb.len, P.key.p, P.idx_in.p, P.bytes.p);
+    hipLaunchKernelGGL(plan_key_kernel, grid_for(n), dim3(256), 0, s, n, q, t, qe, te, E.ddb.len, tab, P.key.p, P.idx_in.p, P.bytes.p);
     size_t tb = 0;
     UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, P.key.p, P.key2.p, P.idx_in.p, P.idx.p, (size_t)n, 0u, 45u, s));
     tmp.reserve(tb + 256);
     UC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, P.key.p, P.key2.p, P.idx_in.p, P.idx.p, (size_t)n, 0u, 45u, s));
     hipLaunchKernelGGL(plan_gather_kernel, grid_for(n), dim3(256), 0, s, n, P.key2.p, P.idx.p, t, qe, te, P.sq.p, P.st.p, P.sqe.p, P.ste.p, P.head.p);
     scan_u32(E, tmp, P.head.p, P.segstart.p, n, true);
-    hipLaunchKernelGGL(plan_taskflag_kernel, grid_for(n), dim3(256), 0, s, n, P.key2.p, P.segstart.p, P.flag.p);
+    hipLaunchKernelGGL(plan_taskflag_kernel, grid_for(n), dim3(256), 0, s, n, P.key2.p, P.segstart.p, tab, P.flag.p);
     scan_u32(E, tmp, P.flag.p, P.tpos.p, n, false);
     P.ntasks = scan_total(E, P.flag.p, P.tpos.p, n);
     P.tasks.reserve(P.ntasks); P.tcls.reserve(P.ntasks);
@@ -256,36 +283,36 @@ static void build_plan(Engine &E, SwPlan &P, DevBuf<char> &tmp, uint32_t n, cons
     UC_HIP(hipMemcpyAsync(P.tasks_in.p, P.tasks.p, (size_t)P.ntasks * sizeof(SwTask), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(plan_taskgather_kernel, grid_for(P.ntasks), dim3(256), 0, s, P.ntasks, P.tidx2.p, P.tasks_in.p, P.tasks.p);
     hipLaunchKernelGGL(plan_bounds_kernel, dim3(1), dim3(64), 0, s, P.ntasks, P.tcls.p, n, P.key2.p, P.bounds.p);
-    uint32_t hb[36];
+    uint32_t hb[2 * NB];
     unsigned long long bytes[2] = {0, 0};
     UC_HIP(hipMemcpyAsync(hb, P.bounds.p, sizeof hb, hipMemcpyDeviceToHost, s));
     UC_HIP(hipMemcpyAsync(bytes, P.bytes.p, 16, hipMemcpyDeviceToHost, s));
     UC_HIP(hipStreamSynchronize(s));
     UC_HIP(hipGetLastError());
-    memcpy(P.task_base, hb, 18 * 4);
-    memcpy(P.pair_base, hb + 18, 18 * 4);
+    memcpy(P.task_base, hb, NB * 4);
+    memcpy(P.pair_base, hb + NB, NB * 4);
     P.alg_bytes = bytes[0];
     P.cells = bytes[1];
 }
 
-// one launch per populated class; outputs are in the plan's sorted order
-static void run_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t *oqe, int32_t *ote, DevBuf<int32_t> &work) {
-    if (!P.n) return;
+// one launch per populated class; outputs are in the plan's sorted order.  Returns the number of launches.
+static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t *oqe, int32_t *ote, DevBuf<int32_t> &work) {
+    const ClassTable &tab = h_tab[P.tab];
     SwArgs a;
     a.db = E.ddb; a.tasks = P.tasks.p; a.pt = P.st.p; a.pqe = P.sqe.p; a.pte = P.ste.p;
     a.oscore = os; a.oqe = oqe; a.ote = ote; a.open = E.p.gap_open; a.ext = E.p.gap_ext;
     uint64_t launches = 0;
-    E.timed_ms_begin();
-    for (int c = 0; c < 16; c++) {
+    for (int c = 0; c < tab.n; c++) {
         const uint32_t nt = P.task_base[c + 1] - P.task_base[c];
         if (!nt) continue;
         SwArgs ac = a;
         ac.tasks = P.tasks.p + P.task_base[c];
-        launch_sw_class(h_cls_g[c], h_cls_r[c], mode, ac, nt, E.stream);
+        if (tab.pk[c]) launch_sw_pk_class(tab.G[c], tab.R[c], mode, ac, nt, E.stream);
+        else launch_sw_class(tab.G[c], tab.R[c], mode, ac, nt, E.stream);
         UC_HIP(hipGetLastError());
         launches++;
     }
-    const uint32_t gb = P.pair_base[16], ngen = P.n - gb;
+    const uint32_t gb = P.pair_base[tab.n], ngen = P.n - gb;
     if (ngen) {   // queries longer than the largest systolic class
         const size_t lanes = (size_t)((ngen + 63) / 64) * 64;
         work.reserve(2 * (size_t)E.max_len * lanes);
@@ -300,9 +327,122 @@ static void run_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t *oqe, 
         UC_HIP(hipGetLastError());
         launches++;
     }
-    E.stats.sw_kernel_ms += E.timed_ms_end();
+    return launches;
+}
+
+// pairs of the packed classes whose result is not final: ambiguous end row (qe == -2) or a value near the
+// u16 range -> they are re-run by the int32 kernel
+__global__ void __launch_bounds__(256) pk_flag_kernel(uint32_t n_pk, const int32_t *os, const int32_t *oqe, int ovf, int ovf_only, uint32_t *flag) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_pk; i += gridDim.x * 256)
+        flag[i] = (os[i] >= ovf || (!ovf_only && oqe && oqe[i] == -2)) ? 1u : 0u;
+}
+// deferred variant: only the pairs that passed the E-value gate need their exact end row
+__global__ void __launch_bounds__(256) amb_flag_kernel(uint32_t n2, const int32_t *qe2, uint32_t *flag) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) flag[i] = qe2[i] == -2 ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) amb_gather_kernel(uint32_t n2, const uint32_t *flag, const uint32_t *pos, const uint32_t *q2,
+                                                         const uint32_t *t2, uint32_t *q3, uint32_t *t3, uint32_t *link3) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
+        if (!flag[i]) continue;
+        const uint32_t w = pos[i];
+        q3[w] = q2[i]; t3[w] = t2[i]; link3[w] = i;
+    }
+}
+__global__ void __launch_bounds__(256) amb_putback_kernel(uint32_t n3, const uint32_t *idx3, const uint32_t *link3, const uint32_t *link,
+                                                          const int32_t *qe3, const int32_t *te3, int32_t *qe2, int32_t *te2,
+                                                          int32_t *qe0, int32_t *te0) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n3; i += gridDim.x * 256) {
+        const uint32_t j = link3[idx3[i]];
+        qe2[j] = qe3[i]; te2[j] = te3[i];
+        qe0[link[j]] = qe3[i]; te0[link[j]] = te3[i];
+    }
+}
+__global__ void __launch_bounds__(256) pk_gather_kernel(uint32_t n_pk, const uint32_t *flag, const uint32_t *pos, const uint32_t *sq,
+                                                        const uint32_t *st, const int32_t *sqe, const int32_t *ste, uint32_t *q2,
+                                                        uint32_t *t2, int32_t *qe2, int32_t *te2, uint32_t *link) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_pk; i += gridDim.x * 256) {
+        if (!flag[i]) continue;
+        const uint32_t w = pos[i];
+        q2[w] = sq[i]; t2[w] = st[i]; link[w] = i;
+        if (sqe) { qe2[w] = sqe[i]; te2[w] = ste[i]; }
+    }
+}
+__global__ void __launch_bounds__(256) pk_putback_kernel(uint32_t n2, const uint32_t *idx2, const uint32_t *link, const int32_t *s,
+                                                         const int32_t *qe, const int32_t *te, int32_t *os, int32_t *oqe, int32_t *ote) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
+        const uint32_t o = link[idx2[i]];
+        os[o] = s[i];
+        if (oqe) { oqe[o] = qe[i]; ote[o] = te[i]; }
+    }
+}
+
+struct RerunBufs {
+    DevBuf<uint32_t> flag, pos, q2, t2, link;
+    DevBuf<int32_t> qe2, te2, s, qe, te;
+};
+
+// ovf_only: re-run immediately only what saturated; ambiguous end rows (qe == -2) are left for the caller
+static void run_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t *oqe, int32_t *ote, DevBuf<int32_t> &work,
+                     DevBuf<char> &tmp, bool ovf_only = false) {
+    if (!P.n) return;
+    E.timed_ms_begin();
+    uint64_t launches = launch_plan(E, P, mode, os, oqe, ote, work);
+    double ms = E.timed_ms_end();
+    const ClassTable &tab = h_tab[P.tab];
+    int npk = 0;
+    while (npk < tab.n && tab.pk[npk]) npk++;
+    const uint32_t n_pk = P.pair_base[npk];   // packed classes form a prefix of the sorted pair list
+    if (n_pk) {
+        static RerunBufs B;
+        static SwPlan P2;
+        hipStream_t s = E.stream;
+        B.flag.reserve(n_pk); B.pos.reserve(n_pk);
+        hipLaunchKernelGGL(pk_flag_kernel, grid_for(n_pk), dim3(256), 0, s, n_pk, os, oqe, SW_PK_OVF_HOST, ovf_only ? 1 : 0, B.flag.p);
+        scan_u32(E, tmp, B.flag.p, B.pos.p, n_pk, false);
+        const uint32_t n2 = scan_total(E, B.flag.p, B.pos.p, n_pk);
+        E.stats.n_pk_reruns += n2;
+        if (n2) {
+            B.q2.reserve(n2); B.t2.reserve(n2); B.link.reserve(n2); B.s.reserve(n2);
+            if (P.has_ends) { B.qe2.reserve(n2); B.te2.reserve(n2); }
+            if (oqe) { B.qe.reserve(n2); B.te.reserve(n2); }
+            hipLaunchKernelGGL(pk_gather_kernel, grid_for(n_pk), dim3(256), 0, s, n_pk, B.flag.p, B.pos.p, P.sq.p, P.st.p,
+                               P.has_ends ? P.sqe.p : nullptr, P.has_ends ? P.ste.p : nullptr, B.q2.p, B.t2.p, B.qe2.p, B.te2.p, B.link.p);
+            build_plan(E, P2, tmp, n2, B.q2.p, B.t2.p, P.has_ends ? B.qe2.p : nullptr, P.has_ends ? B.te2.p : nullptr, 0);
+            E.timed_ms_begin();
+            launches += launch_plan(E, P2, mode, B.s.p, oqe ? B.qe.p : nullptr, oqe ? B.te.p : nullptr, work);
+            ms += E.timed_ms_end();
+            hipLaunchKernelGGL(pk_putback_kernel, grid_for(n2), dim3(256), 0, s, n2, P2.idx.p, B.link.p, B.s.p,
+                               oqe ? B.qe.p : nullptr, oqe ? B.te.p : nullptr, os, oqe, ote);
+            UC_HIP(hipGetLastError());
+        }
+    }
+    E.stats.sw_kernel_ms += ms;
     E.stats.sw_kernel_launches += launches;
     E.stats.sw_algorithmic_bytes += P.alg_bytes;
+}
+
+// exact (qEnd, tEnd) by the int32 forward kernel for the gate-passing pairs the packed kernel left ambiguous
+static void fix_ambiguous_ends(Engine &E, uint32_t n2, const uint32_t *q2, const uint32_t *t2, int32_t *qe2, int32_t *te2,
+                               const uint32_t *link, int32_t *qe0, int32_t *te0, DevBuf<int32_t> &work, DevBuf<char> &tmp) {
+    static RerunBufs B;
+    static SwPlan P3;
+    hipStream_t s = E.stream;
+    B.flag.reserve(n2); B.pos.reserve(n2);
+    hipLaunchKernelGGL(amb_flag_kernel, grid_for(n2), dim3(256), 0, s, n2, qe2, B.flag.p);
+    scan_u32(E, tmp, B.flag.p, B.pos.p, n2, false);
+    const uint32_t n3 = scan_total(E, B.flag.p, B.pos.p, n2);
+    E.stats.n_pk_reruns += n3;
+    if (!n3) return;
+    B.q2.reserve(n3); B.t2.reserve(n3); B.link.reserve(n3); B.s.reserve(n3); B.qe.reserve(n3); B.te.reserve(n3);
+    hipLaunchKernelGGL(amb_gather_kernel, grid_for(n2), dim3(256), 0, s, n2, B.flag.p, B.pos.p, q2, t2, B.q2.p, B.t2.p, B.link.p);
+    build_plan(E, P3, tmp, n3, B.q2.p, B.t2.p, nullptr, nullptr, 0);
+    E.timed_ms_begin();
+    const uint64_t launches = launch_plan(E, P3, 0, B.s.p, B.qe.p, B.te.p, work);
+    E.stats.sw_kernel_ms += E.timed_ms_end();
+    E.stats.sw_kernel_launches += launches;
+    E.stats.sw_algorithmic_bytes += P3.alg_bytes;
+    hipLaunchKernelGGL(amb_putback_kernel, grid_for(n3), dim3(256), 0, s, n3, P3.idx.p, B.link.p, link, B.qe.p, B.te.p, qe2, te2, qe0, te0);
+    UC_HIP(hipGetLastError());
 }
 
 // ---- kernel-level entry point: arbitrary pair list from the host -----------------------------------
@@ -337,8 +477,8 @@ void Engine::sw_batch(int mode, const std::vector<PairIn> &pairs, int32_t *score
     }
     if (track) { oq.reserve(n); ot.reserve(n); rq.reserve(n); rt.reserve(n); }
     SwPlan P;
-    build_plan(*this, P, tmp, (uint32_t)n, dq.p, dt.p, dqe.p, dte.p);
-    run_plan(*this, P, mode, os.p, oq.p, ot.p, work);
+    build_plan(*this, P, tmp, (uint32_t)n, dq.p, dt.p, dqe.p, dte.p, p.sw_pk ? 1 : 0);
+    run_plan(*this, P, mode, os.p, oq.p, ot.p, work, tmp);
     hipLaunchKernelGGL(scatter3_kernel, grid_for(n), dim3(256), 0, stream, (uint32_t)n, P.idx.p, os.p, oq.p, ot.p, rs.p, rq.p, rt.p);
     UC_HIP(hipMemcpyAsync(score, rs.p, n * 4, hipMemcpyDeviceToHost, stream));
     if (track && qe) UC_HIP(hipMemcpyAsync(qe, rq.p, n * 4, hipMemcpyDeviceToHost, stream));
@@ -385,22 +525,25 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
         const uint32_t n = (uint32_t)(hit_off[qb] - b);
         if (n) {
             s0.reserve(n); qe0.reserve(n); te0.reserve(n); gflag.reserve(n); gpos.reserve(n);
-            build_plan(*this, P0, tmp, n, d_hq.p + b, d_ht.p + b, nullptr, nullptr);
-            run_plan(*this, P0, 0, s0.p, qe0.p, te0.p, work);
+            build_plan(*this, P0, tmp, n, d_hq.p + b, d_ht.p + b, nullptr, nullptr, p.sw_pk ? 1 : 0);
+            run_plan(*this, P0, 0, s0.p, qe0.p, te0.p, work, tmp, /*ovf_only=*/true);
             stats.cells_fwd += P0.cells;
-            if (p.rev_correction) { s1.reserve(n); run_plan(*this, P0, 1, s1.p, nullptr, nullptr, work); stats.cells_rev += P0.cells; }
+            if (p.rev_correction) { s1.reserve(n); run_plan(*this, P0, 1, s1.p, nullptr, nullptr, work, tmp); stats.cells_rev += P0.cells; }
             const int32_t *s1p = p.rev_correction ? s1.p : nullptr;
             hipLaunchKernelGGL(gate_kernel, grid_for(n), dim3(256), 0, s, n, P0.sq.p, s0.p, s1p, d_ms.p, qbegin, gflag.p);
             scan_u32(*this, tmp, gflag.p, gpos.p, n, false);
             const uint32_t n2 = scan_total(*this, gflag.p, gpos.p, n);
-            hipLaunchKernelGGL(aln_basic_kernel, grid_for(n), dim3(256), 0, s, n, P0.idx.p, s0.p, s1p, qe0.p, te0.p, gflag.p, d_alns.p + b);
             if (n2) {
                 q2.reserve(n2); t2.reserve(n2); qe2.reserve(n2); te2.reserve(n2); link.reserve(n2);
                 s2.reserve(n2); q2o.reserve(n2); t2o.reserve(n2); eflag.reserve(n2); epos.reserve(n2);
                 hipLaunchKernelGGL(gate_scatter_kernel, grid_for(n), dim3(256), 0, s, n, gflag.p, gpos.p, P0.sq.p, P0.st.p, qe0.p, te0.p,
                                    q2.p, t2.p, qe2.p, te2.p, link.p);
-                build_plan(*this, P2, tmp, n2, q2.p, t2.p, qe2.p, te2.p);
-                run_plan(*this, P2, 2, s2.p, q2o.p, t2o.p, work);
+                if (p.sw_pk) fix_ambiguous_ends(*this, n2, q2.p, t2.p, qe2.p, te2.p, link.p, qe0.p, te0.p, work, tmp);
+            }
+            hipLaunchKernelGGL(aln_basic_kernel, grid_for(n), dim3(256), 0, s, n, P0.idx.p, s0.p, s1p, qe0.p, te0.p, gflag.p, d_alns.p + b);
+            if (n2) {
+                build_plan(*this, P2, tmp, n2, q2.p, t2.p, qe2.p, te2.p, p.sw_pk ? 1 : 0);
+                run_plan(*this, P2, 2, s2.p, q2o.p, t2o.p, work, tmp);
                 stats.cells_start += P2.cells;
                 hipLaunchKernelGGL(finalize_kernel, grid_for(n2), dim3(256), 0, s, n2, P2.idx.p, link.p, P0.idx.p, P2.sq.p, P2.st.p, s2.p,
                                    q2o.p, t2o.p, ddb.len, p.cov, p.cov_mode, d_alns.p + b, eflag.p, mism.p);

@@ -35,6 +35,7 @@ constexpr int SW_MAX_ROWS = 2048;   // largest single-strip class (G=64, R=32)
 
 // host launchers (uc_sw.hip / uc_prefilter.hip)
 void launch_sw_class(int G, int R, int mode, const SwArgs &a, uint32_t n_tasks, hipStream_t s);
+void launch_sw_pk_class(int G, int R, int mode, const SwArgs &a, uint32_t n_tasks, hipStream_t s);
 void launch_sw_generic(int mode, const SwArgs &a, uint32_t n_pairs, const uint32_t *pq, int32_t *work, uint32_t max_lq, hipStream_t s);
 void launch_ungapped(const DeviceDb &db, uint64_t n, const uint32_t *q, const uint32_t *t, const int32_t *diag,
                      int32_t *score, unsigned long long *overlap_sum /* nullable */, hipStream_t s);

@@ -21,6 +21,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "uc_device.h"
 
 namespace uc {
@@ -114,18 +117,20 @@ __global__ void __launch_bounds__(NW * 64) sw_group_kernel(const SwArgs a) {
         int Tlast = -open, prevTup = -open;
         uint32_t fout = 0;
 
-        auto load_letter = [&](int st) -> uint32_t {
-            uint32_t c = SW_PADPACK;
-            if (g == 0 && st < tlen) {
-                const uint32_t p = toff + (uint32_t)(REVT ? tlast - st : st);
-                c = (uint32_t)a.db.s3[p] | ((uint32_t)a.db.sa[p] << 8);
-            }
-            return c;
+        // target letters: branch-free byte loads (clamped index, uniform within the group), combined one full
+        // step after they were issued so that no step waits on global-memory latency
+        struct RawLetter { uint32_t c3, ca; };
+        auto issue_letter = [&](int st) -> RawLetter {
+            const int i = max(min(st, tlen - 1), 0);
+            const uint32_t p = toff + (uint32_t)(REVT ? max(tlast - i, 0) : i);
+            RawLetter r;
+            r.c3 = a.db.s3[p]; r.ca = a.db.sa[p];
+            return r;
         };
-        // letters are fetched three columns ahead, the profile words of a column one step ahead:
-        // neither the global nor the LDS latency sits on the step's dependency chain
-        uint32_t c1 = load_letter(1), c2 = load_letter(2);
-        uint32_t cin = (uint32_t)shift_from_prev_lane<G>((int)SW_PADPACK, (int)load_letter(0), g);
+        auto pack_letter = [&](const RawLetter &r, int st) -> uint32_t { return st < tlen ? (r.c3 | (r.ca << 8)) : SW_PADPACK; };
+        uint32_t c1 = pack_letter(issue_letter(1), 1);
+        RawLetter r2 = issue_letter(2);
+        uint32_t cin = (uint32_t)shift_from_prev_lane<G>((int)SW_PADPACK, (int)pack_letter(issue_letter(0), 0), g);
         uint32_t n3[RW], na[RW];
         {
             const uint32_t *p3 = P3 + (cin & 0xff) * RSW + g * BW, *pa = PA + (cin >> 8) * RSW + g * BW;
@@ -145,8 +150,8 @@ __global__ void __launch_bounds__(NW * 64) sw_group_kernel(const SwArgs a) {
             }
             // next column's letters and profile words
             cin = (uint32_t)shift_from_prev_lane<G>((int)cin, (int)c1, g);
-            c1 = c2;
-            c2 = load_letter(st + 3);
+            c1 = pack_letter(r2, st + 2);
+            r2 = issue_letter(st + 3);
             {
                 const uint32_t *p3 = P3 + (cin & 0xff) * RSW + g * BW, *pa = PA + (cin >> 8) * RSW + g * BW;
 #pragma unroll
@@ -270,6 +275,8 @@ void launch_sw_class_mode(int G, int R, const SwArgs &a, uint32_t n_tasks, hipSt
     UC_SW_CASE(32, 20) UC_SW_CASE(32, 24) UC_SW_CASE(32, 28) UC_SW_CASE(32, 32)
     UC_SW_CASE(64, 20) UC_SW_CASE(64, 24) UC_SW_CASE(64, 28) UC_SW_CASE(64, 32)
 #undef UC_SW_CASE
+    fprintf(stderr, "unicore-cluster: no SW kernel for class (G=%d, R=%d)\n", G, R);
+    abort();
 }
 
 }  // namespace uc

@@ -1,0 +1,274 @@
+// uc_sw_pk_impl.hpp — packed 16-bit variant of the gapped DP kernel (stage E5; see uc_sw_impl.hpp for the
+// systolic-group design it shares).  The int32 kernel is integer-VALU-bound (every int32 VALU instruction
+// occupies its SIMD for 4 cycles, profiles/r1b_pmc_sw.txt), so the only lever left is instructions per cell:
+// here every DP register holds TWO alignments of the same query (target A in the low, target B in the high
+// 16 bits) and the recurrence runs on v_pk_{add,sub,max}_u16, i.e. ~6.6 VALU ops per cell instead of ~9.7.
+//
+//  * unsigned floored domain: H >= 0, E/F/T floored at 0 by saturating subtraction (exact for local
+//    alignment); x = sat_sub(sat_add(Hdiag, s + 128), 128) = max(Hdiag + s, 0); H = max(x, e, f).
+//  * profile bytes are (S3+64) and (SA+64) so the packed byte sum is s+128 (PAD = 0 => s = -128); one
+//    v_perm_b32 per row interleaves byte r of target A's and target B's word into two zero-extended u16.
+//  * end tracking: per lane the running maximum gives (score, first column) per half; per-row maxima
+//    (rowbest) identify the row: if exactly one row of the alignment ever reaches the optimum it must be the
+//    row of the first column too, so (qEnd, tEnd) is exact.  Otherwise — or if a value came within 256 of the
+//    u16 range — the pair is flagged (qEnd = -2 / score >= SW_PK_OVF) and re-run by the int32 kernel.
+//  * slot streaming: a "slot" is two consecutive pairs of the task (A, B).  Every lane group pulls its next
+//    slot from an LDS counter as soon as it has finished the previous one, so the groups of a wave do NOT
+//    run in lockstep over the longest of their targets (hit lists mix family members with unrelated hits of
+//    very different lengths; lockstep cost ~40 % of the issued instructions, profiles/r1e).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "uc_device.h"
+#include "uc_sw_impl.hpp"
+
+namespace uc {
+
+constexpr int SW_PK_OVF = 65535 - 256;   // scores at or above this are recomputed in int32
+
+typedef uint16_t u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2_t pk_v(uint32_t x) { return __builtin_bit_cast(u16x2_t, x); }
+__device__ __forceinline__ uint32_t pk_u(u16x2_t v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b) { return pk_u(__builtin_elementwise_add_sat(pk_v(a), pk_v(b))); }
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) { return pk_u(__builtin_elementwise_sub_sat(pk_v(a), pk_v(b))); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return pk_u(__builtin_elementwise_max(pk_v(a), pk_v(b))); }
+
+template <int G, int R, int MODE, int NW>
+__global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
+    constexpr bool TRACK = MODE != 1, MASK = MODE == 2, REVQ = MODE != 0, REVT = MODE == 2;
+    constexpr int RW = R / 4, BW = RW | 1, RSW = G * BW, NT = NW * 64;
+    static_assert(R % 4 == 0 && R <= 32, "R must be a multiple of 4, <= 32");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *P3 = lds, *PA = lds + SW_NLET * RSW;
+    uint32_t *slot_ctr = lds + 2 * SW_NLET * RSW;   // work counter of the task (one dword behind the profile)
+
+    const SwTask task = a.tasks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int g = lane % G;
+    const uint32_t qoff = a.db.off[task.q];
+    const int lq = (int)a.db.len[task.q];
+    const uint32_t open2 = (uint32_t)a.open * 0x10001u, ext2 = (uint32_t)a.ext * 0x10001u, bias2 = 128u * 0x10001u;
+    const uint32_t nslots = (task.count + 1) >> 1;
+
+    // ---- query profile in LDS: bytes S3+64 and SA+64 (sum = s+128), PAD letters / rows = 0 ----
+    for (int idx = tid; idx < SW_NLET * G * RW; idx += NT) {
+        const int c = idx / (G * RW), rem = idx % (G * RW), gg = rem / RW, k = rem % RW;
+        uint32_t w3 = 0, wa = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int row = gg * R + 4 * k + b;
+            if (row < lq && c < 21) {
+                const int qi = REVQ ? lq - 1 - row : row;
+                const int q3 = a.db.s3[qoff + qi], qa = a.db.sa[qoff + qi];
+                w3 |= (uint32_t)(a.db.S3[q3 * 21 + c] + 64) << (8 * b);
+                wa |= (uint32_t)(a.db.SA[qa * 21 + c] + 64) << (8 * b);
+            }
+        }
+        P3[c * RSW + gg * BW + k] = w3;
+        PA[c * RSW + gg * BW + k] = wa;
+    }
+    if (tid == 0) *slot_ctr = 0;
+    __syncthreads();
+
+    // ---- per-group state (all group-uniform scalars live replicated in the group's lanes) ----
+    uint32_t H[R], T[R], E[R], rowbest[TRACK ? R : 1];
+    uint32_t mskA[MASK ? RW : 1], mskB[MASK ? RW : 1];
+    uint32_t best = 0, Hlast = 0, prevHup = 0, fout = 0;
+    int colA = -1, colB = -1;
+    uint32_t gA = 0, gB = 0, toffA = 0, toffB = 0;
+    int tlenA = 0, tlenB = 0, rowoffA = 0, rowoffB = 0;
+    bool vB = false, active = false;
+    int lst = 0, nst = 0;
+    uint32_t c1 = 0, cin = 0;
+    struct RawLetters { uint32_t a3, aa, b3, ba; } r2 = {0, 0, 0, 0};
+    uint32_t nA3[RW], nAa[RW], nB3[RW], nBa[RW];
+
+    // letters of both targets travel as one dword: [c3A | caA << 8 | c3B << 16 | caB << 24].  The byte loads are
+    // branch-free (clamped index, every lane of the group reads the same address) and are only combined a full
+    // step after they were issued, so no step waits on global-memory latency.
+    auto issue_letters = [&](int st) -> RawLetters {
+        const int ia = max(min(st, tlenA - 1), 0), ib = max(min(st, tlenB - 1), 0);
+        const uint32_t pa = toffA + (uint32_t)(REVT ? max(tlenA - 1 - ia, 0) : ia);
+        const uint32_t pb_ = toffB + (uint32_t)(REVT ? max(tlenB - 1 - ib, 0) : ib);
+        RawLetters r;
+        r.a3 = a.db.s3[pa]; r.aa = a.db.sa[pa]; r.b3 = a.db.s3[pb_]; r.ba = a.db.sa[pb_];
+        return r;
+    };
+    auto pack_letters = [&](const RawLetters &r, int st) -> uint32_t {
+        const uint32_t ca_ = st < tlenA ? (r.a3 | (r.aa << 8)) : SW_PADPACK;
+        const uint32_t cb_ = st < tlenB ? (r.b3 | (r.ba << 8)) : SW_PADPACK;
+        return ca_ | (cb_ << 16);
+    };
+    auto fetch_profile = [&]() __attribute__((always_inline)) {
+        const uint32_t *pA3 = P3 + (cin & 0xff) * RSW + g * BW, *pAa = PA + ((cin >> 8) & 0xff) * RSW + g * BW;
+        const uint32_t *pB3 = P3 + ((cin >> 16) & 0xff) * RSW + g * BW, *pBa = PA + (cin >> 24) * RSW + g * BW;
+#pragma unroll
+        for (int k = 0; k < RW; k++) { nA3[k] = pA3[k]; nAa[k] = pAa[k]; nB3[k] = pB3[k]; nBa[k] = pBa[k]; }
+    };
+
+    // pull the next slot of the task for this group and reset the group's DP state (group-uniform control flow)
+    auto start_slot = [&]() {
+        uint32_t idx = 0;
+        if (g == 0) idx = atomicAdd(slot_ctr, 1u);
+        idx = (uint32_t)__shfl((int)idx, lane - g, 64);
+        active = idx < nslots;
+        if (!active) return;
+        const uint32_t iA = 2 * idx, iB = iA + 1;
+        vB = iB < task.count;
+        gA = task.begin + iA;
+        gB = task.begin + (vB ? iB : iA);
+        const uint32_t tA = a.pt[gA], tB = a.pt[gB];
+        toffA = a.db.off[tA]; toffB = a.db.off[tB];
+        tlenA = REVT ? a.pte[gA] + 1 : (int)a.db.len[tA];
+        tlenB = vB ? (REVT ? a.pte[gB] + 1 : (int)a.db.len[tB]) : 0;
+        if constexpr (MASK) {
+            rowoffA = lq - 1 - a.pqe[gA];
+            rowoffB = lq - 1 - a.pqe[gB];
+#pragma unroll
+            for (int k = 0; k < RW; k++) {
+                uint32_t ma = 0, mb = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    ma |= (g * R + 4 * k + b >= rowoffA ? 0xFFu : 0u) << (8 * b);
+                    mb |= (g * R + 4 * k + b >= rowoffB ? 0xFFu : 0u) << (8 * b);
+                }
+                mskA[k] = ma; mskB[k] = mb;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) { H[r] = 0; T[r] = 0; E[r] = 0; }
+        if constexpr (TRACK) {
+#pragma unroll
+            for (int r = 0; r < R; r++) rowbest[r] = 0;
+        }
+        best = 0; colA = -1; colB = -1; Hlast = 0; prevHup = 0; fout = 0;
+        lst = 0;
+        nst = (max(tlenA, tlenB) + G) & ~1;      // Lt + G - 1 steps, rounded up to the 2-step loop trip
+        c1 = pack_letters(issue_letters(1), 1);
+        r2 = issue_letters(2);
+        cin = (uint32_t)shift_from_prev_lane<G>((int)(SW_PADPACK * 0x10001u), (int)pack_letters(issue_letters(0), 0), g);
+        fetch_profile();
+    };
+
+    auto do_step = [&](const int st) __attribute__((always_inline)) {
+        uint32_t sA[RW], sB[RW];
+#pragma unroll
+        for (int k = 0; k < RW; k++) {
+            sA[k] = nA3[k] + nAa[k];
+            sB[k] = nB3[k] + nBa[k];
+            if constexpr (MASK) { sA[k] &= mskA[k]; sB[k] &= mskB[k]; }
+        }
+        cin = (uint32_t)shift_from_prev_lane<G>((int)cin, (int)c1, g);
+        c1 = pack_letters(r2, st + 2);
+        r2 = issue_letters(st + 3);
+        fetch_profile();
+        const uint32_t Hup = (uint32_t)shift_from_prev_lane<G>((int)Hlast, 0, g);
+        uint32_t f = (uint32_t)shift_from_prev_lane<G>((int)fout, 0, g);
+        uint32_t diag = prevHup;
+        uint32_t colmax = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            // {byte r of A's word, 0, byte r of B's word, 0}
+            const uint32_t ub = __builtin_amdgcn_perm(sB[r >> 2], sA[r >> 2], 0x0c000c00u | ((4u + (r & 3)) << 16) | (uint32_t)(r & 3));
+            const uint32_t x = pk_sub_sat(pk_add_sat(diag, ub), bias2);
+            const uint32_t e = pk_max(pk_sub_sat(E[r], ext2), T[r]);
+            const uint32_t h = pk_max(pk_max(x, e), f);
+            diag = H[r];
+            H[r] = h;
+            T[r] = pk_sub_sat(h, open2);
+            E[r] = e;
+            f = pk_max(pk_sub_sat(f, ext2), T[r]);
+            if constexpr (TRACK) rowbest[r] = pk_max(rowbest[r], h);
+            colmax = pk_max(colmax, h);
+        }
+        if constexpr (TRACK) {
+            const uint32_t cmA = colmax & 0xffffu, cmB = colmax >> 16;
+            colA = cmA > (best & 0xffffu) ? st - g : colA;
+            colB = cmB > (best >> 16) ? st - g : colB;
+        }
+        best = pk_max(best, colmax);
+        Hlast = H[R - 1];
+        fout = f;
+        prevHup = Hup;
+    };
+
+    // per-half reduction over the G lanes: (score desc, col asc); then the row from rowbest; write results
+    auto finish_slot = [&]() {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            int score = half ? (int)(best >> 16) : (int)(best & 0xffffu);
+            int col = half ? colB : colA;
+#pragma unroll
+            for (int m = 1; m < G; m <<= 1) {
+                const int os = __shfl_xor(score, m, 64), oc = __shfl_xor(col, m, 64);
+                const bool take = os > score || (os == score && oc < col);
+                score = take ? os : score;
+                col = take ? oc : col;
+            }
+            int cnt = 0, minrow = 1 << 30;
+            if constexpr (TRACK) {
+#pragma unroll
+                for (int r = R - 1; r >= 0; r--) {
+                    const int rb = half ? (int)(rowbest[r] >> 16) : (int)(rowbest[r] & 0xffffu);
+                    if (rb == score) { cnt++; minrow = g * R + r; }
+                }
+#pragma unroll
+                for (int m = 1; m < G; m <<= 1) {
+                    cnt += __shfl_xor(cnt, m, 64);
+                    minrow = min(minrow, __shfl_xor(minrow, m, 64));
+                }
+            }
+            const bool valid = half ? vB : true;
+            const uint32_t gp = half ? gB : gA;
+            if (g == 0 && valid) {
+                a.oscore[gp] = score;
+                if constexpr (TRACK) {
+                    const int rowoff = half ? rowoffB : rowoffA;
+                    int qe = -1, te = -1;
+                    if (score > 0) { te = col; qe = (cnt == 1 && score < SW_PK_OVF) ? minrow - rowoff : -2; }
+                    a.oqe[gp] = qe;
+                    a.ote[gp] = te;
+                }
+            }
+        }
+    };
+
+    start_slot();
+    while (__builtin_amdgcn_ballot_w64(active) != 0) {
+        if (active) {
+            do_step(lst);
+            do_step(lst + 1);
+            lst += 2;
+            if (lst >= nst) {
+                finish_slot();
+                start_slot();
+            }
+        }
+    }
+}
+
+template <int MODE>
+void launch_sw_pk_class_mode(int G, int R, const SwArgs &a, uint32_t n_tasks, hipStream_t s) {
+#define UC_SW_CASE(GG, RR)                                                                              \
+    if (G == GG && R == RR) {                                                                           \
+        constexpr int BW = ((RR / 4) | 1);                                                              \
+        constexpr int NW = GG == 16 ? 1 : (GG == 32 ? 2 : 8);   /* small workgroups share one LDS profile */ \
+        const size_t lds = (size_t)2 * SW_NLET * GG * BW * 4 + 16;                                      \
+        static bool attr_set = false;                                                                   \
+        if (!attr_set && lds > 64 * 1024) {                                                             \
+            (void)hipFuncSetAttribute((const void *)sw_pk_kernel<GG, RR, MODE, NW>,                     \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+            attr_set = true;                                                                            \
+        }                                                                                               \
+        hipLaunchKernelGGL((sw_pk_kernel<GG, RR, MODE, NW>), dim3(n_tasks), dim3(NW * 64), lds, s, a);  \
+        return;                                                                                         \
+    }
+    // ~5.5R live registers per lane keep the packed kernel to R <= 24 (queries up to 1536 rows)
+    UC_SW_CASE(16, 4) UC_SW_CASE(16, 8) UC_SW_CASE(16, 12) UC_SW_CASE(16, 16) UC_SW_CASE(16, 20) UC_SW_CASE(16, 24)
+    UC_SW_CASE(32, 16) UC_SW_CASE(32, 20) UC_SW_CASE(32, 24) UC_SW_CASE(64, 16) UC_SW_CASE(64, 20) UC_SW_CASE(64, 24)
+#undef UC_SW_CASE
+    fprintf(stderr, "unicore-cluster: no packed SW kernel for class (G=%d, R=%d)\n", G, R);
+    abort();
+}
+
+}  // namespace uc
