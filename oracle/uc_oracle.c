@@ -667,17 +667,26 @@ uint64_t uco_sample_run(const uco_db *db, const uco_index *ix, const uco_params 
         hcnt[k] = (uint32_t)uco_prefilter_query(db, ix, queries[k], p, hits + (size_t)k * M, NULL);
     double t1 = now_s();
     const uint64_t dbres = db->off[db->n];
+    /* flatten (query, hit) pairs: per-query work is heavy-tailed (long queries x long hit lists), so the
+       parallel loop runs over pairs, not queries */
     uint64_t pairs = 0, acc = 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : pairs, acc)
-    for (int64_t k = 0; k < (int64_t)n_queries; k++) {
+    uint64_t *poff = (uint64_t *)malloc(((size_t)n_queries + 1) * sizeof(uint64_t));
+    for (uint32_t k = 0; k < n_queries; k++) { poff[k] = pairs; pairs += hcnt[k]; }
+    poff[n_queries] = pairs;
+    uint32_t *pq = (uint32_t *)malloc((pairs + 1) * sizeof(uint32_t)), *pt = (uint32_t *)malloc((pairs + 1) * sizeof(uint32_t));
+    int32_t *pms = (int32_t *)malloc((pairs + 1) * sizeof(int32_t));
+    for (uint32_t k = 0; k < n_queries; k++) {
         const uint32_t q = queries[k];
         const int32_t ms = uco_min_score(p, (int)(db->off[q + 1] - db->off[q]), dbres);
-        for (uint32_t h = 0; h < hcnt[k]; h++) {
-            uco_aln a;
-            uco_align_pair(db, q, hits[(size_t)k * M + h].t, p, ms, &a);
-            pairs++; acc += (uint64_t)a.accepted;
-        }
+        for (uint32_t h = 0; h < hcnt[k]; h++) { pq[poff[k] + h] = q; pt[poff[k] + h] = hits[(size_t)k * M + h].t; pms[poff[k] + h] = ms; }
     }
+#pragma omp parallel for schedule(dynamic, 8) reduction(+ : acc)
+    for (int64_t i = 0; i < (int64_t)pairs; i++) {
+        uco_aln a;
+        uco_align_pair(db, pq[i], pt[i], p, pms[i], &a);
+        acc += (uint64_t)a.accepted;
+    }
+    free(poff); free(pq); free(pt); free(pms);
     double t2 = now_s();
     seconds[0] = t1 - t0; seconds[1] = t2 - t1;
     free(hits); free(hcnt);

@@ -109,7 +109,8 @@ def test_sw_long_query_fallback(O):
         assert (s2[k], q2[k], t2[k]) == exp, i
 
 
-@pytest.mark.parametrize("opts", ["-c 0.8", "-c 0.5 -s 6 --max-seqs 5", "-c 0.8 --cov-mode 1 -e 1e-6 --rev-correction 0"])
+@pytest.mark.parametrize("opts", ["-c 0.8", "-c 0.5 -s 6 --max-seqs 5", "-c 0.8 --cov-mode 1 -e 1e-6 --rev-correction 0",
+                                  "-c 0.5 --min-seq-id 0.3", "-c 0.8 --cov-mode 2 --min-seq-id 0.55"])
 def test_pipeline_stage_parity(O, small, opts):
     """prefilter hit lists, per-pair alignment records, edges and the set cover all equal the oracle's"""
     import unicore_amd as U
@@ -130,6 +131,12 @@ def test_pipeline_stage_parity(O, small, opts):
     pe = al["pass_evalue"] == 1
     for f in ("qstart", "qend", "tstart", "tend"):
         assert np.array_equal(al[f][pe], ra[f][pe]), f
+    for f in ("aln_len", "idents"):          # traceback statistics (only computed under --min-seq-id)
+        assert np.array_equal(al[f], ra[f]), f
+    if "--min-seq-id" in opts:
+        assert (ra["aln_len"] > 0).sum() > 50
+        if "0.55" in opts:
+            assert 0 < ra["accepted"][ra["aln_len"] > 0].mean() < 1   # the identity gate bites both ways
     st = e.stats()
     c = ref["counts"]
     for a, b in (("n_sim_kmers", "n_sim_kmers"), ("n_kmer_hits", "n_kmer_hits"), ("n_candidates", "n_candidates"),
@@ -163,3 +170,35 @@ def test_cluster_end_to_end_tsv_bytes(O, tmp_path):
     assert st["n_clusters"] == ref["counts"]["n_clusters"] and st["n_gapped_alignments"] == ref["counts"]["n_alignments"]
     U.rmdb(out + "_cluster")
     assert not os.path.exists(out + "_cluster") and not os.path.exists(out + "_cluster.index")
+
+
+def test_long_query_pipeline_with_seqid(O):
+    """queries beyond the largest systolic class go through the generic kernel in every pass, including the
+    traceback-statistics pass of --min-seq-id"""
+    rng = np.random.default_rng(19)
+    base3, basea = rng.integers(0, 20, 2500, dtype=np.uint8), rng.integers(0, 20, 2500, dtype=np.uint8)
+    s3, sa = [], []
+    for m in range(5):
+        keep = rng.random(2500) > 0.03
+        a3, aa = base3[keep].copy(), basea[keep].copy()
+        mut = rng.random(len(a3)) < 0.2
+        a3[mut] = rng.integers(0, 20, int(mut.sum()), dtype=np.uint8)
+        muta = rng.random(len(aa)) < 0.45
+        aa[muta] = rng.integers(0, 20, int(muta.sum()), dtype=np.uint8)
+        s3.append(a3); sa.append(aa)
+    s3.append(base3[:900].copy()); sa.append(basea[:900].copy())
+    off, c3, ca = util.flat(s3, sa)
+    import unicore_amd as U
+    opts = "-c 0.3 --min-seq-id 0.5"
+    e = U.Engine(opts, verbosity=1)
+    e.set_db(off, c3, ca)
+    e.prefilter(); e.align()
+    ref = O.cluster(O.OracleDb(s3=s3, sa=sa), util.oracle_params(O, opts), threads=4)
+    cnt, hits = e.hits()
+    assert np.array_equal(cnt, ref["hit_cnt"])
+    al = e.alns()
+    ra = np.concatenate([ref["aln"][i, : cnt[i]] for i in range(len(cnt))])
+    for f in ("score", "score_rev", "pass_evalue", "accepted", "aln_len", "idents"):
+        assert np.array_equal(al[f], ra[f]), f
+    assert (ra["aln_len"] > 2000).any() and 0 < ra["accepted"].mean() < 1
+    assert np.array_equal(U.setcover(e.n, e.edges()), ref["assign"])

@@ -59,14 +59,15 @@ inline dim3 grid_for(uint64_t n, uint32_t cap = 16384) {
 
 // key = [ class : 5 | query : 24 | 65535 - effective target length : 16 ]
 __global__ void __launch_bounds__(256) plan_key_kernel(uint32_t n, const uint32_t *q, const uint32_t *t, const int32_t *qe,
-                                                       const int32_t *te, const uint32_t *len, int tab, uint64_t *key, uint32_t *idx,
+                                                       const int32_t *te, const int32_t *qs, const int32_t *ts,
+                                                       const uint32_t *len, int tab, uint64_t *key, uint32_t *idx,
                                                        unsigned long long *alg_bytes /* [0] bytes, [1] DP cells */) {
     unsigned long long bytes = 0, cells = 0;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const uint32_t qq = q[i];
         const uint32_t lq = len[qq];
-        const uint32_t tl = te ? (uint32_t)te[i] + 1 : len[t[i]];
-        const uint32_t ql = qe ? (uint32_t)qe[i] + 1 : lq;
+        const uint32_t tl = te ? (uint32_t)(te[i] + 1 - (ts ? ts[i] : 0)) : len[t[i]];
+        const uint32_t ql = qe ? (uint32_t)(qe[i] + 1 - (qs ? qs[i] : 0)) : lq;
         key[i] = ((uint64_t)class_of((int)lq, tab) << 40) | ((uint64_t)qq << 16) | (uint64_t)(65535u - tl);
         idx[i] = i;
         bytes += 2ull * (ql + tl) + 32;
@@ -77,14 +78,16 @@ __global__ void __launch_bounds__(256) plan_key_kernel(uint32_t n, const uint32_
 }
 
 __global__ void __launch_bounds__(256) plan_gather_kernel(uint32_t n, const uint64_t *key, const uint32_t *idx, const uint32_t *t,
-                                                          const int32_t *qe, const int32_t *te, uint32_t *sq, uint32_t *st,
-                                                          int32_t *sqe, int32_t *ste, uint32_t *head) {
+                                                          const int32_t *qe, const int32_t *te, const int32_t *qs, const int32_t *ts,
+                                                          uint32_t *sq, uint32_t *st, int32_t *sqe, int32_t *ste, int32_t *sqs,
+                                                          int32_t *sts, uint32_t *head) {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const uint64_t k = key[i];
         const uint32_t o = idx[i];
         sq[i] = (uint32_t)(k >> 16) & 0xFFFFFFu;
         st[i] = t[o];
         if (qe) { sqe[i] = qe[o]; ste[i] = te[o]; }
+        if (qs) { sqs[i] = qs[o]; sts[i] = ts[o]; }
         head[i] = (i == 0 || (key[i - 1] >> 16) != (k >> 16)) ? i : 0u;
     }
 }
@@ -194,6 +197,35 @@ __global__ void __launch_bounds__(256) finalize_kernel(uint32_t n2, const uint32
     }
 }
 
+// seq-id stage (only with --min-seq-id > 0): pairs that passed the coverage gate get their traceback statistics
+__global__ void __launch_bounds__(256) tb_gather_kernel(uint32_t n2, const uint32_t *eflag, const uint32_t *epos, const uint32_t *idx2,
+                                                        const uint32_t *link, const uint32_t *idx0, const uint32_t *sq2, const uint32_t *st2,
+                                                        const uc_aln *alns, uint32_t *q3, uint32_t *t3, int32_t *qs3, int32_t *qe3,
+                                                        int32_t *ts3, int32_t *te3, uint32_t *src3) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
+        if (!eflag[i]) continue;
+        const uint32_t w = epos[i], o = idx0[link[idx2[i]]];
+        const uc_aln a = alns[o];
+        q3[w] = sq2[i]; t3[w] = st2[i]; qs3[w] = a.qstart; qe3[w] = a.qend; ts3[w] = a.tstart; te3[w] = a.tend;
+        src3[w] = i;
+    }
+}
+__global__ void __launch_bounds__(256) tb_apply_kernel(uint32_t n3, const uint32_t *idx3, const uint32_t *src3, const int32_t *pack,
+                                                       const uint32_t *idx2, const uint32_t *link, const uint32_t *idx0, float min_seq_id,
+                                                       uc_aln *alns, uint32_t *eflag) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n3; i += gridDim.x * 256) {
+        const uint32_t i2 = src3[idx3[i]];
+        uc_aln &a = alns[idx0[link[idx2[i2]]]];
+        const uint32_t pk = (uint32_t)pack[i];
+        a.aln_len = (int32_t)(pk >> 16);
+        a.idents = (int32_t)(pk & 0xffffu);
+        const float sid = a.aln_len > 0 ? (float)a.idents / (float)a.aln_len : 0.0f;
+        const bool ok = sid >= min_seq_id;
+        a.accepted = ok;
+        eflag[i2] = ok;
+    }
+}
+
 __global__ void __launch_bounds__(256) edge_scatter_kernel(uint32_t n2, const uint32_t *eflag, const uint32_t *epos, const uint32_t *sq2,
                                                            const uint32_t *st2, uint32_t *edges) {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
@@ -214,14 +246,14 @@ struct SwPlan {
     uint32_t n = 0, ntasks = 0;
     DevBuf<uint64_t> key, key2;
     DevBuf<uint32_t> idx_in, idx, sq, st, head, segstart, flag, tpos, tcls, bounds;
-    DevBuf<int32_t> sqe, ste;
+    DevBuf<int32_t> sqe, ste, sqs, sts;
     DevBuf<SwTask> tasks, tasks_in;
     DevBuf<uint64_t> tkey, tkey2;
     DevBuf<uint32_t> tidx, tidx2;
     DevBuf<unsigned long long> bytes;
     uint32_t task_base[NB] = {0}, pair_base[NB] = {0};
     uint64_t alg_bytes = 0, cells = 0;
-    bool has_ends = false;
+    bool has_ends = false, has_starts = false;
     int tab = 0;
 };
 
@@ -249,10 +281,10 @@ static uint32_t scan_total(Engine &E, const uint32_t *flag, const uint32_t *pos,
 }
 
 static void build_plan(Engine &E, SwPlan &P, DevBuf<char> &tmp, uint32_t n, const uint32_t *q, const uint32_t *t,
-                       const int32_t *qe, const int32_t *te, int tab) {
+                       const int32_t *qe, const int32_t *te, int tab, const int32_t *qs = nullptr, const int32_t *ts = nullptr) {
     static bool tables_uploaded = false;
     if (!tables_uploaded) { UC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), h_tab, sizeof h_tab)); tables_uploaded = true; }
-    P.n = n; P.ntasks = 0; P.alg_bytes = 0; P.cells = 0; P.has_ends = qe != nullptr; P.tab = tab;
+    P.n = n; P.ntasks = 0; P.alg_bytes = 0; P.cells = 0; P.has_ends = qe != nullptr; P.has_starts = qs != nullptr; P.tab = tab;
     memset(P.task_base, 0, sizeof P.task_base);
     memset(P.pair_base, 0, sizeof P.pair_base);
     if (!n) return;
@@ -260,14 +292,15 @@ static void build_plan(Engine &E, SwPlan &P, DevBuf<char> &tmp, uint32_t n, cons
     P.key.reserve(n); P.key2.reserve(n); P.idx_in.reserve(n); P.idx.reserve(n);
     P.sq.reserve(n); P.st.reserve(n); P.head.reserve(n); P.segstart.reserve(n); P.flag.reserve(n); P.tpos.reserve(n);
     if (qe) { P.sqe.reserve(n); P.ste.reserve(n); }
+    if (qs) { P.sqs.reserve(n); P.sts.reserve(n); }
     P.bytes.reserve(2); P.bounds.reserve(2 * NB);
     UC_HIP(hipMemsetAsync(P.bytes.p, 0, 16, s));
-    hipLaunchKernelGGL(plan_key_kernel, grid_for(n), dim3(256), 0, s, n, q, t, qe, te, E.ddb.len, tab, P.key.p, P.idx_in.p, P.bytes.p);
+    hipLaunchKernelGGL(plan_key_kernel, grid_for(n), dim3(256), 0, s, n, q, t, qe, te, qs, ts, E.ddb.len, tab, P.key.p, P.idx_in.p, P.bytes.p);
     size_t tb = 0;
     UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, P.key.p, P.key2.p, P.idx_in.p, P.idx.p, (size_t)n, 0u, 45u, s));
     tmp.reserve(tb + 256);
     UC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, P.key.p, P.key2.p, P.idx_in.p, P.idx.p, (size_t)n, 0u, 45u, s));
-    hipLaunchKernelGGL(plan_gather_kernel, grid_for(n), dim3(256), 0, s, n, P.key2.p, P.idx.p, t, qe, te, P.sq.p, P.st.p, P.sqe.p, P.ste.p, P.head.p);
+    hipLaunchKernelGGL(plan_gather_kernel, grid_for(n), dim3(256), 0, s, n, P.key2.p, P.idx.p, t, qe, te, qs, ts, P.sq.p, P.st.p, P.sqe.p, P.ste.p, P.sqs.p, P.sts.p, P.head.p);
     scan_u32(E, tmp, P.head.p, P.segstart.p, n, true);
     hipLaunchKernelGGL(plan_taskflag_kernel, grid_for(n), dim3(256), 0, s, n, P.key2.p, P.segstart.p, tab, P.flag.p);
     scan_u32(E, tmp, P.flag.p, P.tpos.p, n, false);
@@ -300,6 +333,7 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
     const ClassTable &tab = h_tab[P.tab];
     SwArgs a;
     a.db = E.ddb; a.tasks = P.tasks.p; a.pt = P.st.p; a.pqe = P.sqe.p; a.pte = P.ste.p;
+    a.pqs = P.has_starts ? P.sqs.p : nullptr; a.pts = P.has_starts ? P.sts.p : nullptr;
     a.oscore = os; a.oqe = oqe; a.ote = ote; a.open = E.p.gap_open; a.ext = E.p.gap_ext;
     uint64_t launches = 0;
     for (int c = 0; c < tab.n; c++) {
@@ -315,11 +349,13 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
     const uint32_t gb = P.pair_base[tab.n], ngen = P.n - gb;
     if (ngen) {   // queries longer than the largest systolic class
         const size_t lanes = (size_t)((ngen + 63) / 64) * 64;
-        work.reserve(2 * (size_t)E.max_len * lanes);
+        work.reserve((mode == 3 ? 4 : 2) * (size_t)E.max_len * lanes);
         SwArgs ag = a;
         ag.pt = P.st.p + gb;
         ag.pqe = P.has_ends ? P.sqe.p + gb : nullptr;
         ag.pte = P.has_ends ? P.ste.p + gb : nullptr;
+        ag.pqs = P.has_starts ? P.sqs.p + gb : nullptr;
+        ag.pts = P.has_starts ? P.sts.p + gb : nullptr;
         ag.oscore = os + gb;
         ag.oqe = oqe ? oqe + gb : nullptr;
         ag.ote = ote ? ote + gb : nullptr;
@@ -491,8 +527,6 @@ void Engine::sw_batch(int mode, const std::vector<PairIn> &pairs, int32_t *score
 void Engine::align(uint32_t qbegin, uint32_t qend) {
     if (!have_db) fail(UC_ERR_ARGS, "no database loaded");
     if (qbegin > qend || qend > hdb.n) fail(UC_ERR_ARGS, "align: bad query range");
-    if (p.min_seq_id > 0.0f)
-        fail(UC_ERR_ARGS, "--min-seq-id > 0 needs the traceback pass, which this build does not implement yet");
     UC_HIP(hipSetDevice(device));
     Timer tm;
     hipStream_t s = stream;
@@ -548,7 +582,27 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                 hipLaunchKernelGGL(finalize_kernel, grid_for(n2), dim3(256), 0, s, n2, P2.idx.p, link.p, P0.idx.p, P2.sq.p, P2.st.p, s2.p,
                                    q2o.p, t2o.p, ddb.len, p.cov, p.cov_mode, d_alns.p + b, eflag.p, mism.p);
                 scan_u32(*this, tmp, eflag.p, epos.p, n2, false);
-                const uint32_t ne = scan_total(*this, eflag.p, epos.p, n2);
+                uint32_t ne = scan_total(*this, eflag.p, epos.p, n2);
+                if (p.min_seq_id > 0.0f && ne) {
+                    // sequence-identity gate: (alignment length, identities) of the traceback on the box, computed by
+                    // the MODE 3 pass of the gapped kernel for the pairs that passed the coverage gate
+                    static DevBuf<uint32_t> q3, t3, src3;
+                    static DevBuf<int32_t> qs3, qe3, ts3, te3, pack3;
+                    static SwPlan P3;
+                    q3.reserve(ne); t3.reserve(ne); src3.reserve(ne); qs3.reserve(ne); qe3.reserve(ne); ts3.reserve(ne); te3.reserve(ne); pack3.reserve(ne);
+                    hipLaunchKernelGGL(tb_gather_kernel, grid_for(n2), dim3(256), 0, s, n2, eflag.p, epos.p, P2.idx.p, link.p, P0.idx.p, P2.sq.p,
+                                       P2.st.p, d_alns.p + b, q3.p, t3.p, qs3.p, qe3.p, ts3.p, te3.p, src3.p);
+                    build_plan(*this, P3, tmp, ne, q3.p, t3.p, qe3.p, te3.p, 0, qs3.p, ts3.p);
+                    timed_ms_begin();
+                    const uint64_t launches = launch_plan(*this, P3, 3, pack3.p, nullptr, nullptr, work);
+                    stats.sw_kernel_ms += timed_ms_end();
+                    stats.sw_kernel_launches += launches;
+                    stats.sw_algorithmic_bytes += P3.alg_bytes;
+                    hipLaunchKernelGGL(tb_apply_kernel, grid_for(ne), dim3(256), 0, s, ne, P3.idx.p, src3.p, pack3.p, P2.idx.p, link.p, P0.idx.p,
+                                       p.min_seq_id, d_alns.p + b, eflag.p);
+                    scan_u32(*this, tmp, eflag.p, epos.p, n2, false);
+                    ne = scan_total(*this, eflag.p, epos.p, n2);
+                }
                 if (ne) {
                     d_e.reserve(2 * (size_t)ne);
                     hipLaunchKernelGGL(edge_scatter_kernel, grid_for(n2), dim3(256), 0, s, n2, eflag.p, epos.p, P2.sq.p, P2.st.p, d_e.p);

@@ -26,7 +26,8 @@ struct SwArgs {
     DeviceDb db;
     const SwTask *tasks;
     const uint32_t *pt;        // target id per pair
-    const int32_t *pqe, *pte;  // mode 2 only: forward end positions (define the reversed prefixes)
+    const int32_t *pqe, *pte;  // mode 2: forward end positions (define the reversed prefixes); mode 3: box ends
+    const int32_t *pqs = nullptr, *pts = nullptr;   // mode 3 only: box starts
     int32_t *oscore, *oqe, *ote;
     int open, ext;
 };

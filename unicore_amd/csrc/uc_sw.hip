@@ -7,6 +7,7 @@ namespace uc {
 void launch_sw_class_m0(int G, int R, const SwArgs &a, uint32_t n_tasks, hipStream_t s);
 void launch_sw_class_m1(int G, int R, const SwArgs &a, uint32_t n_tasks, hipStream_t s);
 void launch_sw_class_m2(int G, int R, const SwArgs &a, uint32_t n_tasks, hipStream_t s);
+void launch_sw_class_m3(int G, int R, const SwArgs &a, uint32_t n_tasks, hipStream_t s);
 
 // smallest (G,R) class whose G*R rows hold the query; false if it needs the generic kernel
 bool sw_class_for(int lq, int *G, int *R) {
@@ -21,7 +22,8 @@ void launch_sw_class(int G, int R, int mode, const SwArgs &a, uint32_t n_tasks, 
     if (n_tasks == 0) return;
     if (mode == 0) launch_sw_class_m0(G, R, a, n_tasks, s);
     else if (mode == 1) launch_sw_class_m1(G, R, a, n_tasks, s);
-    else launch_sw_class_m2(G, R, a, n_tasks, s);
+    else if (mode == 2) launch_sw_class_m2(G, R, a, n_tasks, s);
+    else launch_sw_class_m3(G, R, a, n_tasks, s);
 }
 
 void launch_sw_pk_class_m0(int G, int R, const SwArgs &a, uint32_t n_tasks, hipStream_t s);
@@ -40,7 +42,8 @@ void launch_sw_generic(int mode, const SwArgs &a, uint32_t n_pairs, const uint32
     const dim3 grid((n_pairs + 63) / 64), block(64);
     if (mode == 0) hipLaunchKernelGGL(sw_generic_kernel<0>, grid, block, 0, s, a, n_pairs, pq, work, max_lq);
     else if (mode == 1) hipLaunchKernelGGL(sw_generic_kernel<1>, grid, block, 0, s, a, n_pairs, pq, work, max_lq);
-    else hipLaunchKernelGGL(sw_generic_kernel<2>, grid, block, 0, s, a, n_pairs, pq, work, max_lq);
+    else if (mode == 2) hipLaunchKernelGGL(sw_generic_kernel<2>, grid, block, 0, s, a, n_pairs, pq, work, max_lq);
+    else hipLaunchKernelGGL(sw_generic_kernel<3>, grid, block, 0, s, a, n_pairs, pq, work, max_lq);
 }
 
 // ---- stage E3: ungapped diagonal score (MMseqs2 UngappedAlignment on the 3Di track) ----

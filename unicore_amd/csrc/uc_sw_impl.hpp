@@ -51,7 +51,10 @@ __device__ __forceinline__ int shift_from_prev_lane(int v, int boundary, int g) 
 // NW = waves per workgroup: all of them stream targets through the one LDS profile of the task's query
 template <int G, int R, int MODE, int NW>
 __global__ void __launch_bounds__(NW * 64) sw_group_kernel(const SwArgs a) {
-    constexpr bool TRACK = MODE != 1, MASK = MODE == 2, REVQ = MODE != 0, REVT = MODE == 2;
+    // MODE 3 (traceback statistics): forward DP on the box [qs..qe] x [ts..te] carrying (alignment length,
+    // identities) along the chosen predecessor of every state — the numbers the traceback of spec UC-1 E6 yields
+    constexpr bool TB = MODE == 3;
+    constexpr bool TRACK = MODE == 0 || MODE == 2, MASK = MODE == 2 || TB, REVQ = MODE == 1 || MODE == 2, REVT = MODE == 2;
     constexpr int RW = R / 4, BW = RW | 1, RSW = G * BW, GPW = 64 / G, NT = NW * 64;
     static_assert(R % 4 == 0 && R <= 32, "R must be a multiple of 4, <= 32");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -82,19 +85,33 @@ __global__ void __launch_bounds__(NW * 64) sw_group_kernel(const SwArgs a) {
         PA[c * RSW + gg * BW + k] = wa;
     }
     __syncthreads();
+    uint32_t qaw[TB ? RW : 1];   // TB: AA letters of this lane's rows (0xFF beyond the query)
+    if constexpr (TB) {
+#pragma unroll
+        for (int k = 0; k < RW; k++) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int row = g * R + 4 * k + b;
+                w |= (row < lq ? (uint32_t)a.db.sa[qoff + row] : 0xFFu) << (8 * b);
+            }
+            qaw[k] = w;
+        }
+    }
 
     for (uint32_t pb = (uint32_t)wave * GPW; pb < task.count; pb += NW * GPW) {
         const bool pvalid = pb + grp < task.count;
         const uint32_t gp = task.begin + (pvalid ? pb + grp : 0);
         const uint32_t t = a.pt[gp];
         const uint32_t toff = a.db.off[t];
-        int tlen = REVT ? a.pte[gp] + 1 : (int)a.db.len[t];
+        const int tstart = TB ? a.pts[gp] : 0;
+        int tlen = TB ? a.pte[gp] - tstart + 1 : (REVT ? a.pte[gp] + 1 : (int)a.db.len[t]);
         if (!pvalid) tlen = 0;
         const int tlast = tlen - 1;
         int rowoff = 0;
         uint32_t msk[RW];
         if constexpr (MASK) {
-            rowoff = lq - 1 - a.pqe[gp];
+            rowoff = TB ? a.pqs[gp] : lq - 1 - a.pqe[gp];
 #pragma unroll
             for (int k = 0; k < RW; k++) {
                 uint32_t m = 0;
@@ -116,13 +133,21 @@ __global__ void __launch_bounds__(NW * 64) sw_group_kernel(const SwArgs a) {
         int bestcol = -1;
         int Tlast = -open, prevTup = -open;
         uint32_t fout = 0;
+        // TB state: packed (aln_len << 16 | idents) of the path into H / E per row, F flowing down the column
+        uint32_t Hp[TB ? R : 1], Ep[TB ? R : 1];
+        uint32_t HpLast = 0, prevHpUp = 0, FpOut = 0, cap = 0;
+        const int qe_row = TB ? a.pqe[gp] : 0;
+        if constexpr (TB) {
+#pragma unroll
+            for (int r = 0; r < R; r++) { Hp[r] = 0; Ep[r] = 0; }
+        }
 
         // target letters: branch-free byte loads (clamped index, uniform within the group), combined one full
         // step after they were issued so that no step waits on global-memory latency
         struct RawLetter { uint32_t c3, ca; };
         auto issue_letter = [&](int st) -> RawLetter {
             const int i = max(min(st, tlen - 1), 0);
-            const uint32_t p = toff + (uint32_t)(REVT ? max(tlast - i, 0) : i);
+            const uint32_t p = toff + (uint32_t)(REVT ? max(tlast - i, 0) : tstart + i);
             RawLetter r;
             r.c3 = a.db.s3[p]; r.ca = a.db.sa[p];
             return r;
@@ -142,6 +167,7 @@ __global__ void __launch_bounds__(NW * 64) sw_group_kernel(const SwArgs a) {
         // pairs need no copies at the back edge
         auto do_step = [&](const int st) __attribute__((always_inline)) {
             uint32_t ps[RW];
+            [[maybe_unused]] const uint32_t cin_cur = cin;   // letters of the column this step computes
 #pragma unroll
             for (int k = 0; k < RW; k++) {
                 uint32_t s = n3[k] + na[k];
@@ -161,11 +187,31 @@ __global__ void __launch_bounds__(NW * 64) sw_group_kernel(const SwArgs a) {
             uint32_t f = (uint32_t)shift_from_prev_lane<G>((int)fout, 0, g);
             int diagT = prevTup;
             uint32_t colmax = 0;
+            [[maybe_unused]] uint32_t HpUp = 0, fp = 0, dHp = 0;
+            [[maybe_unused]] const uint32_t ca_col = cin_cur >> 8;
+            if constexpr (TB) {
+                HpUp = (uint32_t)shift_from_prev_lane<G>((int)HpLast, 0, g);
+                fp = (uint32_t)shift_from_prev_lane<G>((int)FpOut, 0, g);
+                dHp = prevHpUp;
+            }
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const int x = __builtin_amdgcn_sdot4((int)ps[r >> 2], 1 << (8 * (r & 3)), diagT, false);
-                const int e = max((int)__builtin_elementwise_sub_sat(E[r], (uint32_t)ext), T[r]);
+                const uint32_t esub = __builtin_elementwise_sub_sat(E[r], (uint32_t)ext);
+                const int e = max((int)esub, T[r]);
                 const int h = max(max(x, e), (int)f);
+                if constexpr (TB) {
+                    // predecessor preference of the traceback: diagonal, then F (gap in the target), then E;
+                    // a gap state prefers leaving the gap (open) over staying in it
+                    const uint32_t ep = (T[r] >= (int)esub ? Hp[r] : Ep[r]) + 0x10000u;
+                    const uint32_t ident = ((qaw[r >> 2] >> (8 * (r & 3))) & 0xffu) == ca_col ? 1u : 0u;
+                    const uint32_t hp = h == 0 ? 0u : (x == h ? dHp + 0x10000u + ident : ((int)f == h ? fp : ep));
+                    dHp = Hp[r];
+                    Hp[r] = hp;
+                    Ep[r] = ep;
+                    const uint32_t fsub_ = __builtin_elementwise_sub_sat(f, (uint32_t)ext);
+                    fp = (h - open >= (int)fsub_ ? hp : fp) + 0x10000u;
+                }
                 diagT = T[r];
                 T[r] = h - open;
                 E[r] = (uint32_t)e;
@@ -179,6 +225,16 @@ __global__ void __launch_bounds__(NW * 64) sw_group_kernel(const SwArgs a) {
                 bestcol = upd ? st - g : bestcol;
             } else {
                 best = max(best, colmax);
+            }
+            if constexpr (TB) {
+                if (st - g == tlen - 1) {          // the box's last column: keep the pack of row qe
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+                        if (g * R + r == qe_row) cap = Hp[r];
+                }
+                HpLast = Hp[R - 1];
+                FpOut = fp;
+                prevHpUp = HpUp;
             }
             Tlast = T[R - 1];
             fout = f;
@@ -201,6 +257,11 @@ __global__ void __launch_bounds__(NW * 64) sw_group_kernel(const SwArgs a) {
             col = take ? oc : col;
             row = take ? orow : row;
         }
+        if constexpr (TB) {          // exactly one lane of the group holds row qe
+#pragma unroll
+            for (int m = 1; m < G; m <<= 1) cap |= (uint32_t)__shfl_xor((int)cap, m, 64);
+            score = (int)cap;
+        }
         if (g == 0 && pvalid) {
             a.oscore[gp] = score;
             if constexpr (TRACK) {
@@ -216,41 +277,64 @@ __global__ void __launch_bounds__(NW * 64) sw_group_kernel(const SwArgs a) {
 template <int MODE>
 __global__ void __launch_bounds__(64) sw_generic_kernel(const SwArgs a, uint32_t n_pairs, const uint32_t *pq,
                                                         int32_t *work, uint32_t max_lq) {
-    constexpr bool TRACK = MODE != 1, REVQ = MODE != 0, REVT = MODE == 2;
+    constexpr bool TB = MODE == 3, TRACK = MODE == 0 || MODE == 2, REVT = MODE == 2;
     const uint32_t p = blockIdx.x * 64 + threadIdx.x;
     if (p >= n_pairs) return;
     const uint32_t q = pq[p], t = a.pt[p];
-    const uint32_t qoff = a.db.off[q], toff = a.db.off[t];
-    const int lq = REVT ? a.pqe[p] + 1 : (int)a.db.len[q];
-    const int lt = REVT ? a.pte[p] + 1 : (int)a.db.len[t];
+    const int qs = TB ? a.pqs[p] : 0, ts = TB ? a.pts[p] : 0;
+    const uint32_t qoff = a.db.off[q] + (uint32_t)qs, toff = a.db.off[t] + (uint32_t)ts;
+    const int lq = TB ? a.pqe[p] - qs + 1 : (REVT ? a.pqe[p] + 1 : (int)a.db.len[q]);
+    const int lt = TB ? a.pte[p] - ts + 1 : (REVT ? a.pte[p] + 1 : (int)a.db.len[t]);
     const int qfull = (int)a.db.len[q];
     const int open = a.open, ext = a.ext;
     const size_t stride = (size_t)gridDim.x * 64;
     int32_t *H = work + p, *E = work + (size_t)max_lq * stride + p;
-    for (int i = 0; i < lq; i++) { H[(size_t)i * stride] = 0; E[(size_t)i * stride] = 0; }
+    int32_t *HP = work + 2 * (size_t)max_lq * stride + p, *EP = work + 3 * (size_t)max_lq * stride + p;   // TB only
+    for (int i = 0; i < lq; i++) {
+        H[(size_t)i * stride] = 0; E[(size_t)i * stride] = 0;
+        if constexpr (TB) { HP[(size_t)i * stride] = 0; EP[(size_t)i * stride] = 0; }
+    }
     int best = 0, bq = -1, bt = -1;
+    uint32_t cap = 0;
     for (int j = 0; j < lt; j++) {
         const uint32_t tp = toff + (uint32_t)(REVT ? lt - 1 - j : j);
         const int t3 = a.db.s3[tp], ta = a.db.sa[tp];
         int hdiag = 0, hup = 0, f = 0, colbest = 0, colrow = -1;
+        uint32_t dhp = 0, fp = 0;
         for (int i = 0; i < lq; i++) {
             // MODE 1 reverses the whole query; MODE 2 reads the prefix [0..qend] backwards
             const int qi = MODE == 1 ? qfull - 1 - i : (MODE == 2 ? lq - 1 - i : i);
-            const int s = a.db.S3[a.db.s3[qoff + qi] * 21 + t3] + a.db.SA[a.db.sa[qoff + qi] * 21 + ta];
+            const int qa = a.db.sa[qoff + qi];
+            const int s = a.db.S3[a.db.s3[qoff + qi] * 21 + t3] + a.db.SA[qa * 21 + ta];
             const int hleft = H[(size_t)i * stride];
-            const int e = max(max(E[(size_t)i * stride] - ext, hleft - open), 0);
-            f = max(max(f - ext, hup - open), 0);
-            const int h = max(max(hdiag + s, e), f);
+            const int esub = max(E[(size_t)i * stride] - ext, 0);
+            const int e = max(esub, hleft - open);
+            const int fsub = max(f - ext, 0);
+            const int fcur = max(fsub, hup - open);        // F(i,j)
+            const int x = hdiag + s;
+            const int h = max(max(x, e), max(fcur, 0));
+            if constexpr (TB) {
+                const uint32_t hpleft = (uint32_t)HP[(size_t)i * stride], epleft = (uint32_t)EP[(size_t)i * stride];
+                const uint32_t ep = (hleft - open >= esub ? hpleft : epleft) + 0x10000u;
+                const uint32_t fpc = i == 0 ? 0x10000u : fp;    // fp already holds the pack of F(i,j)
+                const uint32_t hp = h == 0 ? 0u : (x == h ? dhp + 0x10000u + (qa == ta ? 1u : 0u) : (fcur == h ? fpc : ep));
+                dhp = hpleft;
+                HP[(size_t)i * stride] = (int32_t)hp;
+                EP[(size_t)i * stride] = (int32_t)ep;
+                // pack of F(i+1,j): open from H(i,j) preferred over extending F(i,j)
+                fp = (h - open >= max(fcur - ext, 0) ? hp : fpc) + 0x10000u;
+                if (j == lt - 1 && i == lq - 1) cap = hp;
+            }
             hdiag = hleft;
             H[(size_t)i * stride] = h;
             E[(size_t)i * stride] = e;
             hup = h;
+            f = fcur;
             if (h > colbest) { colbest = h; colrow = i; }
         }
         if (colbest > best) { best = colbest; bq = colrow; bt = j; }
     }
-    (void)REVQ;
-    a.oscore[p] = best;
+    a.oscore[p] = TB ? (int32_t)cap : best;
     if constexpr (TRACK) { a.oqe[p] = bq; a.ote[p] = bt; }
 }
 
@@ -259,7 +343,7 @@ void launch_sw_class_mode(int G, int R, const SwArgs &a, uint32_t n_tasks, hipSt
 #define UC_SW_CASE(GG, RR)                                                                              \
     if (G == GG && R == RR) {                                                                           \
         constexpr int BW = ((RR / 4) | 1);                                                              \
-        constexpr int NW = sw_waves_per_group(GG, RR);                                                \
+        constexpr int NW = MODE == 3 ? (GG == 64 ? 8 : 4) : sw_waves_per_group(GG, RR);               \
         const size_t lds = (size_t)2 * SW_NLET * GG * BW * 4;                                           \
         static bool attr_set = false;                                                                   \
         if (!attr_set && lds > 64 * 1024) {                                                             \
