@@ -114,11 +114,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    # UC_DIST_BACKEND=gloo + UC_SHARE_GPU=1: debugging aid to exercise the N>1 code path on a single-GPU box
+    # (all ranks on cuda:0, exchange through gloo); the real multi-GPU run uses one GPU per rank and RCCL.
+    backend = os.environ.get("UC_DIST_BACKEND", "nccl")
+    if os.environ.get("UC_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    xdev = dev if backend == "nccl" else torch.device("cpu")      # where the exchanged buffers live
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -142,7 +151,7 @@ def main():
         max_seqs = int(tok[tok.index("--max-seqs") + 1])
 
     def step():
-        return ucdist.cluster_step(eng, lens, rank, world, max_seqs, device=dev if world > 1 else "cpu")
+        return ucdist.cluster_step(eng, lens, rank, world, max_seqs, device=xdev if world > 1 else "cpu")
 
     assign = None
     for _ in range(args.warmup):
@@ -158,10 +167,10 @@ def main():
     dt = time.perf_counter() - t0
     st = eng.stats()
     if world > 1:
-        v = torch.tensor([dt], dtype=torch.float64, device=dev)
+        v = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(v, op=dist.ReduceOp.MAX)
         dt = float(v.item())
-        c = torch.tensor([n_aln], dtype=torch.int64, device=dev)
+        c = torch.tensor([n_aln], dtype=torch.int64, device=xdev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         n_aln = int(c.item())
 

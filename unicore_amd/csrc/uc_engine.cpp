@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <cstring>
 #include <numeric>
+#include <string>
+#include <thread>
 
 namespace uc {
 
@@ -156,26 +158,43 @@ void Engine::get_alns(uint64_t begin, uint64_t n, uc_aln *out) const {
 // max_seqs under the frozen order (score desc, target asc)
 void merge_hits(uint32_t n, int max_seqs, int n_parts, const uint32_t *const *counts, const uc_hit *const *hits,
                 std::vector<uint32_t> &out_cnt, std::vector<uc_hit> &out_hits) {
+    // per-shard start of every query's list, merged size per query, then the per-query merges in parallel
+    std::vector<std::vector<uint64_t>> pos((size_t)n_parts, std::vector<uint64_t>((size_t)n + 1, 0));
     out_cnt.assign(n, 0);
-    out_hits.clear();
-    std::vector<uint64_t> pos((size_t)n_parts, 0);
-    std::vector<uc_hit> tmp;
+    std::vector<uint64_t> ooff((size_t)n + 1, 0);
+    for (int s = 0; s < n_parts; s++)
+        for (uint32_t q = 0; q < n; q++) pos[s][q + 1] = pos[s][q] + counts[s][q];
     for (uint32_t q = 0; q < n; q++) {
-        tmp.clear();
-        for (int s = 0; s < n_parts; s++) {
-            tmp.insert(tmp.end(), hits[s] + pos[s], hits[s] + pos[s] + counts[s][q]);
-            pos[s] += counts[s][q];
-        }
-        std::sort(tmp.begin(), tmp.end(), [](const uc_hit &a, const uc_hit &b) {
-            return a.score != b.score ? a.score > b.score : a.target < b.target;
-        });
-        for (size_t i = 1; i < tmp.size(); i++)
-            if (tmp[i].target == tmp[i - 1].target && tmp[i].score == tmp[i - 1].score)
-                fail(UC_ERR_ARGS, "merge_hits: target %u appears in two shards for query %u", tmp[i].target, q);
-        if (tmp.size() > (size_t)max_seqs) tmp.resize((size_t)max_seqs);
-        out_cnt[q] = (uint32_t)tmp.size();
-        out_hits.insert(out_hits.end(), tmp.begin(), tmp.end());
+        uint64_t tot = 0;
+        for (int s = 0; s < n_parts; s++) tot += counts[s][q];
+        out_cnt[q] = (uint32_t)std::min<uint64_t>(tot, (uint64_t)max_seqs);
+        ooff[q + 1] = ooff[q] + out_cnt[q];
     }
+    out_hits.resize(ooff[n]);
+    const unsigned nthr = n < 4096 ? 1u : std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    std::vector<std::string> errors(nthr);
+    auto work = [&](unsigned t) {
+        std::vector<uc_hit> tmp;
+        for (uint32_t q = (uint32_t)((uint64_t)n * t / nthr); q < (uint32_t)((uint64_t)n * (t + 1) / nthr); q++) {
+            tmp.clear();
+            for (int s = 0; s < n_parts; s++) tmp.insert(tmp.end(), hits[s] + pos[s][q], hits[s] + pos[s][q + 1]);
+            std::sort(tmp.begin(), tmp.end(), [](const uc_hit &a, const uc_hit &b) {
+                return a.score != b.score ? a.score > b.score : a.target < b.target;
+            });
+            for (size_t i = 1; i < tmp.size(); i++)
+                if (tmp[i].target == tmp[i - 1].target && tmp[i].score == tmp[i - 1].score && errors[t].empty())
+                    errors[t] = "merge_hits: target " + std::to_string(tmp[i].target) + " appears in two shards for query " + std::to_string(q);
+            std::copy(tmp.begin(), tmp.begin() + out_cnt[q], out_hits.begin() + ooff[q]);
+        }
+    };
+    if (nthr == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nthr; t++) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    for (const std::string &e : errors)
+        if (!e.empty()) fail(UC_ERR_ARGS, "%s", e.c_str());
 }
 
 }  // namespace uc
