@@ -77,14 +77,6 @@ __global__ void __launch_bounds__(256) kmer_offsets_kernel(const uint32_t *keys,
     }
 }
 
-__global__ void __launch_bounds__(256) split_entries_kernel(const uint64_t *vals, uint32_t n, uint32_t *eseq, uint16_t *epos) {
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
-        const uint64_t v = vals[i];
-        eseq[i] = (uint32_t)(v >> 16);
-        epos[i] = (uint16_t)(v & 0xFFFF);
-    }
-}
-
 // ---------------------------------------------------------------- E2: similar k-mers
 struct SimTables {           // LDS: per query letter a, target letters sorted by score descending
     int8_t sc[KA][KA];
@@ -163,78 +155,184 @@ __device__ __forceinline__ bool query_kmer_at(const DeviceDb &db, const KmerCfg 
     return ok;
 }
 
-__global__ void __launch_bounds__(256) sim_count_kernel(const DeviceDb db, KmerCfg cfg, uint32_t qbegin, uint32_t qend,
-                                                        uint32_t p0, uint32_t p1, const uint32_t *koff, uint32_t *cnt,
-                                                        unsigned long long *n_sim_total) {
-    __shared__ SimTables tab;
-    build_sim_tables(tab, db.S3);
-    __syncthreads();
-    unsigned long long nsim = 0;
-    for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < p1 - p0; idx += (uint64_t)gridDim.x * 256) {
-        uint32_t q, i, c[K], n = 0;
-        if (query_kmer_at(db, cfg, qbegin, qend, p0 + (uint32_t)idx, &q, &i, c))
-            for_each_similar(tab, c, cfg.thr, [&](uint32_t v) { n += koff[v + 1] - koff[v]; nsim++; });
-        cnt[idx] = n;
-    }
-    // one atomic per wave
-    for (int o = 32; o > 0; o >>= 1) nsim += __shfl_down(nsim, o, 64);
-    if ((threadIdx.x & 63) == 0 && nsim) atomicAdd(n_sim_total, nsim);
-}
+// ---- E2 pass 1: enumerate similar k-mers, keep the non-empty index ranges ("runs") ----
+// A run is (first index entry, entry count, query position inside the batch).  Threads enumerate divergently, so
+// runs are staged per wave in LDS and drained to global memory in blocks: whichever lanes are active when the
+// buffer is nearly full copy it out behind ONE global atomic.  Run order is irrelevant (keys get sorted).
+constexpr int RUN_STAGE = 512;    // staged runs per wave
 
-// hit key: [ query - qbegin : 23 | target : 24 | diag + 65536 : 17 ]
-__global__ void __launch_bounds__(256) sim_emit_kernel(const DeviceDb db, KmerCfg cfg, uint32_t qbegin, uint32_t qend,
-                                                       uint32_t p0, uint32_t p1, const uint32_t *koff,
-                                                       const uint32_t *eseq, const uint16_t *epos,
-                                                       const uint64_t *hoff, uint64_t *keys) {
+struct RunList {
+    uint32_t *e0, *cnt, *pidx;
+    uint64_t cap;
+};
+
+// counters: [0] similar k-mers, [1] kept candidates, [2] ungapped overlap, [3] run cursor, [4] k-mer hits, [5] key cursor
+__global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCfg cfg, uint32_t qbegin, uint32_t qend,
+                                                       uint32_t p0, uint32_t p1, const uint32_t *koff, RunList out,
+                                                       unsigned long long *counters) {
     __shared__ SimTables tab;
+    __shared__ uint32_t s_n[4];
+    __shared__ uint32_t s_e0[4][RUN_STAGE], s_cnt[4][RUN_STAGE], s_pi[4][RUN_STAGE];
     build_sim_tables(tab, db.S3);
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) s_n[wv] = 0;
     __syncthreads();
+    volatile uint32_t *vn = &s_n[wv];
+    volatile uint32_t *ve0 = s_e0[wv], *vcnt = s_cnt[wv], *vpi = s_pi[wv];
+
+    auto drain = [&]() {   // runs on whatever subset of the wave is active at the call site
+        const uint64_t act = __builtin_amdgcn_ballot_w64(true);
+        const int nact = __popcll(act), rank = __popcll(act & ((1ull << lane) - 1ull)), leader = __ffsll((long long)act) - 1;
+        const uint32_t n = *vn;
+        uint32_t blo = 0, bhi = 0;
+        if (lane == leader) {
+            const unsigned long long b = atomicAdd(counters + 3, (unsigned long long)n);
+            blo = (uint32_t)b; bhi = (uint32_t)(b >> 32);
+        }
+        blo = (uint32_t)__shfl((int)blo, leader, 64);
+        bhi = (uint32_t)__shfl((int)bhi, leader, 64);
+        const uint64_t base = ((uint64_t)bhi << 32) | blo;
+        for (uint32_t k = rank; k < n; k += nact) {
+            const uint64_t w = base + k;
+            if (w < out.cap) { out.e0[w] = ve0[k]; out.cnt[w] = vcnt[k]; out.pidx[w] = vpi[k]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == leader) *vn = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    unsigned long long nsim = 0, nhit = 0;
     for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < p1 - p0; idx += (uint64_t)gridDim.x * 256) {
         uint32_t q, i, c[K];
         if (!query_kmer_at(db, cfg, qbegin, qend, p0 + (uint32_t)idx, &q, &i, c)) continue;
-        uint64_t w = hoff[idx];
-        const uint64_t qbits = (uint64_t)(q - qbegin) << 41;
         for_each_similar(tab, c, cfg.thr, [&](uint32_t v) {
-            const uint32_t e1 = koff[v + 1];
-            for (uint32_t e = koff[v]; e < e1; e++)
-                keys[w++] = qbits | ((uint64_t)eseq[e] << 17) | (uint64_t)((int)i - (int)epos[e] + 65536);
+            nsim++;
+            const uint32_t e0 = koff[v], n = koff[v + 1] - e0;
+            if (n == 0) return;
+            nhit += n;
+            if (*vn > RUN_STAGE - 64) drain();            // same value in every active lane: uniform among them
+            const uint32_t slot = atomicAdd(&s_n[wv], 1u);
+            ve0[slot] = e0; vcnt[slot] = n; vpi[slot] = (uint32_t)idx;
         });
     }
-}
-
-// one pass over the sorted hit keys: the first key of every (query,target) group walks its group,
-// run-length-counts the diagonals and keeps the best (count desc, diagonal asc); flag = candidate
-__global__ void __launch_bounds__(256) diag_select_kernel(const uint64_t *keys, uint64_t n, int min_hits,
-                                                          uint32_t *flag, int32_t *bestdiag) {
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
-        const uint64_t k = keys[i], grp = k >> 17;
-        uint32_t fl = 0;
-        if (i == 0 || (keys[i - 1] >> 17) != grp) {
-            int best_cnt = 0, best_d = 0;
-            uint64_t b = i;
-            while (b < n && (keys[b] >> 17) == grp) {
-                const uint64_t kb = keys[b];
-                uint64_t e = b + 1;
-                while (e < n && keys[e] == kb) e++;
-                const int c = (int)(e - b);
-                if (c > best_cnt) { best_cnt = c; best_d = (int)(kb & 0x1FFFF) - 65536; }
-                b = e;
-            }
-            if (best_cnt >= min_hits) { fl = 1; bestdiag[i] = best_d; }
-        }
-        flag[i] = fl;
+    __builtin_amdgcn_wave_barrier();
+    drain();
+    for (int o = 32; o > 0; o >>= 1) { nsim += __shfl_down(nsim, o, 64); nhit += __shfl_down(nhit, o, 64); }
+    if (lane == 0) {
+        if (nsim) atomicAdd(counters + 0, nsim);
+        if (nhit) atomicAdd(counters + 4, nhit);
     }
 }
 
-__global__ void __launch_bounds__(256) cand_scatter_kernel(const uint64_t *keys, uint64_t n, const uint32_t *flag,
-                                                           const uint64_t *pos, const int32_t *bestdiag, uint32_t qbegin,
-                                                           uint32_t *cq, uint32_t *ct, int32_t *cd) {
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
-        if (!flag[i]) continue;
-        const uint64_t k = keys[i], w = pos[i];
-        cq[w] = qbegin + (uint32_t)(k >> 41);
-        ct[w] = (uint32_t)(k >> 17) & 0xFFFFFFu;
-        cd[w] = bestdiag[i];
+// hit key: [ query - qbegin | target : tbits | diagonal + dbias : dbits ]; the field widths follow the database
+// (number of sequences, longest sequence) so that the radix sort touches as few digits as possible
+struct KeyFmt {
+    int dbits, tbits;
+    int dbias;
+};
+
+// ---- E2 pass 2: expand runs into hit keys, load-balanced ----
+// A workgroup takes 256 runs, scans their lengths, reserves the tile's key range with one atomic and then lets
+// thread k write key k of the tile (binary search in the LDS prefix): loads of index entries touch a handful of
+// lines per wave and the key stores are fully coalesced.
+__global__ void __launch_bounds__(256) expand_kernel(const DeviceDb db, uint32_t qbegin, uint32_t qend, uint32_t p0, RunList runs,
+                                                     uint64_t n_runs, const uint64_t *ent, KeyFmt fmt,
+                                                     unsigned long long *key_cursor, uint64_t *keys, uint64_t key_cap) {
+    __shared__ uint64_t s_pref[257];
+    __shared__ uint64_t s_qb[256];
+    __shared__ uint32_t s_e0[256];
+    __shared__ int32_t s_i[256];
+    __shared__ uint64_t s_wsum[4];
+    __shared__ unsigned long long s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (uint64_t tile = blockIdx.x; tile * 256 < n_runs; tile += gridDim.x) {
+        const uint64_t r = tile * 256 + tid;
+        uint64_t c = 0;
+        if (r < n_runs) {
+            c = runs.cnt[r];
+            const uint32_t p = p0 + runs.pidx[r];
+            const uint32_t s = find_seq(db.off, qbegin, qend, p);
+            s_e0[tid] = runs.e0[r];
+            s_i[tid] = (int32_t)(p - db.off[s]) + fmt.dbias;
+            s_qb[tid] = (uint64_t)(s - qbegin) << (fmt.tbits + fmt.dbits);
+        }
+        uint64_t inc = c;   // inclusive scan inside the wave, then across the 4 waves
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t up = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) s_wsum[wv] = inc;
+        __syncthreads();
+        uint64_t woff = 0;
+        for (int w = 0; w < wv; w++) woff += s_wsum[w];
+        s_pref[tid] = woff + inc - c;
+        if (tid == 255) {
+            const uint64_t total = woff + inc;
+            s_pref[256] = total;
+            s_base = total ? atomicAdd(key_cursor, (unsigned long long)total) : 0ull;
+        }
+        __syncthreads();
+        const uint64_t total = s_pref[256], base = s_base;
+        for (uint64_t k = tid; k < total; k += 256) {
+            int lo = 0, hi = 256;          // last run with pref <= k
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_pref[mid] <= k) lo = mid; else hi = mid;
+            }
+            const uint64_t e = ent[s_e0[lo] + (uint32_t)(k - s_pref[lo])];
+            const uint64_t key = s_qb[lo] | ((e >> 16) << fmt.dbits) | (uint64_t)(s_i[lo] - (int32_t)(e & 0xFFFF));
+            if (base + k < key_cap) keys[base + k] = key;
+        }
+        __syncthreads();
+    }
+}
+
+// one pass over the sorted hit keys: the first key of every (query,target) group walks its group, run-length-
+// counts the diagonals and keeps the best (count desc, diagonal asc).  Candidates are appended behind a wave-
+// aggregated atomic; their order is irrelevant (E4 sorts on a unique key).
+__global__ void __launch_bounds__(256) diag_select_kernel(const uint64_t *keys, uint64_t n, int min_hits, KeyFmt fmt, uint32_t qbegin,
+                                                          unsigned long long *n_cand, uint64_t cap,
+                                                          uint32_t *cq, uint32_t *ct, int32_t *cd) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t dmask = (1ull << fmt.dbits) - 1, tmask = (1ull << fmt.tbits) - 1;
+    const uint64_t nround = (n + 255) / 256 * 256;   // whole waves stay in the loop (ballot below)
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nround; i += (uint64_t)gridDim.x * 256) {
+        bool cand = false;
+        int best_d = 0;
+        uint64_t grp = 0;
+        if (i < n) {
+            grp = keys[i] >> fmt.dbits;
+            if (i == 0 || (keys[i - 1] >> fmt.dbits) != grp) {
+                int best_cnt = 0;
+                uint64_t b = i;
+                while (b < n && (keys[b] >> fmt.dbits) == grp) {
+                    const uint64_t kb = keys[b];
+                    uint64_t e = b + 1;
+                    while (e < n && keys[e] == kb) e++;
+                    const int c = (int)(e - b);
+                    if (c > best_cnt) { best_cnt = c; best_d = (int)(kb & dmask) - fmt.dbias; }
+                    b = e;
+                }
+                cand = best_cnt >= min_hits;
+            }
+        }
+        const uint64_t m = __builtin_amdgcn_ballot_w64(cand);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t blo = 0, bhi = 0;
+            if (lane == leader) {
+                const unsigned long long b = atomicAdd(n_cand, (unsigned long long)__popcll(m));
+                blo = (uint32_t)b; bhi = (uint32_t)(b >> 32);
+            }
+            blo = (uint32_t)__shfl((int)blo, leader, 64);
+            bhi = (uint32_t)__shfl((int)bhi, leader, 64);
+            const uint64_t w = (((uint64_t)bhi << 32) | blo) + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (cand && w < cap) {
+                cq[w] = qbegin + (uint32_t)(grp >> fmt.tbits);
+                ct[w] = (uint32_t)(grp & tmask);
+                cd[w] = best_d;
+            }
+        }
     }
 }
 
@@ -312,9 +410,12 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend) {
     alns_valid = false;
     edges.clear();
 
-    DevBuf<unsigned long long> d_counters;   // [0] sim k-mers, [1] kept candidates, [2] ungapped overlap residues
-    d_counters.reserve(3);
-    UC_HIP(hipMemsetAsync(d_counters.p, 0, 24, stream));
+    if (n > (1u << 24)) fail(UC_ERR_GENERIC, "prefilter: %u sequences exceed the 2^24 limit of the hit keys", n);
+    // counters: [0] similar k-mers, [1] kept candidates, [2] ungapped overlap residues, [3] run cursor,
+    //           [4] k-mer hits of the batch, [5] key cursor, [6] candidate cursor
+    DevBuf<unsigned long long> d_counters;
+    d_counters.reserve(8);
+    UC_HIP(hipMemsetAsync(d_counters.p, 0, 64, stream));
     DevBuf<char> d_temp;
     auto temp_reserve = [&](size_t bytes) { d_temp.reserve(bytes + 256); };
 
@@ -323,30 +424,25 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend) {
     timed_ms_begin();
     const uint32_t tp0 = h_poff[tbegin], tp1 = h_poff[tend];
     const uint32_t nres = tp1 - tp0;
-    DevBuf<uint32_t> d_koff, d_eseq;
-    DevBuf<uint16_t> d_epos;
+    DevBuf<uint32_t> d_koff;
+    DevBuf<uint64_t> d_ent;      // index entries sorted by k-mer: [sequence : 32 | position : 16]
     d_koff.reserve((size_t)KSPACE + 1);
     uint32_t n_entries = 0;
     {
         DevBuf<uint32_t> k_in, k_out;
-        DevBuf<uint64_t> v_in, v_out;
+        DevBuf<uint64_t> v_in;
         const size_t cap = std::max<uint32_t>(nres, 1);
-        k_in.reserve(cap); k_out.reserve(cap); v_in.reserve(cap); v_out.reserve(cap);
+        k_in.reserve(cap); k_out.reserve(cap); v_in.reserve(cap); d_ent.reserve(cap);
         if (nres) {
             hipLaunchKernelGGL(kmer_extract_kernel, grid_for(nres), dim3(256), 0, stream, ddb, tbegin, tend, cfg, tp0, tp1, k_in.p, v_in.p);
             size_t tb = 0;
-            UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, k_in.p, k_out.p, v_in.p, v_out.p, (size_t)nres, 0u, 32u, stream));
+            UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, k_in.p, k_out.p, v_in.p, d_ent.p, (size_t)nres, 0u, 32u, stream));
             temp_reserve(tb);
-            UC_HIP(rocprim::radix_sort_pairs(d_temp.p, tb, k_in.p, k_out.p, v_in.p, v_out.p, (size_t)nres, 0u, 32u, stream));
+            UC_HIP(rocprim::radix_sort_pairs(d_temp.p, tb, k_in.p, k_out.p, v_in.p, d_ent.p, (size_t)nres, 0u, 32u, stream));
         }
-        // number of valid entries = first index with key >= KSPACE: reuse the offsets kernel's last slot
+        // number of valid entries = first index with key >= KSPACE: the offsets kernel's last slot
         hipLaunchKernelGGL(kmer_offsets_kernel, grid_for((uint64_t)KSPACE + 1), dim3(256), 0, stream, k_out.p, nres, d_koff.p);
         UC_HIP(hipMemcpyAsync(&n_entries, d_koff.p + KSPACE, 4, hipMemcpyDeviceToHost, stream));
-        UC_HIP(hipStreamSynchronize(stream));
-        d_eseq.reserve(std::max<uint32_t>(n_entries, 1));
-        d_epos.reserve(std::max<uint32_t>(n_entries, 1));
-        if (n_entries)
-            hipLaunchKernelGGL(split_entries_kernel, grid_for(n_entries), dim3(256), 0, stream, v_out.p, n_entries, d_eseq.p, d_epos.p);
         UC_HIP(hipStreamSynchronize(stream));
     }
     UC_HIP(hipGetLastError());
@@ -357,11 +453,22 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend) {
 
     // ------------------------------------------------------------ E2-E4 over query batches
     const uint64_t HIT_CAP = 1ull << 30;       // keys per batch (8 GiB + 8 GiB sort double buffer)
-    double hits_per_res = 64.0;                // adaptive estimate
-    DevBuf<uint32_t> d_cnt, d_flag, d_cq, d_ct;
-    DevBuf<uint64_t> d_hoff, d_keys, d_keys2, d_pos, d_skey, d_skey2;
-    DevBuf<int32_t> d_bestdiag, d_cd, d_cd2, d_score;
-    uint64_t n_hits_total = 0, n_cand_total = 0;
+    const uint64_t RUN_MAX = 1ull << 28;       // runs per batch (3 GiB)
+    double hits_per_res = 64.0;                // adaptive estimates
+    uint64_t run_cap = 1ull << 20;
+    KeyFmt fmt;
+    {
+        const uint32_t m = std::min<uint32_t>(std::max<uint32_t>(max_len, 2), 65536u);
+        fmt.dbits = 1;
+        while ((1u << (fmt.dbits - 1)) < m) fmt.dbits++;
+        fmt.dbias = 1 << (fmt.dbits - 1);
+        fmt.tbits = 1;
+        while ((1u << fmt.tbits) < n) fmt.tbits++;
+    }
+    DevBuf<uint32_t> d_cnt, d_flag, d_cq, d_ct, d_re0, d_rcnt, d_rpidx;
+    DevBuf<uint64_t> d_keys, d_keys2, d_pos, d_skey, d_skey2;
+    DevBuf<int32_t> d_cd, d_cd2, d_score;
+    uint64_t n_hits_total = 0, n_cand_total = 0, cand_cap = 0;
     double t_kmer = 0, t_ung = 0, t_sel = 0;
 
     for (uint32_t qa = 0; qa < n;) {
@@ -378,59 +485,66 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend) {
                 qb++;
             }
         }
-        uint64_t total_hits = 0;
+        uint64_t total_hits = 0, n_runs = 0;
         uint32_t qp0 = 0, qp1 = 0, nq_res = 0;
-        for (;;) {   // count; shrink the batch if it overflows the cap
+        for (;;) {   // pass 1: runs + exact hit count; shrink the batch / grow the run list if it does not fit
             qp0 = h_poff[qa]; qp1 = h_poff[qb]; nq_res = qp1 - qp0;
-            d_cnt.reserve(nq_res); d_hoff.reserve((size_t)nq_res + 1);
-            hipLaunchKernelGGL(sim_count_kernel, grid_for(nq_res), dim3(256), 0, stream, ddb, cfg, qa, qb, qp0, qp1, d_koff.p, d_cnt.p, d_counters.p);
-            size_t tb = 0;
-            auto in = rocprim::make_transform_iterator(d_cnt.p, WidenU32());
-            UC_HIP(rocprim::exclusive_scan(nullptr, tb, in, d_hoff.p, (uint64_t)0, (size_t)nq_res, rocprim::plus<uint64_t>(), stream));
-            temp_reserve(tb);
-            UC_HIP(rocprim::exclusive_scan(d_temp.p, tb, in, d_hoff.p, (uint64_t)0, (size_t)nq_res, rocprim::plus<uint64_t>(), stream));
-            uint64_t last_off = 0; uint32_t last_cnt = 0;
-            UC_HIP(hipMemcpyAsync(&last_off, d_hoff.p + (nq_res - 1), 8, hipMemcpyDeviceToHost, stream));
-            UC_HIP(hipMemcpyAsync(&last_cnt, d_cnt.p + (nq_res - 1), 4, hipMemcpyDeviceToHost, stream));
+            run_cap = std::min<uint64_t>(RUN_MAX, std::max<uint64_t>(run_cap, (uint64_t)nq_res * 16));
+            d_re0.reserve(run_cap); d_rcnt.reserve(run_cap); d_rpidx.reserve(run_cap);
+            UC_HIP(hipMemsetAsync(d_counters.p + 3, 0, 32, stream));   // run cursor, batch hits, key cursor, candidate cursor
+            UC_HIP(hipMemsetAsync(d_counters.p, 0, 8, stream));
+            const RunList rl{d_re0.p, d_rcnt.p, d_rpidx.p, run_cap};
+            hipLaunchKernelGGL(sim_runs_kernel, grid_for(nq_res), dim3(256), 0, stream, ddb, cfg, qa, qb, qp0, qp1, d_koff.p, rl, d_counters.p);
+            unsigned long long c5[5];
+            UC_HIP(hipMemcpyAsync(c5, d_counters.p, 40, hipMemcpyDeviceToHost, stream));
             UC_HIP(hipStreamSynchronize(stream));
-            total_hits = last_off + last_cnt;
-            if (total_hits <= HIT_CAP || qb - qa == 1) break;
-            // too many: the sim counter over-counts on a retry, so remember and subtract
-            qb = qa + std::max<uint32_t>(1, (qb - qa) / 2);
-            UC_HIP(hipMemsetAsync(d_counters.p, 0, 8, stream));   // n_sim restarts for this batch (accumulated on host below)
+            n_runs = c5[3];
+            total_hits = c5[4];
+            const bool single = qb - qa == 1;
+            if (total_hits > HIT_CAP && !single) { qb = qa + std::max<uint32_t>(1, (qb - qa) / 2); continue; }
+            if (n_runs > run_cap) {
+                if (run_cap < RUN_MAX || single) {
+                    if (n_runs > (1ull << 32)) fail(UC_ERR_GENERIC, "query %u alone produces %llu index ranges", qa, (unsigned long long)n_runs);
+                    run_cap = single ? n_runs : std::min<uint64_t>(RUN_MAX, std::max<uint64_t>(n_runs, run_cap * 2));
+                    if (n_runs > run_cap) qb = qa + std::max<uint32_t>(1, (qb - qa) / 2);
+                    continue;
+                }
+                qb = qa + std::max<uint32_t>(1, (qb - qa) / 2);
+                continue;
+            }
+            stats.n_sim_kmers += c5[0];
+            break;
         }
         if (total_hits > (1ull << 34)) fail(UC_ERR_GENERIC, "query %u alone produces %llu k-mer hits", qa, (unsigned long long)total_hits);
         hits_per_res = std::max(1.0, (double)total_hits / std::max<uint32_t>(1, nq_res)) * 1.25;
         n_hits_total += total_hits;
-        // harvest the similar-k-mer counter of this batch
-        {
-            unsigned long long ns = 0;
-            UC_HIP(hipMemcpy(&ns, d_counters.p, 8, hipMemcpyDeviceToHost));
-            stats.n_sim_kmers += ns;
-            UC_HIP(hipMemsetAsync(d_counters.p, 0, 8, stream));
-        }
         uint64_t n_cand = 0;
         if (total_hits) {
+            // pass 2: expand runs into keys, sort, pick the best diagonal per (query, target)
             d_keys.reserve(total_hits); d_keys2.reserve(total_hits);
-            hipLaunchKernelGGL(sim_emit_kernel, grid_for(nq_res), dim3(256), 0, stream, ddb, cfg, qa, qb, qp0, qp1,
-                               d_koff.p, d_eseq.p, d_epos.p, d_hoff.p, d_keys.p);
+            const RunList rl{d_re0.p, d_rcnt.p, d_rpidx.p, run_cap};
+            hipLaunchKernelGGL(expand_kernel, grid_for(n_runs), dim3(256), 0, stream, ddb, qa, qb, qp0, rl, n_runs, d_ent.p, fmt,
+                               d_counters.p + 5, d_keys.p, total_hits);
             unsigned qbits = 1;
             while ((1u << qbits) < qb - qa) qbits++;
+            const unsigned kbits = (unsigned)(fmt.dbits + fmt.tbits) + qbits;
             size_t tb = 0;
-            UC_HIP(rocprim::radix_sort_keys(nullptr, tb, d_keys.p, d_keys2.p, (size_t)total_hits, 0u, 41u + qbits, stream));
+            UC_HIP(rocprim::radix_sort_keys(nullptr, tb, d_keys.p, d_keys2.p, (size_t)total_hits, 0u, kbits, stream));
             temp_reserve(tb);
-            UC_HIP(rocprim::radix_sort_keys(d_temp.p, tb, d_keys.p, d_keys2.p, (size_t)total_hits, 0u, 41u + qbits, stream));
-            d_flag.reserve(total_hits); d_bestdiag.reserve(total_hits); d_pos.reserve(total_hits);
-            hipLaunchKernelGGL(diag_select_kernel, grid_for(total_hits), dim3(256), 0, stream, d_keys2.p, total_hits, p.min_diag_hits, d_flag.p, d_bestdiag.p);
-            auto fin = rocprim::make_transform_iterator(d_flag.p, WidenU32());
-            UC_HIP(rocprim::exclusive_scan(nullptr, tb, fin, d_pos.p, (uint64_t)0, (size_t)total_hits, rocprim::plus<uint64_t>(), stream));
-            temp_reserve(tb);
-            UC_HIP(rocprim::exclusive_scan(d_temp.p, tb, fin, d_pos.p, (uint64_t)0, (size_t)total_hits, rocprim::plus<uint64_t>(), stream));
-            uint64_t lp = 0; uint32_t lf = 0;
-            UC_HIP(hipMemcpyAsync(&lp, d_pos.p + (total_hits - 1), 8, hipMemcpyDeviceToHost, stream));
-            UC_HIP(hipMemcpyAsync(&lf, d_flag.p + (total_hits - 1), 4, hipMemcpyDeviceToHost, stream));
-            UC_HIP(hipStreamSynchronize(stream));
-            n_cand = lp + lf;
+            UC_HIP(rocprim::radix_sort_keys(d_temp.p, tb, d_keys.p, d_keys2.p, (size_t)total_hits, 0u, kbits, stream));
+            cand_cap = std::max<uint64_t>(cand_cap, std::max<uint64_t>(1u << 20, total_hits / 32));
+            for (;;) {
+                d_cq.reserve(cand_cap); d_ct.reserve(cand_cap); d_cd.reserve(cand_cap);
+                UC_HIP(hipMemsetAsync(d_counters.p + 6, 0, 8, stream));
+                hipLaunchKernelGGL(diag_select_kernel, grid_for(total_hits), dim3(256), 0, stream, d_keys2.p, total_hits, p.min_diag_hits, fmt, qa,
+                                   d_counters.p + 6, cand_cap, d_cq.p, d_ct.p, d_cd.p);
+                unsigned long long nc = 0;
+                UC_HIP(hipMemcpyAsync(&nc, d_counters.p + 6, 8, hipMemcpyDeviceToHost, stream));
+                UC_HIP(hipStreamSynchronize(stream));
+                n_cand = nc;
+                if (n_cand <= cand_cap) break;
+                cand_cap = n_cand;     // rare: more candidates than provisioned, run the selection again
+            }
         }
         UC_HIP(hipGetLastError());
         gpu_ms += timed_ms_end();
@@ -441,9 +555,7 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend) {
             // -------------------------------------------------------- E3: ungapped rescoring
             Timer t_u;
             timed_ms_begin();
-            d_cq.reserve(n_cand); d_ct.reserve(n_cand); d_cd.reserve(n_cand); d_score.reserve(n_cand);
-            hipLaunchKernelGGL(cand_scatter_kernel, grid_for(total_hits), dim3(256), 0, stream, d_keys2.p, total_hits, d_flag.p, d_pos.p,
-                               d_bestdiag.p, qa, d_cq.p, d_ct.p, d_cd.p);
+            d_score.reserve(n_cand);
             launch_ungapped(ddb, n_cand, d_cq.p, d_ct.p, d_cd.p, d_score.p, d_counters.p + 2, stream);
             UC_HIP(hipGetLastError());
             gpu_ms += timed_ms_end();
