@@ -202,7 +202,7 @@ def main():
             "stages_s_per_step": {k: v / steps for k, v in zip(U.STAGES, st["stage_seconds"])},
             "prefilter_kernel_ms_per_step": st["prefilter_kernel_ms"] / steps,
             "sw_kernel_ms_per_step": st["sw_kernel_ms"] / steps,
-            "counts_rank0_per_step": {k: st[k] // steps for k in ("n_sim_kmers", "n_kmer_hits", "n_candidates", "n_prefilter_hits",
+            "counts_rank0_per_step": {k: st[k] // steps for k in ("n_sim_kmers", "n_kmer_hits", "n_filtered_hits", "n_candidates", "n_prefilter_hits",
                                                                   "n_gapped_alignments", "n_start_alignments", "n_edges")},
         }
         if world == 1 and not args.no_cpu_baseline:

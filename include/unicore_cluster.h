@@ -59,6 +59,7 @@ typedef struct uc_stats {
     uint64_t sw_kernel_launches;
     uint64_t sw_algorithmic_bytes;                       /* sum over launches of 2*(Lq+Lt)+32 per alignment-pass */
     double prefilter_kernel_ms;                          /* all prefilter kernels (HIP events) */
+    uint64_t n_filtered_hits;                            /* k-mer hits that survive the double-hit filter and get sorted */
 } uc_stats;
 
 /* ---- the three calls of cluster.rs ------------------------------------------------------------ */

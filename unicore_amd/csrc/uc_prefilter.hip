@@ -162,7 +162,8 @@ __device__ __forceinline__ bool query_kmer_at(const DeviceDb &db, const KmerCfg 
 constexpr int RUN_STAGE = 512;    // staged runs per wave
 
 struct RunList {
-    uint32_t *e0, *cnt, *pidx;
+    uint32_t *pidx;     // query position inside the batch
+    uint64_t *val;      // [ entry count : 32 | first index entry : 32 ]
     uint64_t cap;
 };
 
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
         const uint64_t base = ((uint64_t)bhi << 32) | blo;
         for (uint32_t k = rank; k < n; k += nact) {
             const uint64_t w = base + k;
-            if (w < out.cap) { out.e0[w] = ve0[k]; out.cnt[w] = vcnt[k]; out.pidx[w] = vpi[k]; }
+            if (w < out.cap) { out.pidx[w] = vpi[k]; out.val[w] = ((uint64_t)vcnt[k] << 32) | ve0[k]; }
         }
         __builtin_amdgcn_wave_barrier();
         if (lane == leader) *vn = 0;
@@ -249,10 +250,11 @@ __global__ void __launch_bounds__(256) expand_kernel(const DeviceDb db, uint32_t
         const uint64_t r = tile * 256 + tid;
         uint64_t c = 0;
         if (r < n_runs) {
-            c = runs.cnt[r];
+            const uint64_t rv = runs.val[r];
+            c = rv >> 32;
             const uint32_t p = p0 + runs.pidx[r];
             const uint32_t s = find_seq(db.off, qbegin, qend, p);
-            s_e0[tid] = runs.e0[r];
+            s_e0[tid] = (uint32_t)rv;
             s_i[tid] = (int32_t)(p - db.off[s]) + fmt.dbias;
             s_qb[tid] = (uint64_t)(s - qbegin) << (fmt.tbits + fmt.dbits);
         }
@@ -287,15 +289,169 @@ __global__ void __launch_bounds__(256) expand_kernel(const DeviceDb db, uint32_t
     }
 }
 
+// ---- E2 pass 2 (min_diag_hits >= 2): expand + double-hit filter, one workgroup per query ----
+// Only hits that share (target, diagonal) with another hit of the same query can make a candidate, and they are a
+// few percent of all hits.  With the runs sorted by query position a workgroup owns one query: sweep 1 expands the
+// query's runs and records every (target, diagonal) hash in two LDS bitmaps (seen once / seen twice); sweep 2
+// expands again and keeps the keys whose hash was seen twice — every key of a real multi-hit diagonal plus a
+// few collisions, which the exact diagonal count after the sort discards again.  Survivors go to a region the
+// query reserved with one atomic (sized by its hit total) and are compacted afterwards.
+constexpr int FB_LOG2 = 19;            // bits per bitmap: 2 x 64 KiB of the CU's 160 KiB LDS
+constexpr int FT = 1024;               // threads per workgroup = runs per tile
+constexpr size_t FILTER_LDS = 2 * ((size_t)1 << FB_LOG2) / 8 + (FT + 1) * 8 + FT * 8 + 16 * 8 + 64;
+
+__global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t qbegin, uint32_t p0, const uint32_t *rpidx,
+                                                    const uint64_t *rval, uint64_t n_runs, const uint64_t *ent, KeyFmt fmt,
+                                                    unsigned long long *region_cursor, uint64_t *keys, uint64_t key_cap,
+                                                    uint64_t *qbase, uint32_t *qsurv) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t f_lds[];
+    constexpr int BW = 1 << (FB_LOG2 - 5);          // words per bitmap
+    uint32_t *B1 = f_lds, *B2 = f_lds + BW;
+    uint64_t *s_pref = (uint64_t *)(f_lds + 2 * BW);            // FT + 1
+    uint32_t *s_e0 = (uint32_t *)(s_pref + FT + 1);             // FT
+    int32_t *s_i = (int32_t *)(s_e0 + FT);                      // FT
+    uint64_t *s_wsum = (uint64_t *)(s_i + FT);                  // 16
+    uint64_t *s_misc = s_wsum + 16;                             // [0] r0, [1] r1, [2] region base, [3] survivor cursor (u32)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t q = qbegin + blockIdx.x;
+    const uint32_t plo = db.off[q] - p0, phi = db.off[q + 1] - p0;
+    if (tid < 2) {
+        const uint32_t want = tid ? phi : plo;
+        uint64_t lo = 0, hi = n_runs;
+        while (lo < hi) { const uint64_t m = (lo + hi) >> 1; if (rpidx[m] < want) lo = m + 1; else hi = m; }
+        s_misc[tid] = lo;
+    }
+    for (int w = tid; w < 2 * BW; w += FT) f_lds[w] = 0;
+    __syncthreads();
+    const uint64_t r0 = s_misc[0], r1 = s_misc[1];
+    if (r0 == r1) {
+        if (tid == 0) { qbase[blockIdx.x] = 0; qsurv[blockIdx.x] = 0; }
+        return;
+    }
+    const uint64_t qbits = (uint64_t)blockIdx.x << (fmt.tbits + fmt.dbits);
+
+    // loads one tile of runs, leaves the exclusive prefix of their lengths in s_pref[0..FT] (s_pref[FT] = total)
+    auto load_tile = [&](uint64_t tile) {
+        const uint64_t r = tile + tid;
+        uint64_t c = 0;
+        if (r < r1) {
+            const uint64_t rv = rval[r];
+            c = rv >> 32;
+            s_e0[tid] = (uint32_t)rv;
+            s_i[tid] = (int32_t)(rpidx[r] - plo) + fmt.dbias;
+        }
+        uint64_t inc = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t up = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) s_wsum[wv] = inc;
+        __syncthreads();
+        uint64_t woff = 0;
+        for (int w = 0; w < wv; w++) woff += s_wsum[w];
+        s_pref[tid] = woff + inc - c;
+        if (tid == FT - 1) s_pref[FT] = woff + inc;
+        __syncthreads();
+    };
+    // key k of the current tile: (target << dbits | diagonal + dbias)
+    auto key_at = [&](uint64_t k) -> uint64_t {
+        int lo = 0, hi = FT;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_pref[mid] <= k) lo = mid; else hi = mid;
+        }
+        const uint64_t e = ent[s_e0[lo] + (uint32_t)(k - s_pref[lo])];
+        return ((e >> 16) << fmt.dbits) | (uint64_t)(s_i[lo] - (int32_t)(e & 0xFFFF));
+    };
+    auto slot_of = [&](uint64_t td) -> uint32_t {
+        const uint32_t x = (uint32_t)td * 0x9E3779B1u ^ (uint32_t)(td >> 32) * 0x85EBCA6Bu;
+        return (x * 0x2C1B3C6Du) >> (32 - FB_LOG2);
+    };
+
+    uint64_t total = 0;
+    for (uint64_t tile = r0; tile < r1; tile += FT) {
+        load_tile(tile);
+        const uint64_t T = s_pref[FT];
+        for (uint64_t k = tid; k < T; k += FT) {
+            const uint32_t h = slot_of(key_at(k)), bit = 1u << (h & 31);
+            const uint32_t old = atomicOr(&B1[h >> 5], bit);
+            if (old & bit) atomicOr(&B2[h >> 5], bit);
+        }
+        total += T;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        s_misc[2] = atomicAdd(region_cursor, (unsigned long long)total);
+        *(uint32_t *)&s_misc[3] = 0;
+    }
+    __syncthreads();
+    const uint64_t base = s_misc[2];
+    uint32_t *cur = (uint32_t *)&s_misc[3];
+    for (uint64_t tile = r0; tile < r1; tile += FT) {
+        load_tile(tile);
+        const uint64_t T = s_pref[FT];
+        const uint64_t Tr = (T + 63) & ~63ull;       // whole waves stay in the loop (ballot)
+        for (uint64_t k = tid; k < Tr; k += FT) {
+            uint64_t td = 0;
+            bool keep = false;
+            if (k < T) {
+                td = key_at(k);
+                const uint32_t h = slot_of(td);
+                keep = (B2[h >> 5] >> (h & 31)) & 1u;
+            }
+            const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+            if (m) {
+                uint32_t s0 = 0;
+                if (lane == 0) s0 = atomicAdd(cur, (uint32_t)__popcll(m));
+                s0 = (uint32_t)__shfl((int)s0, 0, 64);
+                const uint64_t w = base + s0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (keep && w < key_cap) keys[w] = qbits | td;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { qbase[blockIdx.x] = base; qsurv[blockIdx.x] = *cur; }
+}
+
+// moves every query's surviving keys from its region to a dense array
+__global__ void __launch_bounds__(256) compact_kernel(const uint64_t *keys, const uint64_t *qbase, const uint32_t *qsurv,
+                                                      const uint64_t *soff, uint32_t nq, uint64_t *out) {
+    for (uint32_t b = blockIdx.x; b < nq; b += gridDim.x) {
+        const uint64_t src = qbase[b], dst = soff[b];
+        const uint32_t n = qsurv[b];
+        for (uint32_t k = threadIdx.x; k < n; k += 256) out[dst + k] = keys[src + k];
+    }
+}
+
 // one pass over the sorted hit keys: the first key of every (query,target) group walks its group, run-length-
-// counts the diagonals and keeps the best (count desc, diagonal asc).  Candidates are appended behind a wave-
-// aggregated atomic; their order is irrelevant (E4 sorts on a unique key).
+// counts the diagonals and keeps the best (count desc, diagonal asc).  Candidates are staged per wave in LDS and
+// appended in blocks of >= 64 behind one global atomic (one atomic per wave ballot serialised on a single
+// address: +90 ms per step, profiles/r1g); their order is irrelevant (E4 sorts on a unique key).
 __global__ void __launch_bounds__(256) diag_select_kernel(const uint64_t *keys, uint64_t n, int min_hits, KeyFmt fmt, uint32_t qbegin,
                                                           unsigned long long *n_cand, uint64_t cap,
                                                           uint32_t *cq, uint32_t *ct, int32_t *cd) {
-    const int lane = threadIdx.x & 63;
+    __shared__ uint32_t s_q[4][128], s_t[4][128];
+    __shared__ int32_t s_d[4][128];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint64_t dmask = (1ull << fmt.dbits) - 1, tmask = (1ull << fmt.tbits) - 1;
     const uint64_t nround = (n + 255) / 256 * 256;   // whole waves stay in the loop (ballot below)
+    uint32_t staged = 0;                             // wave-uniform
+    auto drain = [&]() {
+        uint32_t blo = 0, bhi = 0;
+        if (lane == 0) {
+            const unsigned long long b = atomicAdd(n_cand, (unsigned long long)staged);
+            blo = (uint32_t)b; bhi = (uint32_t)(b >> 32);
+        }
+        blo = (uint32_t)__shfl((int)blo, 0, 64);
+        bhi = (uint32_t)__shfl((int)bhi, 0, 64);
+        const uint64_t base = ((uint64_t)bhi << 32) | blo;
+        for (uint32_t k = lane; k < staged; k += 64) {
+            const uint64_t w = base + k;
+            if (w < cap) { cq[w] = s_q[wv][k]; ct[w] = s_t[wv][k]; cd[w] = s_d[wv][k]; }
+        }
+        staged = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nround; i += (uint64_t)gridDim.x * 256) {
         bool cand = false;
         int best_d = 0;
@@ -318,22 +474,18 @@ __global__ void __launch_bounds__(256) diag_select_kernel(const uint64_t *keys, 
         }
         const uint64_t m = __builtin_amdgcn_ballot_w64(cand);
         if (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            uint32_t blo = 0, bhi = 0;
-            if (lane == leader) {
-                const unsigned long long b = atomicAdd(n_cand, (unsigned long long)__popcll(m));
-                blo = (uint32_t)b; bhi = (uint32_t)(b >> 32);
+            if (cand) {
+                const uint32_t k = staged + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                s_q[wv][k] = qbegin + (uint32_t)(grp >> fmt.tbits);
+                s_t[wv][k] = (uint32_t)(grp & tmask);
+                s_d[wv][k] = best_d;
             }
-            blo = (uint32_t)__shfl((int)blo, leader, 64);
-            bhi = (uint32_t)__shfl((int)bhi, leader, 64);
-            const uint64_t w = (((uint64_t)bhi << 32) | blo) + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (cand && w < cap) {
-                cq[w] = qbegin + (uint32_t)(grp >> fmt.tbits);
-                ct[w] = (uint32_t)(grp & tmask);
-                cd[w] = best_d;
-            }
+            staged += (uint32_t)__popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            if (staged >= 64) drain();
         }
     }
+    if (staged) drain();
 }
 
 // E4 sort key: [ query : 32 | 255 - score : 8 | target : 24 ]; score < min -> all-ones (sorted last)
@@ -465,8 +617,8 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend) {
         fmt.tbits = 1;
         while ((1u << fmt.tbits) < n) fmt.tbits++;
     }
-    DevBuf<uint32_t> d_cnt, d_flag, d_cq, d_ct, d_re0, d_rcnt, d_rpidx;
-    DevBuf<uint64_t> d_keys, d_keys2, d_pos, d_skey, d_skey2;
+    DevBuf<uint32_t> d_cnt, d_flag, d_cq, d_ct, d_rpidx, d_rpidx2, d_qsurv;
+    DevBuf<uint64_t> d_keys, d_keys2, d_pos, d_skey, d_skey2, d_rval, d_rval2, d_qbase, d_soff;
     DevBuf<int32_t> d_cd, d_cd2, d_score;
     uint64_t n_hits_total = 0, n_cand_total = 0, cand_cap = 0;
     double t_kmer = 0, t_ung = 0, t_sel = 0;
@@ -490,10 +642,10 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend) {
         for (;;) {   // pass 1: runs + exact hit count; shrink the batch / grow the run list if it does not fit
             qp0 = h_poff[qa]; qp1 = h_poff[qb]; nq_res = qp1 - qp0;
             run_cap = std::min<uint64_t>(RUN_MAX, std::max<uint64_t>(run_cap, (uint64_t)nq_res * 16));
-            d_re0.reserve(run_cap); d_rcnt.reserve(run_cap); d_rpidx.reserve(run_cap);
+            d_rpidx.reserve(run_cap); d_rval.reserve(run_cap);
             UC_HIP(hipMemsetAsync(d_counters.p + 3, 0, 32, stream));   // run cursor, batch hits, key cursor, candidate cursor
             UC_HIP(hipMemsetAsync(d_counters.p, 0, 8, stream));
-            const RunList rl{d_re0.p, d_rcnt.p, d_rpidx.p, run_cap};
+            const RunList rl{d_rpidx.p, d_rval.p, run_cap};
             hipLaunchKernelGGL(sim_runs_kernel, grid_for(nq_res), dim3(256), 0, stream, ddb, cfg, qa, qb, qp0, qp1, d_koff.p, rl, d_counters.p);
             unsigned long long c5[5];
             UC_HIP(hipMemcpyAsync(c5, d_counters.p, 40, hipMemcpyDeviceToHost, stream));
@@ -520,24 +672,68 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend) {
         n_hits_total += total_hits;
         uint64_t n_cand = 0;
         if (total_hits) {
-            // pass 2: expand runs into keys, sort, pick the best diagonal per (query, target)
-            d_keys.reserve(total_hits); d_keys2.reserve(total_hits);
-            const RunList rl{d_re0.p, d_rcnt.p, d_rpidx.p, run_cap};
-            hipLaunchKernelGGL(expand_kernel, grid_for(n_runs), dim3(256), 0, stream, ddb, qa, qb, qp0, rl, n_runs, d_ent.p, fmt,
-                               d_counters.p + 5, d_keys.p, total_hits);
+            // pass 2: expand runs into keys (filtered to double hits when the rule allows), sort them
+            d_keys.reserve(total_hits);
             unsigned qbits = 1;
             while ((1u << qbits) < qb - qa) qbits++;
             const unsigned kbits = (unsigned)(fmt.dbits + fmt.tbits) + qbits;
+            const uint64_t *sorted = nullptr;
+            uint64_t n_sort = 0;
             size_t tb = 0;
-            UC_HIP(rocprim::radix_sort_keys(nullptr, tb, d_keys.p, d_keys2.p, (size_t)total_hits, 0u, kbits, stream));
-            temp_reserve(tb);
-            UC_HIP(rocprim::radix_sort_keys(d_temp.p, tb, d_keys.p, d_keys2.p, (size_t)total_hits, 0u, kbits, stream));
+            if (p.min_diag_hits >= 2 && total_hits < (1ull << 32)) {
+                const uint32_t nq = qb - qa;
+                unsigned pbits = 1;
+                while ((1ull << pbits) < nq_res) pbits++;
+                d_rpidx2.reserve(run_cap); d_rval2.reserve(run_cap);
+                UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, d_rpidx.p, d_rpidx2.p, d_rval.p, d_rval2.p, (size_t)n_runs, 0u, pbits, stream));
+                temp_reserve(tb);
+                UC_HIP(rocprim::radix_sort_pairs(d_temp.p, tb, d_rpidx.p, d_rpidx2.p, d_rval.p, d_rval2.p, (size_t)n_runs, 0u, pbits, stream));
+                d_qbase.reserve(nq); d_qsurv.reserve(nq); d_soff.reserve((size_t)nq + 1);
+                static bool attr_set = false;
+                if (!attr_set) {
+                    UC_HIP(hipFuncSetAttribute((const void *)filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FILTER_LDS));
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL(filter_kernel, dim3(nq), dim3(FT), FILTER_LDS, stream, ddb, qa, qp0, d_rpidx2.p, d_rval2.p, n_runs, d_ent.p, fmt,
+                                   d_counters.p + 5, d_keys.p, total_hits, d_qbase.p, d_qsurv.p);
+                auto sin = rocprim::make_transform_iterator(d_qsurv.p, WidenU32());
+                UC_HIP(rocprim::exclusive_scan(nullptr, tb, sin, d_soff.p, (uint64_t)0, (size_t)nq, rocprim::plus<uint64_t>(), stream));
+                temp_reserve(tb);
+                UC_HIP(rocprim::exclusive_scan(d_temp.p, tb, sin, d_soff.p, (uint64_t)0, (size_t)nq, rocprim::plus<uint64_t>(), stream));
+                uint64_t lo = 0; uint32_t ls = 0;
+                UC_HIP(hipMemcpyAsync(&lo, d_soff.p + (nq - 1), 8, hipMemcpyDeviceToHost, stream));
+                UC_HIP(hipMemcpyAsync(&ls, d_qsurv.p + (nq - 1), 4, hipMemcpyDeviceToHost, stream));
+                UC_HIP(hipStreamSynchronize(stream));
+                n_sort = lo + ls;
+                if (n_sort) {
+                    d_keys2.reserve(n_sort);
+                    hipLaunchKernelGGL(compact_kernel, dim3(std::min<uint32_t>(nq, 65535u)), dim3(256), 0, stream, d_keys.p, d_qbase.p, d_qsurv.p,
+                                       d_soff.p, nq, d_keys2.p);
+                    UC_HIP(rocprim::radix_sort_keys(nullptr, tb, d_keys2.p, d_keys.p, (size_t)n_sort, 0u, kbits, stream));
+                    temp_reserve(tb);
+                    UC_HIP(rocprim::radix_sort_keys(d_temp.p, tb, d_keys2.p, d_keys.p, (size_t)n_sort, 0u, kbits, stream));
+                }
+                sorted = d_keys.p;
+                stats.n_filtered_hits += n_sort;
+            } else {
+                d_keys2.reserve(total_hits);
+                const RunList rl{d_rpidx.p, d_rval.p, run_cap};
+                hipLaunchKernelGGL(expand_kernel, grid_for(n_runs), dim3(256), 0, stream, ddb, qa, qb, qp0, rl, n_runs, d_ent.p, fmt,
+                                   d_counters.p + 5, d_keys.p, total_hits);
+                UC_HIP(rocprim::radix_sort_keys(nullptr, tb, d_keys.p, d_keys2.p, (size_t)total_hits, 0u, kbits, stream));
+                temp_reserve(tb);
+                UC_HIP(rocprim::radix_sort_keys(d_temp.p, tb, d_keys.p, d_keys2.p, (size_t)total_hits, 0u, kbits, stream));
+                sorted = d_keys2.p;
+                n_sort = total_hits;
+                stats.n_filtered_hits += n_sort;
+            }
             cand_cap = std::max<uint64_t>(cand_cap, std::max<uint64_t>(1u << 20, total_hits / 32));
             for (;;) {
                 d_cq.reserve(cand_cap); d_ct.reserve(cand_cap); d_cd.reserve(cand_cap);
                 UC_HIP(hipMemsetAsync(d_counters.p + 6, 0, 8, stream));
-                hipLaunchKernelGGL(diag_select_kernel, grid_for(total_hits), dim3(256), 0, stream, d_keys2.p, total_hits, p.min_diag_hits, fmt, qa,
-                                   d_counters.p + 6, cand_cap, d_cq.p, d_ct.p, d_cd.p);
+                if (n_sort)
+                    hipLaunchKernelGGL(diag_select_kernel, grid_for(n_sort), dim3(256), 0, stream, sorted, n_sort, p.min_diag_hits, fmt, qa,
+                                       d_counters.p + 6, cand_cap, d_cq.p, d_ct.p, d_cd.p);
                 unsigned long long nc = 0;
                 UC_HIP(hipMemcpyAsync(&nc, d_counters.p + 6, 8, hipMemcpyDeviceToHost, stream));
                 UC_HIP(hipStreamSynchronize(stream));
