@@ -467,7 +467,9 @@ void uco_align_pair(const uco_db *db, uint32_t q, uint32_t t, const uco_params *
     int lq = (int)(db->off[q + 1] - db->off[q]), lt = (int)(db->off[t + 1] - db->off[t]);
     int32_t qe, te, dq, dt;
     uco_sw(q3, qa, lq, 0, t3, ta, lt, 0, p, &o->score, &qe, &te);
-    if (p->rev_correction) uco_sw(q3, qa, lq, 1, t3, ta, lt, 0, p, &o->score_rev, &dq, &dt);
+    /* UC-1.1: corrected <= score, so a pair whose forward score is below the threshold cannot pass and the
+       reversed-query pass is not run for it (score_rev stays 0) */
+    if (p->rev_correction && o->score >= min_score) uco_sw(q3, qa, lq, 1, t3, ta, lt, 0, p, &o->score_rev, &dq, &dt);
     o->corrected = o->score - o->score_rev;
     o->qend = qe; o->tend = te; o->qstart = -1; o->tstart = -1;
     o->pass_evalue = (o->score > 0 && o->corrected >= min_score);
@@ -602,7 +604,7 @@ int uco_cluster(const uco_db *db, const uco_params *p, int threads, uint32_t *as
             uint32_t t = hits[(size_t)q * M + k].t;
             uco_align_pair(db, (uint32_t)q, t, p, ms, &a);
             int lt = (int)(db->off[t + 1] - db->off[t]);
-            c_f += (uint64_t)lq * lt; if (p->rev_correction) c_r += (uint64_t)lq * lt;
+            c_f += (uint64_t)lq * lt; if (p->rev_correction && a.score >= ms) c_r += (uint64_t)lq * lt;
             if (a.pass_evalue) c_s += (uint64_t)(a.qend + 1) * (a.tend + 1);
             acc[poff[q] + k] = (uint8_t)a.accepted;
             if (aln_out) aln_out[(size_t)q * M + k] = a;

@@ -40,6 +40,8 @@
  *                       with H(i,tEnd) == score.
  *            rev pass : score_rev = max H of (reversed query) x target   (composition correction,
  *                       SURVEY.md A.3);  corrected = score - score_rev   (if rev_correction).
+ *                       UC-1.1: run only if score >= min_score(Lq); otherwise score_rev = 0 (the pair
+ *                       cannot pass accept-1 because corrected <= score), outputs are unchanged.
  *            accept-1 : corrected >= min_score(Lq) where min_score(L) = smallest integer S with
  *                       K * L * db_residues * exp(-lambda * S) <= evalue.
  *            start pass (only if accept-1): same DP on reverse(q[0..qEnd]) x reverse(t[0..tEnd]) with

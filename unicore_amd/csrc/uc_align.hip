@@ -157,6 +157,19 @@ __global__ void __launch_bounds__(256) gate_kernel(uint32_t n, const uint32_t *s
     }
 }
 
+__global__ void __launch_bounds__(256) pair_gather_kernel(uint32_t n, const uint32_t *flag, const uint32_t *pos, const uint32_t *sq,
+                                                          const uint32_t *st, uint32_t *q1, uint32_t *t1, uint32_t *link) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        if (!flag[i]) continue;
+        const uint32_t w = pos[i];
+        q1[w] = sq[i]; t1[w] = st[i]; link[w] = i;
+    }
+}
+// results of a sub-plan (sorted order idx over the gathered list) back to the parent list's positions
+__global__ void __launch_bounds__(256) rev_putback_kernel(uint32_t n1, const uint32_t *idx1, const uint32_t *link, const int32_t *s, int32_t *out) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n1; i += gridDim.x * 256) out[link[idx1[i]]] = s[i];
+}
+
 __global__ void __launch_bounds__(256) gate_scatter_kernel(uint32_t n, const uint32_t *flag, const uint32_t *pos, const uint32_t *sq,
                                                            const uint32_t *st, const int32_t *qe, const int32_t *te, uint32_t *q2,
                                                            uint32_t *t2, int32_t *qe2, int32_t *te2, uint32_t *link) {
@@ -542,10 +555,10 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
         if (m < 0) m = min_score_for(p, (int)h_len[q], dbres);
         h_ms[q - qbegin] = m;
     }
-    DevBuf<int32_t> d_ms, s0, qe0, te0, s1, qe2, te2, s2, q2o, t2o, work;
-    DevBuf<uint32_t> gflag, gpos, q2, t2, link, eflag, epos, mism, d_e;
+    DevBuf<int32_t> d_ms, s0, qe0, te0, s1, s1c, qe2, te2, s2, q2o, t2o, work;
+    DevBuf<uint32_t> gflag, gpos, q1, t1, link1, q2, t2, link, eflag, epos, mism, d_e;
     DevBuf<char> tmp;
-    SwPlan P0, P2;
+    SwPlan P0, P1, P2;
     d_ms.reserve(std::max<size_t>(h_ms.size(), 1));
     if (!h_ms.empty()) UC_HIP(hipMemcpyAsync(d_ms.p, h_ms.data(), h_ms.size() * 4, hipMemcpyHostToDevice, s));
     mism.reserve(1);
@@ -562,7 +575,23 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
             build_plan(*this, P0, tmp, n, d_hq.p + b, d_ht.p + b, nullptr, nullptr, p.sw_pk ? 1 : 0);
             run_plan(*this, P0, 0, s0.p, qe0.p, te0.p, work, tmp, /*ovf_only=*/true);
             stats.cells_fwd += P0.cells;
-            if (p.rev_correction) { s1.reserve(n); run_plan(*this, P0, 1, s1.p, nullptr, nullptr, work, tmp); stats.cells_rev += P0.cells; }
+            if (p.rev_correction) {
+                // spec UC-1.1: the reversed-query pass only runs for pairs whose forward score reaches the E-value
+                // threshold (corrected <= score, so the others cannot pass); their score_rev is reported as 0
+                s1.reserve(n);
+                UC_HIP(hipMemsetAsync(s1.p, 0, (size_t)n * 4, s));
+                hipLaunchKernelGGL(gate_kernel, grid_for(n), dim3(256), 0, s, n, P0.sq.p, s0.p, (const int32_t *)nullptr, d_ms.p, qbegin, gflag.p);
+                scan_u32(*this, tmp, gflag.p, gpos.p, n, false);
+                const uint32_t n1 = scan_total(*this, gflag.p, gpos.p, n);
+                if (n1) {
+                    q1.reserve(n1); t1.reserve(n1); link1.reserve(n1); s1c.reserve(n1);
+                    hipLaunchKernelGGL(pair_gather_kernel, grid_for(n), dim3(256), 0, s, n, gflag.p, gpos.p, P0.sq.p, P0.st.p, q1.p, t1.p, link1.p);
+                    build_plan(*this, P1, tmp, n1, q1.p, t1.p, nullptr, nullptr, p.sw_pk ? 1 : 0);
+                    run_plan(*this, P1, 1, s1c.p, nullptr, nullptr, work, tmp);
+                    hipLaunchKernelGGL(rev_putback_kernel, grid_for(n1), dim3(256), 0, s, n1, P1.idx.p, link1.p, s1c.p, s1.p);
+                    stats.cells_rev += P1.cells;
+                }
+            }
             const int32_t *s1p = p.rev_correction ? s1.p : nullptr;
             hipLaunchKernelGGL(gate_kernel, grid_for(n), dim3(256), 0, s, n, P0.sq.p, s0.p, s1p, d_ms.p, qbegin, gflag.p);
             scan_u32(*this, tmp, gflag.p, gpos.p, n, false);
