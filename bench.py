@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 39.3e12     # int32 VALU: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz — measured: every int32 VALU
                                  # instruction of the SW kernel occupies its SIMD for 4 cycles (profiles/r1b_pmc_sw.txt)
-VALU_OPS_PER_CELL = {"fwd": 6.8, "rev": 6.1, "start": 7.2}    # static ISA counts of the packed kernel's step loop (two cells per
+VALU_OPS_PER_CELL = {"fwd": 6.8, "rev": 6.1, "start": 7.2, "mean": 6.8}    # static ISA counts of the packed kernel's step loop (two cells per
                                  # lane-op; the int32 classes need 9.7/8.7/9.95).  valu_frac = USEFUL cell updates x ops / peak: it
                                  # excludes row padding, pipeline fill/drain and A/B length mismatch (issue utilisation is ~0.94,
                                  # profiles/r1f_pmc_sw.txt)
@@ -181,7 +181,9 @@ def main():
         steps = max(args.steps, 1)
         sw_s = st["sw_kernel_ms"] / 1e3
         achieved = st["sw_algorithmic_bytes"] / sw_s / 1e9 if sw_s > 0 else 0.0
-        cells = st["cells_fwd"] + st["cells_rev"] + st["cells_start"]
+        cells_alg = st["cells_fwd"] + st["cells_rev"] + st["cells_start"]     # what the spec asks for (oracle counts)
+        cells_run = st["cells_run"]                                            # what the kernels executed (mutual hits
+                                                                               # share a DP, flagged pairs run twice)
         out = {
             "metric": "3Di alignments/sec (cluster path)",
             "value": n_aln / dt, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -198,13 +200,14 @@ def main():
                          "avg_launch_ms": st["sw_kernel_ms"] / max(st["sw_kernel_launches"], 1),
                          "launches": st["sw_kernel_launches"],
                          "note": "integer-VALU-bound by design (SURVEY.md 8d): see valu_*",
-                         "valu_gcups": cells / sw_s / 1e9 if sw_s > 0 else 0.0,
+                         "valu_gcups": cells_run / sw_s / 1e9 if sw_s > 0 else 0.0,
+                         "valu_gcups_algorithmic": cells_alg / sw_s / 1e9 if sw_s > 0 else 0.0,
                          "valu_peak_lane_ops": VALU_PEAK_LANE_OPS,
-                         "valu_frac": ((st["cells_fwd"] * VALU_OPS_PER_CELL["fwd"] + st["cells_rev"] * VALU_OPS_PER_CELL["rev"]
-                                        + st["cells_start"] * VALU_OPS_PER_CELL["start"]) / sw_s / VALU_PEAK_LANE_OPS) if sw_s > 0 else 0.0},
+                         "valu_frac": (cells_run * VALU_OPS_PER_CELL["mean"] / sw_s / VALU_PEAK_LANE_OPS) if sw_s > 0 else 0.0},
             "stages_s_per_step": {k: v / steps for k, v in zip(U.STAGES, st["stage_seconds"])},
             "prefilter_kernel_ms_per_step": st["prefilter_kernel_ms"] / steps,
             "sw_kernel_ms_per_step": st["sw_kernel_ms"] / steps,
+            "sw_dp_runs_per_step": st["n_sw_runs"] // steps,
             "counts_rank0_per_step": {k: st[k] // steps for k in ("n_sim_kmers", "n_kmer_hits", "n_filtered_hits", "n_candidates", "n_prefilter_hits",
                                                                   "n_gapped_alignments", "n_start_alignments", "n_edges")},
         }

@@ -60,6 +60,8 @@ typedef struct uc_stats {
     uint64_t sw_algorithmic_bytes;                       /* sum over launches of 2*(Lq+Lt)+32 per alignment-pass */
     double prefilter_kernel_ms;                          /* all prefilter kernels (HIP events) */
     uint64_t n_filtered_hits;                            /* k-mer hits that survive the double-hit filter and get sorted */
+    uint64_t n_sw_runs;                                  /* DP problems actually executed over all passes (mutual hits share one, re-runs add) */
+    uint64_t cells_run;                                  /* DP cell updates actually executed (cells_* above are the algorithmic counts) */
 } uc_stats;
 
 /* ---- the three calls of cluster.rs ------------------------------------------------------------ */

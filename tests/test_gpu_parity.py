@@ -111,7 +111,8 @@ def test_sw_long_query_fallback(O):
 
 @pytest.mark.parametrize("opts", ["-c 0.8", "-c 0.5 -s 6 --max-seqs 5", "-c 0.8 --cov-mode 1 -e 1e-6 --rev-correction 0",
                                   "-c 0.5 --min-seq-id 0.3", "-c 0.8 --cov-mode 2 --min-seq-id 0.55",
-                                  "-c 0.8 --min-diag-hits 1 --k-score 40", "-c 0.7 --min-diag-hits 3 -s 5"])
+                                  "-c 0.8 --min-diag-hits 1 --k-score 40", "-c 0.7 --min-diag-hits 3 -s 5",
+                                  "-c 0.8 --sym-dedup 0", "-c 0.5 -e 1e-6 --sym-dedup 0 --rev-correction 0"])
 def test_pipeline_stage_parity(O, small, opts):
     """prefilter hit lists, per-pair alignment records, edges and the set cover all equal the oracle's"""
     import unicore_amd as U

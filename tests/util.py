@@ -109,7 +109,7 @@ def oracle_params(O, opts=""):
         elif f == "--rev-correction": kw["rev_correction"] = int(v)
         elif f == "--gap-open": kw["gap_open"] = int(v)
         elif f == "--gap-extend": kw["gap_ext"] = int(v)
-        elif f == "--sw-kernel": pass                      # engine-side kernel choice, no effect on results
+        elif f in ("--sw-kernel", "--sym-dedup"): pass      # engine-side execution choices, no effect on results
         else: raise ValueError(f)
         i += 2
     p = O.default_params(**kw)

@@ -29,7 +29,8 @@ class UcStats(C.Structure):
         "n_gapped_alignments", "n_start_alignments", "n_pk_reruns", "n_edges", "n_clusters", "cells_fwd", "cells_rev", "cells_start")] + [
         ("algorithmic_bytes", C.c_uint64 * NSTAGE), ("stage_seconds", C.c_double * NSTAGE),
         ("sw_kernel_ms", C.c_double), ("sw_kernel_launches", C.c_uint64), ("sw_algorithmic_bytes", C.c_uint64),
-        ("prefilter_kernel_ms", C.c_double), ("n_filtered_hits", C.c_uint64)]
+        ("prefilter_kernel_ms", C.c_double), ("n_filtered_hits", C.c_uint64), ("n_sw_runs", C.c_uint64),
+        ("cells_run", C.c_uint64)]
 
     def as_dict(self):
         d = {}

@@ -170,6 +170,70 @@ __global__ void __launch_bounds__(256) rev_putback_kernel(uint32_t n1, const uin
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n1; i += gridDim.x * 256) out[link[idx1[i]]] = s[i];
 }
 
+// ---- mutual hits: (q,t) and (t,q) have the same forward and reversed-query score when both substitution
+// matrices are symmetric (the recurrence treats the two gap directions alike), so one DP serves both ----
+// key = [ min(q,t) : 24 | max(q,t) : 24 | direction : 1 ]; direction 0 = the orientation with the shorter query
+// (fewer DP rows -> smaller systolic group -> less pipeline fill per pair; ties: q < t)
+__global__ void __launch_bounds__(256) ukey_kernel(uint32_t n, const uint32_t *q, const uint32_t *t, const uint32_t *len,
+                                                   uint64_t *key, uint32_t *idx) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t a = q[i], b = t[i], lo = min(a, b), hi = max(a, b);
+        const uint32_t la = len[a], lb = len[b];
+        const uint32_t worse = (la > lb || (la == lb && a > b)) ? 1u : 0u;
+        key[i] = ((((uint64_t)lo << 24) | hi) << 1) | worse;
+        idx[i] = i;
+    }
+}
+// over the key-sorted list: entry j is a mirror iff its predecessor is the same unordered pair
+__global__ void __launch_bounds__(256) umark_kernel(uint32_t n, const uint64_t *key, const uint32_t *idx, const uint32_t *q,
+                                                    const uint32_t *t, uint32_t *fq, uint32_t *ft, uint32_t *mirror, uint32_t *rep) {
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const uint32_t m = (j > 0 && (key[j] >> 1) == (key[j - 1] >> 1)) ? 1u : 0u;
+        mirror[j] = m;
+        rep[j] = m ^ 1u;
+        fq[j] = q[idx[j]];
+        ft[j] = t[idx[j]];
+    }
+}
+__global__ void __launch_bounds__(256) ugather_kernel(uint32_t n, const uint32_t *rep, const uint32_t *rpos, const uint32_t *fq,
+                                                      const uint32_t *ft, uint32_t *qr, uint32_t *tr, uint32_t *jrep) {
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        if (!rep[j]) continue;
+        const uint32_t w = rpos[j];
+        qr[w] = fq[j]; tr[w] = ft[j]; jrep[w] = j;
+    }
+}
+// forward results of the representatives (plan order) -> full key-sorted list; a mirror gets the score and the
+// "end unknown" mark (-2), which the exact re-run resolves for the pairs that pass the E-value gate
+__global__ void __launch_bounds__(256) uscatter_kernel(uint32_t nu, uint32_t n, const uint32_t *pidx, const uint32_t *jrep,
+                                                       const uint32_t *mirror, const int32_t *su, const int32_t *qeu, const int32_t *teu,
+                                                       int32_t *s0, int32_t *qe0, int32_t *te0) {
+    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nu; k += gridDim.x * 256) {
+        const uint32_t j = jrep[pidx[k]];
+        s0[j] = su[k]; qe0[j] = qeu[k]; te0[j] = teu[k];
+        if (j + 1 < n && mirror[j + 1]) { s0[j + 1] = su[k]; qe0[j + 1] = su[k] > 0 ? -2 : -1; te0[j + 1] = su[k] > 0 ? -2 : -1; }
+    }
+}
+// reversed-query pass: a flagged mirror whose representative is flagged too takes its value instead of running
+__global__ void __launch_bounds__(256) rev_dedup_kernel(uint32_t n, const uint32_t *mirror, uint32_t *flag, uint32_t *copy) {
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) copy[j] = (mirror[j] && flag[j] && flag[j - 1]) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) rev_unflag_kernel(uint32_t n, const uint32_t *copy, uint32_t *flag) {
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) if (copy[j]) flag[j] = 0;
+}
+__global__ void __launch_bounds__(256) rev_copy_kernel(uint32_t n, const uint32_t *copy, int32_t *s1) {
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) if (copy[j]) s1[j] = s1[j - 1];
+}
+// algorithmic DP cells (Lq x Lt) of the listed (optionally flagged) pairs
+__global__ void __launch_bounds__(256) cells_kernel(uint32_t n, const uint32_t *q, const uint32_t *t, const uint32_t *flag,
+                                                    const uint32_t *len, unsigned long long *out) {
+    unsigned long long c = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        if (!flag || flag[i]) c += (unsigned long long)len[q[i]] * len[t[i]];
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
 __global__ void __launch_bounds__(256) gate_scatter_kernel(uint32_t n, const uint32_t *flag, const uint32_t *pos, const uint32_t *sq,
                                                            const uint32_t *st, const int32_t *qe, const int32_t *te, uint32_t *q2,
                                                            uint32_t *t2, int32_t *qe2, int32_t *te2, uint32_t *link) {
@@ -460,6 +524,8 @@ static void run_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t *oqe, 
             E.timed_ms_begin();
             launches += launch_plan(E, P2, mode, B.s.p, oqe ? B.qe.p : nullptr, oqe ? B.te.p : nullptr, work);
             ms += E.timed_ms_end();
+            E.stats.cells_run += P2.cells;
+            E.stats.n_sw_runs += P2.n;
             hipLaunchKernelGGL(pk_putback_kernel, grid_for(n2), dim3(256), 0, s, n2, P2.idx.p, B.link.p, B.s.p,
                                oqe ? B.qe.p : nullptr, oqe ? B.te.p : nullptr, os, oqe, ote);
             UC_HIP(hipGetLastError());
@@ -468,6 +534,8 @@ static void run_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t *oqe, 
     E.stats.sw_kernel_ms += ms;
     E.stats.sw_kernel_launches += launches;
     E.stats.sw_algorithmic_bytes += P.alg_bytes;
+    E.stats.cells_run += P.cells;
+    E.stats.n_sw_runs += P.n;
 }
 
 // exact (qEnd, tEnd) by the int32 forward kernel for the gate-passing pairs the packed kernel left ambiguous
@@ -490,6 +558,8 @@ static void fix_ambiguous_ends(Engine &E, uint32_t n2, const uint32_t *q2, const
     E.stats.sw_kernel_ms += E.timed_ms_end();
     E.stats.sw_kernel_launches += launches;
     E.stats.sw_algorithmic_bytes += P3.alg_bytes;
+    E.stats.cells_run += P3.cells;
+    E.stats.n_sw_runs += P3.n;
     hipLaunchKernelGGL(amb_putback_kernel, grid_for(n3), dim3(256), 0, s, n3, P3.idx.p, B.link.p, link, B.qe.p, B.te.p, qe2, te2, qe0, te0);
     UC_HIP(hipGetLastError());
 }
@@ -557,6 +627,11 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
     }
     DevBuf<int32_t> d_ms, s0, qe0, te0, s1, s1c, qe2, te2, s2, q2o, t2o, work;
     DevBuf<uint32_t> gflag, gpos, q1, t1, link1, q2, t2, link, eflag, epos, mism, d_e;
+    DevBuf<uint64_t> ukey, ukey2;
+    DevBuf<uint32_t> uidx_in, uidx, fq, ft, mirror, rep, rpos, qr, tr, jrep, rcopy;
+    DevBuf<int32_t> su, qeu, teu;
+    DevBuf<unsigned long long> d_cells;
+    d_cells.reserve(2);
     DevBuf<char> tmp;
     SwPlan P0, P1, P2;
     d_ms.reserve(std::max<size_t>(h_ms.size(), 1));
@@ -572,43 +647,86 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
         const uint32_t n = (uint32_t)(hit_off[qb] - b);
         if (n) {
             s0.reserve(n); qe0.reserve(n); te0.reserve(n); gflag.reserve(n); gpos.reserve(n);
-            build_plan(*this, P0, tmp, n, d_hq.p + b, d_ht.p + b, nullptr, nullptr, p.sw_pk ? 1 : 0);
-            run_plan(*this, P0, 0, s0.p, qe0.p, te0.p, work, tmp, /*ovf_only=*/true);
-            stats.cells_fwd += P0.cells;
+            const uint32_t *dq = d_hq.p + b, *dt = d_ht.p + b;
+            const int tab = p.sw_pk ? 1 : 0;
+            // the directed pair list the gates work on: sorted (query, target) + position in the hit list
+            const uint32_t *Lsq = nullptr, *Lst = nullptr, *Lidx = nullptr;
+            const bool dedup = p.sym_dedup && p.mat_symmetric && n >= 2 && hdb.n <= (1u << 24);
+            UC_HIP(hipMemsetAsync(d_cells.p, 0, 16, s));
+            if (!dedup) {
+                build_plan(*this, P0, tmp, n, dq, dt, nullptr, nullptr, tab);
+                run_plan(*this, P0, 0, s0.p, qe0.p, te0.p, work, tmp, /*ovf_only=*/true);
+                stats.cells_fwd += P0.cells;
+                Lsq = P0.sq.p; Lst = P0.st.p; Lidx = P0.idx.p;
+            } else {
+                // mutual hits share one forward DP, computed in the orientation with the shorter query
+                ukey.reserve(n); ukey2.reserve(n); uidx_in.reserve(n); uidx.reserve(n);
+                fq.reserve(n); ft.reserve(n); mirror.reserve(n); rep.reserve(n); rpos.reserve(n);
+                hipLaunchKernelGGL(ukey_kernel, grid_for(n), dim3(256), 0, s, n, dq, dt, ddb.len, ukey.p, uidx_in.p);
+                size_t tb = 0;
+                UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, ukey.p, ukey2.p, uidx_in.p, uidx.p, (size_t)n, 0u, 49u, s));
+                tmp.reserve(tb + 256);
+                UC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, ukey.p, ukey2.p, uidx_in.p, uidx.p, (size_t)n, 0u, 49u, s));
+                hipLaunchKernelGGL(umark_kernel, grid_for(n), dim3(256), 0, s, n, ukey2.p, uidx.p, dq, dt, fq.p, ft.p, mirror.p, rep.p);
+                scan_u32(*this, tmp, rep.p, rpos.p, n, false);
+                const uint32_t nu = scan_total(*this, rep.p, rpos.p, n);
+                qr.reserve(nu); tr.reserve(nu); jrep.reserve(nu); su.reserve(nu); qeu.reserve(nu); teu.reserve(nu);
+                hipLaunchKernelGGL(ugather_kernel, grid_for(n), dim3(256), 0, s, n, rep.p, rpos.p, fq.p, ft.p, qr.p, tr.p, jrep.p);
+                build_plan(*this, P0, tmp, nu, qr.p, tr.p, nullptr, nullptr, tab);
+                run_plan(*this, P0, 0, su.p, qeu.p, teu.p, work, tmp, /*ovf_only=*/true);
+                hipLaunchKernelGGL(uscatter_kernel, grid_for(nu), dim3(256), 0, s, nu, n, P0.idx.p, jrep.p, mirror.p, su.p, qeu.p, teu.p,
+                                   s0.p, qe0.p, te0.p);
+                hipLaunchKernelGGL(cells_kernel, grid_for(n), dim3(256), 0, s, n, fq.p, ft.p, (const uint32_t *)nullptr, ddb.len, d_cells.p);
+                Lsq = fq.p; Lst = ft.p; Lidx = uidx.p;
+            }
             if (p.rev_correction) {
                 // spec UC-1.1: the reversed-query pass only runs for pairs whose forward score reaches the E-value
                 // threshold (corrected <= score, so the others cannot pass); their score_rev is reported as 0
                 s1.reserve(n);
                 UC_HIP(hipMemsetAsync(s1.p, 0, (size_t)n * 4, s));
-                hipLaunchKernelGGL(gate_kernel, grid_for(n), dim3(256), 0, s, n, P0.sq.p, s0.p, (const int32_t *)nullptr, d_ms.p, qbegin, gflag.p);
+                hipLaunchKernelGGL(gate_kernel, grid_for(n), dim3(256), 0, s, n, Lsq, s0.p, (const int32_t *)nullptr, d_ms.p, qbegin, gflag.p);
+                if (dedup) {
+                    rcopy.reserve(n);
+                    hipLaunchKernelGGL(cells_kernel, grid_for(n), dim3(256), 0, s, n, Lsq, Lst, gflag.p, ddb.len, d_cells.p + 1);
+                    hipLaunchKernelGGL(rev_dedup_kernel, grid_for(n), dim3(256), 0, s, n, mirror.p, gflag.p, rcopy.p);
+                    hipLaunchKernelGGL(rev_unflag_kernel, grid_for(n), dim3(256), 0, s, n, rcopy.p, gflag.p);
+                }
                 scan_u32(*this, tmp, gflag.p, gpos.p, n, false);
                 const uint32_t n1 = scan_total(*this, gflag.p, gpos.p, n);
                 if (n1) {
                     q1.reserve(n1); t1.reserve(n1); link1.reserve(n1); s1c.reserve(n1);
-                    hipLaunchKernelGGL(pair_gather_kernel, grid_for(n), dim3(256), 0, s, n, gflag.p, gpos.p, P0.sq.p, P0.st.p, q1.p, t1.p, link1.p);
-                    build_plan(*this, P1, tmp, n1, q1.p, t1.p, nullptr, nullptr, p.sw_pk ? 1 : 0);
+                    hipLaunchKernelGGL(pair_gather_kernel, grid_for(n), dim3(256), 0, s, n, gflag.p, gpos.p, Lsq, Lst, q1.p, t1.p, link1.p);
+                    build_plan(*this, P1, tmp, n1, q1.p, t1.p, nullptr, nullptr, tab);
                     run_plan(*this, P1, 1, s1c.p, nullptr, nullptr, work, tmp);
                     hipLaunchKernelGGL(rev_putback_kernel, grid_for(n1), dim3(256), 0, s, n1, P1.idx.p, link1.p, s1c.p, s1.p);
-                    stats.cells_rev += P1.cells;
+                    if (!dedup) stats.cells_rev += P1.cells;
                 }
+                if (dedup) hipLaunchKernelGGL(rev_copy_kernel, grid_for(n), dim3(256), 0, s, n, rcopy.p, s1.p);
+            }
+            if (dedup) {
+                unsigned long long hc[2] = {0, 0};
+                UC_HIP(hipMemcpyAsync(hc, d_cells.p, 16, hipMemcpyDeviceToHost, s));
+                UC_HIP(hipStreamSynchronize(s));
+                stats.cells_fwd += hc[0];
+                stats.cells_rev += hc[1];
             }
             const int32_t *s1p = p.rev_correction ? s1.p : nullptr;
-            hipLaunchKernelGGL(gate_kernel, grid_for(n), dim3(256), 0, s, n, P0.sq.p, s0.p, s1p, d_ms.p, qbegin, gflag.p);
+            hipLaunchKernelGGL(gate_kernel, grid_for(n), dim3(256), 0, s, n, Lsq, s0.p, s1p, d_ms.p, qbegin, gflag.p);
             scan_u32(*this, tmp, gflag.p, gpos.p, n, false);
             const uint32_t n2 = scan_total(*this, gflag.p, gpos.p, n);
             if (n2) {
                 q2.reserve(n2); t2.reserve(n2); qe2.reserve(n2); te2.reserve(n2); link.reserve(n2);
                 s2.reserve(n2); q2o.reserve(n2); t2o.reserve(n2); eflag.reserve(n2); epos.reserve(n2);
-                hipLaunchKernelGGL(gate_scatter_kernel, grid_for(n), dim3(256), 0, s, n, gflag.p, gpos.p, P0.sq.p, P0.st.p, qe0.p, te0.p,
+                hipLaunchKernelGGL(gate_scatter_kernel, grid_for(n), dim3(256), 0, s, n, gflag.p, gpos.p, Lsq, Lst, qe0.p, te0.p,
                                    q2.p, t2.p, qe2.p, te2.p, link.p);
-                if (p.sw_pk) fix_ambiguous_ends(*this, n2, q2.p, t2.p, qe2.p, te2.p, link.p, qe0.p, te0.p, work, tmp);
+                if (p.sw_pk || dedup) fix_ambiguous_ends(*this, n2, q2.p, t2.p, qe2.p, te2.p, link.p, qe0.p, te0.p, work, tmp);
             }
-            hipLaunchKernelGGL(aln_basic_kernel, grid_for(n), dim3(256), 0, s, n, P0.idx.p, s0.p, s1p, qe0.p, te0.p, gflag.p, d_alns.p + b);
+            hipLaunchKernelGGL(aln_basic_kernel, grid_for(n), dim3(256), 0, s, n, Lidx, s0.p, s1p, qe0.p, te0.p, gflag.p, d_alns.p + b);
             if (n2) {
-                build_plan(*this, P2, tmp, n2, q2.p, t2.p, qe2.p, te2.p, p.sw_pk ? 1 : 0);
+                build_plan(*this, P2, tmp, n2, q2.p, t2.p, qe2.p, te2.p, tab);
                 run_plan(*this, P2, 2, s2.p, q2o.p, t2o.p, work, tmp);
                 stats.cells_start += P2.cells;
-                hipLaunchKernelGGL(finalize_kernel, grid_for(n2), dim3(256), 0, s, n2, P2.idx.p, link.p, P0.idx.p, P2.sq.p, P2.st.p, s2.p,
+                hipLaunchKernelGGL(finalize_kernel, grid_for(n2), dim3(256), 0, s, n2, P2.idx.p, link.p, Lidx, P2.sq.p, P2.st.p, s2.p,
                                    q2o.p, t2o.p, ddb.len, p.cov, p.cov_mode, d_alns.p + b, eflag.p, mism.p);
                 scan_u32(*this, tmp, eflag.p, epos.p, n2, false);
                 uint32_t ne = scan_total(*this, eflag.p, epos.p, n2);
@@ -619,7 +737,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                     static DevBuf<int32_t> qs3, qe3, ts3, te3, pack3;
                     static SwPlan P3;
                     q3.reserve(ne); t3.reserve(ne); src3.reserve(ne); qs3.reserve(ne); qe3.reserve(ne); ts3.reserve(ne); te3.reserve(ne); pack3.reserve(ne);
-                    hipLaunchKernelGGL(tb_gather_kernel, grid_for(n2), dim3(256), 0, s, n2, eflag.p, epos.p, P2.idx.p, link.p, P0.idx.p, P2.sq.p,
+                    hipLaunchKernelGGL(tb_gather_kernel, grid_for(n2), dim3(256), 0, s, n2, eflag.p, epos.p, P2.idx.p, link.p, Lidx, P2.sq.p,
                                        P2.st.p, d_alns.p + b, q3.p, t3.p, qs3.p, qe3.p, ts3.p, te3.p, src3.p);
                     build_plan(*this, P3, tmp, ne, q3.p, t3.p, qe3.p, te3.p, 0, qs3.p, ts3.p);
                     timed_ms_begin();
@@ -627,7 +745,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                     stats.sw_kernel_ms += timed_ms_end();
                     stats.sw_kernel_launches += launches;
                     stats.sw_algorithmic_bytes += P3.alg_bytes;
-                    hipLaunchKernelGGL(tb_apply_kernel, grid_for(ne), dim3(256), 0, s, ne, P3.idx.p, src3.p, pack3.p, P2.idx.p, link.p, P0.idx.p,
+                    hipLaunchKernelGGL(tb_apply_kernel, grid_for(ne), dim3(256), 0, s, ne, P3.idx.p, src3.p, pack3.p, P2.idx.p, link.p, Lidx,
                                        p.min_seq_id, d_alns.p + b, eflag.p);
                     scan_u32(*this, tmp, eflag.p, epos.p, n2, false);
                     ne = scan_total(*this, eflag.p, epos.p, n2);

@@ -104,6 +104,7 @@ void parse_cluster_options(const std::string &opts, Params &p) {
         else if (f == "--gap-extend") { p.gap_ext = to_int(f, value()); if (p.gap_ext < 0 || p.gap_ext > 31) fail(UC_ERR_ARGS, "--gap-extend must be in [0,31]"); }
         else if (f == "--spaced-kmer-pattern") { p.pattern = value(); }
         else if (f == "--rev-correction") { p.rev_correction = to_int(f, value()) != 0; }
+        else if (f == "--sym-dedup") { p.sym_dedup = to_int(f, value()) != 0; }
         else if (f == "--sw-kernel") { const std::string &v = value(); if (v == "pk16") p.sw_pk = 1; else if (v == "i32") p.sw_pk = 0; else fail(UC_ERR_ARGS, "--sw-kernel must be pk16 or i32"); }
         else if (f == "--evalue-lambda") { p.lambda = to_double(f, value()); }
         else if (f == "--evalue-k") { p.Kconst = to_double(f, value()); }
@@ -139,6 +140,10 @@ void finalize_params(Params &p, const std::string &data_dir_in) {
     if (p.mataa_path.empty()) p.mataa_path = dd + "/blosum62.out";
     load_matrix(p.mat3di_path, p.S3);
     load_matrix(p.mataa_path, p.SA);
+    p.mat_symmetric = true;
+    for (int a = 0; a < A; a++)
+        for (int b = 0; b < a; b++)
+            if (p.S3[a * A + b] != p.S3[b * A + a] || p.SA[a * A + b] != p.SA[b * A + a]) p.mat_symmetric = false;
     // pattern
     int n = 0;
     p.span = (int)p.pattern.size();
