@@ -154,7 +154,8 @@ def main():
         max_seqs = int(tok[tok.index("--max-seqs") + 1])
 
     def step():
-        return ucdist.cluster_step(eng, lens, rank, world, max_seqs, device=xdev if world > 1 else "cpu")
+        return ucdist.cluster_step(eng, lens, rank, world, max_seqs, device=xdev if world > 1 else "cpu",
+                                   gpu_device=dev if (world > 1 and not os.environ.get("UC_HOST_EXCHANGE")) else None)
 
     assign = None
     for _ in range(args.warmup):
@@ -192,7 +193,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: %d synthetic proteomes, %d seqs, %d residues, options '%s', gen_synth seed %#x"
                                    % (args.proteomes, n, int(lens.sum()), args.options, seed),
                        "alignments_per_step": n_aln // steps, "clusters": int((assign == np.arange(n)).sum()) if assign is not None else None,
-                       "parallelism": "target-shard x%d + RCCL hit all-gather" % world if world > 1 else "single GPU"},
+                       "parallelism": "target-shard x%d + RCCL hit all-gather (device-resident), pair-hash partition of the gapped stage" % world if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "sw_group_kernel (gapped 3Di+AA SW, all passes)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic_per_launch(),

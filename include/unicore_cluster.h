@@ -117,6 +117,17 @@ int uc_hits_merge(uint32_t n_seqs, int32_t max_seqs, int n_parts, const uint32_t
                   const uc_hit *const *hits, uint32_t *out_counts, uc_hit *out_hits, uint64_t out_capacity,
                   uint64_t *out_n);
 
+/* ---- device-resident exchange for the multi-GPU layout: the hit lists never visit the host.
+ * export: copy the engine's hit lists (hits_size elements per array, grouped by query) into caller-provided
+ *         DEVICE buffers (e.g. the storage of a torch tensor that RCCL then all-gathers).
+ * import: install the union of all shards' lists given as DEVICE arrays in any order: merge per query under the
+ *         frozen order (score desc, target asc), keep max_seqs, and - if world > 1 - keep only the pairs owned by
+ *         `rank`.  Ownership is a hash of the UNORDERED pair, so (q,t) and (t,q) land on the same rank and share
+ *         their DP there; over all ranks every merged pair is aligned exactly once.  *n_kept = pairs installed. */
+int uc_engine_hits_export_dev(const uc_engine *e, uint32_t *d_query, uint32_t *d_target, int32_t *d_score, int32_t *d_diag);
+int uc_engine_hits_import_dev(uc_engine *e, uint64_t n, const uint32_t *d_query, const uint32_t *d_target, const int32_t *d_score,
+                              const int32_t *d_diag, uint32_t rank, uint32_t world, uint64_t *n_kept);
+
 /* E5-E6 for queries [qbegin,qend) of the engine's hit lists; results are kept per hit */
 int uc_engine_align(uc_engine *e, uint32_t qbegin, uint32_t qend);
 int uc_engine_alns_get(const uc_engine *e, uint32_t qbegin, uint32_t qend, uc_aln *out);   /* one per hit */

@@ -8,6 +8,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# torch bundles its own HIP runtime: load it BEFORE libunicore_cluster.so so the process has one runtime (a second
+# one initialised later reports "No HIP GPUs are available"); bench.py and unicore_amd.dist import torch first too
+try:
+    import torch  # noqa: F401
+except Exception:   # pragma: no cover
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the driver's GPU tier)")
 

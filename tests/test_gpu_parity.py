@@ -204,3 +204,66 @@ def test_long_query_pipeline_with_seqid(O):
         assert np.array_equal(al[f], ra[f]), f
     assert (ra["aln_len"] > 2000).any() and 0 < ra["accepted"].mean() < 1
     assert np.array_equal(U.setcover(e.n, e.edges()), ref["assign"])
+
+
+def test_device_exchange_virtual_ranks(O):
+    """multi-GPU layout on one GPU: W virtual target shards -> device-side export, union, merge (== unsharded lists),
+    pair-hash partition over W virtual ranks: every pair is aligned exactly once, mutual hits meet on one rank, and
+    the union of the ranks' accepted edges equals the single-GPU edge set."""
+    import torch
+    import unicore_amd as U
+    from unicore_amd import dist as ucdist
+    s3, sa = util.family_db(29, n_fam=12, members=6, lmin=60, lmax=260)
+    off, c3, ca = util.flat(s3, sa)
+    lens = np.array([len(x) for x in s3])
+    opts = "-c 0.8 --max-seqs 7"
+    e = U.Engine(opts, verbosity=1)
+    e.set_db(off, c3, ca)
+    e.prefilter()
+    cnt_ref, hits_ref = e.hits()
+    e.align()
+    edges_ref = set(map(tuple, e.edges().tolist()))
+    assert len(edges_ref) > 50
+    W = 3
+    bufs = []
+    for tb, te in ucdist.shard_ranges(lens, W):
+        e.prefilter(tb, te)
+        n = e.hits_size()
+        t = torch.empty((4, max(n, 1)), dtype=torch.int32, device="cuda")
+        e.hits_export_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr())
+        bufs.append(t[:, :n])
+    allh = torch.cat(bufs, dim=1).contiguous()
+    torch.cuda.synchronize()
+    ptrs = [allh[i].data_ptr() for i in range(4)]
+    ntot = int(allh.shape[1])
+    assert ntot >= len(hits_ref)                      # per-shard top-M lists: the union is a superset
+    assert e.hits_import_dev(ntot, *ptrs, 0, 1) == len(hits_ref)
+    cnt, hits = e.hits()
+    assert np.array_equal(cnt, cnt_ref) and hits.tobytes() == hits_ref.tobytes()
+    total, edges, seen = 0, set(), set()
+    for r in range(W):
+        k = e.hits_import_dev(ntot, *ptrs, r, W)
+        total += k
+        cnt, hits = e.hits()
+        q = np.repeat(np.arange(len(cnt)), cnt)
+        pairs = set(zip(q.tolist(), hits["target"].tolist()))
+        assert not (pairs & seen)
+        seen |= pairs
+        for (a, b) in pairs:                          # a mutual hit is owned by the same rank
+            if (b, a) in ref_pairs(cnt_ref, hits_ref):
+                assert (b, a) in pairs
+        e.align()
+        edges |= set(map(tuple, e.edges().tolist()))
+    assert total == len(hits_ref) and seen == ref_pairs(cnt_ref, hits_ref)
+    assert edges == edges_ref
+
+
+_REF_PAIRS = {}
+
+
+def ref_pairs(cnt, hits):
+    key = (cnt.tobytes(), hits.tobytes())
+    if key not in _REF_PAIRS:
+        q = np.repeat(np.arange(len(cnt)), cnt)
+        _REF_PAIRS[key] = set(zip(q.tolist(), hits["target"].tolist()))
+    return _REF_PAIRS[key]

@@ -49,6 +49,7 @@ SYMBOLS = (
     "uc_cluster", "uc_createtsv", "uc_rmdb", "uc_last_error", "uc_version", "uc_check_options",
     "uc_engine_create", "uc_engine_destroy", "uc_engine_load_db", "uc_engine_set_db", "uc_engine_num_seqs",
     "uc_engine_prefilter", "uc_engine_hits_size", "uc_engine_hits_get", "uc_engine_hits_set", "uc_engine_hits_merge",
+    "uc_engine_hits_export_dev", "uc_engine_hits_import_dev",
     "uc_hits_merge", "uc_engine_align", "uc_engine_alns_get", "uc_engine_edges_size", "uc_engine_edges_get",
     "uc_engine_stats", "uc_engine_reset_stats", "uc_setcover", "uc_write_cluster_db",
     "uc_engine_ungapped_batch", "uc_engine_sw_batch",
@@ -89,6 +90,8 @@ def lib():
     L.uc_engine_hits_get.argtypes = [vp, vp, vp]
     L.uc_engine_hits_set.argtypes = [vp, vp, vp]
     L.uc_engine_hits_merge.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]
+    L.uc_engine_hits_export_dev.argtypes = [vp, vp, vp, vp, vp]
+    L.uc_engine_hits_import_dev.argtypes = [vp, u64, vp, vp, vp, vp, u32, u32, C.POINTER(u64)]
     L.uc_hits_merge.argtypes = [u32, i32, C.c_int, C.POINTER(vp), C.POINTER(vp), vp, vp, u64, C.POINTER(u64)]
     L.uc_engine_align.argtypes = [vp, u32, u32]
     L.uc_engine_alns_get.argtypes = [vp, u32, u32, vp]
@@ -217,6 +220,16 @@ class Engine:
         counts = np.ascontiguousarray(counts, np.uint32)
         hits = np.ascontiguousarray(hits, HIT_DTYPE)
         _check(lib().uc_engine_hits_set(self._h, counts.ctypes.data, hits.ctypes.data))
+
+    def hits_export_dev(self, d_query, d_target, d_score, d_diag):
+        """copy the device-resident hit lists into caller-owned DEVICE buffers (raw pointers, hits_size() x 4 B each)"""
+        _check(lib().uc_engine_hits_export_dev(self._h, d_query, d_target, d_score, d_diag))
+
+    def hits_import_dev(self, n, d_query, d_target, d_score, d_diag, rank=0, world=1):
+        """install the merged union of shard lists given as DEVICE arrays; keeps the pairs owned by `rank`"""
+        k = C.c_uint64()
+        _check(lib().uc_engine_hits_import_dev(self._h, n, d_query, d_target, d_score, d_diag, rank, world, C.byref(k)))
+        return int(k.value)
 
     def align(self, qbegin=0, qend=None):
         _check(lib().uc_engine_align(self._h, qbegin, self.n if qend is None else qend))

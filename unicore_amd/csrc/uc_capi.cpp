@@ -169,6 +169,25 @@ int uc_engine_hits_merge(uc_engine *e, int n_parts, const uint32_t *const *count
     });
 }
 
+int uc_engine_hits_export_dev(const uc_engine *e, uint32_t *d_query, uint32_t *d_target, int32_t *d_score, int32_t *d_diag) {
+    return guard([&] {
+        require(e, "engine");
+        if (e->e->n_hits) { require(d_query, "d_query"); require(d_target, "d_target"); require(d_score, "d_score"); require(d_diag, "d_diag"); }
+        e->e->export_hits_dev(d_query, d_target, d_score, d_diag);
+    });
+}
+
+int uc_engine_hits_import_dev(uc_engine *e, uint64_t n, const uint32_t *d_query, const uint32_t *d_target, const int32_t *d_score,
+                              const int32_t *d_diag, uint32_t rank, uint32_t world, uint64_t *n_kept) {
+    return guard([&] {
+        require(e, "engine");
+        if (n) { require(d_query, "d_query"); require(d_target, "d_target"); require(d_score, "d_score"); require(d_diag, "d_diag"); }
+        if (world < 1 || rank >= world) fail(UC_ERR_ARGS, "hits_import_dev: rank %u outside world %u", rank, world);
+        const uint64_t k = e->e->import_hits_dev(n, d_query, d_target, d_score, d_diag, rank, world);
+        if (n_kept) *n_kept = k;
+    });
+}
+
 int uc_engine_align(uc_engine *e, uint32_t qbegin, uint32_t qend) {
     return guard([&] { require(e, "engine"); e->e->align(qbegin, qend); });
 }

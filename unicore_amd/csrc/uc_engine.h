@@ -84,6 +84,9 @@ struct Engine {
     void prefilter(uint32_t tbegin, uint32_t tend);                       // uc_prefilter.hip
     void set_hits(const uint32_t *counts, const uc_hit *h);
     void get_hits(uc_hit *out) const;                        // D2H of the device hit arrays
+    void export_hits_dev(uint32_t *dq, uint32_t *dt, int32_t *ds, int32_t *dd) const;
+    uint64_t import_hits_dev(uint64_t n, const uint32_t *dq, const uint32_t *dt, const int32_t *ds, const int32_t *dd,
+                             uint32_t rank, uint32_t world);
     void get_alns(uint64_t begin, uint64_t n, uc_aln *out) const;
     void finish_hit_lists();                                  // counts/offsets from the device arrays
     void align(uint32_t qbegin, uint32_t qend);

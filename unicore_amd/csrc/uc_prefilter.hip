@@ -537,6 +537,27 @@ __global__ void __launch_bounds__(256) hit_count_kernel(const uint32_t *hq, uint
     }
 }
 
+// ---- multi-GPU: merge of the all-gathered shard lists + pair ownership, on the device ----
+// owner of the unordered pair {a,b}: mutual hits (q,t)/(t,q) must meet on one rank to share their DP
+__device__ __forceinline__ uint32_t pair_owner(uint32_t a, uint32_t b, uint32_t world) {
+    const uint32_t lo = min(a, b), hi = max(a, b);
+    uint32_t h = lo * 0x9E3779B1u ^ hi * 0x85EBCA6Bu;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    return h % world;
+}
+__global__ void __launch_bounds__(256) merge_key_kernel(uint64_t n, const uint32_t *q, const uint32_t *t, const int32_t *score,
+                                                        uint32_t nseq, uint64_t *key, uint32_t *bad) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const int s = score[i];
+        if (q[i] >= nseq || t[i] >= nseq || s < 0 || s > 255) atomicAdd(bad, 1u);
+        key[i] = ((uint64_t)q[i] << 32) | ((uint64_t)(255 - (s & 255)) << 24) | (t[i] & 0xFFFFFFu);
+    }
+}
+__global__ void __launch_bounds__(256) owner_flag_kernel(const uint64_t *skey, uint64_t n, uint32_t rank, uint32_t world, uint32_t *flag) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+        if (flag[i] && pair_owner((uint32_t)(skey[i] >> 32), (uint32_t)(skey[i] & 0xFFFFFFu), world) != rank) flag[i] = 0;
+}
+
 static inline dim3 grid_for(uint64_t n, uint32_t cap = 16384) {
     const uint64_t b = (n + 255) / 256;
     return dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(b, cap)));
@@ -815,6 +836,71 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend) {
     stats.stage_seconds[UC_ST_UNGAPPED] += t_ung;
     stats.stage_seconds[UC_ST_SELECT] += t_sel;
     stats.prefilter_kernel_ms += gpu_ms;
+}
+
+void Engine::export_hits_dev(uint32_t *dq, uint32_t *dt, int32_t *ds, int32_t *dd) const {
+    if (!n_hits) return;
+    UC_HIP(hipSetDevice(device));
+    UC_HIP(hipMemcpyAsync(dq, d_hq.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+    UC_HIP(hipMemcpyAsync(dt, d_ht.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+    UC_HIP(hipMemcpyAsync(ds, d_hs.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+    UC_HIP(hipMemcpyAsync(dd, d_hd.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+    UC_HIP(hipStreamSynchronize(stream));
+}
+
+uint64_t Engine::import_hits_dev(uint64_t n_in, const uint32_t *dq, const uint32_t *dt, const int32_t *ds, const int32_t *dd,
+                                 uint32_t rank, uint32_t world) {
+    if (!have_db) fail(UC_ERR_ARGS, "no database loaded");
+    UC_HIP(hipSetDevice(device));
+    const uint32_t n = hdb.n;
+    if (n > (1u << 24)) fail(UC_ERR_GENERIC, "hits_import_dev: %u sequences exceed the 2^24 limit of the hit keys", n);
+    hit_cnt.assign(n, 0);
+    hit_off.assign((size_t)n + 1, 0);
+    n_hits = 0;
+    alns_valid = false;
+    edges.clear();
+    if (!n_in) return 0;
+    Timer tm;
+    timed_ms_begin();
+    DevBuf<uint64_t> skey, skey2, pos;
+    DevBuf<int32_t> cd2;
+    DevBuf<uint32_t> flag, bad, cnt;
+    DevBuf<char> tmp;
+    skey.reserve(n_in); skey2.reserve(n_in); cd2.reserve(n_in); flag.reserve(n_in); pos.reserve(n_in); bad.reserve(1);
+    UC_HIP(hipMemsetAsync(bad.p, 0, 4, stream));
+    hipLaunchKernelGGL(merge_key_kernel, grid_for(n_in), dim3(256), 0, stream, n_in, dq, dt, ds, n, skey.p, bad.p);
+    size_t tb = 0;
+    UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, skey.p, skey2.p, dd, cd2.p, (size_t)n_in, 0u, 64u, stream));
+    tmp.reserve(tb + 256);
+    UC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, skey.p, skey2.p, dd, cd2.p, (size_t)n_in, 0u, 64u, stream));
+    hipLaunchKernelGGL(rank_flag_kernel, grid_for(n_in), dim3(256), 0, stream, skey2.p, n_in, (uint32_t)p.max_seqs, flag.p);
+    if (world > 1) hipLaunchKernelGGL(owner_flag_kernel, grid_for(n_in), dim3(256), 0, stream, skey2.p, n_in, rank, world, flag.p);
+    auto rin = rocprim::make_transform_iterator(flag.p, WidenU32());
+    UC_HIP(rocprim::exclusive_scan(nullptr, tb, rin, pos.p, (uint64_t)0, (size_t)n_in, rocprim::plus<uint64_t>(), stream));
+    tmp.reserve(tb + 256);
+    UC_HIP(rocprim::exclusive_scan(tmp.p, tb, rin, pos.p, (uint64_t)0, (size_t)n_in, rocprim::plus<uint64_t>(), stream));
+    uint64_t lp = 0; uint32_t lf = 0, hbad = 0;
+    UC_HIP(hipMemcpyAsync(&lp, pos.p + (n_in - 1), 8, hipMemcpyDeviceToHost, stream));
+    UC_HIP(hipMemcpyAsync(&lf, flag.p + (n_in - 1), 4, hipMemcpyDeviceToHost, stream));
+    UC_HIP(hipMemcpyAsync(&hbad, bad.p, 4, hipMemcpyDeviceToHost, stream));
+    UC_HIP(hipStreamSynchronize(stream));
+    if (hbad) fail(UC_ERR_ARGS, "hits_import_dev: %u records with a sequence id or score out of range", hbad);
+    const uint64_t keep = lp + lf;
+    if (keep) {
+        d_hq.reserve(keep); d_ht.reserve(keep); d_hs.reserve(keep); d_hd.reserve(keep);
+        hipLaunchKernelGGL(hit_scatter_kernel, grid_for(n_in), dim3(256), 0, stream, skey2.p, cd2.p, n_in, flag.p, pos.p, d_hq.p, d_ht.p, d_hs.p, d_hd.p);
+        n_hits = keep;
+        cnt.reserve(n);
+        hipLaunchKernelGGL(hit_count_kernel, grid_for(n), dim3(256), 0, stream, d_hq.p, n_hits, n, cnt.p);
+        UC_HIP(hipMemcpyAsync(hit_cnt.data(), cnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+        UC_HIP(hipStreamSynchronize(stream));
+    }
+    UC_HIP(hipGetLastError());
+    for (uint32_t q = 0; q < n; q++) hit_off[q + 1] = hit_off[q] + hit_cnt[q];
+    if (hit_off[n] != n_hits) fail(UC_ERR_GENERIC, "hits_import_dev: hit list bookkeeping mismatch");
+    stats.prefilter_kernel_ms += timed_ms_end();
+    stats.stage_seconds[UC_ST_SELECT] += tm.seconds();
+    return keep;
 }
 
 }  // namespace uc

@@ -4,7 +4,9 @@
     exchange: all-gather of the ragged hit lists (torch.distributed; backend "nccl" is RCCL over xGMI on
               ROCm, "gloo" on CPU for the tests) — the ONE collective of the path
     every rank: merge the shard lists per query under the frozen order (score desc, target asc), keep
-              max_seqs  ->  align its query range (E5/E6)  ->  accepted edges
+              max_seqs  ->  align its share of the pairs (E5/E6)  ->  accepted edges
+              (GPU path: merge + share selection on the device, share = hash of the unordered pair so that
+               mutual hits meet on one rank; host path used by the CPU tests: contiguous query ranges)
     gather:   edges to rank 0, which runs the host-side set cover (E7) and writes the result.
 
 The target DB is range-partitioned by residue count; per-shard truncation to max_seqs is lossless because
@@ -83,18 +85,56 @@ def gather_edges(edges, device="cpu", group=None):
     return np.concatenate([p.view(np.uint32).reshape(-1, 2) for p in parts]) if parts else np.zeros((0, 2), np.uint32)
 
 
+def exchange_hits_device(engine, rank, world, device, group=None):
+    """Device-resident exchange: the shard's hit lists go from the engine into one int32 tensor [4, n] on the GPU,
+    are all-gathered (RCCL over xGMI with backend "nccl"), and the union is merged, truncated and reduced to the
+    pairs this rank owns inside the engine - nothing visits the host but the per-rank sizes.
+    Returns the number of pairs installed (= gapped alignments of this rank)."""
+    import torch
+    import torch.distributed as dist
+
+    nloc = engine.hits_size()
+    buf = torch.empty((4, max(nloc, 1)), dtype=torch.int32, device=device)
+    if nloc:
+        engine.hits_export_dev(buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), buf[3].data_ptr())
+    sz = torch.tensor([nloc], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(sz) for _ in range(world)]
+    dist.all_gather(sizes, sz, group=group)
+    sizes = [int(x.item()) for x in sizes]
+    m = max(max(sizes), 1)
+    pad = torch.zeros((4, m), dtype=torch.int32, device=device)
+    pad[:, :nloc] = buf[:, :nloc]
+    if dist.get_backend(group) == "nccl":
+        out = torch.empty((world, 4, m), dtype=torch.int32, device=device)
+        dist.all_gather_into_tensor(out, pad, group=group)          # RCCL all-gather, GPU to GPU
+        parts = [out[r, :, : sizes[r]] for r in range(world)]
+    else:                                                           # gloo (tests / one shared GPU): hop through the host
+        outs = [torch.empty((4, m), dtype=torch.int32) for _ in range(world)]
+        dist.all_gather(outs, pad.cpu(), group=group)
+        parts = [outs[r][:, : sizes[r]].to(device) for r in range(world)]
+    allh = torch.cat(parts, dim=1).contiguous()
+    torch.cuda.synchronize(device)
+    ntot = int(allh.shape[1])
+    kept = engine.hits_import_dev(ntot, allh[0].data_ptr(), allh[1].data_ptr(), allh[2].data_ptr(), allh[3].data_ptr(), rank, world)
+    return kept
+
+
 def merged_hits(parts, n_seqs, max_seqs):
     return hits_merge(n_seqs, max_seqs, parts)
 
 
-def cluster_step(engine, lens, rank, world, max_seqs, device="cpu", group=None, setcover=None):
+def cluster_step(engine, lens, rank, world, max_seqs, device="cpu", group=None, setcover=None, gpu_device=None):
     """One pass of the sharded hot path on this rank.  Returns (assign or None, n_alignments_this_rank)."""
     from . import setcover as host_setcover
 
     n = len(lens)
     tb, te = shard_ranges(lens, world)[rank]
     engine.prefilter(tb, te)
-    if world > 1:
+    if world > 1 and gpu_device is not None:
+        # device-resident exchange; every rank then aligns the pairs it owns (unordered-pair hash) over all queries
+        qb, qe = 0, n
+        n_aln = exchange_hits_device(engine, rank, world, gpu_device, group)
+    elif world > 1:
         counts, hits = engine.hits()
         parts = exchange_hits(counts, hits, device, group)
         counts, hits = merged_hits(parts, n, max_seqs)
