@@ -87,6 +87,7 @@ def lib():
     L.uco_align_pair.argtypes = [C.POINTER(Db), C.c_uint32, C.c_uint32, C.POINTER(Params), C.c_int32, C.POINTER(Aln)]
     L.uco_setcover.argtypes = [C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
     L.uco_cluster.argtypes = [C.POINTER(Db), C.POINTER(Params), C.c_int, C.c_void_p, C.POINTER(Counts), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.uco_cluster_cascade.argtypes = [C.POINTER(Db), C.POINTER(Params), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.POINTER(Counts), C.c_void_p]
     L.uco_write_tsv.argtypes = [C.c_char_p, C.POINTER(Db), C.c_void_p]
     L.uco_sample_run.argtypes = [C.POINTER(Db), C.POINTER(Index), C.POINTER(Params), C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
     L.uco_sample_run.restype = C.c_uint64
@@ -210,6 +211,30 @@ def cluster(odb, p, threads=0, dumps=True):
     if rc != 0:
         raise RuntimeError("uco_cluster failed: %d" % rc)
     return dict(assign=assign, counts={f: getattr(cnt, f) for f, _ in Counts._fields_}, hits=hits, hit_cnt=hcnt, aln=aln)
+
+
+def cascade_thresholds(p_single, sensitivity, steps, base=None):
+    """k-mer threshold per round: sensitivity rises linearly from 1 to the target; same s -> threshold rule as
+    the single step (round(6 * mean diag + 3 - 2 s), see uc_options.cpp / tests/util.py)."""
+    diag = np.mean([p_single.S3[a * 21 + a] for a in range(20)])
+    out = []
+    for r in range(steps):
+        s = sensitivity if steps == 1 else 1.0 + (sensitivity - 1.0) * r / (steps - 1)
+        out.append(int(np.floor(6 * diag + 3.0 - 2.0 * s + 0.5)))
+    return out
+
+
+def cluster_cascade(odb, p, thr, threads=0):
+    """E8: rounds on representatives + merge.  Returns dict(assign, counts, round_sizes)."""
+    n, steps = odb.n, len(thr)
+    assign = np.zeros(n, np.uint32)
+    cnt = Counts()
+    rs = np.zeros(steps, np.uint32)
+    t = (C.c_int * steps)(*thr)
+    rc = lib().uco_cluster_cascade(C.byref(odb.db), C.byref(p), steps, t, threads, assign.ctypes.data, C.byref(cnt), rs.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("uco_cluster_cascade failed: %d" % rc)
+    return dict(assign=assign, counts={f: getattr(cnt, f) for f, _ in Counts._fields_}, round_sizes=rs)
 
 
 def write_tsv(path, odb, assign):

@@ -627,6 +627,54 @@ int uco_cluster(const uco_db *db, const uco_params *p, int threads, uint32_t *as
 }
 
 /* ------------------------------------------------------------------ E9: `foldseek createtsv` (cluster.rs:59-64) */
+/* ------------------------------------------------------------------ E8: cascade (rounds on representatives + merge) */
+int uco_cluster_cascade(const uco_db *db, const uco_params *p, int steps, const int *thr, int threads,
+                        uint32_t *assign, uco_counts *cnt, uint32_t *round_sizes) {
+    const uint32_t n = db->n;
+    if (steps < 1) return -1;
+    uint32_t *cur = (uint32_t *)malloc((size_t)(n ? n : 1) * sizeof(uint32_t));
+    uint32_t *posmap = (uint32_t *)malloc((size_t)(n ? n : 1) * sizeof(uint32_t));
+    uint32_t ncur = n;
+    for (uint32_t i = 0; i < n; i++) { cur[i] = i; assign[i] = i; }
+    uco_counts total; memset(&total, 0, sizeof total);
+    int rc = 0;
+    for (int r = 0; r < steps && rc == 0; r++) {
+        if (round_sizes) round_sizes[r] = ncur;
+        uco_db sub; memset(&sub, 0, sizeof sub);
+        sub.n = ncur;
+        sub.off = (uint64_t *)malloc(((size_t)ncur + 1) * sizeof(uint64_t));
+        uint64_t tot = 0;
+        for (uint32_t i = 0; i < ncur; i++) { sub.off[i] = tot; tot += db->off[cur[i] + 1] - db->off[cur[i]]; }
+        sub.off[ncur] = tot;
+        sub.s3 = (uint8_t *)malloc(tot ? tot : 1); sub.sa = (uint8_t *)malloc(tot ? tot : 1);
+        for (uint32_t i = 0; i < ncur; i++) {
+            const uint64_t len = db->off[cur[i] + 1] - db->off[cur[i]];
+            memcpy(sub.s3 + sub.off[i], db->s3 + db->off[cur[i]], len);
+            memcpy(sub.sa + sub.off[i], db->sa + db->off[cur[i]], len);
+        }
+        uco_params pr = *p;
+        pr.kmer_thr = thr[r];
+        uint32_t *sa_ = (uint32_t *)malloc((size_t)(ncur ? ncur : 1) * sizeof(uint32_t));
+        uco_counts c; memset(&c, 0, sizeof c);
+        rc = uco_cluster(&sub, &pr, threads, sa_, &c, NULL, NULL, NULL);
+        if (rc == 0) {
+            total.n_sim_kmers += c.n_sim_kmers; total.n_kmer_hits += c.n_kmer_hits; total.n_candidates += c.n_candidates;
+            total.n_prefilter_hits += c.n_prefilter_hits; total.n_alignments += c.n_alignments; total.n_edges += c.n_edges;
+            total.cells_fwd += c.cells_fwd; total.cells_rev += c.cells_rev; total.cells_start += c.cells_start;
+            for (uint32_t i = 0; i < ncur; i++) posmap[cur[i]] = i;
+            for (uint32_t x = 0; x < n; x++) assign[x] = cur[sa_[posmap[assign[x]]]];
+            uint32_t k = 0;
+            for (uint32_t i = 0; i < ncur; i++) if (sa_[i] == i) cur[k++] = cur[i];
+            ncur = k;
+        }
+        free(sa_); free(sub.off); free(sub.s3); free(sub.sa);
+    }
+    total.n_clusters = ncur;
+    if (cnt) *cnt = total;
+    free(cur); free(posmap);
+    return rc;
+}
+
 int uco_write_tsv(const char *path, const uco_db *db, const uint32_t *assign) {
     FILE *f = fopen(path, "w");
     if (!f) return -1;

@@ -52,6 +52,9 @@
  * E7 set-cover  undirected graph on accepted pairs (plus self loops); repeat: pick the unassigned
  *            node with most unassigned neighbours (itself included; tie: smallest id) as
  *            representative and assign all its unassigned neighbours to it.
+ * E8 cascade (only on request, steps > 1): `steps` rounds of E1-E7, round r on the representatives of round
+ *            r-1, k-mer threshold from sensitivity s_r = 1 + (s-1) r/(steps-1); final representative =
+ *            representative of the representative (mergeclusters).  No linclust pre-step.
  * E9 TSV     clusters by ascending representative id; rows "rep\tmember": representative first,
  *            then the other members by ascending id.
  * ---------------------------------------------------------------------------------------------
@@ -149,6 +152,15 @@ int  uco_setcover(uint32_t n, const uint32_t *edges, uint64_t n_edges, uint32_t 
    hits_out/hit_cnt_out: n*max_seqs hits and n counts;  aln_out aligned with hits_out */
 int  uco_cluster(const uco_db *db, const uco_params *p, int threads, uint32_t *assign, uco_counts *cnt,
                  uco_hit *hits_out, uint32_t *hit_cnt_out, uco_aln *aln_out);
+
+/* E8 cascade (spec UC-1 E8; Foldseek's default clustering workflow, SURVEY.md A.6, EXT-UNVERIFIED): `steps` rounds
+   of the full pipeline, round r on the representatives of round r-1 with k-mer threshold thr[r] (sensitivity
+   rising to the target: s_r = 1 + (s - 1) * r / (steps - 1), thr = the same sensitivity -> threshold rule as the
+   single step); every round sees its own database size (E-value); the final representative of a sequence is
+   the representative of its representative ... (== mergeclusters).  No linear-time (linclust) pre-step.
+   steps == 1 is uco_cluster.  cnt (optional) receives the sums over the rounds. */
+int  uco_cluster_cascade(const uco_db *db, const uco_params *p, int steps, const int *thr, int threads,
+                         uint32_t *assign, uco_counts *cnt, uint32_t *round_sizes);
 
 int  uco_write_tsv(const char *path, const uco_db *db, const uint32_t *assign);
 

@@ -174,6 +174,28 @@ def test_cluster_end_to_end_tsv_bytes(O, tmp_path):
     assert not os.path.exists(out + "_cluster") and not os.path.exists(out + "_cluster.index")
 
 
+@pytest.mark.parametrize("opts,steps,sens", [("-c 0.8 --cluster-steps 3", 3, 4.0), ("-c 0.5 -s 6 --cluster-steps 2 --max-seqs 20", 2, 6.0)])
+def test_cascade_end_to_end_tsv_bytes(O, tmp_path, opts, steps, sens):
+    """E8: rounds on representatives with rising sensitivity + merge == the oracle's cascade"""
+    import unicore_amd as U
+    db = util.gen_synth_db(str(tmp_path / "db"), 6, 0x5EED0003, 40, 0.6)
+    out = str(tmp_path / "clust")
+    st = U.cluster(db, out + "_cluster", str(tmp_path / "tmp"), opts, threads=4)
+    U.createtsv(db, out + "_cluster", out + ".tsv")
+    odb = O.OracleDb(db)
+    p = util.oracle_params(O, opts.replace(" --cluster-steps %d" % steps, ""))
+    thr = O.cascade_thresholds(p, sens, steps)
+    assert thr[-1] == p.kmer_thr and thr[0] > thr[-1]
+    ref = O.cluster_cascade(odb, p, thr, threads=8)
+    O.write_tsv(str(tmp_path / "ref.tsv"), odb, ref["assign"])
+    assert open(out + ".tsv", "rb").read() == open(str(tmp_path / "ref.tsv"), "rb").read()
+    util.tsv_invariants(out + ".tsv", odb.names())
+    assert st["n_clusters"] == ref["counts"]["n_clusters"] and st["n_gapped_alignments"] == ref["counts"]["n_alignments"]
+    single = O.cluster(odb, p, threads=8, dumps=False)
+    assert ref["round_sizes"][1] < odb.n                                  # the first round removed something
+    assert ref["counts"]["n_alignments"] != single["counts"]["n_alignments"]   # and the cascade is not the single step
+
+
 def test_long_query_pipeline_with_seqid(O):
     """queries beyond the largest systolic class go through the generic kernel in every pass, including the
     traceback-statistics pass of --min-seq-id"""

@@ -274,3 +274,26 @@ def test_pipeline_on_family_db_recovers_families_and_tsv_invariants(tmp_path):
         assert key == sorted(key) and len(h) <= p.max_seqs
         if len(s3[q]) >= 30 and (s3[q] < 20).all():
             assert q in h["t"].tolist()
+
+
+def test_cascade_oracle_invariants():
+    """E8: one round == the single step; the merged assignment is idempotent (a representative represents
+    itself), coarser than round 1, and every round runs on the representatives of the previous one"""
+    import util
+    from oracle import oracle_py as O
+    s3, sa = util.family_db(5, n_fam=10, members=6, lmin=50, lmax=200)
+    odb = O.OracleDb(s3=s3, sa=sa)
+    p = util.oracle_params(O, "-c 0.8")
+    one = O.cluster(odb, p, threads=4, dumps=False)
+    c1 = O.cluster_cascade(odb, p, [p.kmer_thr], threads=4)
+    assert np.array_equal(one["assign"], c1["assign"]) and c1["round_sizes"].tolist() == [odb.n]
+    thr = O.cascade_thresholds(p, 4.0, 3)
+    assert thr[-1] == p.kmer_thr and thr[0] > thr[1] > thr[2]
+    c3 = O.cluster_cascade(odb, p, thr, threads=4)
+    a = c3["assign"]
+    assert all(a[a[i]] == a[i] for i in range(odb.n))
+    rs = c3["round_sizes"].tolist()
+    assert rs[0] == odb.n and rs[0] > rs[1] >= rs[2] >= c3["counts"]["n_clusters"] == len(set(a.tolist()))
+    # round 1 alone (highest threshold) is a refinement of the merged result
+    r1 = O.cluster_cascade(odb, p, thr[:1], threads=4)["assign"]
+    assert all(a[r1[i]] == a[i] for i in range(odb.n))

@@ -276,22 +276,54 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
         logf(3, "unicore-cluster: reading %s\n", db);
         read_seq_db(db, E.hdb, false);
         E.stats.stage_seconds[UC_ST_LOAD] += tl.seconds();
-        E.upload_db();
-        logf(3, "unicore-cluster: %u sequences, %llu residues on device %d\n", E.hdb.n, (unsigned long long)E.hdb.residues(), E.device);
-        E.prefilter(0, E.hdb.n);
-        logf(3, "unicore-cluster: prefilter kept %llu pairs (k-score %d, max-seqs %d)\n", (unsigned long long)E.n_hits, p.kmer_thr, p.max_seqs);
-        E.align(0, E.hdb.n);
-        logf(3, "unicore-cluster: %llu alignments, %llu accepted\n", (unsigned long long)E.stats.n_gapped_alignments, (unsigned long long)E.stats.n_edges);
-        Timer tc;
-        std::vector<uint32_t> assign(E.hdb.n);
-        set_cover(E.hdb.n, E.edges.data(), E.edges.size() / 2, assign.data());
-        uint64_t ncl = 0;
-        for (uint32_t i = 0; i < E.hdb.n; i++) ncl += assign[i] == i;
-        E.stats.n_clusters = ncl;
-        E.stats.algorithmic_bytes[UC_ST_SETCOVER] = 8ull * (E.edges.size() / 2) + 4ull * E.hdb.n;
-        E.stats.stage_seconds[UC_ST_SETCOVER] += tc.seconds();
+        const HostDb full = E.hdb;            // round 0 runs on the whole DB; later rounds on representatives (createsubdb)
+        const uint32_t n = full.n;
+        logf(3, "unicore-cluster: %u sequences, %llu residues, device %d, %d clustering step(s)\n", n, (unsigned long long)full.residues(),
+             E.device, p.cluster_steps);
+        std::vector<uint32_t> assign(n), cur(n), posmap(n);
+        for (uint32_t i = 0; i < n; i++) { assign[i] = i; cur[i] = i; }
+        for (int r = 0; r < p.cluster_steps; r++) {
+            if (r > 0) {   // sub-database of the current representatives
+                HostDb sub;
+                sub.n = (uint32_t)cur.size();
+                sub.off.resize((size_t)sub.n + 1);
+                uint64_t tot = 0;
+                for (uint32_t i = 0; i < sub.n; i++) { sub.off[i] = tot; tot += full.len(cur[i]); }
+                sub.off[sub.n] = tot;
+                sub.s3.resize(tot); sub.sa.resize(tot); sub.keys.resize(sub.n);
+                for (uint32_t i = 0; i < sub.n; i++) {
+                    memcpy(sub.s3.data() + sub.off[i], full.s3.data() + full.off[cur[i]], full.len(cur[i]));
+                    memcpy(sub.sa.data() + sub.off[i], full.sa.data() + full.off[cur[i]], full.len(cur[i]));
+                    sub.keys[i] = full.keys[cur[i]];
+                }
+                E.hdb = std::move(sub);
+            }
+            if (p.cluster_steps > 1 && !p.kmer_thr_explicit)   // sensitivity rises linearly from 1 to the target (spec UC-1 E8)
+                E.p.kmer_thr = kmer_thr_for(p, 1.0 + (p.sensitivity - 1.0) * r / (p.cluster_steps - 1));
+            E.upload_db();
+            E.prefilter(0, E.hdb.n);
+            logf(3, "unicore-cluster: step %d: %u sequences, prefilter kept %llu pairs (k-score %d, max-seqs %d)\n", r + 1, E.hdb.n,
+                 (unsigned long long)E.n_hits, E.p.kmer_thr, p.max_seqs);
+            E.align(0, E.hdb.n);
+            Timer tc;
+            std::vector<uint32_t> sa(E.hdb.n);
+            set_cover(E.hdb.n, E.edges.data(), E.edges.size() / 2, sa.data());
+            // mergeclusters: the representative of a sequence is the representative of its representative
+            for (uint32_t i = 0; i < cur.size(); i++) posmap[cur[i]] = i;
+            for (uint32_t x = 0; x < n; x++) assign[x] = cur[sa[posmap[assign[x]]]];
+            std::vector<uint32_t> next;
+            for (uint32_t i = 0; i < cur.size(); i++) if (sa[i] == i) next.push_back(cur[i]);
+            E.stats.algorithmic_bytes[UC_ST_SETCOVER] += 8ull * (E.edges.size() / 2) + 4ull * E.hdb.n;
+            E.stats.stage_seconds[UC_ST_SETCOVER] += tc.seconds();
+            logf(3, "unicore-cluster: step %d: %llu accepted pairs, %zu representatives\n", r + 1, (unsigned long long)(E.edges.size() / 2), next.size());
+            cur.swap(next);
+        }
+        E.stats.n_clusters = cur.size();
+        E.stats.n_seqs = n;
+        E.stats.n_residues = full.residues();
+        const uint64_t ncl = cur.size();
         Timer to;
-        write_cluster_db(out_cluster_db, E.hdb.keys, assign.data(), E.hdb.n);
+        write_cluster_db(out_cluster_db, full.keys, assign.data(), n);
         E.stats.stage_seconds[UC_ST_OUTPUT] += to.seconds();
         logf(3, "unicore-cluster: %llu clusters -> %s\n", (unsigned long long)ncl, out_cluster_db);
         if (stats_out) *stats_out = E.stats;

@@ -111,7 +111,7 @@ void parse_cluster_options(const std::string &opts, Params &p) {
         else if (f == "--mat3di") { p.mat3di_path = value(); }
         else if (f == "--mat-aa") { p.mataa_path = value(); }
         else if (f == "--cluster-mode") { p.cluster_mode = to_int(f, value()); if (p.cluster_mode != 0) fail(UC_ERR_ARGS, "--cluster-mode %d unsupported (only 0 = greedy set cover)", p.cluster_mode); }
-        else if (f == "--single-step-clustering") { p.single_step = opt_bool(); }
+        else if (f == "--single-step-clustering") { p.single_step = opt_bool(); p.single_step_given = true; }
         else if (f == "--cluster-steps") { p.cluster_steps = to_int(f, value()); }
         else if (f == "--alignment-type") { int v = to_int(f, value()); if (v != 2) fail(UC_ERR_ARGS, "--alignment-type %d unsupported (only 2 = 3Di+AA)", v); }
         else if (f == "--alignment-mode") { int v = to_int(f, value()); if (v < 0 || v > 3) fail(UC_ERR_ARGS, "--alignment-mode %d unsupported", v); }
@@ -153,16 +153,23 @@ void finalize_params(Params &p, const std::string &data_dir_in) {
         else if (p.pattern[i] != '0') fail(UC_ERR_ARGS, "--spaced-kmer-pattern must consist of 0/1");
     }
     if (n != K || p.pattern.front() != '1' || p.pattern.back() != '1') fail(UC_ERR_ARGS, "--spaced-kmer-pattern needs exactly 6 ones and 1 at both ends");
-    if (p.kmer_thr < 0) {
-        // sensitivity -> k-mer threshold: mean self score of a k-mer + 3 - 2*s  (data-driven stand-in for
-        // Foldseek's threshold table, SURVEY.md A.2 EXT-UNVERIFIED; --k-score overrides)
-        double diag = 0;
-        for (int a = 0; a < KA; a++) diag += p.S3[a * A + a];
-        p.kmer_thr = (int)std::lround(K * diag / KA + 3.0 - 2.0 * p.sensitivity);
-    }
-    if (!p.single_step || p.cluster_steps != 1)
-        logf(2, "Warning: cascaded clustering is not implemented; running single-step clustering\n");
+    p.kmer_thr_explicit = p.kmer_thr >= 0;
+    if (p.kmer_thr < 0) p.kmer_thr = kmer_thr_for(p, p.sensitivity);
+    if (p.cluster_steps < 1 || p.cluster_steps > 16) fail(UC_ERR_ARGS, "--cluster-steps must be in [1,16]");
+    // rounds of the clustering workflow: Foldseek cascades by default (3 steps); THIS build runs a single step unless
+    // asked (--cluster-steps N > 1, or --single-step-clustering 0 => 3 steps) — DESIGN.md 2, deviation kept on purpose
+    if (p.single_step_given && p.single_step) p.cluster_steps = 1;
+    else if (p.single_step_given && !p.single_step && p.cluster_steps == 1) p.cluster_steps = 3;
+    p.single_step = p.cluster_steps == 1;
     if (p.threads < 1) p.threads = 1;
+}
+
+// sensitivity -> k-mer threshold: mean self score of a k-mer + 3 - 2*s  (data-driven stand-in for Foldseek's
+// threshold table, SURVEY.md A.2 EXT-UNVERIFIED; --k-score overrides)
+int kmer_thr_for(const Params &p, double sensitivity) {
+    double diag = 0;
+    for (int a = 0; a < KA; a++) diag += p.S3[a * A + a];
+    return (int)std::lround(K * diag / KA + 3.0 - 2.0 * sensitivity);
 }
 
 int32_t min_score_for(const Params &p, int lq, uint64_t db_residues) {

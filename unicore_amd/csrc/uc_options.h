@@ -40,8 +40,10 @@ struct Params {
     float min_seq_id = 0.0f;
     // clustering
     int cluster_mode = 0;
-    int cluster_steps = 1;
+    int cluster_steps = 1;      // > 1: cascade (E8) — rounds on representatives with rising sensitivity, merged at the end
+    bool kmer_thr_explicit = false;   // --k-score given: every cascade round uses it
     bool single_step = true;
+    bool single_step_given = false;
     // runtime
     int threads = 1;
     int verbosity = 3;
@@ -56,6 +58,8 @@ void parse_cluster_options(const std::string &opts, Params &p);
 void finalize_params(Params &p, const std::string &data_dir);
 std::string default_data_dir();
 // smallest integer score S with K * lq * db_residues * exp(-lambda*S) <= evalue
+// sensitivity -> k-mer threshold (the rule of finalize_params)
+int kmer_thr_for(const Params &p, double sensitivity);
 int32_t min_score_for(const Params &p, int lq, uint64_t db_residues);
 
 }  // namespace uc
