@@ -194,7 +194,7 @@ def main():
                                    % (args.proteomes, n, int(lens.sum()), args.options, seed),
                        "alignments_per_step": n_aln // steps, "clusters": int((assign == np.arange(n)).sum()) if assign is not None else None,
                        "parallelism": "target-shard x%d + RCCL hit all-gather (device-resident), pair-hash partition of the gapped stage" % world if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "sw_group_kernel (gapped 3Di+AA SW, all passes)",
+            "roofline": {"bound": "hbm", "kernel": "sw_pk_kernel + sw_group_kernel (gapped 3Di+AA SW, all classes and passes)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic_per_launch(),
                          "algorithmic_bytes_per_launch": st["sw_algorithmic_bytes"] / max(st["sw_kernel_launches"], 1),
