@@ -72,6 +72,14 @@ int uc_createtsv(const char *db, const char *cluster_db, const char *out_tsv, co
 /* == `foldseek rmdb <out>_cluster -v V`                                         (cluster.rs:67-76) */
 int uc_rmdb(const char *db_prefix);
 
+/* ---- the calls of src/modules/search.rs, same kernels, query DB vs target DB --------------- */
+/* == `foldseek search --threads T <queryDB> <targetDB> <out>_aln <tmp> <opts...>`  (search.rs:44-50; note that Unicore
+ *    passes its TARGET argument first, i.e. as Foldseek's query DB).  Defaults as for cluster except -e 10 and
+ *    --max-seqs 1000; traceback statistics for every accepted pair. */
+int uc_search(const char *query_db, const char *target_db, const char *out_aln_db, const char *tmp, const uc_opts *o, uc_stats *stats_out);
+/* == `foldseek convertalis --threads T <queryDB> <targetDB> <out>_aln <out>.m8`    (search.rs:52-57) */
+int uc_convertalis(const char *query_db, const char *target_db, const char *aln_db, const char *out_m8, const uc_opts *o);
+
 const char *uc_last_error(void);
 const char *uc_version(void);
 /* validates a Foldseek-style option string without running anything (0 or UC_ERR_ARGS) */
@@ -91,6 +99,7 @@ typedef struct uc_aln {          /* one gapped alignment result (stage E5/E6 out
     int32_t qstart, qend, tstart, tend;    /* valid iff pass_evalue */
     int32_t aln_len, idents;               /* valid iff a seq-id threshold is active */
     int32_t pass_evalue, accepted;
+    int32_t gap_opens;                     /* with aln_len/idents: number of gaps on the traceback (search path) */
 } uc_aln;
 
 int uc_engine_create(const uc_opts *o, uc_engine **out);
@@ -103,6 +112,8 @@ uint32_t uc_engine_num_seqs(const uc_engine *e);
 
 /* E1-E4: index targets [tbegin,tend), match ALL queries against it, keep per-query top max_seqs */
 int uc_engine_prefilter(uc_engine *e, uint32_t tbegin, uint32_t tend);
+/* the same with the queries restricted to [qbegin,qend): query DB vs target DB inside one loaded set (search path) */
+int uc_engine_prefilter_range(uc_engine *e, uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend);
 /* hit lists live in the engine: counts[n_seqs], hits flat, grouped by query in query order */
 int uc_engine_hits_size(const uc_engine *e, uint64_t *n_hits);
 int uc_engine_hits_get(const uc_engine *e, uint32_t *counts, uc_hit *hits);

@@ -22,7 +22,7 @@ class Params(C.Structure):
         ("kmer_thr", C.c_int), ("min_diag_hits", C.c_int), ("min_ungapped", C.c_int), ("max_seqs", C.c_int),
         ("gap_open", C.c_int), ("gap_ext", C.c_int), ("rev_correction", C.c_int),
         ("evalue", C.c_double), ("lambda_", C.c_double), ("K", C.c_double),
-        ("cov", C.c_float), ("cov_mode", C.c_int), ("min_seq_id", C.c_float),
+        ("cov", C.c_float), ("cov_mode", C.c_int), ("min_seq_id", C.c_float), ("want_tb", C.c_int),
     ]
 
 
@@ -43,7 +43,8 @@ class Hit(C.Structure):
 class Aln(C.Structure):
     _fields_ = [("score", C.c_int32), ("score_rev", C.c_int32), ("corrected", C.c_int32),
                 ("qstart", C.c_int32), ("qend", C.c_int32), ("tstart", C.c_int32), ("tend", C.c_int32),
-                ("aln_len", C.c_int32), ("idents", C.c_int32), ("pass_evalue", C.c_int32), ("accepted", C.c_int32)]
+                ("aln_len", C.c_int32), ("idents", C.c_int32), ("pass_evalue", C.c_int32), ("accepted", C.c_int32),
+                ("gap_opens", C.c_int32)]
 
 
 class Counts(C.Structure):
@@ -53,7 +54,7 @@ class Counts(C.Structure):
 
 HIT_DTYPE = np.dtype([("t", "<u4"), ("score", "<i4"), ("diag", "<i4")])
 ALN_DTYPE = np.dtype([(n, "<i4") for n in ("score", "score_rev", "corrected", "qstart", "qend", "tstart", "tend",
-                                            "aln_len", "idents", "pass_evalue", "accepted")])
+                                            "aln_len", "idents", "pass_evalue", "accepted", "gap_opens")])
 
 _lib = None
 
@@ -89,6 +90,8 @@ def lib():
     L.uco_cluster.argtypes = [C.POINTER(Db), C.POINTER(Params), C.c_int, C.c_void_p, C.POINTER(Counts), C.c_void_p, C.c_void_p, C.c_void_p]
     L.uco_cluster_cascade.argtypes = [C.POINTER(Db), C.POINTER(Params), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.POINTER(Counts), C.c_void_p]
     L.uco_write_tsv.argtypes = [C.c_char_p, C.POINTER(Db), C.c_void_p]
+    L.uco_search.argtypes = [C.POINTER(Db), C.POINTER(Db), C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Counts)]
+    L.uco_write_m8.argtypes = [C.c_char_p, C.POINTER(Db), C.POINTER(Db), C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]
     L.uco_sample_run.argtypes = [C.POINTER(Db), C.POINTER(Index), C.POINTER(Params), C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
     L.uco_sample_run.restype = C.c_uint64
     _lib = L
@@ -235,6 +238,25 @@ def cluster_cascade(odb, p, thr, threads=0):
     if rc != 0:
         raise RuntimeError("uco_cluster_cascade failed: %d" % rc)
     return dict(assign=assign, counts={f: getattr(cnt, f) for f, _ in Counts._fields_}, round_sizes=rs)
+
+
+def search(qdb, tdb, p, threads=0):
+    """search path: every query of qdb against tdb.  Returns dict(hits, hit_cnt, aln, counts) (nq x max_seqs)."""
+    nq, M = qdb.n, p.max_seqs
+    hits = np.zeros((nq, M), HIT_DTYPE)
+    hcnt = np.zeros(nq, np.uint32)
+    aln = np.zeros((nq, M), ALN_DTYPE)
+    cnt = Counts()
+    rc = lib().uco_search(C.byref(qdb.db), C.byref(tdb.db), C.byref(p), threads, hits.ctypes.data, hcnt.ctypes.data, aln.ctypes.data, C.byref(cnt))
+    if rc != 0:
+        raise RuntimeError("uco_search failed: %d" % rc)
+    return dict(hits=hits, hit_cnt=hcnt, aln=aln, counts={f: getattr(cnt, f) for f, _ in Counts._fields_})
+
+
+def write_m8(path, qdb, tdb, p, res):
+    if lib().uco_write_m8(path.encode(), C.byref(qdb.db), C.byref(tdb.db), C.byref(p), res["hits"].ctypes.data,
+                          res["hit_cnt"].ctypes.data, res["aln"].ctypes.data) != 0:
+        raise IOError(path)
 
 
 def write_tsv(path, odb, assign):

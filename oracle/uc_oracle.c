@@ -414,7 +414,7 @@ int32_t uco_min_score(const uco_params *p, int lq, uint64_t db_residues) {
 
 /* traceback on the [qs..qe]x[ts..te] box (spec E6): returns aln_len and idents */
 static void traceback(const uco_db *db, uint32_t q, uint32_t t, const uco_params *p,
-                      int qs, int qe, int ts, int te, int32_t *aln_len, int32_t *idents) {
+                      int qs, int qe, int ts, int te, int32_t *aln_len, int32_t *idents, int32_t *gap_opens) {
     const uint8_t *q3 = db->s3 + db->off[q] + qs, *qa = db->sa + db->off[q] + qs;
     const uint8_t *t3 = db->s3 + db->off[t] + ts, *ta = db->sa + db->off[t] + ts;
     int lq = qe - qs + 1, lt = te - ts + 1;
@@ -436,15 +436,15 @@ static void traceback(const uco_db *db, uint32_t q, uint32_t t, const uco_params
             if (h < 0) h = 0;
             H[i * W + j] = h; E[i * W + j] = e; F[i * W + j] = f;
         }
-    int i = lq, j = lt, state = 0, len = 0, id = 0;
+    int i = lq, j = lt, state = 0, len = 0, id = 0, gaps = 0;
     while (i > 0 && j > 0) {
         if (state == 0) {
             int32_t h = H[i * W + j];
             if (h == 0) break;
             int s = p->S3[q3[i - 1] * UCO_A + t3[j - 1]] + p->SA[qa[i - 1] * UCO_A + ta[j - 1]];
             if (h == H[(i - 1) * W + j - 1] + s) { len++; id += (qa[i - 1] == ta[j - 1]); i--; j--; }
-            else if (h == F[i * W + j]) state = 1;
-            else state = 2;
+            else if (h == F[i * W + j]) { state = 1; gaps++; }
+            else { state = 2; gaps++; }
         } else if (state == 1) { /* gap consuming query residue i */
             len++;
             if (F[i * W + j] == H[(i - 1) * W + j] - open) state = 0;
@@ -456,7 +456,7 @@ static void traceback(const uco_db *db, uint32_t q, uint32_t t, const uco_params
         }
     }
     free(H); free(E); free(F);
-    *aln_len = len; *idents = id;
+    *aln_len = len; *idents = id; *gap_opens = gaps;
 }
 
 /* Foldseek structurealign for one (query, target) pair (call site cluster.rs:45-49). */
@@ -480,10 +480,10 @@ void uco_align_pair(const uco_db *db, uint32_t q, uint32_t t, const uco_params *
     float qcov = (float)(o->qend - o->qstart + 1) / (float)lq;
     float tcov = (float)(o->tend - o->tstart + 1) / (float)lt;
     int ok = p->cov_mode == 0 ? (qcov >= p->cov && tcov >= p->cov) : p->cov_mode == 1 ? (tcov >= p->cov) : (qcov >= p->cov);
-    if (ok && p->min_seq_id > 0.0f) {
-        traceback(db, q, t, p, o->qstart, o->qend, o->tstart, o->tend, &o->aln_len, &o->idents);
+    if (ok && (p->min_seq_id > 0.0f || p->want_tb)) {
+        traceback(db, q, t, p, o->qstart, o->qend, o->tstart, o->tend, &o->aln_len, &o->idents, &o->gap_opens);
         float sid = o->aln_len > 0 ? (float)o->idents / (float)o->aln_len : 0.0f;
-        ok = sid >= p->min_seq_id;
+        if (p->min_seq_id > 0.0f) ok = sid >= p->min_seq_id;
     }
     o->accepted = ok;
 }
@@ -627,6 +627,102 @@ int uco_cluster(const uco_db *db, const uco_params *p, int threads, uint32_t *as
 }
 
 /* ------------------------------------------------------------------ E9: `foldseek createtsv` (cluster.rs:59-64) */
+/* ------------------------------------------------------------------ search path == `foldseek search` + `convertalis` (search.rs:44-61) */
+int uco_search(const uco_db *qdb, const uco_db *tdb, const uco_params *p_in, int threads,
+               uco_hit *hits_out, uint32_t *hit_cnt_out, uco_aln *aln_out, uco_counts *cnt) {
+    uco_params pv = *p_in; pv.want_tb = 1;
+    const uco_params *p = &pv;
+    const uint32_t nt = tdb->n, nq = qdb->n, n = nt + nq;
+    const int M = p->max_seqs;
+    /* combined database: targets first, then queries; only [0, nt) is indexed */
+    uco_db db; memset(&db, 0, sizeof db);
+    db.n = n;
+    db.off = (uint64_t *)malloc(((size_t)n + 1) * sizeof(uint64_t));
+    const uint64_t rt = tdb->off[nt], rq = qdb->off[nq];
+    db.s3 = (uint8_t *)malloc(rt + rq + 1); db.sa = (uint8_t *)malloc(rt + rq + 1);
+    memcpy(db.s3, tdb->s3, rt); memcpy(db.sa, tdb->sa, rt);
+    memcpy(db.s3 + rt, qdb->s3, rq); memcpy(db.sa + rt, qdb->sa, rq);
+    for (uint32_t i = 0; i <= nt; i++) db.off[i] = tdb->off[i];
+    for (uint32_t i = 0; i <= nq; i++) db.off[nt + i] = rt + qdb->off[i];
+    uco_index ix;
+    if (uco_index_build(&db, 0, nt, p, &ix) != 0) { free(db.off); free(db.s3); free(db.sa); return -1; }
+    uco_counts total; memset(&total, 0, sizeof total);
+    (void)threads;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel
+    {
+        uco_counts loc; memset(&loc, 0, sizeof loc);
+#pragma omp for schedule(dynamic, 8)
+        for (int64_t q = 0; q < (int64_t)nq; q++)
+            hit_cnt_out[q] = (uint32_t)uco_prefilter_query(&db, &ix, nt + (uint32_t)q, p, hits_out + (size_t)q * M, &loc);
+#pragma omp critical
+        {
+            total.n_sim_kmers += loc.n_sim_kmers; total.n_kmer_hits += loc.n_kmer_hits;
+            total.n_candidates += loc.n_candidates; total.n_prefilter_hits += loc.n_prefilter_hits;
+        }
+    }
+    uco_index_free(&ix);
+    uint64_t npairs = 0, ne = 0, c_f = 0, c_r = 0, c_s = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : c_f, c_r, c_s, npairs, ne)
+    for (int64_t q = 0; q < (int64_t)nq; q++) {
+        const int lq = (int)(qdb->off[q + 1] - qdb->off[q]);
+        const int32_t ms = uco_min_score(p, lq, rt);
+        for (uint32_t k = 0; k < hit_cnt_out[q]; k++) {
+            uco_aln a;
+            const uint32_t t = hits_out[(size_t)q * M + k].t;
+            uco_align_pair(&db, nt + (uint32_t)q, t, p, ms, &a);
+            const int lt = (int)(tdb->off[t + 1] - tdb->off[t]);
+            c_f += (uint64_t)lq * lt; if (p->rev_correction && a.score >= ms) c_r += (uint64_t)lq * lt;
+            if (a.pass_evalue) c_s += (uint64_t)(a.qend + 1) * (a.tend + 1);
+            npairs++; ne += a.accepted;
+            aln_out[(size_t)q * M + k] = a;
+        }
+    }
+    total.n_alignments = npairs; total.n_edges = ne;
+    total.cells_fwd = c_f; total.cells_rev = c_r; total.cells_start = c_s;
+    if (cnt) *cnt = total;
+    free(db.off); free(db.s3); free(db.sa);
+    return 0;
+}
+
+typedef struct { int32_t corrected; uint32_t t; uint32_t k; } m8ord;
+static int m8cmp(const void *a, const void *b) {
+    const m8ord *x = (const m8ord *)a, *y = (const m8ord *)b;
+    if (x->corrected != y->corrected) return x->corrected > y->corrected ? -1 : 1;
+    return x->t < y->t ? -1 : (x->t > y->t ? 1 : 0);
+}
+
+int uco_write_m8(const char *path, const uco_db *qdb, const uco_db *tdb, const uco_params *p,
+                 const uco_hit *hits, const uint32_t *hit_cnt, const uco_aln *aln) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    const int M = p->max_seqs;
+    const double rt = (double)tdb->off[tdb->n];
+    m8ord *ord = (m8ord *)malloc((size_t)(M ? M : 1) * sizeof(m8ord));
+    for (uint32_t q = 0; q < qdb->n; q++) {
+        uint32_t m = 0;
+        for (uint32_t k = 0; k < hit_cnt[q]; k++)
+            if (aln[(size_t)q * M + k].accepted) { ord[m].corrected = aln[(size_t)q * M + k].corrected; ord[m].t = hits[(size_t)q * M + k].t; ord[m].k = k; m++; }
+        qsort(ord, m, sizeof(m8ord), m8cmp);
+        const double lq = (double)(qdb->off[q + 1] - qdb->off[q]);
+        for (uint32_t j = 0; j < m; j++) {
+            const uco_aln *a = &aln[(size_t)q * M + ord[j].k];
+            const int pairs = (a->qend - a->qstart + 1) + (a->tend - a->tstart + 1) - a->aln_len;
+            const double fident = a->aln_len > 0 ? (double)a->idents / (double)a->aln_len : 0.0;
+            const double ev = p->K * lq * rt * exp(-p->lambda * (double)a->corrected);
+            const int bits = (int)((p->lambda * (double)a->corrected - log(p->K)) / log(2.0));
+            if (qdb->names) fprintf(f, "%s\t", qdb->names[q]); else fprintf(f, "%u\t", q);
+            if (tdb->names) fprintf(f, "%s\t", tdb->names[ord[j].t]); else fprintf(f, "%u\t", ord[j].t);
+            fprintf(f, "%.3f\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%.3E\t%d\n", fident, a->aln_len, pairs - a->idents, a->gap_opens,
+                    a->qstart + 1, a->qend + 1, a->tstart + 1, a->tend + 1, ev, bits);
+        }
+    }
+    free(ord);
+    return fclose(f) == 0 ? 0 : -1;
+}
+
 /* ------------------------------------------------------------------ E8: cascade (rounds on representatives + merge) */
 int uco_cluster_cascade(const uco_db *db, const uco_params *p, int steps, const int *thr, int threads,
                         uint32_t *assign, uco_counts *cnt, uint32_t *round_sizes) {

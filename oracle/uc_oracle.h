@@ -55,6 +55,9 @@
  * E8 cascade (only on request, steps > 1): `steps` rounds of E1-E7, round r on the representatives of round
  *            r-1, k-mer threshold from sensitivity s_r = 1 + (s-1) r/(steps-1); final representative =
  *            representative of the representative (mergeclusters).  No linclust pre-step.
+ * S  search (query DB vs target DB): E2-E6 per query against the index of the whole
+ *            target DB, E-value with residues(target DB); traceback statistics (alnlen, idents, gaps) for every
+ *            accepted pair; BLAST-tab rows per query by (corrected desc, target asc) - see uco_write_m8.
  * E9 TSV     clusters by ascending representative id; rows "rep\tmember": representative first,
  *            then the other members by ascending id.
  * ---------------------------------------------------------------------------------------------
@@ -86,6 +89,7 @@ typedef struct uco_params {
     float cov;
     int cov_mode;
     float min_seq_id;
+    int want_tb;                  /* 1: traceback statistics for every accepted pair (search / convertalis) */
 } uco_params;
 
 typedef struct uco_db {           /* sequences as codes 0..20, concatenated, no padding */
@@ -109,6 +113,7 @@ typedef struct uco_aln {
     int32_t qstart, qend, tstart, tend;   /* valid iff pass_evalue */
     int32_t aln_len, idents;              /* valid iff computed (min_seq_id > 0) */
     int32_t pass_evalue, accepted;
+    int32_t gap_opens;                    /* with aln_len/idents: number of gaps on the traceback */
 } uco_aln;
 
 typedef struct uco_counts {
@@ -163,6 +168,20 @@ int  uco_cluster_cascade(const uco_db *db, const uco_params *p, int steps, const
                          uint32_t *assign, uco_counts *cnt, uint32_t *round_sizes);
 
 int  uco_write_tsv(const char *path, const uco_db *db, const uint32_t *assign);
+
+/* ---- search path (`foldseek search` + `convertalis`, reference src/modules/search.rs:44-61) ----
+   spec UC-1 S: every query of qdb against the index of ALL of tdb through E2-E6 unchanged (E-value with the
+   residue count of tdb), traceback statistics for every accepted pair (want_tb is forced on).  hits_out /
+   aln_out: nq * max_seqs records, hit_cnt_out: nq counts. */
+int  uco_search(const uco_db *qdb, const uco_db *tdb, const uco_params *p, int threads,
+                uco_hit *hits_out, uint32_t *hit_cnt_out, uco_aln *aln_out, uco_counts *cnt);
+/* BLAST-tab rows (== convertalis default columns): query target fident alnlen mismatch gapopen qstart qend
+   tstart tend evalue bits; accepted pairs only, queries in DB order, per query (corrected score desc, target asc);
+   positions 1-based; fident %.3f = idents/alnlen; mismatch = aligned pairs - idents with aligned pairs =
+   qspan + tspan - alnlen; evalue %.3E = K*Lq*residues(tdb)*exp(-lambda*corrected); bits %d = trunc((lambda*corrected
+   - ln K)/ln 2) */
+int  uco_write_m8(const char *path, const uco_db *qdb, const uco_db *tdb, const uco_params *p,
+                  const uco_hit *hits, const uint32_t *hit_cnt, const uco_aln *aln);
 
 /* CPU-baseline helper (bench.py cpu_baseline leg): E2-E6 for the listed queries against a prebuilt index;
    returns the number of gapped alignments done; seconds[0] = prefilter wall, seconds[1] = alignment wall */

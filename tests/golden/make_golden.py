@@ -36,6 +36,16 @@ def main():
                             count_names=np.array(sorted(r["counts"])))
         O.write_tsv(os.path.join(HERE, "clust_%s.tsv" % name), odb, r["assign"])
         print(name, opts, "->", odb.n, "seqs,", int(cnt.sum()), "alignments,", len(set(r["assign"].tolist())), "clusters")
+    # cascade (E8) and search (8f rank 3) fixtures on the same DB: the golden DB searched against itself
+    p = util.oracle_params(O, "-c 0.8")
+    thr = O.cascade_thresholds(p, 4.0, 3)
+    rc = O.cluster_cascade(odb, p, thr, threads=4)
+    O.write_tsv(os.path.join(HERE, "clust_cascade3.tsv"), odb, rc["assign"])
+    print("cascade3", thr, "->", rc["round_sizes"].tolist(), "sequences per round,", rc["counts"]["n_clusters"], "clusters")
+    ps = util.oracle_params(O, "-e 10 --max-seqs 1000 -c 0.8")
+    rs = O.search(odb, odb, ps, threads=4)
+    O.write_m8(os.path.join(HERE, "search_self.m8"), odb, odb, ps, rs)
+    print("search_self ->", int(rs["counts"]["n_edges"]), "rows")
 
 
 if __name__ == "__main__":

@@ -64,3 +64,28 @@ def test_hip_path_reproduces_golden(name, tmp_path):
     U.cluster(os.path.join(GOLD, "db"), out + "_cluster", str(tmp_path / "tmp"), opts)
     U.createtsv(os.path.join(GOLD, "db"), out + "_cluster", out + ".tsv")
     assert open(out + ".tsv", "rb").read() == open(os.path.join(GOLD, "clust_%s.tsv" % name), "rb").read()
+
+
+def test_oracle_reproduces_golden_cascade_and_search(tmp_path):
+    from oracle import oracle_py as O
+    odb = O.OracleDb(os.path.join(GOLD, "db"))
+    p = util.oracle_params(O, "-c 0.8")
+    rc = O.cluster_cascade(odb, p, O.cascade_thresholds(p, 4.0, 3), threads=4)
+    O.write_tsv(str(tmp_path / "c.tsv"), odb, rc["assign"])
+    assert open(tmp_path / "c.tsv", "rb").read() == open(os.path.join(GOLD, "clust_cascade3.tsv"), "rb").read()
+    ps = util.oracle_params(O, "-e 10 --max-seqs 1000 -c 0.8")
+    rs = O.search(odb, odb, ps, threads=4)
+    O.write_m8(str(tmp_path / "s.m8"), odb, odb, ps, rs)
+    assert open(tmp_path / "s.m8", "rb").read() == open(os.path.join(GOLD, "search_self.m8"), "rb").read()
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_golden_cascade_and_search(tmp_path):
+    import unicore_amd as U
+    db = os.path.join(GOLD, "db")
+    U.cluster(db, str(tmp_path / "c_cluster"), str(tmp_path / "tmp"), "-c 0.8 --cluster-steps 3")
+    U.createtsv(db, str(tmp_path / "c_cluster"), str(tmp_path / "c.tsv"))
+    assert open(tmp_path / "c.tsv", "rb").read() == open(os.path.join(GOLD, "clust_cascade3.tsv"), "rb").read()
+    U.search(db, db, str(tmp_path / "s_aln"), str(tmp_path / "tmp"), "-c 0.8")
+    U.convertalis(db, db, str(tmp_path / "s_aln"), str(tmp_path / "s.m8"))
+    assert open(tmp_path / "s.m8", "rb").read() == open(os.path.join(GOLD, "search_self.m8"), "rb").read()

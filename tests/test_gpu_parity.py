@@ -289,3 +289,42 @@ def ref_pairs(cnt, hits):
         q = np.repeat(np.arange(len(cnt)), cnt)
         _REF_PAIRS[key] = set(zip(q.tolist(), hits["target"].tolist()))
     return _REF_PAIRS[key]
+
+
+@pytest.mark.parametrize("opts", ["-c 0.8", "-c 0.3 -e 1e-3 --max-seqs 12 --cov-mode 2"])
+def test_search_m8_bytes(O, tmp_path, opts):
+    """uc_search + uc_convertalis (query DB vs target DB, same kernels, traceback statistics for
+    every accepted pair incl. the gap count) == the oracle's search + BLAST-tab writer, byte for byte"""
+    import unicore_amd as U
+    s3, sa = util.family_db(41, n_fam=10, members=7, lmin=40, lmax=300, extra=(900,))
+    order = np.random.default_rng(3).permutation(len(s3))
+    qi, ti = sorted(order[:25].tolist()), sorted(order[25:].tolist())
+    qdbp, tdbp = str(tmp_path / "q"), str(tmp_path / "t")
+    qn = util.write_db(qdbp, [s3[i] for i in qi], [sa[i] for i in qi], ["q_%03d" % i for i in qi])
+    tn = util.write_db(tdbp, [s3[i] for i in ti], [sa[i] for i in ti], ["t_%03d" % i for i in ti])
+    out = str(tmp_path / "res")
+    st = U.search(qdbp, tdbp, out + "_aln", str(tmp_path / "tmp"), opts, threads=4)
+    U.convertalis(qdbp, tdbp, out + "_aln", out + ".m8")
+    qdb, tdb = O.OracleDb(qdbp), O.OracleDb(tdbp)
+    po = util.oracle_params(O, ("-e 10 --max-seqs 1000 " + opts))           # `search` defaults, then the given flags
+    ref = O.search(qdb, tdb, po, threads=8)
+    O.write_m8(str(tmp_path / "ref.m8"), qdb, tdb, po, ref)
+    got, exp = open(out + ".m8", "rb").read(), open(str(tmp_path / "ref.m8"), "rb").read()
+    assert got == exp
+    rows = [l.split("\t") for l in got.decode().splitlines()]
+    assert len(rows) > 30 and all(len(r) == 12 for r in rows)
+    assert any(int(r[5]) > 0 for r in rows) and any(int(r[4]) > 0 for r in rows)      # gaps and mismatches occur
+    assert all(r[0].startswith("q_") and r[1].startswith("t_") for r in rows)
+    qs = [r[0] for r in rows]
+    assert all(qs[i] == qs[i - 1] or qs[i] not in qs[:i] for i in range(1, len(qs)))   # rows grouped by query (profile.rs:50-55)
+    assert st["n_gapped_alignments"] == ref["counts"]["n_alignments"]
+    U.rmdb(out + "_aln")
+    assert not os.path.exists(out + "_aln")
+    if opts == "-c 0.8":     # the module surface: `unicore search INPUT TARGET OUTPUT TMP` hands TARGET to the engine as the query DB
+        import subprocess    # (search.rs:45-46), writes OUTPUT.m8, removes OUTPUT_aln, checkpoint "1"
+        exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "unicore")
+        cout = str(tmp_path / "cli" / "hits")
+        r = subprocess.run([exe, "search", tdbp, qdbp, cout, str(tmp_path / "tmp2"), "-s", opts, "-v", "1"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert open(cout + ".m8", "rb").read() == exp and not os.path.exists(cout + "_aln")
+        assert open(str(tmp_path / "cli" / "search.chk")).read() == "1"

@@ -174,8 +174,18 @@ def test_cli_surface_and_checkpoint_contract(tmp_path):
     assert open(tmp_path / "res" / "cluster.chk").read() == "0"      # started, never finished
     r = subprocess.run([exe, "cluster", "db", str(out), "tmp", "-c", "--frobnicate 3"], capture_output=True, text=True)
     assert r.returncode == 1 and "unknown or unsupported cluster option" in r.stderr
+    # `unicore search` (arg_parser.rs:247-270, search.rs): same contract, its own checkpoint file
+    r = subprocess.run([exe, "search", "a", "b", "c"], capture_output=True, text=True)
+    assert r.returncode == 0x40
+    sout = tmp_path / "sres" / "hits"
+    r = subprocess.run([exe, "search", str(tmp_path / "missing_q"), str(tmp_path / "missing_t"), str(sout), str(tmp_path / "tmp"), "-s", "-c 0.8", "-v", "1"],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and r.stderr.startswith("Error: ")
+    assert open(tmp_path / "sres" / "search.chk").read() == "0"
     shim = os.path.join(ROOT, "bin", "foldseek")
     assert subprocess.run([shim, "version"], capture_output=True).returncode == 0      # config.rs:49-66 handshake
+    assert subprocess.run([shim, "search", "a", "b"], capture_output=True).returncode != 0
+    assert subprocess.run([shim, "convertalis", "a"], capture_output=True).returncode != 0
     assert subprocess.run([shim, "easy-search"], capture_output=True).returncode != 0
     r = subprocess.run([shim, "rmdb", str(tmp_path / "nothing_cluster"), "-v", "2"], capture_output=True)
     assert r.returncode == 0

@@ -42,13 +42,13 @@ class UcStats(C.Structure):
 
 HIT_DTYPE = np.dtype([("target", "<u4"), ("score", "<i4"), ("diag", "<i4")])
 ALN_DTYPE = np.dtype([(n, "<i4") for n in ("score", "score_rev", "corrected", "qstart", "qend", "tstart", "tend",
-                                            "aln_len", "idents", "pass_evalue", "accepted")])
+                                            "aln_len", "idents", "pass_evalue", "accepted", "gap_opens")])
 
 # every symbol include/unicore_cluster.h declares (tests check the library exports all of them)
 SYMBOLS = (
-    "uc_cluster", "uc_createtsv", "uc_rmdb", "uc_last_error", "uc_version", "uc_check_options",
+    "uc_cluster", "uc_createtsv", "uc_rmdb", "uc_search", "uc_convertalis", "uc_last_error", "uc_version", "uc_check_options",
     "uc_engine_create", "uc_engine_destroy", "uc_engine_load_db", "uc_engine_set_db", "uc_engine_num_seqs",
-    "uc_engine_prefilter", "uc_engine_hits_size", "uc_engine_hits_get", "uc_engine_hits_set", "uc_engine_hits_merge",
+    "uc_engine_prefilter", "uc_engine_prefilter_range", "uc_engine_hits_size", "uc_engine_hits_get", "uc_engine_hits_set", "uc_engine_hits_merge",
     "uc_engine_hits_export_dev", "uc_engine_hits_import_dev",
     "uc_hits_merge", "uc_engine_align", "uc_engine_alns_get", "uc_engine_edges_size", "uc_engine_edges_get",
     "uc_engine_stats", "uc_engine_reset_stats", "uc_setcover", "uc_write_cluster_db",
@@ -77,6 +77,9 @@ def lib():
     L.uc_check_options.argtypes = [C.c_char_p]
     L.uc_cluster.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(UcOpts), C.POINTER(UcStats)]
     L.uc_createtsv.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(UcOpts)]
+    L.uc_search.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(UcOpts), C.POINTER(UcStats)]
+    L.uc_convertalis.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(UcOpts)]
+    L.uc_engine_prefilter_range.argtypes = [vp, u32, u32, u32, u32]
     L.uc_rmdb.argtypes = [C.c_char_p]
     L.uc_engine_create.argtypes = [C.POINTER(UcOpts), C.POINTER(vp)]
     L.uc_engine_destroy.argtypes = [vp]
@@ -144,6 +147,19 @@ def createtsv(db, cluster_db, out_tsv, verbosity=1):
     _check(lib().uc_createtsv(db.encode(), cluster_db.encode(), out_tsv.encode(), C.byref(o)))
 
 
+def search(query_db, target_db, out_aln_db, tmp, search_options="-c 0.8", threads=1, verbosity=1, device=-1):
+    """== `foldseek search` (search.rs:44-50).  Returns the stats dict."""
+    o, st = make_opts(search_options, threads, verbosity, device), UcStats()
+    _check(lib().uc_search(query_db.encode(), target_db.encode(), out_aln_db.encode(), tmp.encode(), C.byref(o), C.byref(st)))
+    return st.as_dict()
+
+
+def convertalis(query_db, target_db, aln_db, out_m8, verbosity=1):
+    """== `foldseek convertalis` (search.rs:57-60)"""
+    o = make_opts("", 1, verbosity)
+    _check(lib().uc_convertalis(query_db.encode(), target_db.encode(), aln_db.encode(), out_m8.encode(), C.byref(o)))
+
+
 def rmdb(prefix):
     _check(lib().uc_rmdb(prefix.encode()))
 
@@ -200,8 +216,12 @@ class Engine:
     def n(self):
         return int(lib().uc_engine_num_seqs(self._h))
 
-    def prefilter(self, tbegin=0, tend=None):
-        _check(lib().uc_engine_prefilter(self._h, tbegin, self.n if tend is None else tend))
+    def prefilter(self, tbegin=0, tend=None, qbegin=None, qend=None):
+        tend = self.n if tend is None else tend
+        if qbegin is None and qend is None:
+            _check(lib().uc_engine_prefilter(self._h, tbegin, tend))
+        else:
+            _check(lib().uc_engine_prefilter_range(self._h, tbegin, tend, qbegin or 0, self.n if qend is None else qend))
 
     def hits_size(self):
         nh = C.c_uint64()

@@ -5,6 +5,8 @@
 //   cluster   --threads T -v V <db> <out>_cluster <tmp> <opts...>     cluster.rs:45-49
 //   createtsv --threads T -v V <db> <db> <out>_cluster <out>.tsv      cluster.rs:59-62
 //   rmdb      <out>_cluster -v V                                       cluster.rs:67-73
+//   search    --threads T <queryDB> <targetDB> <out>_aln <tmp> <opts...>   search.rs:44-50
+//   convertalis --threads T <queryDB> <targetDB> <out>_aln <out>.m8        search.rs:57-60
 //   version
 // Exit status is the only error channel (src/util/command.rs:10-14): 0 ok, non-zero + stderr text otherwise.
 #include <cstdio>
@@ -21,7 +23,7 @@ static int die(int rc) {
 }
 
 int main(int argc, char **argv) {
-    if (argc < 2) { fprintf(stderr, "usage: foldseek <cluster|createtsv|rmdb|version> ...\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: foldseek <cluster|createtsv|search|convertalis|rmdb|version> ...\n"); return 2; }
     const std::string cmd = argv[1];
     if (cmd == "version") { puts(uc_version()); return 0; }
     // flags may appear anywhere; --threads / -v are consumed here, everything else that starts with '-'
@@ -36,9 +38,9 @@ int main(int argc, char **argv) {
         else if (a.size() > 1 && a[0] == '-' && !(a[1] >= '0' && a[1] <= '9')) {
             opts += (opts.empty() ? "" : " ") + a;
             // a following token that is not itself a flag is this flag's value
-            if (i + 1 < argc && !(argv[i + 1][0] == '-' && !(argv[i + 1][1] >= '0' && argv[i + 1][1] <= '9')) && pos.size() >= (cmd == "cluster" ? 3u : 99u))
+            if (i + 1 < argc && !(argv[i + 1][0] == '-' && !(argv[i + 1][1] >= '0' && argv[i + 1][1] <= '9')) && pos.size() >= (cmd == "cluster" ? 3u : cmd == "search" ? 4u : 99u))
                 opts += std::string(" ") + argv[++i];
-        } else if (cmd == "cluster" && pos.size() >= 3) opts += (opts.empty() ? "" : " ") + a;
+        } else if ((cmd == "cluster" && pos.size() >= 3) || (cmd == "search" && pos.size() >= 4)) opts += (opts.empty() ? "" : " ") + a;
         else pos.push_back(a);
     }
     uc_opts o;
@@ -58,11 +60,21 @@ int main(int argc, char **argv) {
         int rc = uc_createtsv(pos[0].c_str(), pos[2].c_str(), pos[3].c_str(), &o);
         return rc ? die(rc) : 0;
     }
+    if (cmd == "search") {
+        if (pos.size() != 4) { fprintf(stderr, "Error: search expects <queryDB> <targetDB> <alnDB> <tmp>\n"); return 2; }
+        int rc = uc_search(pos[0].c_str(), pos[1].c_str(), pos[2].c_str(), pos[3].c_str(), &o, nullptr);
+        return rc ? die(rc) : 0;
+    }
+    if (cmd == "convertalis") {
+        if (pos.size() != 4) { fprintf(stderr, "Error: convertalis expects <queryDB> <targetDB> <alnDB> <out.m8>\n"); return 2; }
+        int rc = uc_convertalis(pos[0].c_str(), pos[1].c_str(), pos[2].c_str(), pos[3].c_str(), &o);
+        return rc ? die(rc) : 0;
+    }
     if (cmd == "rmdb") {
         if (pos.size() != 1) { fprintf(stderr, "Error: rmdb expects <db>\n"); return 2; }
         int rc = uc_rmdb(pos[0].c_str());
         return rc ? die(rc) : 0;
     }
-    fprintf(stderr, "Error: sub-command '%s' is not provided by this engine (cluster, createtsv, rmdb, version)\n", cmd.c_str());
+    fprintf(stderr, "Error: sub-command '%s' is not provided by this engine (cluster, createtsv, search, convertalis, rmdb, version)\n", cmd.c_str());
     return 2;
 }

@@ -1,4 +1,4 @@
-// unicore_main.cpp — C++ host mirror of the reference's `unicore cluster` module surface.
+// unicore_main.cpp — C++ host mirror of the reference's `unicore cluster` (and `unicore search`) module surface.
 // (The reference host is Rust; no Rust toolchain exists in this image — SURVEY.md 0.2/D3 — so the host
 // above the C ABI is C++ with the same names, argument meaning and error behaviour.)
 //   CLI surface      /root/reference/src/util/arg_parser.rs:225-246  (Commands::Cluster)
@@ -97,15 +97,63 @@ int cluster_run(const std::string &input, const std::string &output, const std::
     return 0;
 }
 
+void usage_search() {
+    puts("Usage: unicore search [OPTIONS] <INPUT> <TARGET> <OUTPUT> <TMP>\n\n"
+         "Arguments:\n"
+         "  <INPUT>   Input database\n"
+         "  <TARGET>  Target database to search against\n"
+         "  <OUTPUT>  Output prefix; the result will be saved as OUTPUT.m8\n"
+         "  <TMP>     Temp directory\n\n"
+         "Options:\n"
+         "  -k, --keep-aln-db                Keep intermediate Foldseek alignment database\n"
+         "  -s, --search-options <STRING>    Arguments for foldseek-style options in string e.g. -s \"-c 0.8\" [default: \"-c 0.8\"]\n"
+         "      --threads <THREADS>          Number of threads to use; 0 to use all [default: 0]\n"
+         "  -v, --verbosity <VERBOSITY>      Verbosity (0: quiet, 1: +errors, 2: +warnings, 3: +info, 4: +debug) [default: 3]\n"
+         "  -h, --help                       Print help");
+}
+
+// modules::search::run (search.rs:8-84)
+int search_run(const std::string &input, const std::string &target, const std::string &output, const std::string &tmp, bool keep_aln_db,
+               const std::string &search_options, int threads) {
+    const int engine_verbosity = g_verbosity == 4 ? 3 : g_verbosity == 3 ? 2 : g_verbosity;
+    size_t slash = output.find_last_of('/');
+    std::string parent = slash == std::string::npos ? "." : (slash == 0 ? "/" : output.substr(0, slash));   // search.rs:21-29
+    create_dir_all(parent);
+    write_checkpoint(parent + "/search.chk", "0");   // search.rs:32
+    const std::string output_aln_db = output + "_aln", output_m8 = output + ".m8";   // search.rs:43-44
+    uc_opts o;
+    memset(&o, 0, sizeof o);
+    o.struct_size = sizeof o;
+    o.threads = threads;
+    o.verbosity = engine_verbosity;
+    o.device = -1;
+    o.cluster_options = search_options.c_str();
+    print_message("Running search on the MI355X engine...", 3);
+    if (g_verbosity >= 3) putchar('\n');
+    // search.rs:45-46 hands <TARGET> to `foldseek search` as the query DB and <INPUT> as the target DB; kept as is
+    int rc = uc_search(target.c_str(), input.c_str(), output_aln_db.c_str(), tmp.c_str(), &o, nullptr);   // search.rs:45-55
+    if (rc != 0) error(ERR_GENERAL, std::string("search engine failed with code ") + std::to_string(rc) + "\n" + uc_last_error());
+    println_message(" Done", 3);
+    rc = uc_convertalis(target.c_str(), input.c_str(), output_aln_db.c_str(), output_m8.c_str(), &o);     // search.rs:57-63
+    if (rc != 0) error(ERR_GENERAL, std::string("convertalis failed with code ") + std::to_string(rc) + "\n" + uc_last_error());
+    if (!keep_aln_db) {                                                                                   // search.rs:66-75
+        rc = uc_rmdb(output_aln_db.c_str());
+        if (rc != 0) error(ERR_GENERAL, std::string("rmdb failed with code ") + std::to_string(rc) + "\n" + uc_last_error());
+    }
+    write_checkpoint(parent + "/search.chk", "1");   // search.rs:80
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
     if (argc < 2 || !strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) { usage(); return argc < 2 ? 2 : 0; }
     if (!strcmp(argv[1], "version") || !strcmp(argv[1], "--version")) { puts(uc_version()); return 0; }
-    if (strcmp(argv[1], "cluster") != 0) error(0x30 /* ERR_MODULE_NOT_IMPLEMENTED */, argv[1]);
+    const bool is_search = !strcmp(argv[1], "search");
+    if (strcmp(argv[1], "cluster") != 0 && !is_search) error(0x30 /* ERR_MODULE_NOT_IMPLEMENTED */, argv[1]);
     std::vector<std::string> pos;
     bool keep = false;
-    std::string copts = "-c 0.8";   // arg_parser.rs:238-239
+    std::string copts = "-c 0.8";   // arg_parser.rs:238-239 (cluster), :262-263 (search)
     int threads = 0, verbosity = 3;
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i];
@@ -113,16 +161,19 @@ int main(int argc, char **argv) {
             if (i + 1 >= argc) error(ERR_ARGPARSE, "cluster - missing value for " + a);
             return argv[++i];
         };
-        if (a == "-k" || a == "--keep-cluster-db") keep = true;
-        else if (a == "-c" || a == "--cluster-options") copts = value();
-        else if (a.rfind("--cluster-options=", 0) == 0) copts = a.substr(18);
+        if (a == "-k" || a == (is_search ? "--keep-aln-db" : "--keep-cluster-db")) keep = true;
+        else if (!is_search && (a == "-c" || a == "--cluster-options")) copts = value();
+        else if (!is_search && a.rfind("--cluster-options=", 0) == 0) copts = a.substr(18);
+        else if (is_search && (a == "-s" || a == "--search-options")) copts = value();
+        else if (is_search && a.rfind("--search-options=", 0) == 0) copts = a.substr(17);
         else if (a == "--threads") threads = atoi(value().c_str());
         else if (a == "-v" || a == "--verbosity") verbosity = atoi(value().c_str());
-        else if (a == "-h" || a == "--help") { usage(); return 0; }
+        else if (a == "-h" || a == "--help") { if (is_search) usage_search(); else usage(); return 0; }
         else if (a.size() > 1 && a[0] == '-') error(ERR_ARGPARSE, "cluster - unexpected argument " + a);
         else pos.push_back(a);
     }
-    if (pos.size() != 3) { usage(); error(ERR_ARGPARSE, "cluster - expected <INPUT> <OUTPUT> <TMP>"); }
+    if (is_search && pos.size() != 4) { usage_search(); error(ERR_ARGPARSE, "search - expected <INPUT> <TARGET> <OUTPUT> <TMP>"); }
+    if (!is_search && pos.size() != 3) { usage(); error(ERR_ARGPARSE, "cluster - expected <INPUT> <OUTPUT> <TMP>"); }
     if (verbosity < 0 || verbosity > 4) error(ERR_ARGPARSE, "cluster - verbosity");
     g_verbosity = verbosity;
     // set_threads (variables.rs:155-166): 0 -> all CPUs, clamp to the CPU count
@@ -133,5 +184,6 @@ int main(int argc, char **argv) {
         threads = cpus;
     }
     if (threads <= 0) threads = cpus;
+    if (is_search) return search_run(pos[0], pos[1], pos[2], pos[3], keep, copts, threads);
     return cluster_run(pos[0], pos[1], pos[2], keep, copts, threads);
 }

@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(256) aln_basic_kernel(uint32_t n, const uint32
         a.score = s0[i]; a.score_rev = s1 ? s1[i] : 0; a.corrected = a.score - a.score_rev;
         // positions are only defined (and only exact) for pairs that pass the E-value gate
         a.qstart = -1; a.qend = pass[i] ? qe[i] : -1; a.tstart = -1; a.tend = pass[i] ? te[i] : -1;
-        a.aln_len = 0; a.idents = 0; a.pass_evalue = (int32_t)pass[i]; a.accepted = 0;
+        a.aln_len = 0; a.idents = 0; a.pass_evalue = (int32_t)pass[i]; a.accepted = 0; a.gap_opens = 0;
         out[idx[i]] = a;
     }
 }
@@ -288,18 +288,21 @@ __global__ void __launch_bounds__(256) tb_gather_kernel(uint32_t n2, const uint3
     }
 }
 __global__ void __launch_bounds__(256) tb_apply_kernel(uint32_t n3, const uint32_t *idx3, const uint32_t *src3, const int32_t *pack,
-                                                       const uint32_t *idx2, const uint32_t *link, const uint32_t *idx0, float min_seq_id,
-                                                       uc_aln *alns, uint32_t *eflag) {
+                                                       const int32_t *gaps, const uint32_t *idx2, const uint32_t *link, const uint32_t *idx0,
+                                                       float min_seq_id, uc_aln *alns, uint32_t *eflag) {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n3; i += gridDim.x * 256) {
         const uint32_t i2 = src3[idx3[i]];
         uc_aln &a = alns[idx0[link[idx2[i2]]]];
         const uint32_t pk = (uint32_t)pack[i];
         a.aln_len = (int32_t)(pk >> 16);
         a.idents = (int32_t)(pk & 0xffffu);
-        const float sid = a.aln_len > 0 ? (float)a.idents / (float)a.aln_len : 0.0f;
-        const bool ok = sid >= min_seq_id;
-        a.accepted = ok;
-        eflag[i2] = ok;
+        if (gaps) a.gap_opens = gaps[i];
+        if (min_seq_id > 0.0f) {
+            const float sid = a.aln_len > 0 ? (float)a.idents / (float)a.aln_len : 0.0f;
+            const bool ok = sid >= min_seq_id;
+            a.accepted = ok;
+            eflag[i2] = ok;
+        }
     }
 }
 
@@ -406,12 +409,14 @@ static void build_plan(Engine &E, SwPlan &P, DevBuf<char> &tmp, uint32_t n, cons
 }
 
 // one launch per populated class; outputs are in the plan's sorted order.  Returns the number of launches.
-static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t *oqe, int32_t *ote, DevBuf<int32_t> &work) {
+static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t *oqe, int32_t *ote, DevBuf<int32_t> &work,
+                            const uint32_t *tb = nullptr) {
     const ClassTable &tab = h_tab[P.tab];
     SwArgs a;
     a.db = E.ddb; a.tasks = P.tasks.p; a.pt = P.st.p; a.pqe = P.sqe.p; a.pte = P.ste.p;
     a.pqs = P.has_starts ? P.sqs.p : nullptr; a.pts = P.has_starts ? P.sts.p : nullptr;
     a.oscore = os; a.oqe = oqe; a.ote = ote; a.open = E.p.gap_open; a.ext = E.p.gap_ext;
+    if (tb) { a.tb_diag = tb[0]; a.tb_ident = tb[1]; a.tb_open = tb[2]; a.tb_ext = tb[3]; }
     uint64_t launches = 0;
     for (int c = 0; c < tab.n; c++) {
         const uint32_t nt = P.task_base[c + 1] - P.task_base[c];
@@ -613,7 +618,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
     UC_HIP(hipSetDevice(device));
     Timer tm;
     hipStream_t s = stream;
-    const uint64_t dbres = hdb.residues();
+    const uint64_t dbres = evalue_residues ? evalue_residues : hdb.residues();
     if (d_alns.cap < std::max<uint64_t>(n_hits, 1)) {
         d_alns.reserve(std::max<uint64_t>(n_hits, 1));
         UC_HIP(hipMemsetAsync(d_alns.p, 0, n_hits * sizeof(uc_aln), s));
@@ -730,11 +735,11 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                                    q2o.p, t2o.p, ddb.len, p.cov, p.cov_mode, d_alns.p + b, eflag.p, mism.p);
                 scan_u32(*this, tmp, eflag.p, epos.p, n2, false);
                 uint32_t ne = scan_total(*this, eflag.p, epos.p, n2);
-                if (p.min_seq_id > 0.0f && ne) {
+                if ((p.min_seq_id > 0.0f || p.want_tb) && ne) {
                     // sequence-identity gate: (alignment length, identities) of the traceback on the box, computed by
                     // the MODE 3 pass of the gapped kernel for the pairs that passed the coverage gate
                     static DevBuf<uint32_t> q3, t3, src3;
-                    static DevBuf<int32_t> qs3, qe3, ts3, te3, pack3;
+                    static DevBuf<int32_t> qs3, qe3, ts3, te3, pack3, gaps3;
                     static SwPlan P3;
                     q3.reserve(ne); t3.reserve(ne); src3.reserve(ne); qs3.reserve(ne); qe3.reserve(ne); ts3.reserve(ne); te3.reserve(ne); pack3.reserve(ne);
                     hipLaunchKernelGGL(tb_gather_kernel, grid_for(n2), dim3(256), 0, s, n2, eflag.p, epos.p, P2.idx.p, link.p, Lidx, P2.sq.p,
@@ -745,8 +750,21 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                     stats.sw_kernel_ms += timed_ms_end();
                     stats.sw_kernel_launches += launches;
                     stats.sw_algorithmic_bytes += P3.alg_bytes;
-                    hipLaunchKernelGGL(tb_apply_kernel, grid_for(ne), dim3(256), 0, s, ne, P3.idx.p, src3.p, pack3.p, P2.idx.p, link.p, Lidx,
-                                       p.min_seq_id, d_alns.p + b, eflag.p);
+                    stats.cells_run += P3.cells;
+                    stats.n_sw_runs += P3.n;
+                    if (p.want_tb) {   // second statistic of the same traceback: number of gaps (BLAST-tab "gapopen")
+                        static const uint32_t tb_gaps[4] = {0u, 0u, 1u, 0u};
+                        gaps3.reserve(ne);
+                        timed_ms_begin();
+                        const uint64_t l2 = launch_plan(*this, P3, 3, gaps3.p, nullptr, nullptr, work, tb_gaps);
+                        stats.sw_kernel_ms += timed_ms_end();
+                        stats.sw_kernel_launches += l2;
+                        stats.sw_algorithmic_bytes += P3.alg_bytes;
+                        stats.cells_run += P3.cells;
+                        stats.n_sw_runs += P3.n;
+                    }
+                    hipLaunchKernelGGL(tb_apply_kernel, grid_for(ne), dim3(256), 0, s, ne, P3.idx.p, src3.p, pack3.p,
+                                       p.want_tb ? gaps3.p : (const int32_t *)nullptr, P2.idx.p, link.p, Lidx, p.min_seq_id, d_alns.p + b, eflag.p);
                     scan_u32(*this, tmp, eflag.p, epos.p, n2, false);
                     ne = scan_total(*this, eflag.p, epos.p, n2);
                 }

@@ -2,6 +2,8 @@
 // point converts failures into the status classes of the header and records uc_last_error().
 #include <sys/stat.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <memory>
 
@@ -32,8 +34,9 @@ int guard(F &&f) {
     }
 }
 
-Params params_from(const uc_opts *o) {
+Params params_from(const uc_opts *o, bool search = false) {
     Params p;
+    if (search) { p.evalue = 10.0; p.max_seqs = 1000; p.want_tb = 1; }   // `foldseek search` defaults (EXT-UNVERIFIED)
     if (o) {
         if (o->struct_size != sizeof(uc_opts)) fail(UC_ERR_ARGS, "uc_opts.struct_size mismatch (%u != %zu)", o->struct_size, sizeof(uc_opts));
         p.threads = o->threads > 0 ? o->threads : 1;
@@ -125,6 +128,10 @@ uint32_t uc_engine_num_seqs(const uc_engine *e) { return e && e->e ? e->e->hdb.n
 
 int uc_engine_prefilter(uc_engine *e, uint32_t tbegin, uint32_t tend) {
     return guard([&] { require(e, "engine"); e->e->prefilter(tbegin, tend); });
+}
+
+int uc_engine_prefilter_range(uc_engine *e, uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend) {
+    return guard([&] { require(e, "engine"); e->e->prefilter(tbegin, tend, qbegin, qend); });
 }
 
 int uc_engine_hits_size(const uc_engine *e, uint64_t *n_hits) {
@@ -327,6 +334,79 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
         E.stats.stage_seconds[UC_ST_OUTPUT] += to.seconds();
         logf(3, "unicore-cluster: %llu clusters -> %s\n", (unsigned long long)ncl, out_cluster_db);
         if (stats_out) *stats_out = E.stats;
+    });
+}
+
+int uc_search(const char *query_db, const char *target_db, const char *out_aln_db, const char *tmp, const uc_opts *o, uc_stats *stats_out) {
+    return guard([&] {
+        require(query_db, "query_db"); require(target_db, "target_db"); require(out_aln_db, "out_aln_db");
+        Params p = params_from(o, true);
+        p.want_tb = 1;
+        if (tmp && *tmp) mkdir_p(tmp);
+        Engine E(p, o ? o->device : -1);
+        Timer tl;
+        HostDb T, Q;
+        read_seq_db(target_db, T, false);
+        read_seq_db(query_db, Q, false);
+        const uint32_t nt = T.n, nq = Q.n, n = nt + nq;
+        if ((uint64_t)nt + nq >= (1u << 24)) fail(UC_ERR_ARGS, "this build supports < 2^24 sequences (query + target)");
+        // one loaded set: targets first, then queries; only [0, nt) is indexed, only [nt, n) are queries
+        HostDb &C = E.hdb;
+        C.n = n;
+        C.keys = T.keys; C.keys.insert(C.keys.end(), Q.keys.begin(), Q.keys.end());
+        C.off.resize((size_t)n + 1);
+        const uint64_t rt = T.residues();
+        for (uint32_t i = 0; i <= nt; i++) C.off[i] = T.off[i];
+        for (uint32_t i = 0; i <= nq; i++) C.off[nt + i] = rt + Q.off[i];
+        C.s3 = T.s3; C.s3.insert(C.s3.end(), Q.s3.begin(), Q.s3.end());
+        C.sa = T.sa; C.sa.insert(C.sa.end(), Q.sa.begin(), Q.sa.end());
+        E.stats.stage_seconds[UC_ST_LOAD] += tl.seconds();
+        E.evalue_residues = rt;
+        E.upload_db();
+        logf(3, "unicore-search: %u queries vs %u targets (%llu residues) on device %d\n", nq, nt, (unsigned long long)rt, E.device);
+        E.prefilter(0, nt, nt, n);
+        logf(3, "unicore-search: prefilter kept %llu pairs (k-score %d, max-seqs %d)\n", (unsigned long long)E.n_hits, p.kmer_thr, p.max_seqs);
+        E.align(nt, n);
+        Timer to;
+        std::vector<uc_hit> hits(std::max<uint64_t>(E.n_hits, 1));
+        std::vector<uc_aln> alns(std::max<uint64_t>(E.n_hits, 1));
+        if (E.n_hits) { E.get_hits(hits.data()); E.get_alns(0, E.n_hits, alns.data()); }
+        std::vector<std::vector<AlnRow>> rows(nq);
+        uint64_t n_acc = 0;
+        for (uint32_t q = 0; q < nq; q++) {
+            const uint32_t qi = nt + q;
+            const int lq = (int)C.len(qi);
+            std::vector<AlnRow> &rv = rows[q];
+            for (uint64_t k = E.hit_off[qi]; k < E.hit_off[qi + 1]; k++) {
+                const uc_aln &a = alns[k];
+                if (!a.accepted) continue;
+                const uint32_t t = hits[k].target;
+                AlnRow r;
+                r.tkey = T.keys[t];
+                r.corrected = a.corrected;
+                r.bits = (int32_t)((p.lambda * (double)a.corrected - std::log(p.Kconst)) / std::log(2.0));
+                r.evalue = p.Kconst * (double)lq * (double)rt * std::exp(-p.lambda * (double)a.corrected);
+                r.fident = a.aln_len > 0 ? (double)a.idents / (double)a.aln_len : 0.0;
+                r.qstart = a.qstart; r.qend = a.qend; r.qlen = lq; r.tstart = a.tstart; r.tend = a.tend; r.tlen = (int32_t)T.len(t);
+                r.aln_len = a.aln_len; r.idents = a.idents; r.gap_opens = a.gap_opens;
+                rv.push_back(r);
+            }
+            std::sort(rv.begin(), rv.end(), [](const AlnRow &x, const AlnRow &y) { return x.corrected != y.corrected ? x.corrected > y.corrected : x.tkey < y.tkey; });
+            n_acc += rv.size();
+        }
+        write_aln_db(out_aln_db, Q.keys, rows);
+        E.stats.stage_seconds[UC_ST_OUTPUT] += to.seconds();
+        logf(3, "unicore-search: %llu alignments, %llu accepted -> %s\n", (unsigned long long)E.stats.n_gapped_alignments, (unsigned long long)n_acc, out_aln_db);
+        E.stats.n_seqs = n;
+        if (stats_out) *stats_out = E.stats;
+    });
+}
+
+int uc_convertalis(const char *query_db, const char *target_db, const char *aln_db, const char *out_m8, const uc_opts *o) {
+    return guard([&] {
+        require(query_db, "query_db"); require(target_db, "target_db"); require(aln_db, "aln_db"); require(out_m8, "out_m8");
+        if (o) g_verbosity = o->verbosity;
+        convert_alis(query_db, target_db, aln_db, out_m8);
     });
 }
 

@@ -178,6 +178,83 @@ void create_tsv(const std::string &db_prefix, const std::string &cluster_db, con
     if (bad || rename(tmp.c_str(), out_tsv.c_str()) != 0) fail(UC_ERR_IO, "write error on %s", out_tsv.c_str());
 }
 
+void write_aln_db(const std::string &prefix, const std::vector<uint64_t> &qkeys, const std::vector<std::vector<AlnRow>> &rows) {
+    std::string tmpd = prefix + ".tmp_data", tmpi = prefix + ".tmp_index";
+    FILE *fd = fopen(tmpd.c_str(), "wb"), *fi = fopen(tmpi.c_str(), "wb");
+    if (!fd || !fi) { if (fd) fclose(fd); if (fi) fclose(fi); fail(UC_ERR_IO, "cannot write alignment DB %s", prefix.c_str()); }
+    uint64_t off = 0;
+    for (size_t q = 0; q < qkeys.size(); q++) {
+        uint64_t len = 0;
+        for (const AlnRow &r : rows[q]) {
+            const int k = fprintf(fd, "%llu\t%d\t%.3f\t%.3E\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n", (unsigned long long)r.tkey, r.bits, r.fident,
+                                  r.evalue, r.qstart, r.qend, r.qlen, r.tstart, r.tend, r.tlen, r.aln_len, r.idents, r.gap_opens, r.corrected);
+            if (k > 0) len += (uint64_t)k;
+        }
+        fputc(0, fd); len += 1;
+        fprintf(fi, "%llu\t%llu\t%llu\n", (unsigned long long)qkeys[q], (unsigned long long)off, (unsigned long long)len);
+        off += len;
+    }
+    bool bad = ferror(fd) || ferror(fi);
+    bad |= fclose(fd) != 0;
+    bad |= fclose(fi) != 0;
+    if (bad) fail(UC_ERR_IO, "write error on alignment DB %s", prefix.c_str());
+    if (rename(tmpd.c_str(), prefix.c_str()) != 0 || rename(tmpi.c_str(), (prefix + ".index").c_str()) != 0)
+        fail(UC_ERR_IO, "cannot finalize alignment DB %s", prefix.c_str());
+    write_dbtype(prefix + ".dbtype", 5);
+}
+
+static std::unordered_map<uint64_t, std::string> header_names(const std::string &db_prefix) {
+    std::vector<IndexEntry> ih = read_index(db_prefix + "_h.index");
+    std::string dh = read_whole_file(db_prefix + "_h");
+    std::unordered_map<uint64_t, std::string> name;
+    name.reserve(ih.size() * 2);
+    for (const IndexEntry &e : ih) {
+        size_t b = e.off, x = b;
+        while (x < dh.size() && dh[x] && dh[x] != ' ' && dh[x] != '\t' && dh[x] != '\n') x++;
+        name[e.key] = dh.substr(b, x - b);
+    }
+    return name;
+}
+
+void convert_alis(const std::string &query_db, const std::string &target_db, const std::string &aln_db, const std::string &out_m8) {
+    const auto qname = header_names(query_db);
+    const auto tname_own = query_db == target_db ? std::unordered_map<uint64_t, std::string>() : header_names(target_db);
+    const auto &tname = query_db == target_db ? qname : tname_own;
+    std::vector<IndexEntry> ia = read_index(aln_db + ".index");
+    std::string da = read_whole_file(aln_db);
+    std::string tmp = out_m8 + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) fail(UC_ERR_IO, "cannot write %s", out_m8.c_str());
+    for (const IndexEntry &e : ia) {
+        auto qit = qname.find(e.key);
+        if (qit == qname.end()) { fclose(f); fail(UC_ERR_IO, "alignment DB query key %llu not in %s_h", (unsigned long long)e.key, query_db.c_str()); }
+        size_t p = e.off;
+        const size_t end = std::min<size_t>(e.off + e.len, da.size());
+        while (p < end && da[p]) {
+            size_t eol = p;
+            while (eol < end && da[eol] && da[eol] != '\n') eol++;
+            const std::string line = da.substr(p, eol - p);
+            p = eol < end && da[eol] == '\n' ? eol + 1 : eol;
+            unsigned long long tkey = 0;
+            int bits, qs, qe, ql, ts, te, tl, alen, idents, gaps, corrected;
+            char fid[32], ev[32];
+            if (sscanf(line.c_str(), "%llu\t%d\t%31s\t%31s\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d", &tkey, &bits, fid, ev, &qs, &qe, &ql, &ts, &te, &tl,
+                       &alen, &idents, &gaps, &corrected) != 14) {
+                fclose(f);
+                fail(UC_ERR_IO, "malformed row in alignment DB %s: '%s'", aln_db.c_str(), line.c_str());
+            }
+            auto tit = tname.find(tkey);
+            if (tit == tname.end()) { fclose(f); fail(UC_ERR_IO, "alignment DB target key %llu not in %s_h", tkey, target_db.c_str()); }
+            const int pairs = (qe - qs + 1) + (te - ts + 1) - alen;
+            fprintf(f, "%s\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%s\t%d\n", qit->second.c_str(), tit->second.c_str(), fid, alen, pairs - idents, gaps,
+                    qs + 1, qe + 1, ts + 1, te + 1, ev, bits);
+        }
+    }
+    bool bad = ferror(f);
+    bad |= fclose(f) != 0;
+    if (bad || rename(tmp.c_str(), out_m8.c_str()) != 0) fail(UC_ERR_IO, "write error on %s", out_m8.c_str());
+}
+
 void remove_db(const std::string &prefix) {
     static const char *sfx[] = {"", ".index", ".dbtype", ".lookup", ".source", "_h", "_h.index", "_h.dbtype", ".tmp_data", ".tmp_index"};
     for (const char *s : sfx) unlink((prefix + s).c_str());

@@ -30,6 +30,18 @@ void read_seq_db(const std::string &prefix, HostDb &db, bool with_headers);
 void write_cluster_db(const std::string &prefix, const std::vector<uint64_t> &keys, const uint32_t *assign, uint32_t n);
 // == foldseek createtsv (cluster.rs:59-64): "rep_name\tmember_name\n"
 void create_tsv(const std::string &db_prefix, const std::string &cluster_db, const std::string &out_tsv);
+// alignment DB (== `foldseek search` result kept by `unicore search -k`, search.rs:44-61): one entry per query key;
+// rows "targetKey bits fident evalue qstart qend qlen tstart tend tlen alnlen idents gapopen corrected" (tab separated,
+// positions 0-based, MMseqs2 column order + the integer statistics convertalis needs), entry "\0"-terminated; dbtype 5
+struct AlnRow {
+    uint64_t tkey;
+    int32_t bits, qstart, qend, qlen, tstart, tend, tlen, aln_len, idents, gap_opens, corrected;
+    double fident, evalue;
+};
+void write_aln_db(const std::string &prefix, const std::vector<uint64_t> &qkeys, const std::vector<std::vector<AlnRow>> &rows);
+// == foldseek convertalis (search.rs:52-57): BLAST-tab "query target fident alnlen mismatch gapopen qstart qend tstart
+// tend evalue bits", positions 1-based; names = first token of the header entries of the two DBs
+void convert_alis(const std::string &query_db, const std::string &target_db, const std::string &aln_db, const std::string &out_m8);
 // == foldseek rmdb (cluster.rs:67-76)
 void remove_db(const std::string &prefix);
 

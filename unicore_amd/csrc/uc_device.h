@@ -30,6 +30,9 @@ struct SwArgs {
     const int32_t *pqs = nullptr, *pts = nullptr;   // mode 3 only: box starts
     int32_t *oscore, *oqe, *ote;
     int open, ext;
+    // mode 3: what the traceback statistic adds per path step (diagonal step, identical AA on it, first residue of a gap,
+    // further gap residues).  Default = (alignment length << 16 | identities); (0,0,1,0) counts the gaps instead.
+    uint32_t tb_diag = 0x10000u, tb_ident = 1u, tb_open = 0x10000u, tb_ext = 0x10000u;
 };
 
 constexpr int SW_MAX_ROWS = 2048;   // largest single-strip class (G=64, R=32)

@@ -64,6 +64,7 @@ struct Engine {
     DeviceDb ddb;
 
     uint32_t max_len = 1;
+    uint64_t evalue_residues = 0;   // search path: residue count of the target DB (0 = the whole loaded DB)
 
     // stage outputs.  Hit lists (E4) and alignment records (E5/E6) are device-resident, grouped by query
     // in query order; the host keeps only the per-query counts/offsets and the accepted edges.
@@ -81,7 +82,8 @@ struct Engine {
     explicit Engine(const Params &pp, int dev);
     ~Engine();
     void upload_db();
-    void prefilter(uint32_t tbegin, uint32_t tend);                       // uc_prefilter.hip
+    // E1-E4: index targets [tbegin,tend), match queries [qbegin,qend) (default: all) against it       (uc_prefilter.hip)
+    void prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin = 0, uint32_t qend = UINT32_MAX);
     void set_hits(const uint32_t *counts, const uc_hit *h);
     void get_hits(uc_hit *out) const;                        // D2H of the device hit arrays
     void export_hits_dev(uint32_t *dq, uint32_t *dt, int32_t *ds, int32_t *dd) const;

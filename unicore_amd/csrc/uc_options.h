@@ -31,6 +31,7 @@ struct Params {
     // gapped alignment
     int gap_open = 10, gap_ext = 1;
     int rev_correction = 1;
+    int want_tb = 0;            // 1: traceback statistics (alnlen, idents, gaps) for every accepted pair (search path)
     int sym_dedup = 1;          // 1: mutual hits (q,t)/(t,q) share one forward and one reversed-query DP (needs symmetric matrices)
     bool mat_symmetric = false; // set by finalize_params
     int sw_pk = 1;              // 1: packed 16-bit DP kernel for queries <= 1024 rows (int32 re-run when flagged)

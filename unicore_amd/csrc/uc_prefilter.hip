@@ -567,9 +567,11 @@ struct WidenU32 {
     __host__ __device__ uint64_t operator()(uint32_t x) const { return (uint64_t)x; }
 };
 
-void Engine::prefilter(uint32_t tbegin, uint32_t tend) {
+void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend) {
     if (!have_db) fail(UC_ERR_ARGS, "no database loaded");
     if (tbegin > tend || tend > hdb.n) fail(UC_ERR_ARGS, "prefilter: bad target range");
+    if (qend == UINT32_MAX) qend = hdb.n;
+    if (qbegin > qend || qend > hdb.n) fail(UC_ERR_ARGS, "prefilter: bad query range");
     UC_HIP(hipSetDevice(device));
     const uint32_t n = hdb.n;
     KmerCfg cfg;
@@ -644,7 +646,7 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend) {
     uint64_t n_hits_total = 0, n_cand_total = 0, cand_cap = 0;
     double t_kmer = 0, t_ung = 0, t_sel = 0;
 
-    for (uint32_t qa = 0; qa < n;) {
+    for (uint32_t qa = qbegin; qa < qend;) {
         Timer t_b;
         timed_ms_begin();
         // choose batch [qa, qb) by estimated hits
@@ -652,7 +654,7 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend) {
         {
             const double budget = (double)HIT_CAP * 0.5;
             uint64_t res = 0;
-            while (qb < n && qb - qa < (1u << 23) - 1) {
+            while (qb < qend && qb - qa < (1u << 23) - 1) {
                 res += h_len[qb];
                 if (qb > qa && (double)res * hits_per_res > budget) break;
                 qb++;

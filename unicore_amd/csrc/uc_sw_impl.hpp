@@ -203,14 +203,14 @@ __global__ void __launch_bounds__(NW * 64) sw_group_kernel(const SwArgs a) {
                 if constexpr (TB) {
                     // predecessor preference of the traceback: diagonal, then F (gap in the target), then E;
                     // a gap state prefers leaving the gap (open) over staying in it
-                    const uint32_t ep = (T[r] >= (int)esub ? Hp[r] : Ep[r]) + 0x10000u;
-                    const uint32_t ident = ((qaw[r >> 2] >> (8 * (r & 3))) & 0xffu) == ca_col ? 1u : 0u;
-                    const uint32_t hp = h == 0 ? 0u : (x == h ? dHp + 0x10000u + ident : ((int)f == h ? fp : ep));
+                    const uint32_t ep = T[r] >= (int)esub ? Hp[r] + a.tb_open : Ep[r] + a.tb_ext;
+                    const uint32_t ident = ((qaw[r >> 2] >> (8 * (r & 3))) & 0xffu) == ca_col ? a.tb_ident : 0u;
+                    const uint32_t hp = h == 0 ? 0u : (x == h ? dHp + a.tb_diag + ident : ((int)f == h ? fp : ep));
                     dHp = Hp[r];
                     Hp[r] = hp;
                     Ep[r] = ep;
                     const uint32_t fsub_ = __builtin_elementwise_sub_sat(f, (uint32_t)ext);
-                    fp = (h - open >= (int)fsub_ ? hp : fp) + 0x10000u;
+                    fp = h - open >= (int)fsub_ ? hp + a.tb_open : fp + a.tb_ext;
                 }
                 diagT = T[r];
                 T[r] = h - open;
@@ -315,14 +315,14 @@ __global__ void __launch_bounds__(64) sw_generic_kernel(const SwArgs a, uint32_t
             const int h = max(max(x, e), max(fcur, 0));
             if constexpr (TB) {
                 const uint32_t hpleft = (uint32_t)HP[(size_t)i * stride], epleft = (uint32_t)EP[(size_t)i * stride];
-                const uint32_t ep = (hleft - open >= esub ? hpleft : epleft) + 0x10000u;
-                const uint32_t fpc = i == 0 ? 0x10000u : fp;    // fp already holds the pack of F(i,j)
-                const uint32_t hp = h == 0 ? 0u : (x == h ? dhp + 0x10000u + (qa == ta ? 1u : 0u) : (fcur == h ? fpc : ep));
+                const uint32_t ep = hleft - open >= esub ? hpleft + a.tb_open : epleft + a.tb_ext;
+                const uint32_t fpc = i == 0 ? a.tb_open : fp;    // fp already holds the pack of F(i,j)
+                const uint32_t hp = h == 0 ? 0u : (x == h ? dhp + a.tb_diag + (qa == ta ? a.tb_ident : 0u) : (fcur == h ? fpc : ep));
                 dhp = hpleft;
                 HP[(size_t)i * stride] = (int32_t)hp;
                 EP[(size_t)i * stride] = (int32_t)ep;
                 // pack of F(i+1,j): open from H(i,j) preferred over extending F(i,j)
-                fp = (h - open >= max(fcur - ext, 0) ? hp : fpc) + 0x10000u;
+                fp = h - open >= max(fcur - ext, 0) ? hp + a.tb_open : fpc + a.tb_ext;
                 if (j == lt - 1 && i == lq - 1) cap = hp;
             }
             hdiag = hleft;
