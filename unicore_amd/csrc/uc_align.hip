@@ -203,15 +203,23 @@ __global__ void __launch_bounds__(256) ugather_kernel(uint32_t n, const uint32_t
         qr[w] = fq[j]; tr[w] = ft[j]; jrep[w] = j;
     }
 }
-// forward results of the representatives (plan order) -> full key-sorted list; a mirror gets the score and the
-// "end unknown" mark (-2), which the exact re-run resolves for the pairs that pass the E-value gate
+// forward results of the representatives (plan order) -> full key-sorted list.  A mirror gets the score; its end
+// position is the representative's end with the roles swapped WHEN the packed kernel saw exactly one query row
+// reach the optimum (then that row's first optimal column is the overall first optimal column, so both tie-break
+// orders pick the same cell).  Otherwise it gets the "end unknown" mark (-2), which the exact re-run resolves for
+// the pairs that pass the E-value gate.  k < n_pk: the representative ran in a packed class (unique-row guarantee).
 __global__ void __launch_bounds__(256) uscatter_kernel(uint32_t nu, uint32_t n, const uint32_t *pidx, const uint32_t *jrep,
                                                        const uint32_t *mirror, const int32_t *su, const int32_t *qeu, const int32_t *teu,
-                                                       int32_t *s0, int32_t *qe0, int32_t *te0) {
+                                                       uint32_t n_pk, int ovf, int32_t *s0, int32_t *qe0, int32_t *te0) {
     for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nu; k += gridDim.x * 256) {
         const uint32_t j = jrep[pidx[k]];
         s0[j] = su[k]; qe0[j] = qeu[k]; te0[j] = teu[k];
-        if (j + 1 < n && mirror[j + 1]) { s0[j + 1] = su[k]; qe0[j + 1] = su[k] > 0 ? -2 : -1; te0[j + 1] = su[k] > 0 ? -2 : -1; }
+        if (j + 1 < n && mirror[j + 1]) {
+            const bool swap_ok = k < n_pk && su[k] < ovf && qeu[k] >= 0;
+            s0[j + 1] = su[k];
+            qe0[j + 1] = su[k] > 0 ? (swap_ok ? teu[k] : -2) : -1;
+            te0[j + 1] = su[k] > 0 ? (swap_ok ? qeu[k] : -2) : -1;
+        }
     }
 }
 // reversed-query pass: a flagged mirror whose representative is flagged too takes its value instead of running
@@ -679,8 +687,15 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                 hipLaunchKernelGGL(ugather_kernel, grid_for(n), dim3(256), 0, s, n, rep.p, rpos.p, fq.p, ft.p, qr.p, tr.p, jrep.p);
                 build_plan(*this, P0, tmp, nu, qr.p, tr.p, nullptr, nullptr, tab);
                 run_plan(*this, P0, 0, su.p, qeu.p, teu.p, work, tmp, /*ovf_only=*/true);
+                uint32_t n_pk0 = 0;   // packed classes form a prefix of the plan's sorted pair list
+                {
+                    const ClassTable &ct = h_tab[P0.tab];
+                    int npk = 0;
+                    while (npk < ct.n && ct.pk[npk]) npk++;
+                    n_pk0 = P0.pair_base[npk];
+                }
                 hipLaunchKernelGGL(uscatter_kernel, grid_for(nu), dim3(256), 0, s, nu, n, P0.idx.p, jrep.p, mirror.p, su.p, qeu.p, teu.p,
-                                   s0.p, qe0.p, te0.p);
+                                   n_pk0, SW_PK_OVF_HOST, s0.p, qe0.p, te0.p);
                 hipLaunchKernelGGL(cells_kernel, grid_for(n), dim3(256), 0, s, n, fq.p, ft.p, (const uint32_t *)nullptr, ddb.len, d_cells.p);
                 Lsq = fq.p; Lst = ft.p; Lidx = uidx.p;
             }
