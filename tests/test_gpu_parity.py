@@ -328,3 +328,28 @@ def test_search_m8_bytes(O, tmp_path, opts):
         assert r.returncode == 0, r.stderr
         assert open(cout + ".m8", "rb").read() == exp and not os.path.exists(cout + "_aln")
         assert open(str(tmp_path / "cli" / "search.chk")).read() == "1"
+
+
+def test_chunked_prefilter_equals_unchunked(O, small):
+    """large target ranges are indexed in chunks whose per-query lists are merged on the device: same lists, same
+    records (forced here with a tiny chunk size)"""
+    e = small["eng"]
+    e.prefilter()
+    cnt0, hits0 = e.hits()
+    st0 = e.stats()
+    os.environ["UC_PREFILTER_CHUNK_RES"] = "3000"
+    try:
+        e.prefilter()
+        cnt1, hits1 = e.hits()
+        # a sub-range of targets and of queries too (the search path's shape)
+        e.prefilter(5, 60, 10, 80)
+        cnt2, hits2 = e.hits()
+    finally:
+        del os.environ["UC_PREFILTER_CHUNK_RES"]
+    assert np.array_equal(cnt0, cnt1) and hits0.tobytes() == hits1.tobytes()
+    e.prefilter(5, 60, 10, 80)
+    cnt3, hits3 = e.hits()
+    assert np.array_equal(cnt2, cnt3) and hits2.tobytes() == hits3.tobytes()
+    assert cnt3[:10].sum() == 0 and cnt3[80:].sum() == 0 and cnt3.sum() > 0 and (hits3["target"] >= 5).all() and (hits3["target"] < 60).all()
+    st1 = e.stats()
+    assert st1["n_candidates"] - st0["n_candidates"] > 0

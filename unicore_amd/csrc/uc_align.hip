@@ -652,7 +652,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
     mism.reserve(1);
     UC_HIP(hipMemsetAsync(mism.p, 0, 4, s));
 
-    const uint64_t CHUNK = 64ull << 20;   // pairs per device batch
+    const uint64_t CHUNK = 256ull << 20;  // pairs per device batch (~150 B of plan/result state per pair; mutual hits only share a DP inside a batch)
     for (uint32_t qa = qbegin; qa < qend;) {
         uint32_t qb = qa;
         while (qb < qend && (qb == qa || hit_off[qb + 1] - hit_off[qa] <= CHUNK)) qb++;

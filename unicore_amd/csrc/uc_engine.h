@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "uc_common.h"
@@ -24,6 +25,7 @@ struct DevBuf {   // plain owning device allocation (hipMalloc), grows geometric
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(cap, o.cap); }
     void reserve(size_t n) {   // contents are NOT preserved
         if (n <= cap) return;
         release();
@@ -84,6 +86,8 @@ struct Engine {
     void upload_db();
     // E1-E4: index targets [tbegin,tend), match queries [qbegin,qend) (default: all) against it       (uc_prefilter.hip)
     void prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin = 0, uint32_t qend = UINT32_MAX);
+    void prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend, bool count_sims);   // one target chunk
+    uint64_t prefilter_chunk_residues = 96ull << 20;   // target residues per index chunk (keeps hits/query inside the LDS filter)
     void set_hits(const uint32_t *counts, const uc_hit *h);
     void get_hits(uc_hit *out) const;                        // D2H of the device hit arrays
     void export_hits_dev(uint32_t *dq, uint32_t *dt, int32_t *ds, int32_t *dd) const;

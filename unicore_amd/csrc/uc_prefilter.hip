@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -567,11 +568,61 @@ struct WidenU32 {
     __host__ __device__ uint64_t operator()(uint32_t x) const { return (uint64_t)x; }
 };
 
+// E1-E4 for a target range.  Large ranges are processed as several index chunks whose per-query top-M lists are
+// merged on the device (lossless, same argument as the multi-GPU shards): the double-hit filter keeps one query's
+// (target, diagonal) hashes in 2 x 2^19 LDS bits, which only works while a query has well under ~500 k k-mer hits,
+// i.e. up to ~100 M target residues per chunk at default sensitivity (at 760 M residues in one chunk 75 % of the
+// hits survived the filter and the key sort took 2/3 of the run).
 void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend) {
     if (!have_db) fail(UC_ERR_ARGS, "no database loaded");
     if (tbegin > tend || tend > hdb.n) fail(UC_ERR_ARGS, "prefilter: bad target range");
     if (qend == UINT32_MAX) qend = hdb.n;
     if (qbegin > qend || qend > hdb.n) fail(UC_ERR_ARGS, "prefilter: bad query range");
+    uint64_t chunk_res = prefilter_chunk_residues;
+    if (const char *ev = getenv("UC_PREFILTER_CHUNK_RES")) chunk_res = std::max<uint64_t>(1, strtoull(ev, nullptr, 10));
+    std::vector<std::pair<uint32_t, uint32_t>> chunks;
+    for (uint32_t b = tbegin; b < tend;) {
+        uint32_t e = b;
+        uint64_t res = 0;
+        while (e < tend && (e == b || res + h_len[e] <= chunk_res)) res += h_len[e++];
+        chunks.emplace_back(b, e);
+        b = e;
+    }
+    if (chunks.size() <= 1) {
+        prefilter_one(tbegin, tend, qbegin, qend, true);
+        stats.n_prefilter_hits += n_hits;
+        return;
+    }
+    DevBuf<uint32_t> aq, at, tq, tt;
+    DevBuf<int32_t> as, ad, ts, td;
+    uint64_t acc_n = 0;
+    for (size_t c = 0; c < chunks.size(); c++) {
+        prefilter_one(chunks[c].first, chunks[c].second, qbegin, qend, c == 0);
+        if (c == 0 || acc_n == 0) {
+            aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd);
+            acc_n = n_hits;
+        } else if (n_hits) {
+            const uint64_t tot = acc_n + n_hits;
+            tq.reserve(tot); tt.reserve(tot); ts.reserve(tot); td.reserve(tot);
+            UC_HIP(hipMemcpyAsync(tq.p, aq.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+            UC_HIP(hipMemcpyAsync(tt.p, at.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+            UC_HIP(hipMemcpyAsync(ts.p, as.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+            UC_HIP(hipMemcpyAsync(td.p, ad.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+            UC_HIP(hipMemcpyAsync(tq.p + acc_n, d_hq.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+            UC_HIP(hipMemcpyAsync(tt.p + acc_n, d_ht.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+            UC_HIP(hipMemcpyAsync(ts.p + acc_n, d_hs.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+            UC_HIP(hipMemcpyAsync(td.p + acc_n, d_hd.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+            UC_HIP(hipStreamSynchronize(stream));
+            acc_n = import_hits_dev(tot, tq.p, tt.p, ts.p, td.p, 0, 1);      // merge + truncate to max_seqs
+            aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd);
+        }
+    }
+    // install the accumulated lists (also rebuilds the per-query counts)
+    import_hits_dev(acc_n, aq.p, at.p, as.p, ad.p, 0, 1);
+    stats.n_prefilter_hits += n_hits;
+}
+
+void Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend, bool count_sims) {
     UC_HIP(hipSetDevice(device));
     const uint32_t n = hdb.n;
     KmerCfg cfg;
@@ -687,7 +738,7 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t
                 qb = qa + std::max<uint32_t>(1, (qb - qa) / 2);
                 continue;
             }
-            stats.n_sim_kmers += c5[0];
+            if (count_sims) stats.n_sim_kmers += c5[0];
             break;
         }
         if (total_hits > (1ull << 34)) fail(UC_ERR_GENERIC, "query %u alone produces %llu k-mer hits", qa, (unsigned long long)total_hits);
@@ -830,7 +881,6 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t
     const uint64_t ungapped_bytes = ovl + 16ull * n_cand_total;   // (overlap + 16) B per candidate, SURVEY.md 8(d)
     stats.n_kmer_hits += n_hits_total;
     stats.n_candidates += n_cand_total;
-    stats.n_prefilter_hits += n_hits;
     stats.algorithmic_bytes[UC_ST_KMER] += 8ull * stats.n_sim_kmers + 6ull * n_hits_total + 8ull * n_cand_total;
     stats.algorithmic_bytes[UC_ST_UNGAPPED] += ungapped_bytes;
     stats.algorithmic_bytes[UC_ST_SELECT] += 16ull * n_cand_total;
