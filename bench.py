@@ -153,14 +153,17 @@ def main():
     if "--max-seqs" in tok:
         max_seqs = int(tok[tok.index("--max-seqs") + 1])
 
+    phase = {}
+
     def step():
         return ucdist.cluster_step(eng, lens, rank, world, max_seqs, device=xdev if world > 1 else "cpu",
-                                   gpu_device=dev if (world > 1 and not os.environ.get("UC_HOST_EXCHANGE")) else None)
+                                   gpu_device=dev if (world > 1 and not os.environ.get("UC_HOST_EXCHANGE")) else None, timing=phase)
 
     assign = None
     for _ in range(args.warmup):
         assign, _ = step()
     eng.reset_stats()
+    phase.clear()
     barrier()
     t0 = time.perf_counter()
     n_aln = 0
@@ -209,6 +212,7 @@ def main():
             "prefilter_kernel_ms_per_step": st["prefilter_kernel_ms"] / steps,
             "sw_kernel_ms_per_step": st["sw_kernel_ms"] / steps,
             "sw_dp_runs_per_step": st["n_sw_runs"] // steps,
+            "phases_rank0_s_per_step": {k: v / steps for k, v in phase.items()},
             "counts_rank0_per_step": {k: st[k] // steps for k in ("n_sim_kmers", "n_kmer_hits", "n_filtered_hits", "n_candidates", "n_prefilter_hits",
                                                                   "n_gapped_alignments", "n_start_alignments", "n_edges")},
         }

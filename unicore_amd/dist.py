@@ -123,13 +123,23 @@ def merged_hits(parts, n_seqs, max_seqs):
     return hits_merge(n_seqs, max_seqs, parts)
 
 
-def cluster_step(engine, lens, rank, world, max_seqs, device="cpu", group=None, setcover=None, gpu_device=None):
-    """One pass of the sharded hot path on this rank.  Returns (assign or None, n_alignments_this_rank)."""
+def cluster_step(engine, lens, rank, world, max_seqs, device="cpu", group=None, setcover=None, gpu_device=None, timing=None):
+    """One pass of the sharded hot path on this rank.  Returns (assign or None, n_alignments_this_rank).
+    timing: optional dict that receives the wall seconds of the phases on this rank."""
+    import time
     from . import setcover as host_setcover
+
+    t = [time.perf_counter()]
+
+    def lap(name):
+        t.append(time.perf_counter())
+        if timing is not None:
+            timing[name] = timing.get(name, 0.0) + t[-1] - t[-2]
 
     n = len(lens)
     tb, te = shard_ranges(lens, world)[rank]
     engine.prefilter(tb, te)
+    lap("prefilter")
     if world > 1 and gpu_device is not None:
         # device-resident exchange; every rank then aligns the pairs it owns (unordered-pair hash) over all queries
         qb, qe = 0, n
@@ -144,11 +154,15 @@ def cluster_step(engine, lens, rank, world, max_seqs, device="cpu", group=None, 
     else:   # single GPU: the hit lists never leave HBM
         qb, qe = 0, n
         n_aln = engine.hits_size()
+    lap("exchange")
     engine.align(qb, qe)
+    lap("align")
     edges = engine.edges()
     if world > 1:
         edges = gather_edges(edges, device, group)
+    lap("edges")
     assign = None
     if rank == 0:
         assign = (setcover or host_setcover)(n, edges)
+    lap("setcover")
     return assign, n_aln
