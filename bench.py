@@ -192,7 +192,7 @@ def main():
             "metric": "3Di alignments/sec (cluster path)",
             "value": n_aln / dt, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "int32", "data": "synthetic",
+            "dtype": "u16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %d synthetic proteomes, %d seqs, %d residues, options '%s', gen_synth seed %#x"
                                    % (args.proteomes, n, int(lens.sum()), args.options, seed),
                        "alignments_per_step": n_aln // steps, "clusters": int((assign == np.arange(n)).sum()) if assign is not None else None,
@@ -203,6 +203,9 @@ def main():
                          "algorithmic_bytes_per_launch": st["sw_algorithmic_bytes"] / max(st["sw_kernel_launches"], 1),
                          "avg_launch_ms": st["sw_kernel_ms"] / max(st["sw_kernel_launches"], 1),
                          "launches": st["sw_kernel_launches"],
+                         "launch_overlap": "the length classes of a pass run concurrently on 4 HIP streams; avg_launch_ms = wall time of the "
+                                           "fork/join regions (HIP events on the engine stream) / launches, so the per-kernel durations "
+                                           "of a rocprofv3 trace sum to more than launches x avg_launch_ms",
                          "note": "integer-VALU-bound by design (SURVEY.md 8d): see valu_*",
                          "valu_gcups": cells_run / sw_s / 1e9 if sw_s > 0 else 0.0,
                          "valu_gcups_algorithmic": cells_alg / sw_s / 1e9 if sw_s > 0 else 0.0,

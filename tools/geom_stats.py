@@ -20,15 +20,22 @@ _, first = np.unique(key, return_index=True)          # one representative per u
 a, b = q[first], t[first]
 la, lb = lens[a], lens[b]
 lq, lt = np.minimum(la, lb), np.maximum(la, lb)       # shorter sequence is the query
-caps = np.array([64, 128, 192, 256, 320, 384, 512, 640, 768, 1024, 1280, 1536, 1792, 2048])
-G = np.array([16, 16, 16, 16, 16, 16, 32, 32, 32, 64, 64, 64, 64, 64])
-cls = np.searchsorted(caps, lq, side="left")
 print("unordered pairs", len(lq), "of directed", len(q))
-tot_u = tot_p = tot_f = 0
-for c in range(len(caps)):
-    m = cls == c
-    if not m.any(): continue
-    useful = (lq[m] * lt[m]).sum(); padded = (caps[c] * lt[m]).sum(); filled = (caps[c] * (lt[m] + G[c] - 1)).sum()
-    tot_u += useful; tot_p += padded; tot_f += filled
-    print("class cap %4d G %2d: pairs %8d  rows-eff %.3f  fill-eff %.3f  total %.3f  share-of-issued %.3f" % (caps[c], G[c], m.sum(), useful / padded, padded / filled, useful / filled, 0))
-print("ALL: rows-eff %.3f fill-eff %.3f total %.3f" % (tot_u / tot_p, tot_p / tot_f, tot_u / tot_f))
+TABLES = {
+    "current": ([64, 128, 192, 256, 320, 384, 512, 640, 768, 1024, 1280, 1536, 1792, 2048], [16] * 6 + [32] * 3 + [64] * 5),
+    "R%2 (32/64/128-row steps)": (list(range(32, 385, 32)) + list(range(448, 769, 64)) + list(range(896, 1537, 128)) + [1792, 2048],
+                                  [16] * 12 + [32] * 6 + [64] * 6 + [64, 64]),
+    "G=8 below 192": ([32, 64, 96, 128, 160, 192, 256, 320, 384, 512, 640, 768, 1024, 1280, 1536, 1792, 2048], [8] * 6 + [16] * 3 + [32] * 3 + [64] * 5),
+}
+for name, (caps, G) in TABLES.items():
+    caps, G = np.array(caps), np.array(G)
+    cls = np.searchsorted(caps, lq, side="left")
+    tot_u = tot_p = tot_f = 0
+    issued = []
+    for c in range(len(caps)):
+        m = cls == c
+        if not m.any(): issued.append(0); continue
+        useful = (lq[m] * lt[m]).sum(); padded = (caps[c] * lt[m]).sum(); filled = (caps[c] * (lt[m] + G[c] - 1)).sum()
+        tot_u += useful; tot_p += padded; tot_f += filled; issued.append(filled)
+    print("%-28s rows-eff %.3f fill-eff %.3f total %.3f  issued-share by class: %s" % (name, tot_u / tot_p, tot_p / tot_f, tot_u / tot_f,
+          " ".join("%d:%.2f" % (caps[c], issued[c] / tot_f) for c in range(len(caps)) if issued[c])))

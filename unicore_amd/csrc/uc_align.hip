@@ -20,8 +20,9 @@ constexpr int SW_PK_OVF_HOST = 65535 - 256;   // == SW_PK_OVF of uc_sw_pk_impl.h
 namespace {
 
 // Length classes.  Table 0: int32 kernel for everything (16 systolic classes + generic).  Table 1: the packed
-// 16-bit kernel for queries <= 1024 rows (its 4R+ registers per lane limit R to 16), int32 classes above.
-constexpr int MAXCLS = 20;
+// 16-bit kernel for queries <= 1536 rows in 24 classes with even R (its ~7R live registers limit R to 24), two int32
+// classes above.
+constexpr int MAXCLS = 28;
 struct ClassTable {
     int n;                 // systolic classes; index n = generic fallback (queries > cap[n-1])
     int cap[MAXCLS], G[MAXCLS], R[MAXCLS], pk[MAXCLS];
@@ -36,12 +37,12 @@ const ClassTable h_tab[2] = {
      {4, 8, 12, 16, 20, 24, 28, 32, 20, 24, 28, 32, 20, 24, 28, 32},
      {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
      {256, 256, 256, 256, 256, 256, 256, 256, 64, 64, 64, 64, 24, 24, 24, 24}},
-    {14,
-     {64, 128, 192, 256, 320, 384, 512, 640, 768, 1024, 1280, 1536, 1792, 2048},
-     {16, 16, 16, 16, 16, 16, 32, 32, 32, 64, 64, 64, 64, 64},
-     {4, 8, 12, 16, 20, 24, 16, 20, 24, 16, 20, 24, 28, 32},
-     {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0},
-     {64, 64, 64, 64, 64, 64, 64, 64, 64, 48, 48, 48, 24, 24}},
+    {26,
+     {32, 64, 96, 128, 160, 192, 224, 256, 288, 320, 352, 384, 448, 512, 576, 640, 704, 768, 896, 1024, 1152, 1280, 1408, 1536, 1792, 2048},
+     {16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 32, 32, 32, 32, 32, 32, 64, 64, 64, 64, 64, 64, 64, 64},
+     {2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 14, 16, 18, 20, 22, 24, 14, 16, 18, 20, 22, 24, 28, 32},
+     {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0},
+     {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 48, 48, 48, 48, 48, 48, 24, 24}},
 };
 __device__ __constant__ ClassTable c_tab[2];
 
@@ -426,15 +427,25 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
     a.oscore = os; a.oqe = oqe; a.ote = ote; a.open = E.p.gap_open; a.ext = E.p.gap_ext;
     if (tb) { a.tb_diag = tb[0]; a.tb_ident = tb[1]; a.tb_open = tb[2]; a.tb_ext = tb[3]; }
     uint64_t launches = 0;
-    for (int c = 0; c < tab.n; c++) {
+    // fork: the classes run concurrently on the auxiliary streams, largest classes first on distinct streams
+    UC_HIP(hipEventRecord(E.ev_fork, E.stream));
+    for (int i = 0; i < Engine::N_AUX; i++) UC_HIP(hipStreamWaitEvent(E.aux[i], E.ev_fork, 0));
+    int slot = 0;
+    for (int c = tab.n - 1; c >= 0; c--) {
         const uint32_t nt = P.task_base[c + 1] - P.task_base[c];
         if (!nt) continue;
         SwArgs ac = a;
         ac.tasks = P.tasks.p + P.task_base[c];
-        if (tab.pk[c]) launch_sw_pk_class(tab.G[c], tab.R[c], mode, ac, nt, E.stream);
-        else launch_sw_class(tab.G[c], tab.R[c], mode, ac, nt, E.stream);
+        hipStream_t st = slot % (Engine::N_AUX + 1) == 0 ? E.stream : E.aux[slot % (Engine::N_AUX + 1) - 1];
+        slot++;
+        if (tab.pk[c]) launch_sw_pk_class(tab.G[c], tab.R[c], mode, ac, nt, st);
+        else launch_sw_class(tab.G[c], tab.R[c], mode, ac, nt, st);
         UC_HIP(hipGetLastError());
         launches++;
+    }
+    for (int i = 0; i < Engine::N_AUX; i++) {   // join
+        UC_HIP(hipEventRecord(E.ev_join[i], E.aux[i]));
+        UC_HIP(hipStreamWaitEvent(E.stream, E.ev_join[i], 0));
     }
     const uint32_t gb = P.pair_base[tab.n], ngen = P.n - gb;
     if (ngen) {   // queries longer than the largest systolic class

@@ -23,6 +23,11 @@ Engine::Engine(const Params &pp, int dev) : p(pp) {
     UC_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     UC_HIP(hipEventCreate(&ev0));
     UC_HIP(hipEventCreate(&ev1));
+    UC_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < N_AUX; i++) {
+        UC_HIP(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
+        UC_HIP(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+    }
     d_S3.reserve(A * A);
     d_SA.reserve(A * A);
     UC_HIP(hipMemcpy(d_S3.p, p.S3, A * A, hipMemcpyHostToDevice));
@@ -33,6 +38,11 @@ Engine::Engine(const Params &pp, int dev) : p(pp) {
 Engine::~Engine() {
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    for (int i = 0; i < N_AUX; i++) {
+        if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+        if (aux[i]) (void)hipStreamDestroy(aux[i]);
+    }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (stream) (void)hipStreamDestroy(stream);
 }
 

@@ -36,8 +36,8 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return pk_u
 template <int G, int R, int MODE, int NW>
 __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
     constexpr bool TRACK = MODE != 1, MASK = MODE == 2, REVQ = MODE != 0, REVT = MODE == 2;
-    constexpr int RW = R / 4, BW = RW | 1, RSW = G * BW, NT = NW * 64;
-    static_assert(R % 4 == 0 && R <= 32, "R must be a multiple of 4, <= 32");
+    constexpr int RW = (R + 3) / 4, BW = RW | 1, RSW = G * BW, NT = NW * 64;   // R % 4 == 2: the last profile dword is half used
+    static_assert(R % 2 == 0 && R <= 32, "R must be even, <= 32");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *P3 = lds, *PA = lds + SW_NLET * RSW;
     uint32_t *slot_ctr = lds + 2 * SW_NLET * RSW;   // work counter of the task (one dword behind the profile)
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             const int row = gg * R + 4 * k + b;
-            if (row < lq && c < 21) {
+            if (row < lq && c < 21 && 4 * k + b < R) {
                 const int qi = REVQ ? lq - 1 - row : row;
                 const int q3 = a.db.s3[qoff + qi], qa = a.db.sa[qoff + qi];
                 w3 |= (uint32_t)(a.db.S3[q3 * 21 + c] + 64) << (8 * b);
@@ -251,7 +251,7 @@ template <int MODE>
 void launch_sw_pk_class_mode(int G, int R, const SwArgs &a, uint32_t n_tasks, hipStream_t s) {
 #define UC_SW_CASE(GG, RR)                                                                              \
     if (G == GG && R == RR) {                                                                           \
-        constexpr int BW = ((RR / 4) | 1);                                                              \
+        constexpr int BW = (((RR + 3) / 4) | 1);                                                        \
         constexpr int NW = GG == 16 ? 1 : (GG == 32 ? 2 : 8);   /* small workgroups share one LDS profile */ \
         const size_t lds = (size_t)2 * SW_NLET * GG * BW * 4 + 16;                                      \
         static bool attr_set = false;                                                                   \
@@ -264,8 +264,11 @@ void launch_sw_pk_class_mode(int G, int R, const SwArgs &a, uint32_t n_tasks, hi
         return;                                                                                         \
     }
     // ~5.5R live registers per lane keep the packed kernel to R <= 24 (queries up to 1536 rows)
-    UC_SW_CASE(16, 4) UC_SW_CASE(16, 8) UC_SW_CASE(16, 12) UC_SW_CASE(16, 16) UC_SW_CASE(16, 20) UC_SW_CASE(16, 24)
-    UC_SW_CASE(32, 16) UC_SW_CASE(32, 20) UC_SW_CASE(32, 24) UC_SW_CASE(64, 16) UC_SW_CASE(64, 20) UC_SW_CASE(64, 24)
+    // even R: 32-row class steps for G=16, 64 for G=32, 128 for G=64 (row padding 11.7 % -> 6.2 % at C2, tools/geom_stats.py)
+    UC_SW_CASE(16, 2) UC_SW_CASE(16, 4) UC_SW_CASE(16, 6) UC_SW_CASE(16, 8) UC_SW_CASE(16, 10) UC_SW_CASE(16, 12)
+    UC_SW_CASE(16, 14) UC_SW_CASE(16, 16) UC_SW_CASE(16, 18) UC_SW_CASE(16, 20) UC_SW_CASE(16, 22) UC_SW_CASE(16, 24)
+    UC_SW_CASE(32, 14) UC_SW_CASE(32, 16) UC_SW_CASE(32, 18) UC_SW_CASE(32, 20) UC_SW_CASE(32, 22) UC_SW_CASE(32, 24)
+    UC_SW_CASE(64, 14) UC_SW_CASE(64, 16) UC_SW_CASE(64, 18) UC_SW_CASE(64, 20) UC_SW_CASE(64, 22) UC_SW_CASE(64, 24)
 #undef UC_SW_CASE
     fprintf(stderr, "unicore-cluster: no packed SW kernel for class (G=%d, R=%d)\n", G, R);
     abort();
