@@ -353,3 +353,50 @@ def test_chunked_prefilter_equals_unchunked(O, small):
     assert cnt3[:10].sum() == 0 and cnt3[80:].sum() == 0 and cnt3.sum() > 0 and (hits3["target"] >= 5).all() and (hits3["target"] < 60).all()
     st1 = e.stats()
     assert st1["n_candidates"] - st0["n_candidates"] > 0
+
+
+def _scaled_matrix(src, dst, factor):
+    out = []
+    for line in open(src):
+        tok = line.split()
+        if line.startswith("#") or not tok or not tok[0].isalpha() or len(tok) < 3 or not tok[1].lstrip("-").isdigit():
+            out.append(line)
+        else:
+            out.append(tok[0] + " " + " ".join(str(max(-48, min(48, int(v) * factor))) for v in tok[1:]) + "\n")
+    open(dst, "w").writelines(out)
+
+
+def test_packed_kernel_overflow_is_rerun_in_int32(O, tmp_path):
+    """scores beyond the packed kernel's 16-bit range (0x7C00: H = max3 runs on f16 bit patterns) are detected and
+    recomputed exactly by the int32 kernel - forced with 4x-scaled matrices on near-identical 1400-residue pairs"""
+    import ctypes
+    import unicore_amd as U
+    m3, ma = str(tmp_path / "m3.out"), str(tmp_path / "ma.out")
+    _scaled_matrix(os.path.join(util.ROOT, "unicore_amd", "data", "mat3di_synthetic.out"), m3, 4)
+    _scaled_matrix(os.path.join(util.ROOT, "unicore_amd", "data", "blosum62.out"), ma, 4)
+    rng = np.random.default_rng(77)
+    s3, sa = [], []
+    for L in (1400, 1100, 700, 300):
+        b3, ba = rng.integers(0, 20, L, dtype=np.uint8), rng.integers(0, 20, L, dtype=np.uint8)
+        for _ in range(3):
+            a3, aa = b3.copy(), ba.copy()
+            mut = rng.random(L) < 0.03
+            a3[mut] = rng.integers(0, 20, int(mut.sum()), dtype=np.uint8)
+            s3.append(a3); sa.append(aa)
+    off, c3, ca = util.flat(s3, sa)
+    e = U.Engine("-c 0.8 --mat3di %s --mat-aa %s" % (m3, ma), verbosity=1)
+    e.set_db(off, c3, ca)
+    p = O.default_params()
+    assert O.lib().uco_load_matrix(m3.encode(), p.S3) == 0 and O.lib().uco_load_matrix(ma.encode(), p.SA) == 0
+    N = len(s3)
+    q, t = np.repeat(np.arange(N), N), np.tile(np.arange(N), N)
+    st0 = e.stats()["n_pk_reruns"]
+    for mode in (0, 1):
+        s, qe, te = e.sw(mode, q, t)
+        for i in range(len(q)):
+            exp = O.sw(s3[q[i]], sa[q[i]], s3[t[i]], sa[t[i]], p, rev_q=mode)
+            assert s[i] == exp[0], (mode, i)
+            if mode == 0:
+                assert (qe[i], te[i]) == exp[1:], (mode, i)
+    assert s.max() >= 0 and e.sw(0, q, t)[0].max() > 0x7C00         # the range was actually exceeded
+    assert e.stats()["n_pk_reruns"] > st0

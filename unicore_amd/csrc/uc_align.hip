@@ -15,7 +15,7 @@
 
 namespace uc {
 
-constexpr int SW_PK_OVF_HOST = 65535 - 256;   // == SW_PK_OVF of uc_sw_pk_impl.hpp
+constexpr int SW_PK_OVF_HOST = 0x7C00 - 256;   // == SW_PK_OVF of uc_sw_pk_impl.hpp
 
 namespace {
 

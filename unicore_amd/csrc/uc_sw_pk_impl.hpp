@@ -2,7 +2,7 @@
 // systolic-group design it shares).  The int32 kernel is integer-VALU-bound (every int32 VALU instruction
 // occupies its SIMD for 4 cycles, profiles/r1b_pmc_sw.txt), so the only lever left is instructions per cell:
 // here every DP register holds TWO alignments of the same query (target A in the low, target B in the high
-// 16 bits) and the recurrence runs on v_pk_{add,sub,max}_u16, i.e. ~6.6 VALU ops per cell instead of ~9.7.
+// 16 bits) and the recurrence runs on v_pk_{add,sub,max}_u16, i.e. ~6.3 VALU ops per cell instead of ~9.7.
 //
 //  * unsigned floored domain: H >= 0, E/F/T floored at 0 by saturating subtraction (exact for local
 //    alignment); x = sat_sub(sat_add(Hdiag, s + 128), 128) = max(Hdiag + s, 0); H = max(x, e, f).
@@ -11,7 +11,7 @@
 //  * end tracking: per lane the running maximum gives (score, first column) per half; per-row maxima
 //    (rowbest) identify the row: if exactly one row of the alignment ever reaches the optimum it must be the
 //    row of the first column too, so (qEnd, tEnd) is exact.  Otherwise — or if a value came within 256 of the
-//    u16 range — the pair is flagged (qEnd = -2 / score >= SW_PK_OVF) and re-run by the int32 kernel.
+//    packed score range (0x7C00, see SW_PK_OVF) — the pair is flagged (qEnd = -2 / score >= SW_PK_OVF) and re-run by the int32 kernel.
 //  * slot streaming: a "slot" is two consecutive pairs of the task (A, B).  Every lane group pulls its next
 //    slot from an LDS counter as soon as it has finished the previous one, so the groups of a wave do NOT
 //    run in lockstep over the longest of their targets (hit lists mix family members with unrelated hits of
@@ -24,7 +24,11 @@
 
 namespace uc {
 
-constexpr int SW_PK_OVF = 65535 - 256;   // scores at or above this are recomputed in int32
+// H = max(x, e, f) is ONE instruction: v_pk_maximum3_f16 orders non-negative 16-bit integers below 0x7C00 (the f16
+// infinity pattern) exactly like an unsigned max, denormal range included, at full rate, and returns >= 0x7C00 as
+// soon as an operand is >= 0x7C00 (tools/ubench/pk_max3_f16.hip: exhaustive check on gfx950) - so the packed score
+// range ends at 0x7C00 and an overflow is never lost (best/colmax are integer maxima, the flag is sticky).
+constexpr int SW_PK_OVF = 0x7C00 - 256;   // scores at or above this are recomputed in int32
 
 typedef uint16_t u16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2_t pk_v(uint32_t x) { return __builtin_bit_cast(u16x2_t, x); }
@@ -32,6 +36,11 @@ __device__ __forceinline__ uint32_t pk_u(u16x2_t v) { return __builtin_bit_cast(
 __device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b) { return pk_u(__builtin_elementwise_add_sat(pk_v(a), pk_v(b))); }
 __device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) { return pk_u(__builtin_elementwise_sub_sat(pk_v(a), pk_v(b))); }
 __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return pk_u(__builtin_elementwise_max(pk_v(a), pk_v(b))); }
+__device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 template <int G, int R, int MODE, int NW>
 __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
@@ -172,7 +181,7 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
             const uint32_t ub = __builtin_amdgcn_perm(sB[r >> 2], sA[r >> 2], 0x0c000c00u | ((4u + (r & 3)) << 16) | (uint32_t)(r & 3));
             const uint32_t x = pk_sub_sat(pk_add_sat(diag, ub), bias2);
             const uint32_t e = pk_max(pk_sub_sat(E[r], ext2), T[r]);
-            const uint32_t h = pk_max(pk_max(x, e), f);
+            const uint32_t h = pk_max3(x, e, f);
             diag = H[r];
             H[r] = h;
             T[r] = pk_sub_sat(h, open2);
