@@ -160,7 +160,7 @@ __device__ __forceinline__ bool query_kmer_at(const DeviceDb &db, const KmerCfg 
 // A run is (first index entry, entry count, query position inside the batch).  Threads enumerate divergently, so
 // runs are staged per wave in LDS and drained to global memory in blocks: whichever lanes are active when the
 // buffer is nearly full copy it out behind ONE global atomic.  Run order is irrelevant (keys get sorted).
-constexpr int RUN_STAGE = 512;    // staged runs per wave
+constexpr int RUN_STAGE = 256;    // staged runs per wave (12 KB of LDS per workgroup: 8 workgroups = 32 waves per CU hide the offset-table latency)
 
 struct RunList {
     uint32_t *pidx;     // query position inside the batch
