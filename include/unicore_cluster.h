@@ -150,6 +150,9 @@ void uc_engine_reset_stats(uc_engine *e);
 
 /* E7 (host, as the north star prescribes): greedy set cover over (a,b) pairs; assign[i] = representative */
 int uc_setcover(uint32_t n, const uint32_t *edges, uint64_t n_edges, uint32_t *assign);
+/* the same result with the graph built on the engine's GPU (sort + unique of the edge list) and only the greedy
+ * cover on the host: what uc_cluster and the bench step use */
+int uc_engine_setcover(uc_engine *e, const uint32_t *edges, uint64_t n_edges, uint32_t *assign);
 /* E8/E9 outputs from an assignment: cluster DB (<prefix>, .index, .dbtype) */
 int uc_write_cluster_db(const char *out_cluster_db, uint32_t n, const uint32_t *assign);
 

@@ -147,6 +147,7 @@ def test_pipeline_stage_parity(O, small, opts):
         assert st[a] == c[b], (a, st[a], c[b])
     assign = U.setcover(e.n, e.edges())
     assert np.array_equal(assign, ref["assign"])
+    assert np.array_equal(e.setcover(e.edges()), ref["assign"])          # graph built on the GPU, greedy cover on the host
     assert len(set(assign.tolist())) < e.n   # something actually clustered
     # the int32-only kernel path gives the same records
     e2 = U.Engine(opts + " --sw-kernel i32", verbosity=1)

@@ -49,7 +49,7 @@ SYMBOLS = (
     "uc_cluster", "uc_createtsv", "uc_rmdb", "uc_search", "uc_convertalis", "uc_last_error", "uc_version", "uc_check_options",
     "uc_engine_create", "uc_engine_destroy", "uc_engine_load_db", "uc_engine_set_db", "uc_engine_num_seqs",
     "uc_engine_prefilter", "uc_engine_prefilter_range", "uc_engine_hits_size", "uc_engine_hits_get", "uc_engine_hits_set", "uc_engine_hits_merge",
-    "uc_engine_hits_export_dev", "uc_engine_hits_import_dev",
+    "uc_engine_hits_export_dev", "uc_engine_hits_import_dev", "uc_engine_setcover",
     "uc_hits_merge", "uc_engine_align", "uc_engine_alns_get", "uc_engine_edges_size", "uc_engine_edges_get",
     "uc_engine_stats", "uc_engine_reset_stats", "uc_setcover", "uc_write_cluster_db",
     "uc_engine_ungapped_batch", "uc_engine_sw_batch",
@@ -94,6 +94,7 @@ def lib():
     L.uc_engine_hits_set.argtypes = [vp, vp, vp]
     L.uc_engine_hits_merge.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]
     L.uc_engine_hits_export_dev.argtypes = [vp, vp, vp, vp, vp]
+    L.uc_engine_setcover.argtypes = [vp, vp, u64, vp]
     L.uc_engine_hits_import_dev.argtypes = [vp, u64, vp, vp, vp, vp, u32, u32, C.POINTER(u64)]
     L.uc_hits_merge.argtypes = [u32, i32, C.c_int, C.POINTER(vp), C.POINTER(vp), vp, vp, u64, C.POINTER(u64)]
     L.uc_engine_align.argtypes = [vp, u32, u32]
@@ -250,6 +251,13 @@ class Engine:
         k = C.c_uint64()
         _check(lib().uc_engine_hits_import_dev(self._h, n, d_query, d_target, d_score, d_diag, rank, world, C.byref(k)))
         return int(k.value)
+
+    def setcover(self, edges):
+        """E7 with the graph built on this engine's GPU and the greedy cover on the host (same result as setcover())"""
+        e = np.ascontiguousarray(edges, np.uint32).reshape(-1, 2)
+        assign = np.zeros(self.n, np.uint32)
+        _check(lib().uc_engine_setcover(self._h, e.ctypes.data, len(e), assign.ctypes.data))
+        return assign
 
     def align(self, qbegin=0, qend=None):
         _check(lib().uc_engine_align(self._h, qbegin, self.n if qend is None else qend))

@@ -818,4 +818,69 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
     stats.stage_seconds[UC_ST_GAPPED] += tm.seconds();
 }
 
+// ---- E7 graph construction on the device (the greedy cover itself stays on the host, as the north star asks) ----
+// both directions of every accepted pair as 64-bit keys, self loops -> all-ones (sorted last, dropped)
+__global__ void __launch_bounds__(256) edge_key_kernel(uint64_t n_edges, const uint32_t *e, uint32_t n, uint64_t *key, uint32_t *bad) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_edges; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t a = e[2 * i], b = e[2 * i + 1];
+        if (a >= n || b >= n) { atomicAdd(bad, 1u); key[2 * i] = ~0ull; key[2 * i + 1] = ~0ull; continue; }
+        key[2 * i] = a == b ? ~0ull : ((uint64_t)a << 32) | b;
+        key[2 * i + 1] = a == b ? ~0ull : ((uint64_t)b << 32) | a;
+    }
+}
+__global__ void __launch_bounds__(256) edge_uniq_kernel(uint64_t m, const uint64_t *key, uint32_t *flag) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (uint64_t)gridDim.x * 256)
+        flag[i] = (key[i] != ~0ull && (i == 0 || key[i] != key[i - 1])) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) edge_adj_kernel(uint64_t m, const uint64_t *key, const uint32_t *flag, const uint32_t *pos,
+                                                       uint64_t *ukey, uint32_t *adj) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (uint64_t)gridDim.x * 256)
+        if (flag[i]) { ukey[pos[i]] = key[i]; adj[pos[i]] = (uint32_t)key[i]; }
+}
+__global__ void __launch_bounds__(256) edge_off_kernel(uint32_t n, const uint64_t *ukey, uint64_t mu, uint64_t *off) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i <= n; i += gridDim.x * 256) {
+        const uint64_t want = (uint64_t)i << 32;
+        uint64_t lo = 0, hi = mu;
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (ukey[mid] < want) lo = mid + 1; else hi = mid; }
+        off[i] = lo;
+    }
+}
+
+void Engine::set_cover_device(uint32_t n, const uint32_t *h_edges, uint64_t n_edges, uint32_t *assign) {
+    if (n_edges >= (1ull << 31)) { set_cover(n, h_edges, n_edges, assign); return; }   // 32-bit scan positions below
+    UC_HIP(hipSetDevice(device));
+    std::vector<uint64_t> off((size_t)n + 1, 0);
+    std::vector<uint32_t> adj;
+    if (n_edges) {
+        const uint64_t m = 2 * n_edges;
+        DevBuf<uint32_t> d_e, flag, pos, d_adj, bad;
+        DevBuf<uint64_t> key, key2, ukey, d_off;
+        DevBuf<char> tmp;
+        d_e.reserve(m); key.reserve(m); key2.reserve(m); flag.reserve(m); pos.reserve(m); bad.reserve(1); d_off.reserve((size_t)n + 1);
+        UC_HIP(hipMemcpyAsync(d_e.p, h_edges, m * 4, hipMemcpyHostToDevice, stream));
+        UC_HIP(hipMemsetAsync(bad.p, 0, 4, stream));
+        hipLaunchKernelGGL(edge_key_kernel, grid_for(n_edges), dim3(256), 0, stream, n_edges, d_e.p, n, key.p, bad.p);
+        size_t tb = 0;
+        UC_HIP(rocprim::radix_sort_keys(nullptr, tb, key.p, key2.p, (size_t)m, 0u, 64u, stream));
+        tmp.reserve(tb + 256);
+        UC_HIP(rocprim::radix_sort_keys(tmp.p, tb, key.p, key2.p, (size_t)m, 0u, 64u, stream));
+        hipLaunchKernelGGL(edge_uniq_kernel, grid_for(m), dim3(256), 0, stream, m, key2.p, flag.p);
+        scan_u32(*this, tmp, flag.p, pos.p, (uint32_t)m, false);
+        const uint32_t mu = scan_total(*this, flag.p, pos.p, (uint32_t)m);
+        uint32_t hbad = 0;
+        UC_HIP(hipMemcpy(&hbad, bad.p, 4, hipMemcpyDeviceToHost));
+        if (hbad) fail(UC_ERR_ARGS, "set cover: %u edges with an endpoint out of range", hbad);
+        ukey.reserve(std::max<uint32_t>(mu, 1)); d_adj.reserve(std::max<uint32_t>(mu, 1));
+        hipLaunchKernelGGL(edge_adj_kernel, grid_for(m), dim3(256), 0, stream, m, key2.p, flag.p, pos.p, ukey.p, d_adj.p);
+        hipLaunchKernelGGL(edge_off_kernel, grid_for((uint64_t)n + 1), dim3(256), 0, stream, n, ukey.p, (uint64_t)mu, d_off.p);
+        adj.resize(std::max<uint32_t>(mu, 1));
+        UC_HIP(hipMemcpyAsync(off.data(), d_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, stream));
+        if (mu) UC_HIP(hipMemcpyAsync(adj.data(), d_adj.p, (size_t)mu * 4, hipMemcpyDeviceToHost, stream));
+        UC_HIP(hipStreamSynchronize(stream));
+        UC_HIP(hipGetLastError());
+    }
+    if (adj.empty()) adj.resize(1);
+    set_cover_csr(n, off.data(), adj.data(), assign);
+}
+
 }  // namespace uc

@@ -240,6 +240,18 @@ int uc_setcover(uint32_t n, const uint32_t *edges, uint64_t n_edges, uint32_t *a
     });
 }
 
+int uc_engine_setcover(uc_engine *e, const uint32_t *edges, uint64_t n_edges, uint32_t *assign) {
+    return guard([&] {
+        require(e, "engine");
+        const uint32_t n = e->e->hdb.n;
+        if (n) require(assign, "assign");
+        if (n_edges) require(edges, "edges");
+        Timer tc;
+        e->e->set_cover_device(n, edges, n_edges, assign);
+        e->e->stats.stage_seconds[UC_ST_SETCOVER] += tc.seconds();
+    });
+}
+
 int uc_write_cluster_db(const char *out_cluster_db, uint32_t n, const uint32_t *assign) {
     return guard([&] {
         require(out_cluster_db, "out_cluster_db");
@@ -314,7 +326,7 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
             E.align(0, E.hdb.n);
             Timer tc;
             std::vector<uint32_t> sa(E.hdb.n);
-            set_cover(E.hdb.n, E.edges.data(), E.edges.size() / 2, sa.data());
+            E.set_cover_device(E.hdb.n, E.edges.data(), E.edges.size() / 2, sa.data());
             // mergeclusters: the representative of a sequence is the representative of its representative
             for (uint32_t i = 0; i < cur.size(); i++) posmap[cur[i]] = i;
             for (uint32_t x = 0; x < n; x++) assign[x] = cur[sa[posmap[assign[x]]]];

@@ -101,6 +101,8 @@ struct Engine {
     void get_alns(uint64_t begin, uint64_t n, uc_aln *out) const;
     void finish_hit_lists();                                  // counts/offsets from the device arrays
     void align(uint32_t qbegin, uint32_t qend);
+    // E7: adjacency (sort + unique of both edge directions) on the device, greedy cover on the host
+    void set_cover_device(uint32_t n, const uint32_t *h_edges, uint64_t n_edges, uint32_t *assign);
     // kernel-level
     void ungapped_batch(uint64_t n, const uint32_t *q, const uint32_t *t, const int32_t *diag, int32_t *out);
     void sw_batch(int mode, const std::vector<PairIn> &pairs, int32_t *score, int32_t *qe, int32_t *te);
@@ -110,6 +112,7 @@ struct Engine {
 };
 
 void set_cover(uint32_t n, const uint32_t *edges, uint64_t n_edges, uint32_t *assign);
+void set_cover_csr(uint32_t n, const uint64_t *off, const uint32_t *adj, uint32_t *assign);
 void merge_hits(uint32_t n, int max_seqs, int n_parts, const uint32_t *const *counts, const uc_hit *const *hits,
                 std::vector<uint32_t> &out_cnt, std::vector<uc_hit> &out_hits);
 const char *last_error_cstr();

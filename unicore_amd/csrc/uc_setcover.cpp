@@ -7,8 +7,13 @@
 // queue: counts only ever decrease, so buckets are drained from the top; a node sits in ONE bucket (a min-heap
 // by id) and is moved down lazily when it surfaces with a stale count — no push per decrement.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <queue>
 #include <thread>
 #include <vector>
@@ -17,43 +22,8 @@
 
 namespace uc {
 
-void set_cover(uint32_t n, const uint32_t *edges, uint64_t n_edges, uint32_t *assign) {
-    // ---- adjacency (both directions, self loops dropped), duplicates removed per node ----
-    std::vector<uint64_t> off((size_t)n + 2, 0);
-    for (uint64_t e = 0; e < n_edges; e++) {
-        const uint32_t a = edges[2 * e], b = edges[2 * e + 1];
-        if (a >= n || b >= n) fail(UC_ERR_ARGS, "set cover: edge (%u,%u) out of range", a, b);
-        if (a == b) continue;
-        off[a + 2]++; off[b + 2]++;
-    }
-    for (uint32_t i = 0; i < n; i++) off[i + 2] += off[i + 1];
-    std::vector<uint32_t> adj(off[n + 1]);
-    for (uint64_t e = 0; e < n_edges; e++) {       // off[i+1] is the fill cursor of node i
-        const uint32_t a = edges[2 * e], b = edges[2 * e + 1];
-        if (a == b) continue;
-        adj[off[a + 1]++] = b;
-        adj[off[b + 1]++] = a;
-    }
-    // now off[i] .. off[i+1] is node i's (unsorted, possibly duplicated) list
-    std::vector<uint32_t> deg(n);
-    {
-        const unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-        auto work = [&](uint32_t lo, uint32_t hi) {
-            for (uint32_t i = lo; i < hi; i++) {
-                uint32_t *b = adj.data() + off[i], *e = adj.data() + off[i + 1];
-                std::sort(b, e);
-                deg[i] = (uint32_t)(std::unique(b, e) - b);
-            }
-        };
-        if (n < 4096 || nthr == 1) work(0, n);
-        else {
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < nthr; t++)
-                th.emplace_back(work, (uint32_t)((uint64_t)n * t / nthr), (uint32_t)((uint64_t)n * (t + 1) / nthr));
-            for (auto &x : th) x.join();
-        }
-    }
-
+// the greedy cover on a CSR graph (deg[i] entries of node i start at off[i])
+static void greedy_cover(uint32_t n, const uint64_t *off, const uint32_t *adj, const uint32_t *deg, uint32_t *assign) {
     constexpr uint32_t NONE = UINT32_MAX;
     std::vector<uint32_t> cnt(n);
     uint32_t maxc = 1;
@@ -87,6 +57,89 @@ void set_cover(uint32_t n, const uint32_t *edges, uint64_t n_edges, uint32_t *as
     }
     for (uint32_t i = 0; i < n; i++)
         if (assign[i] == NONE) assign[i] = i;   // unreachable: every node has cnt >= 1
+}
+
+void set_cover(uint32_t n, const uint32_t *edges, uint64_t n_edges, uint32_t *assign) {
+    const bool timing = getenv("UC_SETCOVER_TIMING") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "set_cover: %-10s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
+    // ---- adjacency (both directions, self loops dropped), duplicates removed per node ----
+    // threaded counting sort with relaxed atomic counters / cursors (the order inside a node's list is irrelevant:
+    // every list is sorted next, so the result does not depend on the interleaving)
+    const unsigned nthr_all = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const unsigned T = (n_edges < (1u << 16) || n < 1024) ? 1u : std::min(16u, nthr_all);
+    std::vector<std::atomic<uint32_t>> cnt_a(n);
+    for (uint32_t i = 0; i < n; i++) cnt_a[i].store(0, std::memory_order_relaxed);
+    std::vector<int> bad(T, 0);
+    auto run_threads = [&](auto &&fn) {
+        if (T == 1) { fn(0u); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; t++) th.emplace_back(fn, t);
+        for (auto &x : th) x.join();
+    };
+    run_threads([&](unsigned t) {
+        const uint64_t lo = n_edges * t / T, hi = n_edges * (t + 1) / T;
+        for (uint64_t e = lo; e < hi; e++) {
+            const uint32_t a = edges[2 * e], b = edges[2 * e + 1];
+            if (a >= n || b >= n) { bad[t] = 1; return; }
+            if (a == b) continue;
+            cnt_a[a].fetch_add(1, std::memory_order_relaxed);
+            cnt_a[b].fetch_add(1, std::memory_order_relaxed);
+        }
+    });
+    for (unsigned t = 0; t < T; t++)
+        if (bad[t]) fail(UC_ERR_ARGS, "set cover: edge endpoint out of range");
+    std::vector<uint64_t> off((size_t)n + 1, 0);
+    for (uint32_t i = 0; i < n; i++) off[i + 1] = off[i] + cnt_a[i].load(std::memory_order_relaxed);
+    // uninitialised on purpose: a zero-filled 33 MB vector is first-touched (page-faulted) by ONE thread, ~10 ms at C2
+    std::unique_ptr<uint32_t[]> adj_mem(new uint32_t[std::max<uint64_t>(off[n], 1)]);
+    uint32_t *adj = adj_mem.get();
+    for (uint32_t i = 0; i < n; i++) cnt_a[i].store(0, std::memory_order_relaxed);   // now the fill cursor of node i
+    run_threads([&](unsigned t) {
+        const uint64_t lo = n_edges * t / T, hi = n_edges * (t + 1) / T;
+        for (uint64_t e = lo; e < hi; e++) {
+            const uint32_t a = edges[2 * e], b = edges[2 * e + 1];
+            if (a == b) continue;
+            adj[off[a] + cnt_a[a].fetch_add(1, std::memory_order_relaxed)] = b;
+            adj[off[b] + cnt_a[b].fetch_add(1, std::memory_order_relaxed)] = a;
+        }
+    });
+    lap("csr");
+    // now off[i] .. off[i+1] is node i's (unsorted, possibly duplicated) list
+    std::vector<uint32_t> deg(n);
+    {
+        const unsigned nthr = nthr_all;
+        auto work = [&](uint32_t lo, uint32_t hi) {
+            for (uint32_t i = lo; i < hi; i++) {
+                uint32_t *b = adj + off[i], *e = adj + off[i + 1];
+                std::sort(b, e);
+                deg[i] = (uint32_t)(std::unique(b, e) - b);
+            }
+        };
+        if (n < 4096 || nthr == 1) work(0, n);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nthr; t++)
+                th.emplace_back(work, (uint32_t)((uint64_t)n * t / nthr), (uint32_t)((uint64_t)n * (t + 1) / nthr));
+            for (auto &x : th) x.join();
+        }
+    }
+
+    lap("sort");
+    greedy_cover(n, off.data(), adj, deg.data(), assign);
+    lap("greedy");
+}
+
+// same rule on a graph that is already in CSR form with sorted, duplicate-free neighbour lists (off[n+1], adj)
+void set_cover_csr(uint32_t n, const uint64_t *off, const uint32_t *adj, uint32_t *assign) {
+    std::vector<uint32_t> deg(n);
+    for (uint32_t i = 0; i < n; i++) deg[i] = (uint32_t)(off[i + 1] - off[i]);
+    greedy_cover(n, off, adj, deg.data(), assign);
 }
 
 }  // namespace uc

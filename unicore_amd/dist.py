@@ -163,6 +163,6 @@ def cluster_step(engine, lens, rank, world, max_seqs, device="cpu", group=None, 
     lap("edges")
     assign = None
     if rank == 0:
-        assign = (setcover or host_setcover)(n, edges)
+        assign = setcover(n, edges) if setcover else (engine.setcover(edges) if hasattr(engine, "setcover") else host_setcover(n, edges))
     lap("setcover")
     return assign, n_aln
