@@ -243,6 +243,60 @@ __global__ void __launch_bounds__(256) cells_kernel(uint32_t n, const uint32_t *
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 
+// ---- start pass shared between mutual hits ----
+// The start pass of (q,t) with end cell (qe,te) and the one of its mirror (t,q) with end cell (te,qe) are transposed
+// DPs.  If the packed kernel saw exactly ONE row of the representative's DP reach the optimum, both tie-break orders
+// select the same cell, so the mirror's result is the representative's with the roles swapped; otherwise the mirror
+// is computed on its own (second round, together with the representatives whose end row was ambiguous).
+__global__ void __launch_bounds__(256) sm_flag_kernel(uint32_t n2, const uint32_t *link, const uint32_t *mirror, const uint32_t *gflag,
+                                                      const uint32_t *gpos, const int32_t *qe2, const int32_t *te2, const int32_t *qe0,
+                                                      const int32_t *te0, uint32_t *keep, uint32_t *partner) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
+        const uint32_t j = link[i];
+        const bool sm = mirror[j] && j > 0 && gflag[j - 1] && qe0[j - 1] >= 0 && qe2[i] == te0[j - 1] && te2[i] == qe0[j - 1];
+        keep[i] = sm ? 0u : 1u;
+        partner[i] = sm ? gpos[j - 1] : 0xFFFFFFFFu;
+    }
+}
+__global__ void __launch_bounds__(256) sm_gather_kernel(uint32_t n2, const uint32_t *flag, const uint32_t *pos, const uint32_t *q2,
+                                                        const uint32_t *t2, const int32_t *qe2, const int32_t *te2, uint32_t *qa,
+                                                        uint32_t *ta, int32_t *qea, int32_t *tea, uint32_t *map) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
+        if (!flag[i]) continue;
+        const uint32_t w = pos[i];
+        qa[w] = q2[i]; ta[w] = t2[i]; qea[w] = qe2[i]; tea[w] = te2[i]; map[w] = i;
+    }
+}
+// results of a sub-plan (plan order k) -> natural order of the gate-passer list; uniq = packed class, exactly one row
+__global__ void __launch_bounds__(256) sm_scatter_kernel(uint32_t na, const uint32_t *idx, const uint32_t *map, const int32_t *s,
+                                                         const int32_t *qo, const int32_t *to, uint32_t n_pk, int ovf, int32_t *s2,
+                                                         int32_t *q2o, int32_t *t2o, uint32_t *uniq) {
+    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < na; k += gridDim.x * 256) {
+        const uint32_t i = map ? map[idx[k]] : idx[k];
+        s2[i] = s[k]; q2o[i] = qo[k]; t2o[i] = to[k];
+        if (uniq) uniq[i] = (k < n_pk && qo[k] >= 0 && s[k] < ovf) ? 1u : 0u;
+    }
+}
+__global__ void __launch_bounds__(256) sm_resolve_kernel(uint32_t n2, const uint32_t *partner, const uint32_t *uniq, int32_t *s2,
+                                                         int32_t *q2o, int32_t *t2o) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
+        const uint32_t pr = partner[i];
+        if (pr == 0xFFFFFFFFu) continue;
+        if (uniq[pr]) { s2[i] = s2[pr]; q2o[i] = t2o[pr]; t2o[i] = q2o[pr]; }
+        else q2o[i] = -2;
+    }
+}
+__global__ void __launch_bounds__(256) iota_kernel(uint32_t n, uint32_t *out) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[i] = i;
+}
+// algorithmic cells of the start pass: (qEnd+1) x (tEnd+1) per gate passer
+__global__ void __launch_bounds__(256) cells_box_kernel(uint32_t n, const int32_t *qe, const int32_t *te, unsigned long long *out) {
+    unsigned long long c = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) c += (unsigned long long)(qe[i] + 1) * (unsigned long long)(te[i] + 1);
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
 __global__ void __launch_bounds__(256) gate_scatter_kernel(uint32_t n, const uint32_t *flag, const uint32_t *pos, const uint32_t *sq,
                                                            const uint32_t *st, const int32_t *qe, const int32_t *te, uint32_t *q2,
                                                            uint32_t *t2, int32_t *qe2, int32_t *te2, uint32_t *link) {
@@ -653,11 +707,12 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
     DevBuf<uint32_t> gflag, gpos, q1, t1, link1, q2, t2, link, eflag, epos, mism, d_e;
     DevBuf<uint64_t> ukey, ukey2;
     DevBuf<uint32_t> uidx_in, uidx, fq, ft, mirror, rep, rpos, qr, tr, jrep, rcopy;
-    DevBuf<int32_t> su, qeu, teu;
+    DevBuf<int32_t> su, qeu, teu, s2s, q2os, t2os, qe2a, te2a;
+    DevBuf<uint32_t> iota2, smkeep, smpos, partner, uniq, q2a, t2a, mapa;
     DevBuf<unsigned long long> d_cells;
     d_cells.reserve(2);
     DevBuf<char> tmp;
-    SwPlan P0, P1, P2;
+    SwPlan P0, P1, P2, P2b;
     d_ms.reserve(std::max<size_t>(h_ms.size(), 1));
     if (!h_ms.empty()) UC_HIP(hipMemcpyAsync(d_ms.p, h_ms.data(), h_ms.size() * 4, hipMemcpyHostToDevice, s));
     mism.reserve(1);
@@ -754,10 +809,60 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
             }
             hipLaunchKernelGGL(aln_basic_kernel, grid_for(n), dim3(256), 0, s, n, Lidx, s0.p, s1p, qe0.p, te0.p, gflag.p, d_alns.p + b);
             if (n2) {
-                build_plan(*this, P2, tmp, n2, q2.p, t2.p, qe2.p, te2.p, tab);
-                run_plan(*this, P2, 2, s2.p, q2o.p, t2o.p, work, tmp);
-                stats.cells_start += P2.cells;
-                hipLaunchKernelGGL(finalize_kernel, grid_for(n2), dim3(256), 0, s, n2, P2.idx.p, link.p, Lidx, P2.sq.p, P2.st.p, s2.p,
+                // start pass; results end up in the natural order of the gate-passer list (iota2 stands for the plan order)
+                iota2.reserve(n2); s2s.reserve(n2); q2os.reserve(n2); t2os.reserve(n2);
+                hipLaunchKernelGGL(iota_kernel, grid_for(n2), dim3(256), 0, s, n2, iota2.p);
+                UC_HIP(hipMemsetAsync(d_cells.p, 0, 8, s));
+                hipLaunchKernelGGL(cells_box_kernel, grid_for(n2), dim3(256), 0, s, n2, qe2.p, te2.p, d_cells.p);
+                if (dedup && tab == 1) {
+                    smkeep.reserve(n2); smpos.reserve(n2); partner.reserve(n2); uniq.reserve(n2);
+                    UC_HIP(hipMemsetAsync(uniq.p, 0, (size_t)n2 * 4, s));
+                    hipLaunchKernelGGL(sm_flag_kernel, grid_for(n2), dim3(256), 0, s, n2, link.p, mirror.p, gflag.p, gpos.p, qe2.p, te2.p,
+                                       qe0.p, te0.p, smkeep.p, partner.p);
+                    scan_u32(*this, tmp, smkeep.p, smpos.p, n2, false);
+                    const uint32_t n2a = scan_total(*this, smkeep.p, smpos.p, n2);
+                    q2a.reserve(n2a); t2a.reserve(n2a); qe2a.reserve(n2a); te2a.reserve(n2a); mapa.reserve(n2a);
+                    hipLaunchKernelGGL(sm_gather_kernel, grid_for(n2), dim3(256), 0, s, n2, smkeep.p, smpos.p, q2.p, t2.p, qe2.p, te2.p,
+                                       q2a.p, t2a.p, qe2a.p, te2a.p, mapa.p);
+                    build_plan(*this, P2, tmp, n2a, q2a.p, t2a.p, qe2a.p, te2a.p, tab);
+                    run_plan(*this, P2, 2, s2s.p, q2os.p, t2os.p, work, tmp, /*ovf_only=*/true);
+                    uint32_t n_pk2 = 0;
+                    {
+                        const ClassTable &ct = h_tab[P2.tab];
+                        int npk = 0;
+                        while (npk < ct.n && ct.pk[npk]) npk++;
+                        n_pk2 = P2.pair_base[npk];
+                    }
+                    hipLaunchKernelGGL(sm_scatter_kernel, grid_for(n2a), dim3(256), 0, s, n2a, P2.idx.p, mapa.p, s2s.p, q2os.p, t2os.p, n_pk2,
+                                       SW_PK_OVF_HOST, s2.p, q2o.p, t2o.p, uniq.p);
+                    hipLaunchKernelGGL(sm_resolve_kernel, grid_for(n2), dim3(256), 0, s, n2, partner.p, uniq.p, s2.p, q2o.p, t2o.p);
+                    // second round (int32, exact): ambiguous end rows + the mirrors that could not take their partner's result
+                    hipLaunchKernelGGL(amb_flag_kernel, grid_for(n2), dim3(256), 0, s, n2, q2o.p, smkeep.p);
+                    scan_u32(*this, tmp, smkeep.p, smpos.p, n2, false);
+                    const uint32_t n2b = scan_total(*this, smkeep.p, smpos.p, n2);
+                    if (n2b) {
+                        q2a.reserve(n2b); t2a.reserve(n2b); qe2a.reserve(n2b); te2a.reserve(n2b); mapa.reserve(n2b);
+                        hipLaunchKernelGGL(sm_gather_kernel, grid_for(n2), dim3(256), 0, s, n2, smkeep.p, smpos.p, q2.p, t2.p, qe2.p, te2.p,
+                                           q2a.p, t2a.p, qe2a.p, te2a.p, mapa.p);
+                        build_plan(*this, P2b, tmp, n2b, q2a.p, t2a.p, qe2a.p, te2a.p, 0);
+                        run_plan(*this, P2b, 2, s2s.p, q2os.p, t2os.p, work, tmp);
+                        hipLaunchKernelGGL(sm_scatter_kernel, grid_for(n2b), dim3(256), 0, s, n2b, P2b.idx.p, mapa.p, s2s.p, q2os.p, t2os.p, 0u,
+                                           0, s2.p, q2o.p, t2o.p, (uint32_t *)nullptr);
+                        stats.n_pk_reruns += n2b;
+                    }
+                } else {
+                    build_plan(*this, P2, tmp, n2, q2.p, t2.p, qe2.p, te2.p, tab);
+                    run_plan(*this, P2, 2, s2s.p, q2os.p, t2os.p, work, tmp);
+                    hipLaunchKernelGGL(sm_scatter_kernel, grid_for(n2), dim3(256), 0, s, n2, P2.idx.p, (const uint32_t *)nullptr, s2s.p, q2os.p,
+                                       t2os.p, 0u, 0, s2.p, q2o.p, t2o.p, (uint32_t *)nullptr);
+                }
+                {
+                    unsigned long long hc = 0;
+                    UC_HIP(hipMemcpyAsync(&hc, d_cells.p, 8, hipMemcpyDeviceToHost, s));
+                    UC_HIP(hipStreamSynchronize(s));
+                    stats.cells_start += hc;
+                }
+                hipLaunchKernelGGL(finalize_kernel, grid_for(n2), dim3(256), 0, s, n2, iota2.p, link.p, Lidx, q2.p, t2.p, s2.p,
                                    q2o.p, t2o.p, ddb.len, p.cov, p.cov_mode, d_alns.p + b, eflag.p, mism.p);
                 scan_u32(*this, tmp, eflag.p, epos.p, n2, false);
                 uint32_t ne = scan_total(*this, eflag.p, epos.p, n2);
@@ -768,8 +873,8 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                     static DevBuf<int32_t> qs3, qe3, ts3, te3, pack3, gaps3;
                     static SwPlan P3;
                     q3.reserve(ne); t3.reserve(ne); src3.reserve(ne); qs3.reserve(ne); qe3.reserve(ne); ts3.reserve(ne); te3.reserve(ne); pack3.reserve(ne);
-                    hipLaunchKernelGGL(tb_gather_kernel, grid_for(n2), dim3(256), 0, s, n2, eflag.p, epos.p, P2.idx.p, link.p, Lidx, P2.sq.p,
-                                       P2.st.p, d_alns.p + b, q3.p, t3.p, qs3.p, qe3.p, ts3.p, te3.p, src3.p);
+                    hipLaunchKernelGGL(tb_gather_kernel, grid_for(n2), dim3(256), 0, s, n2, eflag.p, epos.p, iota2.p, link.p, Lidx, q2.p,
+                                       t2.p, d_alns.p + b, q3.p, t3.p, qs3.p, qe3.p, ts3.p, te3.p, src3.p);
                     build_plan(*this, P3, tmp, ne, q3.p, t3.p, qe3.p, te3.p, 0, qs3.p, ts3.p);
                     timed_ms_begin();
                     const uint64_t launches = launch_plan(*this, P3, 3, pack3.p, nullptr, nullptr, work);
@@ -790,13 +895,13 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                         stats.n_sw_runs += P3.n;
                     }
                     hipLaunchKernelGGL(tb_apply_kernel, grid_for(ne), dim3(256), 0, s, ne, P3.idx.p, src3.p, pack3.p,
-                                       p.want_tb ? gaps3.p : (const int32_t *)nullptr, P2.idx.p, link.p, Lidx, p.min_seq_id, d_alns.p + b, eflag.p);
+                                       p.want_tb ? gaps3.p : (const int32_t *)nullptr, iota2.p, link.p, Lidx, p.min_seq_id, d_alns.p + b, eflag.p);
                     scan_u32(*this, tmp, eflag.p, epos.p, n2, false);
                     ne = scan_total(*this, eflag.p, epos.p, n2);
                 }
                 if (ne) {
                     d_e.reserve(2 * (size_t)ne);
-                    hipLaunchKernelGGL(edge_scatter_kernel, grid_for(n2), dim3(256), 0, s, n2, eflag.p, epos.p, P2.sq.p, P2.st.p, d_e.p);
+                    hipLaunchKernelGGL(edge_scatter_kernel, grid_for(n2), dim3(256), 0, s, n2, eflag.p, epos.p, q2.p, t2.p, d_e.p);
                     const size_t old = edges.size();
                     edges.resize(old + 2 * (size_t)ne);
                     UC_HIP(hipMemcpyAsync(edges.data() + old, d_e.p, 2 * (size_t)ne * 4, hipMemcpyDeviceToHost, s));
