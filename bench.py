@@ -217,7 +217,7 @@ def main():
             "sw_dp_runs_per_step": st["n_sw_runs"] // steps,
             "phases_rank0_s_per_step": {k: v / steps for k, v in phase.items()},
             "counts_rank0_per_step": {k: st[k] // steps for k in ("n_sim_kmers", "n_kmer_hits", "n_filtered_hits", "n_candidates", "n_prefilter_hits",
-                                                                  "n_gapped_alignments", "n_start_alignments", "n_edges")},
+                                                                  "n_gapped_alignments", "n_start_alignments", "n_pk_reruns", "n_edges")},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prefix, args.options, n, args.cpu_seconds)

@@ -63,7 +63,19 @@ __global__ void __launch_bounds__(256) ungapped_kernel(const DeviceDb db, uint64
         const uint8_t *q3 = db.s3 + db.off[qq], *t3 = db.s3 + db.off[tt];
         const int i0 = d > 0 ? d : 0, i1 = min(lq, lt + d);
         int run = 0, best = 0;
-        for (int i = i0; i < i1; i++) {
+        int i = i0;
+        // four residues per pair of (possibly unaligned) dword loads; every sequence is followed by >= 16 pad bytes
+        for (; i + 4 <= i1; i += 4) {
+            uint32_t wq, wt;
+            __builtin_memcpy(&wq, q3 + i, 4);
+            __builtin_memcpy(&wt, t3 + (i - d), 4);
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                run = max(run + S[((wq >> (8 * b)) & 0xffu) * 21 + ((wt >> (8 * b)) & 0xffu)], 0);
+                best = max(best, run);
+            }
+        }
+        for (; i < i1; i++) {
             run = max(run + S[q3[i] * 21 + t3[i - d]], 0);
             best = max(best, run);
         }
