@@ -401,3 +401,34 @@ def test_packed_kernel_overflow_is_rerun_in_int32(O, tmp_path):
                 assert (qe[i], te[i]) == exp[1:], (mode, i)
     assert s.max() >= 0 and e.sw(0, q, t)[0].max() > 0x7C00         # the range was actually exceeded
     assert e.stats()["n_pk_reruns"] > st0
+
+
+def test_degenerate_databases(O, tmp_path):
+    """one sequence, two unrelated short sequences (no k-mer hit at all), a sequence shorter than the k-mer span:
+    the pipeline, the cascade and the search path all run through and agree with the oracle"""
+    import unicore_amd as U
+    rng = np.random.default_rng(123)
+    cases = {
+        "one": ([rng.integers(0, 20, 80, dtype=np.uint8)], [rng.integers(0, 20, 80, dtype=np.uint8)]),
+        "tiny": ([rng.integers(0, 20, 4, dtype=np.uint8), rng.integers(0, 20, 7, dtype=np.uint8)],
+                 [rng.integers(0, 20, 4, dtype=np.uint8), rng.integers(0, 20, 7, dtype=np.uint8)]),
+        "unrelated": ([rng.integers(0, 20, 30, dtype=np.uint8) for _ in range(3)], [rng.integers(0, 20, 30, dtype=np.uint8) for _ in range(3)]),
+    }
+    for name, (s3, sa) in cases.items():
+        db = str(tmp_path / name)
+        util.write_db(db, s3, sa)
+        odb = O.OracleDb(db)
+        for opts in ("-c 0.8", "-c 0.8 --cluster-steps 2"):
+            out = str(tmp_path / (name + "_c"))
+            U.cluster(db, out + "_cluster", str(tmp_path / "tmp"), opts)
+            U.createtsv(db, out + "_cluster", out + ".tsv")
+            p = util.oracle_params(O, "-c 0.8")
+            ref = O.cluster_cascade(odb, p, O.cascade_thresholds(p, 4.0, 2 if "steps" in opts else 1), threads=2)
+            O.write_tsv(str(tmp_path / "ref.tsv"), odb, ref["assign"])
+            assert open(out + ".tsv", "rb").read() == open(str(tmp_path / "ref.tsv"), "rb").read(), (name, opts)
+        U.search(db, db, str(tmp_path / (name + "_aln")), str(tmp_path / "tmp"), "-c 0.8")
+        U.convertalis(db, db, str(tmp_path / (name + "_aln")), str(tmp_path / (name + ".m8")))
+        ps = util.oracle_params(O, "-e 10 --max-seqs 1000 -c 0.8")
+        rs = O.search(odb, odb, ps, threads=2)
+        O.write_m8(str(tmp_path / "ref.m8"), odb, odb, ps, rs)
+        assert open(str(tmp_path / (name + ".m8")), "rb").read() == open(str(tmp_path / "ref.m8"), "rb").read(), name
