@@ -19,7 +19,7 @@ def O():
 @pytest.fixture(scope="module", params=["pk16", "i32"])
 def small(O, request):
     """both gapped-kernel variants: packed 16-bit (default; int32 re-run of flagged pairs) and pure int32"""
-    s3, sa = util.family_db(11, n_fam=14, members=6, extra=(700, 1100, 1500, 2040))
+    s3, sa = util.family_db(11, n_fam=14, members=6, extra=(700, 1100, 1500, 1650, 1780, 2040))
     off, c3, ca = util.flat(s3, sa)
     import unicore_amd as U
     e = U.Engine("-c 0.8 --sw-kernel " + request.param, verbosity=1)

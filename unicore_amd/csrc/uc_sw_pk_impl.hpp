@@ -272,12 +272,12 @@ void launch_sw_pk_class_mode(int G, int R, const SwArgs &a, uint32_t n_tasks, hi
         hipLaunchKernelGGL((sw_pk_kernel<GG, RR, MODE, NW>), dim3(n_tasks), dim3(NW * 64), lds, s, a);  \
         return;                                                                                         \
     }
-    // ~5.5R live registers per lane keep the packed kernel to R <= 24 (queries up to 1536 rows)
     // even R: 32-row class steps for G=16, 64 for G=32, 128 for G=64 (row padding 11.7 % -> 6.2 % at C2, tools/geom_stats.py)
     UC_SW_CASE(16, 2) UC_SW_CASE(16, 4) UC_SW_CASE(16, 6) UC_SW_CASE(16, 8) UC_SW_CASE(16, 10) UC_SW_CASE(16, 12)
     UC_SW_CASE(16, 14) UC_SW_CASE(16, 16) UC_SW_CASE(16, 18) UC_SW_CASE(16, 20) UC_SW_CASE(16, 22) UC_SW_CASE(16, 24)
     UC_SW_CASE(32, 14) UC_SW_CASE(32, 16) UC_SW_CASE(32, 18) UC_SW_CASE(32, 20) UC_SW_CASE(32, 22) UC_SW_CASE(32, 24)
     UC_SW_CASE(64, 14) UC_SW_CASE(64, 16) UC_SW_CASE(64, 18) UC_SW_CASE(64, 20) UC_SW_CASE(64, 22) UC_SW_CASE(64, 24)
+    UC_SW_CASE(64, 26) UC_SW_CASE(64, 28)   // ~7R + 40 live registers: R = 28 is the last one that fits 256 VGPRs in every mode
 #undef UC_SW_CASE
     fprintf(stderr, "unicore-cluster: no packed SW kernel for class (G=%d, R=%d)\n", G, R);
     abort();
