@@ -20,8 +20,7 @@ constexpr int SW_PK_OVF_HOST = 0x7C00 - 256;   // == SW_PK_OVF of uc_sw_pk_impl.
 namespace {
 
 // Length classes.  Table 0: int32 kernel for everything (16 systolic classes + generic).  Table 1: the packed
-// 16-bit kernel for queries <= 1792 rows in 26 classes with even R (its ~7R + 40 live registers limit R to 28), one
-// int32 class above.
+// 16-bit kernel for all systolic classes: queries <= 2048 rows in 28 classes with even R (~6R + 60 live registers).
 constexpr int MAXCLS = 28;
 struct ClassTable {
     int n;                 // systolic classes; index n = generic fallback (queries > cap[n-1])
@@ -37,12 +36,12 @@ const ClassTable h_tab[2] = {
      {4, 8, 12, 16, 20, 24, 28, 32, 20, 24, 28, 32, 20, 24, 28, 32},
      {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
      {256, 256, 256, 256, 256, 256, 256, 256, 64, 64, 64, 64, 24, 24, 24, 24}},
-    {27,
-     {32, 64, 96, 128, 160, 192, 224, 256, 288, 320, 352, 384, 448, 512, 576, 640, 704, 768, 896, 1024, 1152, 1280, 1408, 1536, 1664, 1792, 2048},
-     {16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 32, 32, 32, 32, 32, 32, 64, 64, 64, 64, 64, 64, 64, 64, 64},
-     {2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 14, 16, 18, 20, 22, 24, 14, 16, 18, 20, 22, 24, 26, 28, 32},
-     {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0},
-     {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 48, 48, 48, 48, 48, 48, 24, 24, 24}},
+    {28,
+     {32, 64, 96, 128, 160, 192, 224, 256, 288, 320, 352, 384, 448, 512, 576, 640, 704, 768, 896, 1024, 1152, 1280, 1408, 1536, 1664, 1792, 1920, 2048},
+     {16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 32, 32, 32, 32, 32, 32, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64},
+     {2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 14, 16, 18, 20, 22, 24, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32},
+     {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1},
+     {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 48, 48, 48, 48, 48, 48, 24, 24, 24, 24}},
 };
 __device__ __constant__ ClassTable c_tab[2];
 

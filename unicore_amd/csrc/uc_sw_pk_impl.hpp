@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
     __syncthreads();
 
     // ---- per-group state (all group-uniform scalars live replicated in the group's lanes) ----
-    uint32_t H[R], T[R], E[R], rowbest[TRACK ? R : 1];
+    uint32_t H[R], E[R], rowbest[TRACK ? R : 1];   // E[r] holds the gap state ENTERING the next column (no separate H - open array)
     uint32_t mskA[MASK ? RW : 1], mskB[MASK ? RW : 1];
     uint32_t best = 0, Hlast = 0, prevHup = 0, fout = 0;
     int colA = -1, colB = -1;
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
             }
         }
 #pragma unroll
-        for (int r = 0; r < R; r++) { H[r] = 0; T[r] = 0; E[r] = 0; }
+        for (int r = 0; r < R; r++) { H[r] = 0; E[r] = 0; }
         if constexpr (TRACK) {
 #pragma unroll
             for (int r = 0; r < R; r++) rowbest[r] = 0;
@@ -180,13 +180,13 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
             // {byte r of A's word, 0, byte r of B's word, 0}
             const uint32_t ub = __builtin_amdgcn_perm(sB[r >> 2], sA[r >> 2], 0x0c000c00u | ((4u + (r & 3)) << 16) | (uint32_t)(r & 3));
             const uint32_t x = pk_sub_sat(pk_add_sat(diag, ub), bias2);
-            const uint32_t e = pk_max(pk_sub_sat(E[r], ext2), T[r]);
+            const uint32_t e = E[r];                          // max(E - ext, H - open) of the previous column
             const uint32_t h = pk_max3(x, e, f);
             diag = H[r];
             H[r] = h;
-            T[r] = pk_sub_sat(h, open2);
-            E[r] = e;
-            f = pk_max(pk_sub_sat(f, ext2), T[r]);
+            const uint32_t t = pk_sub_sat(h, open2);
+            E[r] = pk_max(pk_sub_sat(e, ext2), t);
+            f = pk_max(pk_sub_sat(f, ext2), t);
             if constexpr (TRACK) rowbest[r] = pk_max(rowbest[r], h);
             colmax = pk_max(colmax, h);
         }
@@ -277,7 +277,7 @@ void launch_sw_pk_class_mode(int G, int R, const SwArgs &a, uint32_t n_tasks, hi
     UC_SW_CASE(16, 14) UC_SW_CASE(16, 16) UC_SW_CASE(16, 18) UC_SW_CASE(16, 20) UC_SW_CASE(16, 22) UC_SW_CASE(16, 24)
     UC_SW_CASE(32, 14) UC_SW_CASE(32, 16) UC_SW_CASE(32, 18) UC_SW_CASE(32, 20) UC_SW_CASE(32, 22) UC_SW_CASE(32, 24)
     UC_SW_CASE(64, 14) UC_SW_CASE(64, 16) UC_SW_CASE(64, 18) UC_SW_CASE(64, 20) UC_SW_CASE(64, 22) UC_SW_CASE(64, 24)
-    UC_SW_CASE(64, 26) UC_SW_CASE(64, 28)   // ~7R + 40 live registers: R = 28 is the last one that fits 256 VGPRs in every mode
+    UC_SW_CASE(64, 26) UC_SW_CASE(64, 28) UC_SW_CASE(64, 30) UC_SW_CASE(64, 32)   // ~6R + 60 live registers: R = 32 still fits 256 VGPRs
 #undef UC_SW_CASE
     fprintf(stderr, "unicore-cluster: no packed SW kernel for class (G=%d, R=%d)\n", G, R);
     abort();
