@@ -261,7 +261,7 @@ void launch_sw_pk_class_mode(int G, int R, const SwArgs &a, uint32_t n_tasks, hi
 #define UC_SW_CASE(GG, RR)                                                                              \
     if (G == GG && R == RR) {                                                                           \
         constexpr int BW = (((RR + 3) / 4) | 1);                                                        \
-        constexpr int NW = GG == 16 ? 1 : (GG == 32 ? 2 : 8);   /* small workgroups share one LDS profile */ \
+        constexpr int NW = GG == 16 ? 2 : (GG == 32 ? 4 : 8);   /* small workgroups share one LDS profile */ \
         const size_t lds = (size_t)2 * SW_NLET * GG * BW * 4 + 16;                                      \
         static bool attr_set = false;                                                                   \
         if (!attr_set && lds > 64 * 1024) {                                                             \
