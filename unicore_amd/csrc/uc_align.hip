@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -90,6 +91,10 @@ __global__ void __launch_bounds__(256) plan_gather_kernel(uint32_t n, const uint
         if (qs) { sqs[i] = qs[o]; sts[i] = ts[o]; }
         head[i] = (i == 0 || (key[i - 1] >> 16) != (k >> 16)) ? i : 0u;
     }
+}
+
+__global__ void __launch_bounds__(256) plan_aux_kernel(uint32_t n, const uint32_t *idx, const int32_t *aux, int32_t *saux) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) saux[i] = aux[idx[i]];
 }
 
 __global__ void __launch_bounds__(256) plan_taskflag_kernel(uint32_t n, const uint64_t *key, const uint32_t *segstart, int tab, uint32_t *flag) {
@@ -285,6 +290,10 @@ __global__ void __launch_bounds__(256) sm_resolve_kernel(uint32_t n2, const uint
         else q2o[i] = -2;
     }
 }
+// the start pass reaches exactly the forward score: known score of entry k of a gathered sub-list
+__global__ void __launch_bounds__(256) sm_score_kernel(uint32_t nb, const uint32_t *map, const uint32_t *link, const int32_t *s0, int32_t *out) {
+    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nb; k += gridDim.x * 256) out[k] = s0[link[map[k]]];
+}
 __global__ void __launch_bounds__(256) iota_kernel(uint32_t n, uint32_t *out) {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[i] = i;
 }
@@ -388,14 +397,14 @@ struct SwPlan {
     uint32_t n = 0, ntasks = 0;
     DevBuf<uint64_t> key, key2;
     DevBuf<uint32_t> idx_in, idx, sq, st, head, segstart, flag, tpos, tcls, bounds;
-    DevBuf<int32_t> sqe, ste, sqs, sts;
+    DevBuf<int32_t> sqe, ste, sqs, sts, saux;
     DevBuf<SwTask> tasks, tasks_in;
     DevBuf<uint64_t> tkey, tkey2;
     DevBuf<uint32_t> tidx, tidx2;
     DevBuf<unsigned long long> bytes;
     uint32_t task_base[NB] = {0}, pair_base[NB] = {0};
     uint64_t alg_bytes = 0, cells = 0;
-    bool has_ends = false, has_starts = false;
+    bool has_ends = false, has_starts = false, has_aux = false;
     int tab = 0;
 };
 
@@ -423,10 +432,12 @@ static uint32_t scan_total(Engine &E, const uint32_t *flag, const uint32_t *pos,
 }
 
 static void build_plan(Engine &E, SwPlan &P, DevBuf<char> &tmp, uint32_t n, const uint32_t *q, const uint32_t *t,
-                       const int32_t *qe, const int32_t *te, int tab, const int32_t *qs = nullptr, const int32_t *ts = nullptr) {
+                       const int32_t *qe, const int32_t *te, int tab, const int32_t *qs = nullptr, const int32_t *ts = nullptr,
+                       const int32_t *aux = nullptr /* one value per pair carried into plan order (known scores) */) {
     static bool tables_uploaded = false;
     if (!tables_uploaded) { UC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), h_tab, sizeof h_tab)); tables_uploaded = true; }
     P.n = n; P.ntasks = 0; P.alg_bytes = 0; P.cells = 0; P.has_ends = qe != nullptr; P.has_starts = qs != nullptr; P.tab = tab;
+    P.has_aux = aux != nullptr;
     memset(P.task_base, 0, sizeof P.task_base);
     memset(P.pair_base, 0, sizeof P.pair_base);
     if (!n) return;
@@ -443,6 +454,10 @@ static void build_plan(Engine &E, SwPlan &P, DevBuf<char> &tmp, uint32_t n, cons
     tmp.reserve(tb + 256);
     UC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, P.key.p, P.key2.p, P.idx_in.p, P.idx.p, (size_t)n, 0u, 45u, s));
     hipLaunchKernelGGL(plan_gather_kernel, grid_for(n), dim3(256), 0, s, n, P.key2.p, P.idx.p, t, qe, te, qs, ts, P.sq.p, P.st.p, P.sqe.p, P.ste.p, P.sqs.p, P.sts.p, P.head.p);
+    if (aux) {
+        P.saux.reserve(n);
+        hipLaunchKernelGGL(plan_aux_kernel, grid_for(n), dim3(256), 0, s, n, P.idx.p, aux, P.saux.p);
+    }
     scan_u32(E, tmp, P.head.p, P.segstart.p, n, true);
     hipLaunchKernelGGL(plan_taskflag_kernel, grid_for(n), dim3(256), 0, s, n, P.key2.p, P.segstart.p, tab, P.flag.p);
     scan_u32(E, tmp, P.flag.p, P.tpos.p, n, false);
@@ -479,6 +494,9 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
     a.pqs = P.has_starts ? P.sqs.p : nullptr; a.pts = P.has_starts ? P.sts.p : nullptr;
     a.oscore = os; a.oqe = oqe; a.ote = ote; a.open = E.p.gap_open; a.ext = E.p.gap_ext;
     if (tb) { a.tb_diag = tb[0]; a.tb_ident = tb[1]; a.tb_open = tb[2]; a.tb_ext = tb[3]; }
+    a.pscore = P.has_aux ? P.saux.p : nullptr;
+    const int imode = mode >= 4 ? mode - 4 : mode;   // the int32 and generic kernels have no known-score variant (they are exact anyway)
+    if (mode >= 4 && !P.has_aux) fail(UC_ERR_GENERIC, "known-score pass without scores");
     uint64_t launches = 0;
     // fork: the classes run concurrently on the auxiliary streams, largest classes first on distinct streams
     UC_HIP(hipEventRecord(E.ev_fork, E.stream));
@@ -492,7 +510,7 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
         hipStream_t st = slot % (Engine::N_AUX + 1) == 0 ? E.stream : E.aux[slot % (Engine::N_AUX + 1) - 1];
         slot++;
         if (tab.pk[c]) launch_sw_pk_class(tab.G[c], tab.R[c], mode, ac, nt, st);
-        else launch_sw_class(tab.G[c], tab.R[c], mode, ac, nt, st);
+        else launch_sw_class(tab.G[c], tab.R[c], imode, ac, nt, st);
         UC_HIP(hipGetLastError());
         launches++;
     }
@@ -503,7 +521,7 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
     const uint32_t gb = P.pair_base[tab.n], ngen = P.n - gb;
     if (ngen) {   // queries longer than the largest systolic class
         const size_t lanes = (size_t)((ngen + 63) / 64) * 64;
-        work.reserve((mode == 3 ? 4 : 2) * (size_t)E.max_len * lanes);
+        work.reserve((imode == 3 ? 4 : 2) * (size_t)E.max_len * lanes);
         SwArgs ag = a;
         ag.pt = P.st.p + gb;
         ag.pqe = P.has_ends ? P.sqe.p + gb : nullptr;
@@ -513,7 +531,7 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
         ag.oscore = os + gb;
         ag.oqe = oqe ? oqe + gb : nullptr;
         ag.ote = ote ? ote + gb : nullptr;
-        launch_sw_generic(mode, ag, ngen, P.sq.p + gb, work.p, E.max_len, E.stream);
+        launch_sw_generic(imode, ag, ngen, P.sq.p + gb, work.p, E.max_len, E.stream);
         UC_HIP(hipGetLastError());
         launches++;
     }
@@ -531,11 +549,12 @@ __global__ void __launch_bounds__(256) amb_flag_kernel(uint32_t n2, const int32_
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) flag[i] = qe2[i] == -2 ? 1u : 0u;
 }
 __global__ void __launch_bounds__(256) amb_gather_kernel(uint32_t n2, const uint32_t *flag, const uint32_t *pos, const uint32_t *q2,
-                                                         const uint32_t *t2, uint32_t *q3, uint32_t *t3, uint32_t *link3) {
+                                                         const uint32_t *t2, const uint32_t *link, const int32_t *s0, uint32_t *q3,
+                                                         uint32_t *t3, uint32_t *link3, int32_t *s3) {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
         if (!flag[i]) continue;
         const uint32_t w = pos[i];
-        q3[w] = q2[i]; t3[w] = t2[i]; link3[w] = i;
+        q3[w] = q2[i]; t3[w] = t2[i]; link3[w] = i; s3[w] = s0[link[i]];
     }
 }
 __global__ void __launch_bounds__(256) amb_putback_kernel(uint32_t n3, const uint32_t *idx3, const uint32_t *link3, const uint32_t *link,
@@ -568,7 +587,7 @@ __global__ void __launch_bounds__(256) pk_putback_kernel(uint32_t n2, const uint
 
 struct RerunBufs {
     DevBuf<uint32_t> flag, pos, q2, t2, link;
-    DevBuf<int32_t> qe2, te2, s, qe, te;
+    DevBuf<int32_t> qe2, te2, s, qe, te, sin;
 };
 
 // ovf_only: re-run immediately only what saturated; ambiguous end rows (qe == -2) are left for the caller
@@ -599,7 +618,7 @@ static void run_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t *oqe, 
                                P.has_ends ? P.sqe.p : nullptr, P.has_ends ? P.ste.p : nullptr, B.q2.p, B.t2.p, B.qe2.p, B.te2.p, B.link.p);
             build_plan(E, P2, tmp, n2, B.q2.p, B.t2.p, P.has_ends ? B.qe2.p : nullptr, P.has_ends ? B.te2.p : nullptr, 0);
             E.timed_ms_begin();
-            launches += launch_plan(E, P2, mode, B.s.p, oqe ? B.qe.p : nullptr, oqe ? B.te.p : nullptr, work);
+            launches += launch_plan(E, P2, mode >= 4 ? mode - 4 : mode, B.s.p, oqe ? B.qe.p : nullptr, oqe ? B.te.p : nullptr, work);
             ms += E.timed_ms_end();
             E.stats.cells_run += P2.cells;
             E.stats.n_sw_runs += P2.n;
@@ -616,8 +635,12 @@ static void run_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t *oqe, 
 }
 
 // exact (qEnd, tEnd) by the int32 forward kernel for the gate-passing pairs the packed kernel left ambiguous
+// exact (qEnd, tEnd) for the gate-passing pairs whose end is still unknown (ambiguous end row of the packed kernel, or a
+// mirror that could not take its representative's end): a second forward pass that KNOWS the optimum score (packed
+// MODE 4; int32 kernel for --sw-kernel i32 and for queries beyond the systolic classes)
 static void fix_ambiguous_ends(Engine &E, uint32_t n2, const uint32_t *q2, const uint32_t *t2, int32_t *qe2, int32_t *te2,
-                               const uint32_t *link, int32_t *qe0, int32_t *te0, DevBuf<int32_t> &work, DevBuf<char> &tmp) {
+                               const uint32_t *link, const int32_t *s0, int32_t *qe0, int32_t *te0, DevBuf<int32_t> &work,
+                               DevBuf<char> &tmp) {
     static RerunBufs B;
     static SwPlan P3;
     hipStream_t s = E.stream;
@@ -627,16 +650,11 @@ static void fix_ambiguous_ends(Engine &E, uint32_t n2, const uint32_t *q2, const
     const uint32_t n3 = scan_total(E, B.flag.p, B.pos.p, n2);
     E.stats.n_pk_reruns += n3;
     if (!n3) return;
-    B.q2.reserve(n3); B.t2.reserve(n3); B.link.reserve(n3); B.s.reserve(n3); B.qe.reserve(n3); B.te.reserve(n3);
-    hipLaunchKernelGGL(amb_gather_kernel, grid_for(n2), dim3(256), 0, s, n2, B.flag.p, B.pos.p, q2, t2, B.q2.p, B.t2.p, B.link.p);
-    build_plan(E, P3, tmp, n3, B.q2.p, B.t2.p, nullptr, nullptr, 0);
-    E.timed_ms_begin();
-    const uint64_t launches = launch_plan(E, P3, 0, B.s.p, B.qe.p, B.te.p, work);
-    E.stats.sw_kernel_ms += E.timed_ms_end();
-    E.stats.sw_kernel_launches += launches;
-    E.stats.sw_algorithmic_bytes += P3.alg_bytes;
-    E.stats.cells_run += P3.cells;
-    E.stats.n_sw_runs += P3.n;
+    B.q2.reserve(n3); B.t2.reserve(n3); B.link.reserve(n3); B.s.reserve(n3); B.qe.reserve(n3); B.te.reserve(n3); B.sin.reserve(n3);
+    hipLaunchKernelGGL(amb_gather_kernel, grid_for(n2), dim3(256), 0, s, n2, B.flag.p, B.pos.p, q2, t2, link, s0, B.q2.p, B.t2.p, B.link.p, B.sin.p);
+    const bool pk = E.p.sw_pk != 0;
+    build_plan(E, P3, tmp, n3, B.q2.p, B.t2.p, nullptr, nullptr, pk ? 1 : 0, nullptr, nullptr, pk ? B.sin.p : nullptr);
+    run_plan(E, P3, pk ? 4 : 0, B.s.p, B.qe.p, B.te.p, work, tmp);
     hipLaunchKernelGGL(amb_putback_kernel, grid_for(n3), dim3(256), 0, s, n3, P3.idx.p, B.link.p, link, B.qe.p, B.te.p, qe2, te2, qe0, te0);
     UC_HIP(hipGetLastError());
 }
@@ -706,7 +724,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
     DevBuf<uint32_t> gflag, gpos, q1, t1, link1, q2, t2, link, eflag, epos, mism, d_e;
     DevBuf<uint64_t> ukey, ukey2;
     DevBuf<uint32_t> uidx_in, uidx, fq, ft, mirror, rep, rpos, qr, tr, jrep, rcopy;
-    DevBuf<int32_t> su, qeu, teu, s2s, q2os, t2os, qe2a, te2a;
+    DevBuf<int32_t> su, qeu, teu, s2s, q2os, t2os, qe2a, te2a, sknown;
     DevBuf<uint32_t> iota2, smkeep, smpos, partner, uniq, q2a, t2a, mapa;
     DevBuf<unsigned long long> d_cells;
     d_cells.reserve(2);
@@ -804,7 +822,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                 s2.reserve(n2); q2o.reserve(n2); t2o.reserve(n2); eflag.reserve(n2); epos.reserve(n2);
                 hipLaunchKernelGGL(gate_scatter_kernel, grid_for(n), dim3(256), 0, s, n, gflag.p, gpos.p, Lsq, Lst, qe0.p, te0.p,
                                    q2.p, t2.p, qe2.p, te2.p, link.p);
-                if (p.sw_pk || dedup) fix_ambiguous_ends(*this, n2, q2.p, t2.p, qe2.p, te2.p, link.p, qe0.p, te0.p, work, tmp);
+                if (p.sw_pk || dedup) fix_ambiguous_ends(*this, n2, q2.p, t2.p, qe2.p, te2.p, link.p, s0.p, qe0.p, te0.p, work, tmp);
             }
             hipLaunchKernelGGL(aln_basic_kernel, grid_for(n), dim3(256), 0, s, n, Lidx, s0.p, s1p, qe0.p, te0.p, gflag.p, d_alns.p + b);
             if (n2) {
@@ -843,8 +861,10 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                         q2a.reserve(n2b); t2a.reserve(n2b); qe2a.reserve(n2b); te2a.reserve(n2b); mapa.reserve(n2b);
                         hipLaunchKernelGGL(sm_gather_kernel, grid_for(n2), dim3(256), 0, s, n2, smkeep.p, smpos.p, q2.p, t2.p, qe2.p, te2.p,
                                            q2a.p, t2a.p, qe2a.p, te2a.p, mapa.p);
-                        build_plan(*this, P2b, tmp, n2b, q2a.p, t2a.p, qe2a.p, te2a.p, 0);
-                        run_plan(*this, P2b, 2, s2s.p, q2os.p, t2os.p, work, tmp);
+                        sknown.reserve(n2b);
+                        hipLaunchKernelGGL(sm_score_kernel, grid_for(n2b), dim3(256), 0, s, n2b, mapa.p, link.p, s0.p, sknown.p);
+                        build_plan(*this, P2b, tmp, n2b, q2a.p, t2a.p, qe2a.p, te2a.p, 1, nullptr, nullptr, sknown.p);
+                        run_plan(*this, P2b, 6, s2s.p, q2os.p, t2os.p, work, tmp);   // known-score start pass (packed MODE 6)
                         hipLaunchKernelGGL(sm_scatter_kernel, grid_for(n2b), dim3(256), 0, s, n2b, P2b.idx.p, mapa.p, s2s.p, q2os.p, t2os.p, 0u,
                                            0, s2.p, q2o.p, t2o.p, (uint32_t *)nullptr);
                         stats.n_pk_reruns += n2b;

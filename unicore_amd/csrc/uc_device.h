@@ -28,6 +28,7 @@ struct SwArgs {
     const uint32_t *pt;        // target id per pair
     const int32_t *pqe, *pte;  // mode 2: forward end positions (define the reversed prefixes); mode 3: box ends
     const int32_t *pqs = nullptr, *pts = nullptr;   // mode 3 only: box starts
+    const int32_t *pscore = nullptr;                // packed modes 4/6: the known optimum score per pair
     int32_t *oscore, *oqe, *ote;
     int open, ext;
     // mode 3: what the traceback statistic adds per path step (diagonal step, identical AA on it, first residue of a gap,

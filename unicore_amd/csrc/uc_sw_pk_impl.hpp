@@ -44,7 +44,12 @@ __device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) 
 
 template <int G, int R, int MODE, int NW>
 __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
-    constexpr bool TRACK = MODE != 1, MASK = MODE == 2, REVQ = MODE != 0, REVT = MODE == 2;
+    // MODE 4 / 6 = MODE 0 / 2 with the optimum score of every pair KNOWN (a.pscore): the exact re-run of the pairs whose
+    // end row was ambiguous.  No per-row maxima: the first step at which a lane's column maximum equals the known score
+    // is its first optimal column, and only then (a rare, wave-level branch) the lane looks for its first optimal row.
+    constexpr bool KNOWN = MODE >= 4;
+    constexpr int BASE = KNOWN ? MODE - 4 : MODE;
+    constexpr bool TRACK = BASE != 1, MASK = BASE == 2, REVQ = BASE != 0, REVT = BASE == 2;
     constexpr int RW = (R + 3) / 4, BW = RW | 1, RSW = G * BW, NT = NW * 64;   // R % 4 == 2: the last profile dword is half used
     static_assert(R % 2 == 0 && R <= 32, "R must be even, <= 32");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -80,10 +85,12 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
     __syncthreads();
 
     // ---- per-group state (all group-uniform scalars live replicated in the group's lanes) ----
-    uint32_t H[R], E[R], rowbest[TRACK ? R : 1];   // E[r] holds the gap state ENTERING the next column (no separate H - open array)
+    uint32_t H[R], E[R], rowbest[(TRACK && !KNOWN) ? R : 1];   // E[r] holds the gap state ENTERING the next column (no separate H - open array)
     uint32_t mskA[MASK ? RW : 1], mskB[MASK ? RW : 1];
     uint32_t best = 0, Hlast = 0, prevHup = 0, fout = 0;
     int colA = -1, colB = -1;
+    [[maybe_unused]] int rowA = 0, rowB = 0;
+    [[maybe_unused]] uint32_t knownA = 0, knownB = 0;
     uint32_t gA = 0, gB = 0, toffA = 0, toffB = 0;
     int tlenA = 0, tlenB = 0, rowoffA = 0, rowoffB = 0;
     bool vB = false, active = false;
@@ -146,9 +153,14 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < R; r++) { H[r] = 0; E[r] = 0; }
-        if constexpr (TRACK) {
+        if constexpr (TRACK && !KNOWN) {
 #pragma unroll
             for (int r = 0; r < R; r++) rowbest[r] = 0;
+        }
+        if constexpr (KNOWN) {
+            knownA = (uint32_t)a.pscore[gA];
+            knownB = vB ? (uint32_t)a.pscore[gB] : 0u;
+            rowA = 0; rowB = 0;
         }
         best = 0; colA = -1; colB = -1; Hlast = 0; prevHup = 0; fout = 0;
         lst = 0;
@@ -187,13 +199,29 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
             const uint32_t t = pk_sub_sat(h, open2);
             E[r] = pk_max(pk_sub_sat(e, ext2), t);
             f = pk_max(pk_sub_sat(f, ext2), t);
-            if constexpr (TRACK) rowbest[r] = pk_max(rowbest[r], h);
+            if constexpr (TRACK && !KNOWN) rowbest[r] = pk_max(rowbest[r], h);
             colmax = pk_max(colmax, h);
         }
-        if constexpr (TRACK) {
+        if constexpr (TRACK && !KNOWN) {
             const uint32_t cmA = colmax & 0xffffu, cmB = colmax >> 16;
             colA = cmA > (best & 0xffffu) ? st - g : colA;
             colB = cmB > (best >> 16) ? st - g : colB;
+        }
+        if constexpr (KNOWN) {
+            const bool evA = colA < 0 && knownA != 0 && (colmax & 0xffffu) == knownA;
+            const bool evB = colB < 0 && knownB != 0 && (colmax >> 16) == knownB;
+            if (__builtin_amdgcn_ballot_w64(evA || evB) != 0) {
+                if (evA) {
+                    colA = st - g;
+#pragma unroll
+                    for (int r = R - 1; r >= 0; r--) rowA = (H[r] & 0xffffu) == knownA ? r : rowA;
+                }
+                if (evB) {
+                    colB = st - g;
+#pragma unroll
+                    for (int r = R - 1; r >= 0; r--) rowB = (H[r] >> 16) == knownB ? r : rowB;
+                }
+            }
         }
         best = pk_max(best, colmax);
         Hlast = H[R - 1];
@@ -203,6 +231,25 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
 
     // per-half reduction over the G lanes: (score desc, col asc); then the row from rowbest; write results
     auto finish_slot = [&]() {
+        if constexpr (KNOWN) {
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int col = half ? colB : colA, row = half ? rowB : rowA;
+                int key = col < 0 ? 0x7fffffff : ((col << 11) | (g * R + row));      // (first optimal column, then first row)
+#pragma unroll
+                for (int m = 1; m < G; m <<= 1) key = min(key, __shfl_xor(key, m, 64));
+                const bool valid = half ? vB : true;
+                const uint32_t gp = half ? gB : gA;
+                if (g == 0 && valid) {
+                    const int rowoff = half ? rowoffB : rowoffA;
+                    const bool found = key != 0x7fffffff;
+                    a.oscore[gp] = (int)(half ? knownB : knownA);
+                    a.oqe[gp] = found ? (key & 2047) - rowoff : -2;
+                    a.ote[gp] = found ? (key >> 11) : -2;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             int score = half ? (int)(best >> 16) : (int)(best & 0xffffu);
