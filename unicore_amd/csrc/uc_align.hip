@@ -30,7 +30,7 @@ struct ClassTable {
 };
 // pairs per task: the long-query classes have few queries, so their pair lists are cut finer to keep every
 // CU busy (rebuilding the LDS profile per task is negligible against >= 16 long alignments)
-const ClassTable h_tab[2] = {
+const ClassTable h_tab[3] = {
     {16,
      {64, 128, 192, 256, 320, 384, 448, 512, 640, 768, 896, 1024, 1280, 1536, 1792, 2048},
      {16, 16, 16, 16, 16, 16, 16, 16, 32, 32, 32, 32, 64, 64, 64, 64},
@@ -43,8 +43,16 @@ const ClassTable h_tab[2] = {
      {2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 14, 16, 18, 20, 22, 24, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32},
      {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1},
      {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 48, 48, 48, 48, 48, 48, 24, 24, 24, 24}},
+    // Table 2: the int32 kernel in MODE 3 (traceback statistics) carries two more register arrays: R <= 16 keeps it at
+    // <= 193 VGPRs without AGPR/scratch spills up to 1024 rows (R = 24..32 needed 275-353 registers and spilled)
+    {12,
+     {64, 128, 192, 256, 384, 512, 768, 1024, 1280, 1536, 1792, 2048},
+     {16, 16, 16, 16, 32, 32, 64, 64, 64, 64, 64, 64},
+     {4, 8, 12, 16, 12, 16, 12, 16, 20, 24, 28, 32},
+     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+     {256, 256, 256, 256, 64, 64, 24, 24, 24, 24, 24, 24}},
 };
-__device__ __constant__ ClassTable c_tab[2];
+__device__ __constant__ ClassTable c_tab[3];
 
 __device__ __forceinline__ int class_of(int lq, int tab) {
     int c = 0;
@@ -360,20 +368,67 @@ __global__ void __launch_bounds__(256) tb_gather_kernel(uint32_t n2, const uint3
 }
 __global__ void __launch_bounds__(256) tb_apply_kernel(uint32_t n3, const uint32_t *idx3, const uint32_t *src3, const int32_t *pack,
                                                        const int32_t *gaps, const uint32_t *idx2, const uint32_t *link, const uint32_t *idx0,
-                                                       float min_seq_id, uc_aln *alns, uint32_t *eflag) {
+                                                       float min_seq_id, uc_aln *alns, uint32_t *eflag, uint32_t *tie) {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n3; i += gridDim.x * 256) {
         const uint32_t i2 = src3[idx3[i]];
         uc_aln &a = alns[idx0[link[idx2[i2]]]];
         const uint32_t pk = (uint32_t)pack[i];
-        a.aln_len = (int32_t)(pk >> 16);
+        a.aln_len = (int32_t)((pk >> 16) & 0x7fffu);
         a.idents = (int32_t)(pk & 0xffffu);
-        if (gaps) a.gap_opens = gaps[i];
+        if (tie) tie[i2] = pk >> 31;
+        if (gaps) a.gap_opens = gaps[i] & 0x7fffffff;   // bit 31 is the gap-direction tie mark of the pass
         if (min_seq_id > 0.0f) {
             const float sid = a.aln_len > 0 ? (float)a.idents / (float)a.aln_len : 0.0f;
             const bool ok = sid >= min_seq_id;
             a.accepted = ok;
             eflag[i2] = ok;
         }
+    }
+}
+
+// traceback statistics shared between mutual hits: the box of (t,q) is the transposed box of (q,t); if the
+// representative's traceback never had to choose between the two gap directions, the mirror's path is the transposed
+// path and (alignment length, identities, gaps) are the same
+__global__ void __launch_bounds__(256) tbm_flag_kernel(uint32_t n2, const uint32_t *eflag, const uint32_t *link, const uint32_t *idx0,
+                                                       const uint32_t *mirror, const uint32_t *gflag, const uint32_t *gpos,
+                                                       const uc_aln *alns, uint32_t *run, uint32_t *partner) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
+        uint32_t r = eflag[i], pr = 0xFFFFFFFFu;
+        if (r) {
+            const uint32_t j = link[i];
+            if (mirror[j] && j > 0 && gflag[j - 1]) {
+                const uint32_t ir = gpos[j - 1];
+                if (eflag[ir]) {
+                    const uc_aln am = alns[idx0[j]], ar = alns[idx0[j - 1]];
+                    if (am.qstart == ar.tstart && am.qend == ar.tend && am.tstart == ar.qstart && am.tend == ar.qend) { r = 0; pr = ir; }
+                }
+            }
+        }
+        run[i] = r;
+        partner[i] = pr;
+    }
+}
+__global__ void __launch_bounds__(256) tbm_resolve_kernel(uint32_t n2, const uint32_t *partner, const uint32_t *tie, const uint32_t *link,
+                                                          const uint32_t *idx0, float min_seq_id, uc_aln *alns, uint32_t *eflag_out,
+                                                          uint32_t *run2) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
+        const uint32_t pr = partner[i];
+        uint32_t need = 0;
+        if (pr != 0xFFFFFFFFu) {
+            if (tie[pr]) need = 1;
+            else {
+                uc_aln &am = alns[idx0[link[i]]];
+                const uc_aln ar = alns[idx0[link[pr]]];
+                am.aln_len = ar.aln_len; am.idents = ar.idents; am.gap_opens = ar.gap_opens;
+                if (min_seq_id > 0.0f) {
+                    const float sid = am.aln_len > 0 ? (float)am.idents / (float)am.aln_len : 0.0f;
+                    const bool ok = sid >= min_seq_id;
+                    am.accepted = ok;
+                    eflag_out[i] = ok;
+                }
+            }
+        }
+        run2[i] = need;
     }
 }
 
@@ -886,35 +941,50 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                 scan_u32(*this, tmp, eflag.p, epos.p, n2, false);
                 uint32_t ne = scan_total(*this, eflag.p, epos.p, n2);
                 if ((p.min_seq_id > 0.0f || p.want_tb) && ne) {
-                    // sequence-identity gate: (alignment length, identities) of the traceback on the box, computed by
-                    // the MODE 3 pass of the gapped kernel for the pairs that passed the coverage gate
-                    static DevBuf<uint32_t> q3, t3, src3;
+                    // sequence-identity gate / BLAST-tab statistics: (alignment length, identities[, gaps]) of the traceback on
+                    // the box, computed by the MODE 3 pass of the int32 kernel for the pairs that passed the coverage gate
+                    static DevBuf<uint32_t> q3, t3, src3, trun, tpos, tpart, ttie;
                     static DevBuf<int32_t> qs3, qe3, ts3, te3, pack3, gaps3;
                     static SwPlan P3;
-                    q3.reserve(ne); t3.reserve(ne); src3.reserve(ne); qs3.reserve(ne); qe3.reserve(ne); ts3.reserve(ne); te3.reserve(ne); pack3.reserve(ne);
-                    hipLaunchKernelGGL(tb_gather_kernel, grid_for(n2), dim3(256), 0, s, n2, eflag.p, epos.p, iota2.p, link.p, Lidx, q2.p,
-                                       t2.p, d_alns.p + b, q3.p, t3.p, qs3.p, qe3.p, ts3.p, te3.p, src3.p);
-                    build_plan(*this, P3, tmp, ne, q3.p, t3.p, qe3.p, te3.p, 0, qs3.p, ts3.p);
-                    timed_ms_begin();
-                    const uint64_t launches = launch_plan(*this, P3, 3, pack3.p, nullptr, nullptr, work);
-                    stats.sw_kernel_ms += timed_ms_end();
-                    stats.sw_kernel_launches += launches;
-                    stats.sw_algorithmic_bytes += P3.alg_bytes;
-                    stats.cells_run += P3.cells;
-                    stats.n_sw_runs += P3.n;
-                    if (p.want_tb) {   // second statistic of the same traceback: number of gaps (BLAST-tab "gapopen")
-                        static const uint32_t tb_gaps[4] = {0u, 0u, 1u, 0u};
-                        gaps3.reserve(ne);
+                    trun.reserve(n2); tpos.reserve(n2); tpart.reserve(n2); ttie.reserve(n2);
+                    UC_HIP(hipMemsetAsync(ttie.p, 0, (size_t)n2 * 4, s));
+                    auto run_tb = [&](const uint32_t *flag) {   // MODE 3 for the flagged entries of the gate-passer list
+                        scan_u32(*this, tmp, flag, tpos.p, n2, false);
+                        const uint32_t nt = scan_total(*this, flag, tpos.p, n2);
+                        if (!nt) return;
+                        q3.reserve(nt); t3.reserve(nt); src3.reserve(nt); qs3.reserve(nt); qe3.reserve(nt); ts3.reserve(nt); te3.reserve(nt); pack3.reserve(nt);
+                        hipLaunchKernelGGL(tb_gather_kernel, grid_for(n2), dim3(256), 0, s, n2, flag, tpos.p, iota2.p, link.p, Lidx, q2.p,
+                                           t2.p, d_alns.p + b, q3.p, t3.p, qs3.p, qe3.p, ts3.p, te3.p, src3.p);
+                        build_plan(*this, P3, tmp, nt, q3.p, t3.p, qe3.p, te3.p, 2, qs3.p, ts3.p);
                         timed_ms_begin();
-                        const uint64_t l2 = launch_plan(*this, P3, 3, gaps3.p, nullptr, nullptr, work, tb_gaps);
+                        uint64_t launches = launch_plan(*this, P3, 3, pack3.p, nullptr, nullptr, work);
+                        int passes = 1;
+                        if (p.want_tb) {   // second statistic of the same traceback: number of gaps (BLAST-tab "gapopen")
+                            static const uint32_t tb_gaps[4] = {0u, 0u, 1u, 0u};
+                            gaps3.reserve(nt);
+                            launches += launch_plan(*this, P3, 3, gaps3.p, nullptr, nullptr, work, tb_gaps);
+                            passes = 2;
+                        }
                         stats.sw_kernel_ms += timed_ms_end();
-                        stats.sw_kernel_launches += l2;
-                        stats.sw_algorithmic_bytes += P3.alg_bytes;
-                        stats.cells_run += P3.cells;
-                        stats.n_sw_runs += P3.n;
+                        stats.sw_kernel_launches += launches;
+                        stats.sw_algorithmic_bytes += passes * P3.alg_bytes;
+                        stats.cells_run += passes * P3.cells;
+                        stats.n_sw_runs += (uint64_t)passes * P3.n;
+                        hipLaunchKernelGGL(tb_apply_kernel, grid_for(nt), dim3(256), 0, s, nt, P3.idx.p, src3.p, pack3.p,
+                                           p.want_tb ? gaps3.p : (const int32_t *)nullptr, iota2.p, link.p, Lidx, p.min_seq_id, d_alns.p + b,
+                                           eflag.p, ttie.p);
+                    };
+                    if (dedup) {
+                        hipLaunchKernelGGL(tbm_flag_kernel, grid_for(n2), dim3(256), 0, s, n2, eflag.p, link.p, Lidx, mirror.p, gflag.p, gpos.p,
+                                           d_alns.p + b, trun.p, tpart.p);
+                        run_tb(trun.p);
+                        hipLaunchKernelGGL(tbm_resolve_kernel, grid_for(n2), dim3(256), 0, s, n2, tpart.p, ttie.p, link.p, Lidx, p.min_seq_id,
+                                           d_alns.p + b, eflag.p, trun.p);
+                        run_tb(trun.p);   // mirrors whose representative had a gap-direction tie on its traceback
+                    } else {
+                        UC_HIP(hipMemcpyAsync(trun.p, eflag.p, (size_t)n2 * 4, hipMemcpyDeviceToDevice, s));
+                        run_tb(trun.p);
                     }
-                    hipLaunchKernelGGL(tb_apply_kernel, grid_for(ne), dim3(256), 0, s, ne, P3.idx.p, src3.p, pack3.p,
-                                       p.want_tb ? gaps3.p : (const int32_t *)nullptr, iota2.p, link.p, Lidx, p.min_seq_id, d_alns.p + b, eflag.p);
                     scan_u32(*this, tmp, eflag.p, epos.p, n2, false);
                     ne = scan_total(*this, eflag.p, epos.p, n2);
                 }

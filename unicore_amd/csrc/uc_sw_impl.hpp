@@ -205,7 +205,10 @@ __global__ void __launch_bounds__(NW * 64) sw_group_kernel(const SwArgs a) {
                     // a gap state prefers leaving the gap (open) over staying in it
                     const uint32_t ep = T[r] >= (int)esub ? Hp[r] + a.tb_open : Ep[r] + a.tb_ext;
                     const uint32_t ident = ((qaw[r >> 2] >> (8 * (r & 3))) & 0xffu) == ca_col ? a.tb_ident : 0u;
-                    const uint32_t hp = h == 0 ? 0u : (x == h ? dHp + a.tb_diag + ident : ((int)f == h ? fp : ep));
+                    // bit 31 marks a traceback step that had to choose between the two gap directions (F preferred over E):
+                    // the mirrored pair (t,q) would choose the other one, so only tie-free statistics may be shared with it
+                    const uint32_t tie = (x != h && (int)f == h && e == h) ? 0x80000000u : 0u;
+                    const uint32_t hp = h == 0 ? 0u : (x == h ? dHp + a.tb_diag + ident : ((int)f == h ? (fp | tie) : ep));
                     dHp = Hp[r];
                     Hp[r] = hp;
                     Ep[r] = ep;
@@ -317,7 +320,8 @@ __global__ void __launch_bounds__(64) sw_generic_kernel(const SwArgs a, uint32_t
                 const uint32_t hpleft = (uint32_t)HP[(size_t)i * stride], epleft = (uint32_t)EP[(size_t)i * stride];
                 const uint32_t ep = hleft - open >= esub ? hpleft + a.tb_open : epleft + a.tb_ext;
                 const uint32_t fpc = i == 0 ? a.tb_open : fp;    // fp already holds the pack of F(i,j)
-                const uint32_t hp = h == 0 ? 0u : (x == h ? dhp + a.tb_diag + (qa == ta ? a.tb_ident : 0u) : (fcur == h ? fpc : ep));
+                const uint32_t tie = (x != h && fcur == h && e == h) ? 0x80000000u : 0u;
+                const uint32_t hp = h == 0 ? 0u : (x == h ? dhp + a.tb_diag + (qa == ta ? a.tb_ident : 0u) : (fcur == h ? (fpc | tie) : ep));
                 dhp = hpleft;
                 HP[(size_t)i * stride] = (int32_t)hp;
                 EP[(size_t)i * stride] = (int32_t)ep;
@@ -356,8 +360,8 @@ void launch_sw_class_mode(int G, int R, const SwArgs &a, uint32_t n_tasks, hipSt
     }
     UC_SW_CASE(16, 4) UC_SW_CASE(16, 8) UC_SW_CASE(16, 12) UC_SW_CASE(16, 16)
     UC_SW_CASE(16, 20) UC_SW_CASE(16, 24) UC_SW_CASE(16, 28) UC_SW_CASE(16, 32)
-    UC_SW_CASE(32, 20) UC_SW_CASE(32, 24) UC_SW_CASE(32, 28) UC_SW_CASE(32, 32)
-    UC_SW_CASE(64, 20) UC_SW_CASE(64, 24) UC_SW_CASE(64, 28) UC_SW_CASE(64, 32)
+    UC_SW_CASE(32, 12) UC_SW_CASE(32, 16) UC_SW_CASE(32, 20) UC_SW_CASE(32, 24) UC_SW_CASE(32, 28) UC_SW_CASE(32, 32)
+    UC_SW_CASE(64, 12) UC_SW_CASE(64, 16) UC_SW_CASE(64, 20) UC_SW_CASE(64, 24) UC_SW_CASE(64, 28) UC_SW_CASE(64, 32)
 #undef UC_SW_CASE
     fprintf(stderr, "unicore-cluster: no SW kernel for class (G=%d, R=%d)\n", G, R);
     abort();
