@@ -4,6 +4,9 @@
 // tasks and gathers the kernel inputs; the gates (E-value on the corrected score, coverage) are small
 // kernels with scan-based compaction.  The host only sees a handful of counters and, at the end, the
 // accepted edges (stands for Foldseek's structurealign result handling; spec UC-1 E5/E6).
+// Work that is never launched: the reversed-query pass of pairs below the E-value threshold (UC-1.1),
+// and one of the two DPs of a mutual hit (q,t)/(t,q) in the forward, reversed-query, start and traceback passes
+// whenever the result of the other orientation is provably the transposed one.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

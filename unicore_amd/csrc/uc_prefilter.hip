@@ -3,15 +3,18 @@
 // Stands for the MMseqs2-style prefilter inside `foldseek cluster`
 // (call site /root/reference/src/modules/cluster.rs:45-56; algorithm SURVEY.md A.2; spec UC-1 E1-E4).
 //
-// All of this is HBM-bound scan/sort work:
+// All of this is HBM-bound gather/scan/sort work:
 //   E1  extract (k-mer, seq, pos) per target residue (coalesced scan of the 3Di track) -> radix sort by
 //       k-mer -> CSR offsets by binary search per k-mer slot (20^6 + 1 u32 = 256 MB, lives in HBM/MALL).
-//   E2  per query residue: enumerate similar k-mers (sorted-letter DFS with score bound; tables in LDS),
-//       gather each k-mer's CSR range, emit one 64-bit key (query | target | diagonal) per hit at an offset
-//       fixed by a count + exclusive-scan pre-pass (no atomics, deterministic), radix-sort the keys, then one
-//       pass over the sorted keys run-length-counts diagonals per (query,target) and keeps the best one.
-//   E3  ungapped diagonal score per surviving candidate.   E4  sort by (query, score desc, target) on the
-//       GPU; the final per-query truncation to max_seqs is a linear host pass over the sorted list.
+//       Large target ranges are indexed in chunks; the per-query lists of the chunks are merged on the device.
+//   E2  per query residue: enumerate similar k-mers (sorted-letter DFS with score bound; tables in LDS) and keep
+//       their non-empty index ranges ("runs", staged per wave in LDS) -> runs sorted by query position -> one
+//       workgroup per query expands its runs twice: sweep 1 marks hash(target, diagonal) in two LDS bitmaps
+//       (seen once / twice, two hash positions per key), sweep 2 keeps the keys seen twice -> compaction ->
+//       radix sort of the surviving keys -> one pass run-length-counts diagonals per (query, target) and keeps
+//       the best one (candidates appended per wave in blocks).  min_diag_hits 1 uses a plain expansion.
+//   E3  ungapped diagonal score per candidate.   E4  sort by (query, score desc, target), rank inside the
+//       query's run < max_seqs, scatter into the device-resident hit lists.
 // Sort and scan primitives come from rocPRIM; every kernel below is hand-written for wave64.
 #include <hip/hip_runtime.h>
 

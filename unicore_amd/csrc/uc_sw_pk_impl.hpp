@@ -5,13 +5,16 @@
 // 16 bits) and the recurrence runs on v_pk_{add,sub,max}_u16, i.e. ~6.3 VALU ops per cell instead of ~9.7.
 //
 //  * unsigned floored domain: H >= 0, E/F/T floored at 0 by saturating subtraction (exact for local
-//    alignment); x = sat_sub(sat_add(Hdiag, s + 128), 128) = max(Hdiag + s, 0); H = max(x, e, f).
+//    alignment); x = sat_sub(sat_add(Hdiag, s + 128), 128) = max(Hdiag + s, 0); H = max3(x, e, f) in one
+//    v_pk_maximum3_f16 (see SW_PK_OVF).
 //  * profile bytes are (S3+64) and (SA+64) so the packed byte sum is s+128 (PAD = 0 => s = -128); one
 //    v_perm_b32 per row interleaves byte r of target A's and target B's word into two zero-extended u16.
 //  * end tracking: per lane the running maximum gives (score, first column) per half; per-row maxima
 //    (rowbest) identify the row: if exactly one row of the alignment ever reaches the optimum it must be the
 //    row of the first column too, so (qEnd, tEnd) is exact.  Otherwise — or if a value came within 256 of the
-//    packed score range (0x7C00, see SW_PK_OVF) — the pair is flagged (qEnd = -2 / score >= SW_PK_OVF) and re-run by the int32 kernel.
+//    packed score range (0x7C00, see SW_PK_OVF) — the pair is flagged (qEnd = -2 / score >= SW_PK_OVF): overflows are
+//    re-run by the int32 kernel at once, ambiguous end rows only if the pair passes the E-value gate, by the
+//    known-score variant of this kernel (MODE 4 / 6).
 //  * slot streaming: a "slot" is two consecutive pairs of the task (A, B).  Every lane group pulls its next
 //    slot from an LDS counter as soon as it has finished the previous one, so the groups of a wave do NOT
 //    run in lockstep over the longest of their targets (hit lists mix family members with unrelated hits of
