@@ -432,3 +432,24 @@ def test_degenerate_databases(O, tmp_path):
         rs = O.search(odb, odb, ps, threads=2)
         O.write_m8(str(tmp_path / "ref.m8"), odb, odb, ps, rs)
         assert open(str(tmp_path / (name + ".m8")), "rb").read() == open(str(tmp_path / "ref.m8"), "rb").read(), name
+
+
+def test_full_size_execution_variants_identical(tmp_path):
+    """BASELINE configs[1] at full size (158 k sequences, 14.1 M alignments): the default path (packed kernel, known-score
+    re-runs, mutual hits sharing their DPs) gives byte-identical alignment records, the same edge set and the same
+    clusters as the plain path (int32 kernel, every directed pair computed on its own)"""
+    import unicore_amd as U
+    db = util.gen_synth_db(str(tmp_path / "db"), 50, 0x5EED0002, 6000, 1.0)
+    res = []
+    for opts in ("-c 0.8", "-c 0.8 --sw-kernel i32 --sym-dedup 0"):
+        e = U.Engine(opts, verbosity=1)
+        e.load_db(db)
+        e.prefilter()
+        e.align()
+        al, ed = e.alns(), e.edges()
+        a = e.setcover(ed)
+        key = np.sort(ed[:, 0].astype(np.uint64) << np.uint64(32) | ed[:, 1].astype(np.uint64))
+        res.append((al.tobytes(), key.tobytes(), a.tobytes(), len(al)))
+        del e
+    assert res[0][3] > 10_000_000
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and res[0][2] == res[1][2]
