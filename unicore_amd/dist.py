@@ -85,26 +85,70 @@ def gather_edges(edges, device="cpu", group=None):
     return np.concatenate([p.view(np.uint32).reshape(-1, 2) for p in parts]) if parts else np.zeros((0, 2), np.uint32)
 
 
-def exchange_hits_device(engine, rank, world, device, group=None):
+EXCHANGE_ONE_SHOT_LIMIT = 256 << 20     # hit records in the union above which the exchange is merged shard by shard
+
+
+def _export_hits_tensor(engine, device):
+    import torch
+    n = engine.hits_size()
+    buf = torch.empty((4, max(n, 1)), dtype=torch.int32, device=device)
+    if n:
+        engine.hits_export_dev(buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), buf[3].data_ptr())
+    return buf, n
+
+
+def _import_hits_tensor(engine, t, n, rank, world, device):
+    import torch
+    t = t.contiguous()
+    torch.cuda.synchronize(device)
+    return engine.hits_import_dev(n, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), rank, world)
+
+
+def exchange_hits_device(engine, rank, world, device, group=None, one_shot_limit=None):
     """Device-resident exchange: the shard's hit lists go from the engine into one int32 tensor [4, n] on the GPU,
     are all-gathered (RCCL over xGMI with backend "nccl"), and the union is merged, truncated and reduced to the
     pairs this rank owns inside the engine - nothing visits the host but the per-rank sizes.
+    Unions beyond `one_shot_limit` records (BASELINE configs[2] scale: up to N x n_seqs x max_seqs) are merged shard by
+    shard instead - one broadcast per rank, top-M truncation after every merge - so the peak stays at two lists.
     Returns the number of pairs installed (= gapped alignments of this rank)."""
     import torch
     import torch.distributed as dist
 
-    nloc = engine.hits_size()
-    buf = torch.empty((4, max(nloc, 1)), dtype=torch.int32, device=device)
-    if nloc:
-        engine.hits_export_dev(buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), buf[3].data_ptr())
+    import os
+    limit = int(os.environ.get("UC_EXCHANGE_LIMIT", EXCHANGE_ONE_SHOT_LIMIT)) if one_shot_limit is None else one_shot_limit
+    buf, nloc = _export_hits_tensor(engine, device)
     sz = torch.tensor([nloc], dtype=torch.int64, device=device)
     sizes = [torch.zeros_like(sz) for _ in range(world)]
     dist.all_gather(sizes, sz, group=group)
     sizes = [int(x.item()) for x in sizes]
+    nccl = dist.get_backend(group) == "nccl"
+    if sum(sizes) > limit:
+        acc, nacc = None, 0
+        for r in range(world):
+            m = max(sizes[r], 1)
+            if r == rank:
+                part = buf[:, :m].contiguous()
+            else:
+                part = torch.empty((4, m), dtype=torch.int32, device=device)
+            if nccl:
+                dist.broadcast(part, src=r, group=group)
+            else:                                                   # gloo (tests / one shared GPU): hop through the host
+                h = part.cpu()
+                dist.broadcast(h, src=r, group=group)
+                part = h.to(device)
+            part = part[:, : sizes[r]]
+            if acc is None:
+                acc, nacc = part, sizes[r]
+            elif sizes[r]:
+                both = torch.cat([acc[:, :nacc], part], dim=1)
+                _import_hits_tensor(engine, both, nacc + sizes[r], 0, 1, device)     # merge + top-M, no ownership filter yet
+                del both
+                acc, nacc = _export_hits_tensor(engine, device)
+        return _import_hits_tensor(engine, acc[:, :nacc], nacc, rank, world, device)
     m = max(max(sizes), 1)
     pad = torch.zeros((4, m), dtype=torch.int32, device=device)
     pad[:, :nloc] = buf[:, :nloc]
-    if dist.get_backend(group) == "nccl":
+    if nccl:
         out = torch.empty((world, 4, m), dtype=torch.int32, device=device)
         dist.all_gather_into_tensor(out, pad, group=group)          # RCCL all-gather, GPU to GPU
         parts = [out[r, :, : sizes[r]] for r in range(world)]
@@ -112,11 +156,8 @@ def exchange_hits_device(engine, rank, world, device, group=None):
         outs = [torch.empty((4, m), dtype=torch.int32) for _ in range(world)]
         dist.all_gather(outs, pad.cpu(), group=group)
         parts = [outs[r][:, : sizes[r]].to(device) for r in range(world)]
-    allh = torch.cat(parts, dim=1).contiguous()
-    torch.cuda.synchronize(device)
-    ntot = int(allh.shape[1])
-    kept = engine.hits_import_dev(ntot, allh[0].data_ptr(), allh[1].data_ptr(), allh[2].data_ptr(), allh[3].data_ptr(), rank, world)
-    return kept
+    allh = torch.cat(parts, dim=1)
+    return _import_hits_tensor(engine, allh, int(allh.shape[1]), rank, world, device)
 
 
 def merged_hits(parts, n_seqs, max_seqs):
