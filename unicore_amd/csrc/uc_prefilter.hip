@@ -215,9 +215,12 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
             const uint32_t e0 = koff[v], n = koff[v + 1] - e0;
             if (n == 0) return;
             nhit += n;
-            if (*vn > RUN_STAGE - 64) drain();            // same value in every active lane: uniform among them
+            // append first, check afterwards: at most 64 lanes append between two checks, so a buffer that is drained as
+            // soon as a slot >= RUN_STAGE - 64 was handed out never overflows (one LDS round trip less per run than
+            // reading the fill level before the atomic)
             const uint32_t slot = atomicAdd(&s_n[wv], 1u);
             ve0[slot] = e0; vcnt[slot] = n; vpi[slot] = (uint32_t)idx;
+            if (__builtin_amdgcn_ballot_w64(slot >= RUN_STAGE - 64) != 0) drain();
         });
     }
     __builtin_amdgcn_wave_barrier();
