@@ -177,13 +177,15 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
                                                        unsigned long long *counters) {
     __shared__ SimTables tab;
     __shared__ uint32_t s_n[4];
-    __shared__ uint32_t s_e0[4][RUN_STAGE], s_cnt[4][RUN_STAGE], s_pi[4][RUN_STAGE];
+    __shared__ uint64_t s_val[4][RUN_STAGE];
+    __shared__ uint32_t s_pi[4][RUN_STAGE];
     build_sim_tables(tab, db.S3);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) s_n[wv] = 0;
     __syncthreads();
     volatile uint32_t *vn = &s_n[wv];
-    volatile uint32_t *ve0 = s_e0[wv], *vcnt = s_cnt[wv], *vpi = s_pi[wv];
+    volatile uint64_t *vval = s_val[wv];
+    volatile uint32_t *vpi = s_pi[wv];
 
     auto drain = [&]() {   // runs on whatever subset of the wave is active at the call site
         const uint64_t act = __builtin_amdgcn_ballot_w64(true);
@@ -199,7 +201,7 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
         const uint64_t base = ((uint64_t)bhi << 32) | blo;
         for (uint32_t k = rank; k < n; k += nact) {
             const uint64_t w = base + k;
-            if (w < out.cap) { out.pidx[w] = vpi[k]; out.val[w] = ((uint64_t)vcnt[k] << 32) | ve0[k]; }
+            if (w < out.cap) { out.pidx[w] = vpi[k]; out.val[w] = vval[k]; }
         }
         __builtin_amdgcn_wave_barrier();
         if (lane == leader) *vn = 0;
@@ -219,7 +221,7 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
             // soon as a slot >= RUN_STAGE - 64 was handed out never overflows (one LDS round trip less per run than
             // reading the fill level before the atomic)
             const uint32_t slot = atomicAdd(&s_n[wv], 1u);
-            ve0[slot] = e0; vcnt[slot] = n; vpi[slot] = (uint32_t)idx;
+            vval[slot] = ((uint64_t)n << 32) | e0; vpi[slot] = (uint32_t)idx;
             if (__builtin_amdgcn_ballot_w64(slot >= RUN_STAGE - 64) != 0) drain();
         });
     }
