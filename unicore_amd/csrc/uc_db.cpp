@@ -233,21 +233,31 @@ void convert_alis(const std::string &query_db, const std::string &target_db, con
         while (p < end && da[p]) {
             size_t eol = p;
             while (eol < end && da[eol] && da[eol] != '\n') eol++;
-            const std::string line = da.substr(p, eol - p);
-            p = eol < end && da[eol] == '\n' ? eol + 1 : eol;
-            unsigned long long tkey = 0;
-            int bits, qs, qe, ql, ts, te, tl, alen, idents, gaps, corrected;
-            char fid[32], ev[32];
-            if (sscanf(line.c_str(), "%llu\t%d\t%31s\t%31s\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d", &tkey, &bits, fid, ev, &qs, &qe, &ql, &ts, &te, &tl,
-                       &alen, &idents, &gaps, &corrected) != 14) {
-                fclose(f);
-                fail(UC_ERR_IO, "malformed row in alignment DB %s: '%s'", aln_db.c_str(), line.c_str());
+            // 14 tab-separated fields; fields 2 and 3 (fident, evalue) are passed through as text
+            const char *fld[14];
+            size_t flen[14];
+            int nf = 0;
+            for (size_t b = p; nf < 14;) {
+                size_t x = b;
+                while (x < eol && da[x] != '\t') x++;
+                fld[nf] = da.data() + b; flen[nf] = x - b; nf++;
+                if (x >= eol) break;
+                b = x + 1;
             }
+            if (nf != 14) {
+                fclose(f);
+                fail(UC_ERR_IO, "malformed row in alignment DB %s: '%s'", aln_db.c_str(), da.substr(p, eol - p).c_str());
+            }
+            auto num = [&](int k) { return strtoll(fld[k], nullptr, 10); };
+            const unsigned long long tkey = strtoull(fld[0], nullptr, 10);
+            const int bits = (int)num(1), qs = (int)num(4), qe = (int)num(5), ts = (int)num(7), te = (int)num(8), alen = (int)num(10),
+                      idents = (int)num(11), gaps = (int)num(12);
+            p = eol < end && da[eol] == '\n' ? eol + 1 : eol;
             auto tit = tname.find(tkey);
             if (tit == tname.end()) { fclose(f); fail(UC_ERR_IO, "alignment DB target key %llu not in %s_h", tkey, target_db.c_str()); }
             const int pairs = (qe - qs + 1) + (te - ts + 1) - alen;
-            fprintf(f, "%s\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%s\t%d\n", qit->second.c_str(), tit->second.c_str(), fid, alen, pairs - idents, gaps,
-                    qs + 1, qe + 1, ts + 1, te + 1, ev, bits);
+            fprintf(f, "%s\t%s\t%.*s\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%.*s\t%d\n", qit->second.c_str(), tit->second.c_str(), (int)flen[2], fld[2], alen,
+                    pairs - idents, gaps, qs + 1, qe + 1, ts + 1, te + 1, (int)flen[3], fld[3], bits);
         }
     }
     bool bad = ferror(f);
