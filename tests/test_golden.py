@@ -89,3 +89,31 @@ def test_hip_path_reproduces_golden_cascade_and_search(tmp_path):
     U.search(db, db, str(tmp_path / "s_aln"), str(tmp_path / "tmp"), "-c 0.8")
     U.convertalis(db, db, str(tmp_path / "s_aln"), str(tmp_path / "s.m8"))
     assert open(tmp_path / "s.m8", "rb").read() == open(os.path.join(GOLD, "search_self.m8"), "rb").read()
+
+
+C1 = os.path.join(GOLD, "c1")
+
+
+def test_c1_example_data_oracle_and_consumer_contract(tmp_path):
+    """BASELINE configs[0] as a parity case: 5 proteomes of the reference's example/data in createdb format (stand-in 3Di
+    track, see make_c1.py): the oracle reproduces the committed clust.tsv, which satisfies profile.rs' requirements"""
+    from oracle import oracle_py as O
+    odb = O.OracleDb(os.path.join(C1, "db"))
+    r = O.cluster(odb, util.oracle_params(O, "-c 0.8"), threads=4, dumps=False)
+    O.write_tsv(str(tmp_path / "c.tsv"), odb, r["assign"])
+    assert open(tmp_path / "c.tsv", "rb").read() == open(os.path.join(C1, "clust.tsv"), "rb").read()
+    names = [l.split("\t")[1] for l in open(os.path.join(C1, "db.lookup"))]
+    rows = util.tsv_invariants(os.path.join(C1, "clust.tsv"), names)
+    mapped = {l.split("\t")[0] for l in open(os.path.join(C1, "db.map"))}
+    species = {l.split("\t")[1] for l in open(os.path.join(C1, "db.map"))}
+    assert {r_[1] for r_ in rows} <= mapped and len(species) == 5
+    assert len({r_[0] for r_ in rows}) < len(names)          # orthologs of different species were clustered
+
+
+@pytest.mark.gpu
+def test_c1_example_data_hip_path(tmp_path):
+    import unicore_amd as U
+    db = os.path.join(C1, "db")
+    U.cluster(db, str(tmp_path / "c_cluster"), str(tmp_path / "tmp"), "-c 0.8")
+    U.createtsv(db, str(tmp_path / "c_cluster"), str(tmp_path / "c.tsv"))
+    assert open(tmp_path / "c.tsv", "rb").read() == open(os.path.join(C1, "clust.tsv"), "rb").read()
