@@ -477,3 +477,25 @@ def test_bench_line_contract(tmp_path):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+
+
+def test_traceback_bytes_in_several_batches(O, small):
+    """the traceback-byte matrices of MODE 7 are produced in batches bounded by a scratch budget: a 1 MB budget (many
+    batches) gives the same records as the default single batch"""
+    import unicore_amd as U
+    opts = "-c 0.5 --min-seq-id 0.3"
+    res = []
+    for budget in (None, "1"):
+        if budget:
+            os.environ["UC_TB_BUDGET_MB"] = budget
+        try:
+            e = U.Engine(opts, verbosity=1)
+            e.set_db(small["off"], *util.flat(small["s3"], small["sa"])[1:])
+            e.prefilter()
+            e.align()
+            res.append(e.alns().tobytes())
+        finally:
+            os.environ.pop("UC_TB_BUDGET_MB", None)
+    assert res[0] == res[1]
+    al = np.frombuffer(res[0], U.ALN_DTYPE)
+    assert (al["aln_len"] > 0).sum() > 50

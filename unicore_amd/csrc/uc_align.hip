@@ -21,6 +21,12 @@ namespace uc {
 
 constexpr int SW_PK_OVF_HOST = 0x7C00 - 256;   // == SW_PK_OVF of uc_sw_pk_impl.hpp
 
+// scratch for the traceback-byte matrices of one batch (MODE 7): 144 GiB of the 288 GB, UC_TB_BUDGET_MB overrides (tests)
+static unsigned long long tb_budget_bytes() {
+    if (const char *e = getenv("UC_TB_BUDGET_MB")) return std::max<unsigned long long>(1, strtoull(e, nullptr, 10)) << 20;
+    return 144ull << 30;
+}
+
 namespace {
 
 // Length classes.  Table 0: int32 kernel for everything (16 systolic classes + generic).  Table 1: the packed
@@ -389,6 +395,93 @@ __global__ void __launch_bounds__(256) tb_apply_kernel(uint32_t n3, const uint32
     }
 }
 
+// ---- traceback bytes (packed MODE 7) + walk --------------------------------------------------------------------
+// bytes of pair p's matrix: (longer box of its slot + G + 2) steps x G lanes x RB row bytes; the slot partner is the
+// neighbour inside the workgroup task (pairs 2i, 2i+1 of the task), see sw_pk_kernel::start_slot
+__global__ void __launch_bounds__(256) tb_size_kernel(uint32_t n_pk, const uint64_t *key, const uint32_t *segstart, const int32_t *ste,
+                                                      const int32_t *sts, int tab, unsigned long long *size) {
+    for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < n_pk; p += gridDim.x * 256) {
+        const int cls = (int)(key[p] >> 40);
+        const uint32_t tcap = task_cap(cls, tab), seg = segstart[p];
+        const uint32_t tb = seg + (p - seg) / tcap * tcap, pp = tb + ((p - tb) ^ 1u);
+        int tl = ste[p] - sts[p] + 1;
+        if (pp < n_pk && segstart[pp] == seg && (pp - seg) / tcap == (p - seg) / tcap && (key[pp] >> 16) == (key[p] >> 16))
+            tl = max(tl, ste[pp] - sts[pp] + 1);
+        const int G = c_tab[tab].G[cls], R = c_tab[tab].R[cls], RB = 4 * ((R + 3) / 4);
+        size[p] = (unsigned long long)(tl + G + 2) * (unsigned long long)(G * RB);
+    }
+}
+// one thread per pair follows the decision bytes from the end cell (oracle: traceback(), diag > F > E, a gap is left as soon
+// as it can be): (alignment length << 16 | identities | tie << 31) and the number of gaps
+__global__ void __launch_bounds__(256) tb_walk_kernel(uint32_t n_pk, const DeviceDb db, const uint64_t *key, const uint32_t *st,
+                                                      const int32_t *sqs, const int32_t *sqe, const int32_t *sts, const int32_t *ste,
+                                                      int tab, const uint8_t *tbm, const unsigned long long *tboff, int32_t *pack,
+                                                      int32_t *gaps_out) {
+    for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < n_pk; p += gridDim.x * 256) {
+        const int cls = (int)(key[p] >> 40);
+        const uint32_t q = (uint32_t)(key[p] >> 16) & 0xFFFFFFu, t = st[p];
+        const int G = c_tab[tab].G[cls], R = c_tab[tab].R[cls], RB = 4 * ((R + 3) / 4);
+        const int qs = sqs[p], ts = sts[p];
+        const uint8_t *m = tbm + tboff[p];
+        const uint8_t *qa = db.sa + db.off[q], *ta = db.sa + db.off[t];
+        auto cell = [&](int i, int j) -> uint32_t {   // byte of cell (query row i, target column j)
+            const int lane = i / R;
+            return m[(unsigned long long)(j - ts + lane) * (unsigned long long)(G * RB) + (unsigned long long)lane * RB + (i - lane * R)];
+        };
+        int i = sqe[p], j = ste[p], state = 0;
+        uint32_t len = 0, id = 0, gaps = 0, tie = 0;
+        while (i >= qs && j >= ts) {
+            if (state == 0) {
+                const uint32_t c = cell(i, j);
+                if (!(c & 8u)) break;                                   // H == 0
+                if (!(c & 1u)) { len++; id += qa[i] == ta[j]; i--; j--; }
+                else if (!(c & 2u)) { tie |= (c & 4u) ? 0u : 1u; state = 1; gaps++; }
+                else { state = 2; gaps++; }
+            } else if (state == 1) {                                    // gap consuming query residue i
+                len++;
+                if (i - 1 < qs || !(cell(i - 1, j) & 16u)) state = 0;   // F(i,j) was opened from H(i-1,j)
+                i--;
+            } else {                                                    // gap consuming target residue j
+                len++;
+                if (j - 1 < ts || !(cell(i, j - 1) & 32u)) state = 0;
+                j--;
+            }
+        }
+        pack[p] = (int32_t)((len << 16) | id | (tie << 31));
+        if (gaps_out) gaps_out[p] = (int32_t)gaps;
+    }
+}
+// accepted pairs by forward score: the packed DP of MODE 7 is only valid below its score range
+__global__ void __launch_bounds__(256) tb_split_kernel(uint32_t n2, const uint32_t *flag, const uint32_t *link, const uint32_t *idx0,
+                                                       const uc_aln *alns, int ovf, uint32_t *lo, uint32_t *hi) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
+        const bool big = flag[i] && alns[idx0[link[i]]].score >= ovf;
+        lo[i] = flag[i] && !big;
+        hi[i] = big;
+    }
+}
+// matrix bytes of the flagged pairs (chunking against the scratch budget): the box length from the alignment record, the
+// rows of the query's class; the slot partner may be a little longer, the caller adds a margin
+__global__ void __launch_bounds__(256) tb_estimate_kernel(uint32_t n2, const uint32_t *flag, const uint32_t *q2, const uint32_t *link,
+                                                          const uint32_t *idx0, const uc_aln *alns, const uint32_t *len,
+                                                          unsigned long long *out) {
+    unsigned long long b = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256)
+        if (flag[i]) {
+            const int cls = class_of((int)len[q2[i]], 1);
+            if (cls < c_tab[1].n) {
+                const uc_aln a = alns[idx0[link[i]]];
+                const int G = c_tab[1].G[cls], R = c_tab[1].R[cls], RB = 4 * ((R + 3) / 4);
+                b += (unsigned long long)(a.tend - a.tstart + 1 + G + 2) * (unsigned long long)(G * RB);
+            }
+        }
+    for (int o = 32; o > 0; o >>= 1) b += __shfl_down(b, o, 64);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, b);
+}
+__global__ void __launch_bounds__(256) tb_chunk_kernel(uint32_t n2, const uint32_t *flag, const uint32_t *pos, uint32_t lo, uint32_t hi, uint32_t *out) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) out[i] = (flag[i] && pos[i] >= lo && pos[i] < hi) ? 1u : 0u;
+}
+
 // traceback statistics shared between mutual hits: the box of (t,q) is the transposed box of (q,t); if the
 // representative's traceback never had to choose between the two gap directions, the mirror's path is the transposed
 // path and (alignment length, identities, gaps) are the same
@@ -464,6 +557,8 @@ struct SwPlan {
     uint64_t alg_bytes = 0, cells = 0;
     bool has_ends = false, has_starts = false, has_aux = false;
     int tab = 0;
+    uint8_t *tbm = nullptr;                      // packed mode 7: traceback-byte matrices and per-pair offsets
+    const unsigned long long *tboff = nullptr;
 };
 
 static void scan_u32(Engine &E, DevBuf<char> &tmp, const uint32_t *in, uint32_t *out, uint32_t n, bool inclusive_max) {
@@ -545,7 +640,7 @@ static void build_plan(Engine &E, SwPlan &P, DevBuf<char> &tmp, uint32_t n, cons
 
 // one launch per populated class; outputs are in the plan's sorted order.  Returns the number of launches.
 static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t *oqe, int32_t *ote, DevBuf<int32_t> &work,
-                            const uint32_t *tb = nullptr) {
+                            const uint32_t *tb = nullptr, bool only_generic = false) {
     const ClassTable &tab = h_tab[P.tab];
     SwArgs a;
     a.db = E.ddb; a.tasks = P.tasks.p; a.pt = P.st.p; a.pqe = P.sqe.p; a.pte = P.ste.p;
@@ -554,13 +649,14 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
     if (tb) { a.tb_diag = tb[0]; a.tb_ident = tb[1]; a.tb_open = tb[2]; a.tb_ext = tb[3]; }
     a.pscore = P.has_aux ? P.saux.p : nullptr;
     const int imode = mode >= 4 ? mode - 4 : mode;   // the int32 and generic kernels have no known-score variant (they are exact anyway)
-    if (mode >= 4 && !P.has_aux) fail(UC_ERR_GENERIC, "known-score pass without scores");
+    if ((mode == 4 || mode == 6) && !P.has_aux) fail(UC_ERR_GENERIC, "known-score pass without scores");
+    a.tbm = P.tbm; a.tboff = P.tboff;
     uint64_t launches = 0;
     // fork: the classes run concurrently on the auxiliary streams, largest classes first on distinct streams
     UC_HIP(hipEventRecord(E.ev_fork, E.stream));
     for (int i = 0; i < Engine::N_AUX; i++) UC_HIP(hipStreamWaitEvent(E.aux[i], E.ev_fork, 0));
     int slot = 0;
-    for (int c = tab.n - 1; c >= 0; c--) {
+    for (int c = tab.n - 1; c >= 0 && !only_generic; c--) {
         const uint32_t nt = P.task_base[c + 1] - P.task_base[c];
         if (!nt) continue;
         SwArgs ac = a;
@@ -946,29 +1042,65 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                 if ((p.min_seq_id > 0.0f || p.want_tb) && ne) {
                     // sequence-identity gate / BLAST-tab statistics: (alignment length, identities[, gaps]) of the traceback on
                     // the box, computed by the MODE 3 pass of the int32 kernel for the pairs that passed the coverage gate
-                    static DevBuf<uint32_t> q3, t3, src3, trun, tpos, tpart, ttie;
+                    static DevBuf<uint32_t> q3, t3, src3, trun, tpos, tpart, ttie, tlo, thi, tchunk, tcpos;
+                    static DevBuf<unsigned long long> tbsize, tboff;
+                    static DevBuf<uint8_t> tbm;
                     static DevBuf<int32_t> qs3, qe3, ts3, te3, pack3, gaps3;
                     static SwPlan P3;
                     trun.reserve(n2); tpos.reserve(n2); tpart.reserve(n2); ttie.reserve(n2);
                     UC_HIP(hipMemsetAsync(ttie.p, 0, (size_t)n2 * 4, s));
-                    auto run_tb = [&](const uint32_t *flag) {   // MODE 3 for the flagged entries of the gate-passer list
+                    // one batch: gather the flagged entries, plan, run, apply.  pk: packed MODE 7 (decision bytes) + walk kernel;
+                    // otherwise the int32 kernel carries the statistics through the DP (MODE 3, one pass per statistic)
+                    auto tb_batch = [&](const uint32_t *flag, bool pk) {
                         scan_u32(*this, tmp, flag, tpos.p, n2, false);
                         const uint32_t nt = scan_total(*this, flag, tpos.p, n2);
                         if (!nt) return;
-                        q3.reserve(nt); t3.reserve(nt); src3.reserve(nt); qs3.reserve(nt); qe3.reserve(nt); ts3.reserve(nt); te3.reserve(nt); pack3.reserve(nt);
+                        q3.reserve(nt); t3.reserve(nt); src3.reserve(nt); qs3.reserve(nt); qe3.reserve(nt); ts3.reserve(nt); te3.reserve(nt);
+                        pack3.reserve(nt); gaps3.reserve(nt);
                         hipLaunchKernelGGL(tb_gather_kernel, grid_for(n2), dim3(256), 0, s, n2, flag, tpos.p, iota2.p, link.p, Lidx, q2.p,
                                            t2.p, d_alns.p + b, q3.p, t3.p, qs3.p, qe3.p, ts3.p, te3.p, src3.p);
-                        build_plan(*this, P3, tmp, nt, q3.p, t3.p, qe3.p, te3.p, 2, qs3.p, ts3.p);
-                        timed_ms_begin();
-                        uint64_t launches = launch_plan(*this, P3, 3, pack3.p, nullptr, nullptr, work);
+                        static const uint32_t tb_gaps[4] = {0u, 0u, 1u, 0u};
+                        uint64_t launches = 0;
                         int passes = 1;
-                        if (p.want_tb) {   // second statistic of the same traceback: number of gaps (BLAST-tab "gapopen")
-                            static const uint32_t tb_gaps[4] = {0u, 0u, 1u, 0u};
-                            gaps3.reserve(nt);
-                            launches += launch_plan(*this, P3, 3, gaps3.p, nullptr, nullptr, work, tb_gaps);
-                            passes = 2;
+                        if (!pk) {
+                            build_plan(*this, P3, tmp, nt, q3.p, t3.p, qe3.p, te3.p, 2, qs3.p, ts3.p);
+                            timed_ms_begin();
+                            launches = launch_plan(*this, P3, 3, pack3.p, nullptr, nullptr, work);
+                            if (p.want_tb) {   // second statistic of the same traceback: number of gaps (BLAST-tab "gapopen")
+                                launches += launch_plan(*this, P3, 3, gaps3.p, nullptr, nullptr, work, tb_gaps);
+                                passes = 2;
+                            }
+                            stats.sw_kernel_ms += timed_ms_end();
+                        } else {
+                            build_plan(*this, P3, tmp, nt, q3.p, t3.p, qe3.p, te3.p, 1, qs3.p, ts3.p);
+                            const uint32_t n_pk3 = P3.pair_base[h_tab[1].n];      // every systolic class of table 1 is packed
+                            tbsize.reserve((size_t)n_pk3 + 1); tboff.reserve((size_t)n_pk3 + 1);
+                            unsigned long long total = 0;
+                            if (n_pk3) {
+                                hipLaunchKernelGGL(tb_size_kernel, grid_for(n_pk3), dim3(256), 0, s, n_pk3, P3.key2.p, P3.segstart.p, P3.ste.p,
+                                                   P3.sts.p, 1, tbsize.p);
+                                size_t tbb = 0;
+                                UC_HIP(rocprim::exclusive_scan(nullptr, tbb, tbsize.p, tboff.p, 0ull, (size_t)n_pk3, rocprim::plus<unsigned long long>(), s));
+                                tmp.reserve(tbb + 256);
+                                UC_HIP(rocprim::exclusive_scan(tmp.p, tbb, tbsize.p, tboff.p, 0ull, (size_t)n_pk3, rocprim::plus<unsigned long long>(), s));
+                                unsigned long long lo_ = 0, ls_ = 0;
+                                UC_HIP(hipMemcpyAsync(&lo_, tboff.p + (n_pk3 - 1), 8, hipMemcpyDeviceToHost, s));
+                                UC_HIP(hipMemcpyAsync(&ls_, tbsize.p + (n_pk3 - 1), 8, hipMemcpyDeviceToHost, s));
+                                UC_HIP(hipStreamSynchronize(s));
+                                total = lo_ + ls_;
+                                tbm.reserve(total + 64);
+                            }
+                            P3.tbm = tbm.p; P3.tboff = tboff.p;
+                            timed_ms_begin();
+                            launches = launch_plan(*this, P3, 7, pack3.p, nullptr, nullptr, work);        // generic part: int32 MODE 3
+                            if (p.want_tb && P3.n > n_pk3)
+                                launches += launch_plan(*this, P3, 3, gaps3.p, nullptr, nullptr, work, tb_gaps, /*only_generic=*/true);
+                            if (n_pk3)
+                                hipLaunchKernelGGL(tb_walk_kernel, grid_for(n_pk3), dim3(256), 0, s, n_pk3, ddb, P3.key2.p, P3.st.p, P3.sqs.p, P3.sqe.p,
+                                                   P3.sts.p, P3.ste.p, 1, tbm.p, tboff.p, pack3.p, gaps3.p);
+                            stats.sw_kernel_ms += timed_ms_end();
+                            P3.tbm = nullptr; P3.tboff = nullptr;
                         }
-                        stats.sw_kernel_ms += timed_ms_end();
                         stats.sw_kernel_launches += launches;
                         stats.sw_algorithmic_bytes += passes * P3.alg_bytes;
                         stats.cells_run += passes * P3.cells;
@@ -976,6 +1108,27 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                         hipLaunchKernelGGL(tb_apply_kernel, grid_for(nt), dim3(256), 0, s, nt, P3.idx.p, src3.p, pack3.p,
                                            p.want_tb ? gaps3.p : (const int32_t *)nullptr, iota2.p, link.p, Lidx, p.min_seq_id, d_alns.p + b,
                                            eflag.p, ttie.p);
+                    };
+                    auto run_tb = [&](const uint32_t *flag) {
+                        if (!p.sw_pk) { tb_batch(flag, false); return; }
+                        tlo.reserve(n2); thi.reserve(n2); tchunk.reserve(n2); tcpos.reserve(n2);
+                        hipLaunchKernelGGL(tb_split_kernel, grid_for(n2), dim3(256), 0, s, n2, flag, link.p, Lidx, d_alns.p + b, SW_PK_OVF_HOST, tlo.p, thi.p);
+                        tb_batch(thi.p, false);                               // scores beyond the packed range: int32 MODE 3
+                        UC_HIP(hipMemsetAsync(d_cells.p, 0, 8, s));
+                        hipLaunchKernelGGL(tb_estimate_kernel, grid_for(n2), dim3(256), 0, s, n2, tlo.p, q2.p, link.p, Lidx, d_alns.p + b, ddb.len, d_cells.p);
+                        scan_u32(*this, tmp, tlo.p, tcpos.p, n2, false);
+                        const uint32_t nlo = scan_total(*this, tlo.p, tcpos.p, n2);
+                        unsigned long long est = 0;
+                        UC_HIP(hipMemcpy(&est, d_cells.p, 8, hipMemcpyDeviceToHost));
+                        const unsigned long long budget = tb_budget_bytes();
+                        est += est / 8;                                       // slot partners can be longer than the pair itself
+                        const uint32_t nchunk = (uint32_t)std::max<unsigned long long>(1, (est + budget - 1) / budget);
+                        const uint32_t per = (nlo + nchunk - 1) / std::max<uint32_t>(nchunk, 1);
+                        for (uint32_t c = 0; c < nchunk && nlo; c++) {
+                            if (nchunk == 1) { tb_batch(tlo.p, true); break; }
+                            hipLaunchKernelGGL(tb_chunk_kernel, grid_for(n2), dim3(256), 0, s, n2, tlo.p, tcpos.p, c * per, std::min<uint32_t>(nlo, (c + 1) * per), tchunk.p);
+                            tb_batch(tchunk.p, true);
+                        }
                     };
                     if (dedup) {
                         hipLaunchKernelGGL(tbm_flag_kernel, grid_for(n2), dim3(256), 0, s, n2, eflag.p, link.p, Lidx, mirror.p, gflag.p, gpos.p,

@@ -28,6 +28,8 @@ struct SwArgs {
     const uint32_t *pt;        // target id per pair
     const int32_t *pqe, *pte;  // mode 2: forward end positions (define the reversed prefixes); mode 3: box ends
     const int32_t *pqs = nullptr, *pts = nullptr;   // mode 3 only: box starts
+    uint8_t *tbm = nullptr;                         // packed mode 7: traceback-byte matrices ...
+    const unsigned long long *tboff = nullptr;      // ... and the byte offset of every pair's matrix
     const int32_t *pscore = nullptr;                // packed modes 4/6: the known optimum score per pair
     int32_t *oscore, *oqe, *ote;
     int open, ext;

@@ -31,13 +31,15 @@ void launch_sw_pk_class_m1(int G, int R, const SwArgs &a, uint32_t n_tasks, hipS
 void launch_sw_pk_class_m2(int G, int R, const SwArgs &a, uint32_t n_tasks, hipStream_t s);
 void launch_sw_pk_class_m4(int G, int R, const SwArgs &a, uint32_t n_tasks, hipStream_t s);
 void launch_sw_pk_class_m6(int G, int R, const SwArgs &a, uint32_t n_tasks, hipStream_t s);
+void launch_sw_pk_class_m7(int G, int R, const SwArgs &a, uint32_t n_tasks, hipStream_t s);
 void launch_sw_pk_class(int G, int R, int mode, const SwArgs &a, uint32_t n_tasks, hipStream_t s) {
     if (n_tasks == 0) return;
     if (mode == 0) launch_sw_pk_class_m0(G, R, a, n_tasks, s);
     else if (mode == 1) launch_sw_pk_class_m1(G, R, a, n_tasks, s);
     else if (mode == 2) launch_sw_pk_class_m2(G, R, a, n_tasks, s);
     else if (mode == 4) launch_sw_pk_class_m4(G, R, a, n_tasks, s);
-    else launch_sw_pk_class_m6(G, R, a, n_tasks, s);
+    else if (mode == 6) launch_sw_pk_class_m6(G, R, a, n_tasks, s);
+    else launch_sw_pk_class_m7(G, R, a, n_tasks, s);
 }
 
 void launch_sw_generic(int mode, const SwArgs &a, uint32_t n_pairs, const uint32_t *pq, int32_t *work,

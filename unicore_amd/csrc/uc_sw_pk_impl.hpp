@@ -34,11 +34,19 @@ namespace uc {
 constexpr int SW_PK_OVF = 0x7C00 - 256;   // scores at or above this are recomputed in int32
 
 typedef uint16_t u16x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned wide stores (MODE 7)
+typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ u16x2_t pk_v(uint32_t x) { return __builtin_bit_cast(u16x2_t, x); }
 __device__ __forceinline__ uint32_t pk_u(u16x2_t v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b) { return pk_u(__builtin_elementwise_add_sat(pk_v(a), pk_v(b))); }
 __device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) { return pk_u(__builtin_elementwise_sub_sat(pk_v(a), pk_v(b))); }
 __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return pk_u(__builtin_elementwise_max(pk_v(a), pk_v(b))); }
+// inline asm: the compiler canonicalises min(x, 1) into compare + select per half (13 instructions instead of 1)
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
     asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -50,9 +58,15 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
     // MODE 4 / 6 = MODE 0 / 2 with the optimum score of every pair KNOWN (a.pscore): the exact re-run of the pairs whose
     // end row was ambiguous.  No per-row maxima: the first step at which a lane's column maximum equals the known score
     // is its first optimal column, and only then (a rare, wave-level branch) the lane looks for its first optimal row.
-    constexpr bool KNOWN = MODE >= 4;
-    constexpr int BASE = KNOWN ? MODE - 4 : MODE;
-    constexpr bool TRACK = BASE != 1, MASK = BASE == 2, REVQ = BASE != 0, REVT = BASE == 2;
+    // MODE 7 = traceback bytes: the forward DP on the box [qs..qe] x [ts..te] of an accepted pair; instead of tracking an
+    // end position every cell stores one byte of decisions (bit 0 H != diagonal candidate, 1 H != F, 2 H != E, 3 H != 0,
+    // 4 F of the next row extends (not opened from this H), 5 E of the next column extends) into a per-pair matrix in
+    // HBM, laid out by anti-diagonal step so that a lane group stores G*RB contiguous bytes per step.  A second kernel
+    // (tb_walk_kernel, uc_align.hip) walks every pair's matrix from the end cell: alignment length, identities, gaps.
+    constexpr bool TBB = MODE == 7;
+    constexpr bool KNOWN = MODE == 4 || MODE == 6;
+    constexpr int BASE = KNOWN ? MODE - 4 : (TBB ? 0 : MODE);
+    constexpr bool TRACK = BASE != 1 && !TBB, MASK = BASE == 2 || TBB, REVQ = BASE != 0, REVT = BASE == 2;
     constexpr int RW = (R + 3) / 4, BW = RW | 1, RSW = G * BW, NT = NW * 64;   // R % 4 == 2: the last profile dword is half used
     static_assert(R % 2 == 0 && R <= 32, "R must be even, <= 32");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -95,6 +109,7 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
     [[maybe_unused]] int rowA = 0, rowB = 0;
     [[maybe_unused]] uint32_t knownA = 0, knownB = 0;
     uint32_t gA = 0, gB = 0, toffA = 0, toffB = 0;
+    [[maybe_unused]] unsigned long long tbA = 0, tbB = 0;
     int tlenA = 0, tlenB = 0, rowoffA = 0, rowoffB = 0;
     bool vB = false, active = false;
     int lst = 0, nst = 0;
@@ -140,7 +155,24 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
         toffA = a.db.off[tA]; toffB = a.db.off[tB];
         tlenA = REVT ? a.pte[gA] + 1 : (int)a.db.len[tA];
         tlenB = vB ? (REVT ? a.pte[gB] + 1 : (int)a.db.len[tB]) : 0;
-        if constexpr (MASK) {
+        if constexpr (TBB) {   // the box: target slice [ts, te], query rows [qs, qe]
+            toffA += (uint32_t)a.pts[gA]; toffB += (uint32_t)a.pts[gB];
+            tlenA = a.pte[gA] - a.pts[gA] + 1;
+            tlenB = vB ? a.pte[gB] - a.pts[gB] + 1 : 0;
+            tbA = a.tboff[gA]; tbB = a.tboff[gB];
+            const int qsA = a.pqs[gA], qeA = a.pqe[gA], qsB = a.pqs[gB], qeB = a.pqe[gB];
+#pragma unroll
+            for (int k = 0; k < RW; k++) {
+                uint32_t ma = 0, mb = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int row = g * R + 4 * k + b;
+                    ma |= (row >= qsA && row <= qeA ? 0xFFu : 0u) << (8 * b);
+                    mb |= (row >= qsB && row <= qeB ? 0xFFu : 0u) << (8 * b);
+                }
+                mskA[k] = ma; mskB[k] = mb;
+            }
+        } else if constexpr (MASK) {
             rowoffA = lq - 1 - a.pqe[gA];
             rowoffB = lq - 1 - a.pqe[gB];
 #pragma unroll
@@ -190,6 +222,7 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
         uint32_t f = (uint32_t)shift_from_prev_lane<G>((int)fout, 0, g);
         uint32_t diag = prevHup;
         uint32_t colmax = 0;
+        [[maybe_unused]] uint32_t code[TBB ? R : 1];
 #pragma unroll
         for (int r = 0; r < R; r++) {
             // {byte r of A's word, 0, byte r of B's word, 0}
@@ -200,10 +233,55 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
             diag = H[r];
             H[r] = h;
             const uint32_t t = pk_sub_sat(h, open2);
-            E[r] = pk_max(pk_sub_sat(e, ext2), t);
-            f = pk_max(pk_sub_sat(f, ext2), t);
+            const uint32_t esub = pk_sub_sat(e, ext2), fsub = pk_sub_sat(f, ext2);
+            if constexpr (TBB) {   // one decision byte per cell and half (0/1 per half by min(.,1): no packed compare exists)
+                const uint32_t one2 = 0x00010001u;
+                uint32_t c = pk_min(x ^ h, one2);
+                c |= pk_min(f ^ h, one2) << 1;
+                c |= pk_min(e ^ h, one2) << 2;
+                c |= pk_min(h, one2) << 3;
+                c |= pk_min(pk_sub_sat(fsub, t), one2) << 4;
+                c |= pk_min(pk_sub_sat(esub, t), one2) << 5;
+                code[r] = c;
+            }
+            E[r] = pk_max(esub, t);
+            f = pk_max(fsub, t);
             if constexpr (TRACK && !KNOWN) rowbest[r] = pk_max(rowbest[r], h);
             colmax = pk_max(colmax, h);
+        }
+        if constexpr (TBB) {   // bytes of 4 rows -> one dword per pair; step-major matrix: G*RB contiguous bytes per group and step
+            constexpr int RB = 4 * RW;
+            uint32_t wa[RW], wb[RW];
+#pragma unroll
+            for (int k = 0; k < RW; k++) {
+                const uint32_t c0 = code[4 * k], c1_ = 4 * k + 1 < R ? code[4 * k + 1] : 0u;
+                const uint32_t c2 = 4 * k + 2 < R ? code[4 * k + 2] : 0u, c3 = 4 * k + 3 < R ? code[4 * k + 3] : 0u;
+                const uint32_t p01 = __builtin_amdgcn_perm(c1_, c0, 0x06020400u);   // [A0, A1, B0, B1]
+                const uint32_t p23 = __builtin_amdgcn_perm(c3, c2, 0x06020400u);    // [A2, A3, B2, B3]
+                wa[k] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                wb[k] = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
+            }
+            // every lane writes its RB bytes with as few (dword-aligned) wide stores as possible: the lanes of a group cover
+            // G*RB contiguous bytes, so the stores of a step fill whole lines; streaming (written once, read sparsely)
+            uint8_t *dA = a.tbm + tbA + (unsigned long long)st * (G * RB) + (unsigned long long)g * RB;
+            uint8_t *dB = a.tbm + tbB + (unsigned long long)st * (G * RB) + (unsigned long long)g * RB;
+            auto put = [&](uint8_t *d, const uint32_t *w) __attribute__((always_inline)) {
+                int k = 0;
+#pragma unroll
+                for (; k + 4 <= RW; k += 4) {
+                    u32x4_u v = {w[k], w[k + 1], w[k + 2], w[k + 3]};
+                    *(u32x4_u *)(d + 4 * k) = v;
+                }
+#pragma unroll
+                for (; k + 2 <= RW; k += 2) {
+                    u32x2_u v = {w[k], w[k + 1]};
+                    *(u32x2_u *)(d + 4 * k) = v;
+                }
+#pragma unroll
+                for (; k < RW; k++) *(uint32_t *)(d + 4 * k) = w[k];
+            };
+            put(dA, wa);
+            if (vB) put(dB, wb);
         }
         if constexpr (TRACK && !KNOWN) {
             const uint32_t cmA = colmax & 0xffffu, cmB = colmax >> 16;
@@ -234,6 +312,7 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
 
     // per-half reduction over the G lanes: (score desc, col asc); then the row from rowbest; write results
     auto finish_slot = [&]() {
+        if constexpr (TBB) return;
         if constexpr (KNOWN) {
 #pragma unroll
             for (int half = 0; half < 2; half++) {
