@@ -21,10 +21,15 @@ namespace uc {
 
 constexpr int SW_PK_OVF_HOST = 0x7C00 - 256;   // == SW_PK_OVF of uc_sw_pk_impl.hpp
 
-// scratch for the traceback-byte matrices of one batch (MODE 7): 144 GiB of the 288 GB, UC_TB_BUDGET_MB overrides (tests)
-static unsigned long long tb_budget_bytes() {
+// scratch for the traceback-byte matrices of one batch (MODE 7): up to 144 GiB of the 288 GB, never more than 60 % of what
+// is free right now (plus what the scratch buffer already holds); UC_TB_BUDGET_MB overrides (tests)
+static unsigned long long tb_budget_bytes(size_t already_held) {
     if (const char *e = getenv("UC_TB_BUDGET_MB")) return std::max<unsigned long long>(1, strtoull(e, nullptr, 10)) << 20;
-    return 144ull << 30;
+    size_t free_b = 0, total_b = 0;
+    unsigned long long cap = 144ull << 30;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+        cap = std::min<unsigned long long>(cap, (unsigned long long)((free_b + already_held) * 0.6));
+    return std::max<unsigned long long>(cap, 256ull << 20);
 }
 
 namespace {
@@ -1120,7 +1125,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                         const uint32_t nlo = scan_total(*this, tlo.p, tcpos.p, n2);
                         unsigned long long est = 0;
                         UC_HIP(hipMemcpy(&est, d_cells.p, 8, hipMemcpyDeviceToHost));
-                        const unsigned long long budget = tb_budget_bytes();
+                        const unsigned long long budget = tb_budget_bytes(tbm.cap);
                         est += est / 8;                                       // slot partners can be longer than the pair itself
                         const uint32_t nchunk = (uint32_t)std::max<unsigned long long>(1, (est + budget - 1) / budget);
                         const uint32_t per = (nlo + nchunk - 1) / std::max<uint32_t>(nchunk, 1);
