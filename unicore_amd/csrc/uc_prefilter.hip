@@ -554,10 +554,14 @@ __global__ void __launch_bounds__(256) hit_count_kernel(const uint32_t *hq, uint
 }
 
 // ---- multi-GPU: merge of the all-gathered shard lists + pair ownership, on the device ----
-// owner of the unordered pair {a,b}: mutual hits (q,t)/(t,q) must meet on one rank to share their DP
-__device__ __forceinline__ uint32_t pair_owner(uint32_t a, uint32_t b, uint32_t world) {
-    const uint32_t lo = min(a, b), hi = max(a, b);
-    uint32_t h = lo * 0x9E3779B1u ^ hi * 0x85EBCA6Bu;
+// owner of the unordered pair {a,b}: mutual hits (q,t)/(t,q) must meet on one rank to share their DP.  The owner is a
+// hash of the pair's REPRESENTATIVE QUERY (the shorter sequence, ties: smaller id - the orientation uc_align.hip computes),
+// so a rank owns whole queries of the forward pass: its workgroup tasks stay as large as on one GPU (a hash of the pair
+// itself scattered every query's pairs over all ranks: 8 x smaller tasks, the gapped stage scaled 3.7x on 8 ranks, not 8x)
+__device__ __forceinline__ uint32_t pair_owner(uint32_t a, uint32_t b, const uint32_t *len, uint32_t world) {
+    const uint32_t la = len[a], lb = len[b];
+    const uint32_t rep = (la < lb || (la == lb && a < b)) ? a : b;
+    uint32_t h = rep * 0x9E3779B1u;
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
     return h % world;
 }
@@ -569,9 +573,9 @@ __global__ void __launch_bounds__(256) merge_key_kernel(uint64_t n, const uint32
         key[i] = ((uint64_t)q[i] << 32) | ((uint64_t)(255 - (s & 255)) << 24) | (t[i] & 0xFFFFFFu);
     }
 }
-__global__ void __launch_bounds__(256) owner_flag_kernel(const uint64_t *skey, uint64_t n, uint32_t rank, uint32_t world, uint32_t *flag) {
+__global__ void __launch_bounds__(256) owner_flag_kernel(const uint64_t *skey, uint64_t n, const uint32_t *len, uint32_t rank, uint32_t world, uint32_t *flag) {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
-        if (flag[i] && pair_owner((uint32_t)(skey[i] >> 32), (uint32_t)(skey[i] & 0xFFFFFFu), world) != rank) flag[i] = 0;
+        if (flag[i] && pair_owner((uint32_t)(skey[i] >> 32), (uint32_t)(skey[i] & 0xFFFFFFu), len, world) != rank) flag[i] = 0;
 }
 
 static inline dim3 grid_for(uint64_t n, uint32_t cap = 16384) {
@@ -941,7 +945,7 @@ uint64_t Engine::import_hits_dev(uint64_t n_in, const uint32_t *dq, const uint32
     tmp.reserve(tb + 256);
     UC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, skey.p, skey2.p, dd, cd2.p, (size_t)n_in, 0u, 64u, stream));
     hipLaunchKernelGGL(rank_flag_kernel, grid_for(n_in), dim3(256), 0, stream, skey2.p, n_in, (uint32_t)p.max_seqs, flag.p);
-    if (world > 1) hipLaunchKernelGGL(owner_flag_kernel, grid_for(n_in), dim3(256), 0, stream, skey2.p, n_in, rank, world, flag.p);
+    if (world > 1) hipLaunchKernelGGL(owner_flag_kernel, grid_for(n_in), dim3(256), 0, stream, skey2.p, n_in, ddb.len, rank, world, flag.p);
     auto rin = rocprim::make_transform_iterator(flag.p, WidenU32());
     UC_HIP(rocprim::exclusive_scan(nullptr, tb, rin, pos.p, (uint64_t)0, (size_t)n_in, rocprim::plus<uint64_t>(), stream));
     tmp.reserve(tb + 256);
