@@ -42,6 +42,8 @@ Engine::~Engine() {
         if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
         if (aux[i]) (void)hipStreamDestroy(aux[i]);
     }
+    free_prefilter_scratch(pre);
+    pre = nullptr;
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (stream) (void)hipStreamDestroy(stream);
 }

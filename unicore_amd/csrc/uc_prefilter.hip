@@ -587,6 +587,19 @@ struct WidenU32 {
     __host__ __device__ uint64_t operator()(uint32_t x) const { return (uint64_t)x; }
 };
 
+// work buffers of the prefilter, kept by the engine between calls (hipMalloc / hipFree of multi-GB buffers on every
+// call cost tens of ms per step and, now and then, seconds)
+struct PrefilterScratch {
+    DevBuf<unsigned long long> d_counters;
+    DevBuf<char> d_temp;
+    DevBuf<uint32_t> d_koff, k_in, k_out;
+    DevBuf<uint64_t> d_ent, v_in;
+    DevBuf<uint32_t> d_cnt, d_flag, d_cq, d_ct, d_rpidx, d_rpidx2, d_qsurv;
+    DevBuf<uint64_t> d_keys, d_keys2, d_pos, d_skey, d_skey2, d_rval, d_rval2, d_qbase, d_soff;
+    DevBuf<int32_t> d_cd, d_cd2, d_score;
+};
+void free_prefilter_scratch(PrefilterScratch *p) { delete p; }
+
 // E1-E4 for a target range.  Large ranges are processed as several index chunks whose per-query top-M lists are
 // merged on the device (lossless, same argument as the multi-GPU shards): the double-hit filter keeps one query's
 // (target, diagonal) hashes in 2 x 2^19 LDS bits, which only works while a query has well under ~500 k k-mer hits,
@@ -658,10 +671,12 @@ void Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
     if (n > (1u << 24)) fail(UC_ERR_GENERIC, "prefilter: %u sequences exceed the 2^24 limit of the hit keys", n);
     // counters: [0] similar k-mers, [1] kept candidates, [2] ungapped overlap residues, [3] run cursor,
     //           [4] k-mer hits of the batch, [5] key cursor, [6] candidate cursor
-    DevBuf<unsigned long long> d_counters;
+    if (!pre) pre = new PrefilterScratch;
+    PrefilterScratch &S = *pre;
+    DevBuf<unsigned long long> &d_counters = S.d_counters;
     d_counters.reserve(8);
     UC_HIP(hipMemsetAsync(d_counters.p, 0, 64, stream));
-    DevBuf<char> d_temp;
+    DevBuf<char> &d_temp = S.d_temp;
     auto temp_reserve = [&](size_t bytes) { d_temp.reserve(bytes + 256); };
 
     // ------------------------------------------------------------ E1: index of targets [tbegin, tend)
@@ -669,13 +684,13 @@ void Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
     timed_ms_begin();
     const uint32_t tp0 = h_poff[tbegin], tp1 = h_poff[tend];
     const uint32_t nres = tp1 - tp0;
-    DevBuf<uint32_t> d_koff;
-    DevBuf<uint64_t> d_ent;      // index entries sorted by k-mer: [sequence : 32 | position : 16]
+    DevBuf<uint32_t> &d_koff = S.d_koff;
+    DevBuf<uint64_t> &d_ent = S.d_ent;      // index entries sorted by k-mer: [sequence : 32 | position : 16]
     d_koff.reserve((size_t)KSPACE + 1);
     uint32_t n_entries = 0;
     {
-        DevBuf<uint32_t> k_in, k_out;
-        DevBuf<uint64_t> v_in;
+        DevBuf<uint32_t> &k_in = S.k_in, &k_out = S.k_out;
+        DevBuf<uint64_t> &v_in = S.v_in;
         const size_t cap = std::max<uint32_t>(nres, 1);
         k_in.reserve(cap); k_out.reserve(cap); v_in.reserve(cap); d_ent.reserve(cap);
         if (nres) {
@@ -710,9 +725,10 @@ void Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
         fmt.tbits = 1;
         while ((1u << fmt.tbits) < n) fmt.tbits++;
     }
-    DevBuf<uint32_t> d_cnt, d_flag, d_cq, d_ct, d_rpidx, d_rpidx2, d_qsurv;
-    DevBuf<uint64_t> d_keys, d_keys2, d_pos, d_skey, d_skey2, d_rval, d_rval2, d_qbase, d_soff;
-    DevBuf<int32_t> d_cd, d_cd2, d_score;
+    DevBuf<uint32_t> &d_cnt = S.d_cnt, &d_flag = S.d_flag, &d_cq = S.d_cq, &d_ct = S.d_ct, &d_rpidx = S.d_rpidx, &d_rpidx2 = S.d_rpidx2, &d_qsurv = S.d_qsurv;
+    DevBuf<uint64_t> &d_keys = S.d_keys, &d_keys2 = S.d_keys2, &d_pos = S.d_pos, &d_skey = S.d_skey, &d_skey2 = S.d_skey2, &d_rval = S.d_rval, &d_rval2 = S.d_rval2,
+                     &d_qbase = S.d_qbase, &d_soff = S.d_soff;
+    DevBuf<int32_t> &d_cd = S.d_cd, &d_cd2 = S.d_cd2, &d_score = S.d_score;
     uint64_t n_hits_total = 0, n_cand_total = 0, cand_cap = 0;
     double t_kmer = 0, t_ung = 0, t_sel = 0;
 
