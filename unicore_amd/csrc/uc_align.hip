@@ -818,6 +818,20 @@ static void fix_ambiguous_ends(Engine &E, uint32_t n2, const uint32_t *q2, const
     UC_HIP(hipGetLastError());
 }
 
+// work buffers of the gapped stage, kept by the engine between calls
+struct AlignScratch {
+    DevBuf<int32_t> d_ms, s0, qe0, te0, s1, s1c, qe2, te2, s2, q2o, t2o, work;
+    DevBuf<uint32_t> gflag, gpos, q1, t1, link1, q2, t2, link, eflag, epos, mism, d_e;
+    DevBuf<uint64_t> ukey, ukey2;
+    DevBuf<uint32_t> uidx_in, uidx, fq, ft, mirror, rep, rpos, qr, tr, jrep, rcopy;
+    DevBuf<int32_t> su, qeu, teu, s2s, q2os, t2os, qe2a, te2a, sknown;
+    DevBuf<uint32_t> iota2, smkeep, smpos, partner, uniq, q2a, t2a, mapa;
+    DevBuf<unsigned long long> d_cells;
+    DevBuf<char> tmp;
+    SwPlan P0, P1, P2, P2b;
+};
+void free_align_scratch(AlignScratch *p) { delete p; }
+
 // ---- kernel-level entry point: arbitrary pair list from the host -----------------------------------
 void Engine::sw_batch(int mode, const std::vector<PairIn> &pairs, int32_t *score, int32_t *qe, int32_t *te) {
     if (!have_db) fail(UC_ERR_ARGS, "no database loaded");
@@ -879,16 +893,23 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
         if (m < 0) m = min_score_for(p, (int)h_len[q], dbres);
         h_ms[q - qbegin] = m;
     }
-    DevBuf<int32_t> d_ms, s0, qe0, te0, s1, s1c, qe2, te2, s2, q2o, t2o, work;
-    DevBuf<uint32_t> gflag, gpos, q1, t1, link1, q2, t2, link, eflag, epos, mism, d_e;
-    DevBuf<uint64_t> ukey, ukey2;
-    DevBuf<uint32_t> uidx_in, uidx, fq, ft, mirror, rep, rpos, qr, tr, jrep, rcopy;
-    DevBuf<int32_t> su, qeu, teu, s2s, q2os, t2os, qe2a, te2a, sknown;
-    DevBuf<uint32_t> iota2, smkeep, smpos, partner, uniq, q2a, t2a, mapa;
-    DevBuf<unsigned long long> d_cells;
+    if (!aln) aln = new AlignScratch;
+    AlignScratch &A = *aln;
+    DevBuf<int32_t> &d_ms = A.d_ms, &s0 = A.s0, &qe0 = A.qe0, &te0 = A.te0, &s1 = A.s1, &s1c = A.s1c, &qe2 = A.qe2, &te2 = A.te2, &s2 = A.s2,
+                    &q2o = A.q2o, &t2o = A.t2o, &work = A.work;
+    DevBuf<uint32_t> &gflag = A.gflag, &gpos = A.gpos, &q1 = A.q1, &t1 = A.t1, &link1 = A.link1, &q2 = A.q2, &t2 = A.t2, &link = A.link,
+                     &eflag = A.eflag, &epos = A.epos, &mism = A.mism, &d_e = A.d_e;
+    DevBuf<uint64_t> &ukey = A.ukey, &ukey2 = A.ukey2;
+    DevBuf<uint32_t> &uidx_in = A.uidx_in, &uidx = A.uidx, &fq = A.fq, &ft = A.ft, &mirror = A.mirror, &rep = A.rep, &rpos = A.rpos, &qr = A.qr,
+                     &tr = A.tr, &jrep = A.jrep, &rcopy = A.rcopy;
+    DevBuf<int32_t> &su = A.su, &qeu = A.qeu, &teu = A.teu, &s2s = A.s2s, &q2os = A.q2os, &t2os = A.t2os, &qe2a = A.qe2a, &te2a = A.te2a,
+                    &sknown = A.sknown;
+    DevBuf<uint32_t> &iota2 = A.iota2, &smkeep = A.smkeep, &smpos = A.smpos, &partner = A.partner, &uniq = A.uniq, &q2a = A.q2a, &t2a = A.t2a,
+                     &mapa = A.mapa;
+    DevBuf<unsigned long long> &d_cells = A.d_cells;
     d_cells.reserve(2);
-    DevBuf<char> tmp;
-    SwPlan P0, P1, P2, P2b;
+    DevBuf<char> &tmp = A.tmp;
+    SwPlan &P0 = A.P0, &P1 = A.P1, &P2 = A.P2, &P2b = A.P2b;
     d_ms.reserve(std::max<size_t>(h_ms.size(), 1));
     if (!h_ms.empty()) UC_HIP(hipMemcpyAsync(d_ms.p, h_ms.data(), h_ms.size() * 4, hipMemcpyHostToDevice, s));
     mism.reserve(1);

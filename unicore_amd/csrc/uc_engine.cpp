@@ -44,6 +44,8 @@ Engine::~Engine() {
     }
     free_prefilter_scratch(pre);
     pre = nullptr;
+    free_align_scratch(aln);
+    aln = nullptr;
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (stream) (void)hipStreamDestroy(stream);
 }

@@ -48,6 +48,8 @@ struct DevBuf {   // plain owning device allocation (hipMalloc), grows geometric
 struct PairIn { uint32_t q, t; int32_t qe, te; };
 struct PrefilterScratch;                                  // uc_prefilter.hip
 void free_prefilter_scratch(PrefilterScratch *p);
+struct AlignScratch;                                      // uc_align.hip
+void free_align_scratch(AlignScratch *p);
 
 struct Engine {
     Params p;
@@ -95,6 +97,7 @@ struct Engine {
     void prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin = 0, uint32_t qend = UINT32_MAX);
     void prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend, bool count_sims);   // one target chunk
     PrefilterScratch *pre = nullptr;                       // work buffers kept between prefilter calls
+    AlignScratch *aln = nullptr;                           // ... and between align calls
     uint64_t prefilter_chunk_residues = 96ull << 20;   // target residues per index chunk (keeps hits/query inside the LDS filter)
     void set_hits(const uint32_t *counts, const uc_hit *h);
     void get_hits(uc_hit *out) const;                        // D2H of the device hit arrays
