@@ -90,6 +90,8 @@ def lib():
     L.uco_cluster.argtypes = [C.POINTER(Db), C.POINTER(Params), C.c_int, C.c_void_p, C.POINTER(Counts), C.c_void_p, C.c_void_p, C.c_void_p]
     L.uco_cluster_cascade.argtypes = [C.POINTER(Db), C.POINTER(Params), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.POINTER(Counts), C.c_void_p]
     L.uco_write_tsv.argtypes = [C.c_char_p, C.POINTER(Db), C.c_void_p]
+    L.uco_linclust_pairs.argtypes = [C.POINTER(Db), C.POINTER(Params), C.c_int, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint64)]
+    L.uco_cluster_workflow.argtypes = [C.POINTER(Db), C.POINTER(Params), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.POINTER(Counts), C.c_void_p]
     L.uco_search.argtypes = [C.POINTER(Db), C.POINTER(Db), C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Counts)]
     L.uco_write_m8.argtypes = [C.c_char_p, C.POINTER(Db), C.POINTER(Db), C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]
     L.uco_sample_run.argtypes = [C.POINTER(Db), C.POINTER(Index), C.POINTER(Params), C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
@@ -257,6 +259,30 @@ def write_m8(path, qdb, tdb, p, res):
     if lib().uco_write_m8(path.encode(), C.byref(qdb.db), C.byref(tdb.db), C.byref(p), res["hits"].ctypes.data,
                           res["hit_cnt"].ctypes.data, res["aln"].ctypes.data) != 0:
         raise IOError(path)
+
+
+def linclust_pairs(odb, p, m=20):
+    """E8a candidate pairs (centre, member), sorted and unique."""
+    ptr = C.POINTER(C.c_uint32)()
+    n = C.c_uint64()
+    if lib().uco_linclust_pairs(C.byref(odb.db), C.byref(p), m, C.byref(ptr), C.byref(n)) != 0:
+        raise RuntimeError("uco_linclust_pairs failed")
+    out = np.ctypeslib.as_array(ptr, shape=(max(n.value, 1), 2))[: n.value].copy()
+    C.CDLL(None).free(ptr)
+    return out
+
+
+def cluster_workflow(odb, p, thr, linclust_m=0, threads=0):
+    """optional E8a pre-step + len(thr) cascade rounds.  Returns dict(assign, counts, round_sizes)."""
+    n, steps = odb.n, len(thr)
+    assign = np.zeros(n, np.uint32)
+    cnt = Counts()
+    rs = np.zeros(steps + 1, np.uint32)
+    t = (C.c_int * max(steps, 1))(*thr)
+    rc = lib().uco_cluster_workflow(C.byref(odb.db), C.byref(p), linclust_m, steps, t, threads, assign.ctypes.data, C.byref(cnt), rs.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("uco_cluster_workflow failed: %d" % rc)
+    return dict(assign=assign, counts={f: getattr(cnt, f) for f, _ in Counts._fields_}, round_sizes=rs[: steps + (1 if linclust_m > 0 else 0)])
 
 
 def write_tsv(path, odb, assign):

@@ -723,6 +723,175 @@ int uco_write_m8(const char *path, const uco_db *qdb, const uco_db *tdb, const u
     return fclose(f) == 0 ? 0 : -1;
 }
 
+/* ------------------------------------------------------------------ E8a: linear-time pre-step (Linclust restated) */
+static inline uint64_t lc_hash(uint32_t v) {
+    uint64_t z = (uint64_t)v + 0x9E3779B97F4A7C15ull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+    return z;
+}
+typedef struct { uint64_t h; uint32_t v; uint32_t pos; } lc_cand;
+typedef struct { uint32_t v, seq; } lc_ent;
+static int lc_cand_cmp(const void *a, const void *b) {
+    const lc_cand *x = (const lc_cand *)a, *y = (const lc_cand *)b;
+    if (x->h != y->h) return x->h < y->h ? -1 : 1;
+    return x->pos < y->pos ? -1 : (x->pos > y->pos ? 1 : 0);
+}
+static int lc_ent_cmp(const void *a, const void *b) {
+    const lc_ent *x = (const lc_ent *)a, *y = (const lc_ent *)b;
+    if (x->v != y->v) return x->v < y->v ? -1 : 1;
+    return x->seq < y->seq ? -1 : (x->seq > y->seq ? 1 : 0);
+}
+static int lc_pair_cmp(const void *a, const void *b) {
+    const uint32_t *x = (const uint32_t *)a, *y = (const uint32_t *)b;
+    if (x[0] != y[0]) return x[0] < y[0] ? -1 : 1;
+    return x[1] < y[1] ? -1 : (x[1] > y[1] ? 1 : 0);
+}
+
+int uco_linclust_pairs(const uco_db *db, const uco_params *p, int m, uint32_t **pairs_out, uint64_t *n_pairs) {
+    int off[UCO_K];
+    const int span = uco_pattern_offsets(p->pattern, off);
+    if (span < 0 || m < 1) return -1;
+    const uint32_t n = db->n;
+    lc_ent *ent = (lc_ent *)malloc(((size_t)n * m + 1) * sizeof(lc_ent));
+    size_t ne = 0, ccap = 1024;
+    lc_cand *cand = (lc_cand *)malloc(ccap * sizeof(lc_cand));
+    for (uint32_t t = 0; t < n; t++) {
+        const uint8_t *s = db->s3 + db->off[t];
+        const int64_t l = (int64_t)(db->off[t + 1] - db->off[t]);
+        size_t nc = 0;
+        for (int64_t j = 0; j + span <= l && j <= 65535; j++) {
+            uint32_t v;
+            if (!kmer_at(s + j, off, &v)) continue;
+            if (nc == ccap) { ccap *= 2; cand = (lc_cand *)realloc(cand, ccap * sizeof(lc_cand)); }
+            cand[nc].h = lc_hash(v); cand[nc].v = v; cand[nc].pos = (uint32_t)j; nc++;
+        }
+        qsort(cand, nc, sizeof(lc_cand), lc_cand_cmp);
+        for (size_t k = 0; k < nc && k < (size_t)m; k++) { ent[ne].v = cand[k].v; ent[ne].seq = t; ne++; }
+    }
+    free(cand);
+    qsort(ent, ne, sizeof(lc_ent), lc_ent_cmp);
+    uint32_t *pairs = (uint32_t *)malloc((2 * ne + 2) * sizeof(uint32_t));
+    uint64_t np = 0;
+    for (size_t b = 0; b < ne;) {
+        size_t e = b;
+        while (e < ne && ent[e].v == ent[b].v) e++;
+        /* centre: longest sequence of the group, ties: smallest id (entries are sorted by id) */
+        uint32_t c = ent[b].seq;
+        uint64_t lc = db->off[c + 1] - db->off[c];
+        for (size_t k = b + 1; k < e; k++) {
+            const uint32_t sq = ent[k].seq;
+            const uint64_t ls = db->off[sq + 1] - db->off[sq];
+            if (ls > lc) { c = sq; lc = ls; }
+        }
+        for (size_t k = b; k < e; k++)
+            if (ent[k].seq != c && (k == b || ent[k].seq != ent[k - 1].seq)) { pairs[2 * np] = c; pairs[2 * np + 1] = ent[k].seq; np++; }
+        b = e;
+    }
+    free(ent);
+    qsort(pairs, np, 2 * sizeof(uint32_t), lc_pair_cmp);
+    uint64_t w = 0;
+    for (uint64_t k = 0; k < np; k++)
+        if (k == 0 || pairs[2 * k] != pairs[2 * k - 2] || pairs[2 * k + 1] != pairs[2 * k - 1]) { pairs[2 * w] = pairs[2 * k]; pairs[2 * w + 1] = pairs[2 * k + 1]; w++; }
+    if (n_pairs) *n_pairs = w;
+    if (pairs_out) *pairs_out = pairs; else free(pairs);
+    return 0;
+}
+
+int uco_cluster_linclust(const uco_db *db, const uco_params *p, int m, int threads, uint32_t *assign, uco_counts *cnt) {
+    uint32_t *pairs = NULL;
+    uint64_t np = 0;
+    if (uco_linclust_pairs(db, p, m, &pairs, &np) != 0) return -1;
+    const uint32_t n = db->n;
+    const uint64_t dbres = db->off[n];
+    uint8_t *acc = (uint8_t *)calloc(np + 1, 1);
+    uint64_t c_f = 0, c_r = 0, c_s = 0;
+    (void)threads;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : c_f, c_r, c_s)
+    for (int64_t k = 0; k < (int64_t)np; k++) {
+        const uint32_t q = pairs[2 * k], t = pairs[2 * k + 1];
+        const int lq = (int)(db->off[q + 1] - db->off[q]), lt = (int)(db->off[t + 1] - db->off[t]);
+        const int32_t ms = uco_min_score(p, lq, dbres);
+        uco_aln a;
+        uco_align_pair(db, q, t, p, ms, &a);
+        c_f += (uint64_t)lq * lt; if (p->rev_correction && a.score >= ms) c_r += (uint64_t)lq * lt;
+        if (a.pass_evalue) c_s += (uint64_t)(a.qend + 1) * (a.tend + 1);
+        acc[k] = (uint8_t)a.accepted;
+    }
+    uint32_t *edges = (uint32_t *)malloc((2 * np + 2) * sizeof(uint32_t));
+    uint64_t ne = 0;
+    for (uint64_t k = 0; k < np; k++)
+        if (acc[k]) { edges[2 * ne] = pairs[2 * k]; edges[2 * ne + 1] = pairs[2 * k + 1]; ne++; }
+    uco_setcover(n, edges, ne, assign);
+    if (cnt) {
+        memset(cnt, 0, sizeof *cnt);
+        uint64_t ncl = 0;
+        for (uint32_t i = 0; i < n; i++) ncl += assign[i] == i;
+        cnt->n_prefilter_hits = np; cnt->n_alignments = np; cnt->n_edges = ne; cnt->n_clusters = ncl;
+        cnt->cells_fwd = c_f; cnt->cells_rev = c_r; cnt->cells_start = c_s;
+    }
+    free(edges); free(acc); free(pairs);
+    return 0;
+}
+
+static void uco_subdb(const uco_db *db, const uint32_t *ids, uint32_t k, uco_db *sub) {
+    memset(sub, 0, sizeof *sub);
+    sub->n = k;
+    sub->off = (uint64_t *)malloc(((size_t)k + 1) * sizeof(uint64_t));
+    uint64_t tot = 0;
+    for (uint32_t i = 0; i < k; i++) { sub->off[i] = tot; tot += db->off[ids[i] + 1] - db->off[ids[i]]; }
+    sub->off[k] = tot;
+    sub->s3 = (uint8_t *)malloc(tot ? tot : 1); sub->sa = (uint8_t *)malloc(tot ? tot : 1);
+    for (uint32_t i = 0; i < k; i++) {
+        const uint64_t len = db->off[ids[i] + 1] - db->off[ids[i]];
+        memcpy(sub->s3 + sub->off[i], db->s3 + db->off[ids[i]], len);
+        memcpy(sub->sa + sub->off[i], db->sa + db->off[ids[i]], len);
+    }
+}
+
+int uco_cluster_workflow(const uco_db *db, const uco_params *p, int linclust_m, int steps, const int *thr, int threads,
+                         uint32_t *assign, uco_counts *cnt, uint32_t *round_sizes) {
+    const uint32_t n = db->n;
+    if (steps < 0 || (steps == 0 && linclust_m <= 0)) return -1;
+    uint32_t *cur = (uint32_t *)malloc((size_t)(n ? n : 1) * sizeof(uint32_t));
+    uint32_t *posmap = (uint32_t *)malloc((size_t)(n ? n : 1) * sizeof(uint32_t));
+    uint32_t ncur = n;
+    for (uint32_t i = 0; i < n; i++) { cur[i] = i; assign[i] = i; }
+    uco_counts total; memset(&total, 0, sizeof total);
+    int rc = 0;
+    const int rounds = steps + (linclust_m > 0 ? 1 : 0);
+    for (int r = 0; r < rounds && rc == 0; r++) {
+        if (round_sizes) round_sizes[r] = ncur;
+        uco_db sub;
+        uco_subdb(db, cur, ncur, &sub);
+        uint32_t *sa_ = (uint32_t *)malloc((size_t)(ncur ? ncur : 1) * sizeof(uint32_t));
+        uco_counts c; memset(&c, 0, sizeof c);
+        if (linclust_m > 0 && r == 0) rc = uco_cluster_linclust(&sub, p, linclust_m, threads, sa_, &c);
+        else {
+            uco_params pr = *p;
+            pr.kmer_thr = thr[r - (linclust_m > 0 ? 1 : 0)];
+            rc = uco_cluster(&sub, &pr, threads, sa_, &c, NULL, NULL, NULL);
+        }
+        if (rc == 0) {
+            total.n_sim_kmers += c.n_sim_kmers; total.n_kmer_hits += c.n_kmer_hits; total.n_candidates += c.n_candidates;
+            total.n_prefilter_hits += c.n_prefilter_hits; total.n_alignments += c.n_alignments; total.n_edges += c.n_edges;
+            total.cells_fwd += c.cells_fwd; total.cells_rev += c.cells_rev; total.cells_start += c.cells_start;
+            for (uint32_t i = 0; i < ncur; i++) posmap[cur[i]] = i;
+            for (uint32_t x = 0; x < n; x++) assign[x] = cur[sa_[posmap[assign[x]]]];
+            uint32_t k = 0;
+            for (uint32_t i = 0; i < ncur; i++) if (sa_[i] == i) cur[k++] = cur[i];
+            ncur = k;
+        }
+        free(sa_); free(sub.off); free(sub.s3); free(sub.sa);
+    }
+    total.n_clusters = ncur;
+    if (cnt) *cnt = total;
+    free(cur); free(posmap);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ E8: cascade (rounds on representatives + merge) */
 int uco_cluster_cascade(const uco_db *db, const uco_params *p, int steps, const int *thr, int threads,
                         uint32_t *assign, uco_counts *cnt, uint32_t *round_sizes) {

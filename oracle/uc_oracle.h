@@ -55,6 +55,7 @@
  * E8 cascade (only on request, steps > 1): `steps` rounds of E1-E7, round r on the representatives of round
  *            r-1, k-mer threshold from sensitivity s_r = 1 + (s-1) r/(steps-1); final representative =
  *            representative of the representative (mergeclusters).  No linclust pre-step.
+ * E8a linclust-style pre-step (only on request, --linclust 1): see uco_linclust_pairs.
  * S  search (query DB vs target DB): E2-E6 per query against the index of the whole
  *            target DB, E-value with residues(target DB); traceback statistics (alnlen, idents, gaps) for every
  *            accepted pair; BLAST-tab rows per query by (corrected desc, target asc) - see uco_write_m8.
@@ -166,6 +167,18 @@ int  uco_cluster(const uco_db *db, const uco_params *p, int threads, uint32_t *a
    steps == 1 is uco_cluster.  cnt (optional) receives the sums over the rounds. */
 int  uco_cluster_cascade(const uco_db *db, const uco_params *p, int steps, const int *thr, int threads,
                          uint32_t *assign, uco_counts *cnt, uint32_t *round_sizes);
+
+/* E8a linear-time pre-step (spec UC-1 E8a; restates Linclust, Steinegger & Soeding 2018, EXT-UNVERIFIED for Foldseek's
+   parameters): every sequence keeps the m k-mers (the spaced 3Di k-mers of E1) with the smallest (hash, position),
+   hash = SplitMix64 finaliser of the k-mer value; sequences that kept the same k-mer form a group; the centre of a
+   group is its longest sequence (ties: smallest id); every (centre, member) pair - unique over all groups - goes
+   through E5/E6 with the centre as query; accepted pairs are the edges of an E7 set cover over all sequences.
+   pairs_out (optional): malloc'ed (centre, member) list sorted by (centre, member), caller frees. */
+int  uco_linclust_pairs(const uco_db *db, const uco_params *p, int m, uint32_t **pairs_out, uint64_t *n_pairs);
+int  uco_cluster_linclust(const uco_db *db, const uco_params *p, int m, int threads, uint32_t *assign, uco_counts *cnt);
+/* the clustering workflow: optional E8a pre-step, then `steps` cascade rounds (E8) on its representatives */
+int  uco_cluster_workflow(const uco_db *db, const uco_params *p, int linclust_m, int steps, const int *thr, int threads,
+                          uint32_t *assign, uco_counts *cnt, uint32_t *round_sizes /* steps + 1 */);
 
 int  uco_write_tsv(const char *path, const uco_db *db, const uint32_t *assign);
 

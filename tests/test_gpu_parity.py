@@ -499,3 +499,26 @@ def test_traceback_bytes_in_several_batches(O, small):
     assert res[0] == res[1]
     al = np.frombuffer(res[0], U.ALN_DTYPE)
     assert (al["aln_len"] > 0).sum() > 50
+
+
+@pytest.mark.parametrize("opts,steps,m", [("-c 0.8 --linclust 1", 1, 20), ("-c 0.8 --linclust 1 --cluster-steps 3", 3, 20),
+                                          ("-c 0.5 --linclust 1 --kmer-per-seq 5 --cluster-steps 2", 2, 5)])
+def test_linclust_workflow_tsv_bytes(O, tmp_path, opts, steps, m):
+    """E8a: linear-time pre-step (minimum-hash k-mer groups, centre = longest member, candidate pairs
+    through E5/E6, set cover) in front of the cascade rounds == the oracle's workflow, byte for byte"""
+    import unicore_amd as U
+    db = util.gen_synth_db(str(tmp_path / "db"), 6, 0x5EED0004, 40, 0.6)
+    out = str(tmp_path / "clust")
+    st = U.cluster(db, out + "_cluster", str(tmp_path / "tmp"), opts, threads=4)
+    U.createtsv(db, out + "_cluster", out + ".tsv")
+    odb = O.OracleDb(db)
+    base = " ".join(t for t in opts.replace("--linclust 1", "").replace("--cluster-steps %d" % steps, "").replace("--kmer-per-seq %d" % m, "").split())
+    p = util.oracle_params(O, base)
+    ref = O.cluster_workflow(odb, p, O.cascade_thresholds(p, 4.0, steps), linclust_m=m, threads=8)
+    O.write_tsv(str(tmp_path / "ref.tsv"), odb, ref["assign"])
+    assert open(out + ".tsv", "rb").read() == open(str(tmp_path / "ref.tsv"), "rb").read()
+    util.tsv_invariants(out + ".tsv", odb.names())
+    assert st["n_clusters"] == ref["counts"]["n_clusters"] and st["n_gapped_alignments"] == ref["counts"]["n_alignments"]
+    assert ref["round_sizes"][1] < odb.n                      # the pre-step removed something
+    pr = O.linclust_pairs(odb, p, m)
+    assert len(pr) > 20 and (pr[:, 0] != pr[:, 1]).all()

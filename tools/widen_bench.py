@@ -13,7 +13,7 @@ wq = "/tmp/uc_bench/p5q"
 bench.gen_db(wq, 5, 6000, 1.0, 0x5EED0002)    # same families as the target DB (its first 5 proteomes)
 qdb = os.path.join(wq, "db")
 out = {}
-for name, opts in (("cluster_single", "-c 0.8"), ("cluster_cascade3", "-c 0.8 --cluster-steps 3"), ("cluster_seqid", "-c 0.8 --min-seq-id 0.3")):
+for name, opts in (("cluster_single", "-c 0.8"), ("cluster_cascade3", "-c 0.8 --cluster-steps 3"), ("cluster_linclust_cascade3", "-c 0.8 --linclust 1 --cluster-steps 3"), ("cluster_seqid", "-c 0.8 --min-seq-id 0.3")):
     U.cluster(db, "/tmp/uc_bench/w_cluster", "/tmp/uc_bench/tmp", opts)          # warm-up (allocations, page cache)
     t = time.perf_counter()
     st = U.cluster(db, "/tmp/uc_bench/w_cluster", "/tmp/uc_bench/tmp", opts)

@@ -301,8 +301,10 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
              E.device, p.cluster_steps);
         std::vector<uint32_t> assign(n), cur(n), posmap(n);
         for (uint32_t i = 0; i < n; i++) { assign[i] = i; cur[i] = i; }
-        for (int r = 0; r < p.cluster_steps; r++) {
-            if (r > 0) {   // sub-database of the current representatives
+        const int pre = p.linclust ? 1 : 0;     // E8a: one linear-time pre-clustering round in front of the cascade rounds
+        for (int rr = 0; rr < p.cluster_steps + pre; rr++) {
+            const int r = rr - pre;             // cascade round index (-1 = the pre-step)
+            if (rr > 0) {   // sub-database of the current representatives
                 HostDb sub;
                 sub.n = (uint32_t)cur.size();
                 sub.off.resize((size_t)sub.n + 1);
@@ -317,12 +319,22 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
                 }
                 E.hdb = std::move(sub);
             }
-            if (p.cluster_steps > 1 && !p.kmer_thr_explicit)   // sensitivity rises linearly from 1 to the target (spec UC-1 E8)
+            if (r >= 0 && p.cluster_steps > 1 && !p.kmer_thr_explicit)   // sensitivity rises linearly from 1 to the target (spec UC-1 E8)
                 E.p.kmer_thr = kmer_thr_for(p, 1.0 + (p.sensitivity - 1.0) * r / (p.cluster_steps - 1));
             E.upload_db();
-            E.prefilter(0, E.hdb.n);
-            logf(3, "unicore-cluster: step %d: %u sequences, prefilter kept %llu pairs (k-score %d, max-seqs %d)\n", r + 1, E.hdb.n,
-                 (unsigned long long)E.n_hits, E.p.kmer_thr, p.max_seqs);
+            if (r < 0) {   // E8a: candidate pairs (centre, member) from shared minimum-hash k-mers, the centre is the query
+                const std::vector<uint32_t> pr = linclust_pairs(E.hdb, p, p.threads);
+                std::vector<uint32_t> cnt(E.hdb.n, 0);
+                std::vector<uc_hit> hl(pr.size() / 2);
+                for (size_t k = 0; k < pr.size() / 2; k++) { cnt[pr[2 * k]]++; hl[k].target = pr[2 * k + 1]; hl[k].score = 0; hl[k].diag = 0; }
+                E.set_hits(cnt.data(), hl.data(), /*check_max_seqs=*/false);
+                E.stats.n_prefilter_hits += pr.size() / 2;
+                logf(3, "unicore-cluster: pre-step: %u sequences, %zu candidate pairs (%d k-mers per sequence)\n", E.hdb.n, pr.size() / 2, p.kmer_per_seq);
+            } else {
+                E.prefilter(0, E.hdb.n);
+                logf(3, "unicore-cluster: step %d: %u sequences, prefilter kept %llu pairs (k-score %d, max-seqs %d)\n", r + 1, E.hdb.n,
+                     (unsigned long long)E.n_hits, E.p.kmer_thr, p.max_seqs);
+            }
             E.align(0, E.hdb.n);
             Timer tc;
             std::vector<uint32_t> sa(E.hdb.n);

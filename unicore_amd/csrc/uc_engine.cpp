@@ -121,13 +121,13 @@ void Engine::ungapped_batch(uint64_t n, const uint32_t *q, const uint32_t *t, co
     UC_HIP(hipStreamSynchronize(stream));
 }
 
-void Engine::set_hits(const uint32_t *counts, const uc_hit *h) {
+void Engine::set_hits(const uint32_t *counts, const uc_hit *h, bool check_max_seqs) {
     const uint32_t n = hdb.n;
     UC_HIP(hipSetDevice(device));
     hit_cnt.assign(counts, counts + n);
     hit_off.assign((size_t)n + 1, 0);
     for (uint32_t i = 0; i < n; i++) {
-        if (counts[i] > (uint32_t)p.max_seqs) fail(UC_ERR_ARGS, "hit list of query %u longer than max_seqs", i);
+        if (check_max_seqs && counts[i] > (uint32_t)p.max_seqs) fail(UC_ERR_ARGS, "hit list of query %u longer than max_seqs", i);
         hit_off[i + 1] = hit_off[i] + counts[i];
     }
     n_hits = hit_off[n];

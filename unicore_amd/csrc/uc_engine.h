@@ -99,7 +99,7 @@ struct Engine {
     PrefilterScratch *pre = nullptr;                       // work buffers kept between prefilter calls
     AlignScratch *aln = nullptr;                           // ... and between align calls
     uint64_t prefilter_chunk_residues = 96ull << 20;   // target residues per index chunk (keeps hits/query inside the LDS filter)
-    void set_hits(const uint32_t *counts, const uc_hit *h);
+    void set_hits(const uint32_t *counts, const uc_hit *h, bool check_max_seqs = true);
     void get_hits(uc_hit *out) const;                        // D2H of the device hit arrays
     void export_hits_dev(uint32_t *dq, uint32_t *dt, int32_t *ds, int32_t *dd) const;
     uint64_t import_hits_dev(uint64_t n, const uint32_t *dq, const uint32_t *dt, const int32_t *ds, const int32_t *dd,
@@ -119,6 +119,8 @@ struct Engine {
 
 void set_cover(uint32_t n, const uint32_t *edges, uint64_t n_edges, uint32_t *assign);
 void set_cover_csr(uint32_t n, const uint64_t *off, const uint32_t *adj, uint32_t *assign);
+// E8a: (centre, member) candidate pairs of the linear-time pre-step, sorted by (centre, member), unique   (uc_linclust.cpp)
+std::vector<uint32_t> linclust_pairs(const HostDb &db, const Params &p, int threads);
 void merge_hits(uint32_t n, int max_seqs, int n_parts, const uint32_t *const *counts, const uc_hit *const *hits,
                 std::vector<uint32_t> &out_cnt, std::vector<uc_hit> &out_hits);
 const char *last_error_cstr();

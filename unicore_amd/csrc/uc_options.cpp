@@ -104,6 +104,8 @@ void parse_cluster_options(const std::string &opts, Params &p) {
         else if (f == "--gap-extend") { p.gap_ext = to_int(f, value()); if (p.gap_ext < 0 || p.gap_ext > 31) fail(UC_ERR_ARGS, "--gap-extend must be in [0,31]"); }
         else if (f == "--spaced-kmer-pattern") { p.pattern = value(); }
         else if (f == "--rev-correction") { p.rev_correction = to_int(f, value()) != 0; }
+        else if (f == "--linclust") { p.linclust = to_int(f, value()) != 0; }
+        else if (f == "--kmer-per-seq") { p.kmer_per_seq = to_int(f, value()); if (p.kmer_per_seq < 1 || p.kmer_per_seq > 1000) fail(UC_ERR_ARGS, "--kmer-per-seq must be in [1,1000]"); }
         else if (f == "--sym-dedup") { p.sym_dedup = to_int(f, value()) != 0; }
         else if (f == "--sw-kernel") { const std::string &v = value(); if (v == "pk16") p.sw_pk = 1; else if (v == "i32") p.sw_pk = 0; else fail(UC_ERR_ARGS, "--sw-kernel must be pk16 or i32"); }
         else if (f == "--evalue-lambda") { p.lambda = to_double(f, value()); }

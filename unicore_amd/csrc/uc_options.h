@@ -42,6 +42,8 @@ struct Params {
     // clustering
     int cluster_mode = 0;
     int cluster_steps = 1;      // > 1: cascade (E8) — rounds on representatives with rising sensitivity, merged at the end
+    int linclust = 0;           // 1: linear-time pre-step (E8a) before the clustering rounds
+    int kmer_per_seq = 20;      // k-mers every sequence keeps in the pre-step
     bool kmer_thr_explicit = false;   // --k-score given: every cascade round uses it
     bool single_step = true;
     bool single_step_given = false;
