@@ -42,6 +42,9 @@ def main():
     rc = O.cluster_cascade(odb, p, thr, threads=4)
     O.write_tsv(os.path.join(HERE, "clust_cascade3.tsv"), odb, rc["assign"])
     print("cascade3", thr, "->", rc["round_sizes"].tolist(), "sequences per round,", rc["counts"]["n_clusters"], "clusters")
+    rw = O.cluster_workflow(odb, p, thr, linclust_m=20, threads=4)
+    O.write_tsv(os.path.join(HERE, "clust_linclust_cascade3.tsv"), odb, rw["assign"])
+    print("linclust + cascade3 ->", rw["round_sizes"].tolist(), "sequences per round,", rw["counts"]["n_clusters"], "clusters")
     ps = util.oracle_params(O, "-e 10 --max-seqs 1000 -c 0.8")
     rs = O.search(odb, odb, ps, threads=4)
     O.write_m8(os.path.join(HERE, "search_self.m8"), odb, odb, ps, rs)

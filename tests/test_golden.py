@@ -73,6 +73,9 @@ def test_oracle_reproduces_golden_cascade_and_search(tmp_path):
     rc = O.cluster_cascade(odb, p, O.cascade_thresholds(p, 4.0, 3), threads=4)
     O.write_tsv(str(tmp_path / "c.tsv"), odb, rc["assign"])
     assert open(tmp_path / "c.tsv", "rb").read() == open(os.path.join(GOLD, "clust_cascade3.tsv"), "rb").read()
+    rw = O.cluster_workflow(odb, p, O.cascade_thresholds(p, 4.0, 3), linclust_m=20, threads=4)
+    O.write_tsv(str(tmp_path / "w.tsv"), odb, rw["assign"])
+    assert open(tmp_path / "w.tsv", "rb").read() == open(os.path.join(GOLD, "clust_linclust_cascade3.tsv"), "rb").read()
     ps = util.oracle_params(O, "-e 10 --max-seqs 1000 -c 0.8")
     rs = O.search(odb, odb, ps, threads=4)
     O.write_m8(str(tmp_path / "s.m8"), odb, odb, ps, rs)
@@ -86,6 +89,9 @@ def test_hip_path_reproduces_golden_cascade_and_search(tmp_path):
     U.cluster(db, str(tmp_path / "c_cluster"), str(tmp_path / "tmp"), "-c 0.8 --cluster-steps 3")
     U.createtsv(db, str(tmp_path / "c_cluster"), str(tmp_path / "c.tsv"))
     assert open(tmp_path / "c.tsv", "rb").read() == open(os.path.join(GOLD, "clust_cascade3.tsv"), "rb").read()
+    U.cluster(db, str(tmp_path / "w_cluster"), str(tmp_path / "tmp"), "-c 0.8 --linclust 1 --cluster-steps 3")
+    U.createtsv(db, str(tmp_path / "w_cluster"), str(tmp_path / "w.tsv"))
+    assert open(tmp_path / "w.tsv", "rb").read() == open(os.path.join(GOLD, "clust_linclust_cascade3.tsv"), "rb").read()
     U.search(db, db, str(tmp_path / "s_aln"), str(tmp_path / "tmp"), "-c 0.8")
     U.convertalis(db, db, str(tmp_path / "s_aln"), str(tmp_path / "s.m8"))
     assert open(tmp_path / "s.m8", "rb").read() == open(os.path.join(GOLD, "search_self.m8"), "rb").read()
