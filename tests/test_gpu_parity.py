@@ -522,3 +522,42 @@ def test_linclust_workflow_tsv_bytes(O, tmp_path, opts, steps, m):
     assert ref["round_sizes"][1] < odb.n                      # the pre-step removed something
     pr = O.linclust_pairs(odb, p, m)
     assert len(pr) > 20 and (pr[:, 0] != pr[:, 1]).all()
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_option_sets_against_the_oracle(O, seed):
+    """property test: random small databases x random option strings (gates, gap costs, sensitivity, truncation, execution
+    variants): accepted pairs and the cluster assignment equal the oracle's"""
+    import unicore_amd as U
+    rng = np.random.default_rng(1000 + seed)
+    s3, sa = util.family_db(500 + seed, n_fam=int(rng.integers(4, 12)), members=int(rng.integers(2, 8)), lmin=int(rng.integers(20, 60)),
+                            lmax=int(rng.integers(80, 400)), sub3=float(rng.uniform(0.05, 0.3)), suba=float(rng.uniform(0.1, 0.5)),
+                            indel=float(rng.uniform(0.0, 0.05)), extra=tuple(int(x) for x in rng.integers(300, 1900, int(rng.integers(0, 3)))))
+    opts = ["-c %.2f" % rng.choice([0.3, 0.5, 0.8, 0.9]), "--cov-mode %d" % rng.integers(0, 3), "-e %g" % rng.choice([1e-3, 1e-6, 10.0]),
+            "--max-seqs %d" % rng.choice([3, 20, 300])]
+    if rng.random() < 0.5: opts.append("-s %g" % rng.choice([2.0, 4.0, 6.0]))
+    if rng.random() < 0.3: opts.append("--min-diag-hits %d" % rng.choice([1, 3]))
+    if rng.random() < 0.4: opts.append("--gap-open %d --gap-extend %d" % (rng.choice([8, 10, 12]), rng.choice([1, 2])))
+    if rng.random() < 0.3: opts.append("--rev-correction 0")
+    if rng.random() < 0.4: opts.append("--min-seq-id %.2f" % rng.choice([0.2, 0.4, 0.6]))
+    if rng.random() < 0.3: opts.append("--min-ungapped-score %d" % rng.choice([10, 25]))
+    eng = []
+    if rng.random() < 0.3: eng.append("--sym-dedup 0")
+    if rng.random() < 0.3: eng.append("--sw-kernel i32")
+    ostr = " ".join(opts)
+    off, c3, ca = util.flat(s3, sa)
+    e = U.Engine(ostr + " " + " ".join(eng), verbosity=1)
+    e.set_db(off, c3, ca)
+    e.prefilter()
+    e.align()
+    ref = O.cluster(O.OracleDb(s3=s3, sa=sa), util.oracle_params(O, ostr), threads=8)
+    cnt, hits = e.hits()
+    assert np.array_equal(cnt, ref["hit_cnt"]), ostr
+    al = e.alns()
+    ra = np.concatenate([ref["aln"][i, : cnt[i]] for i in range(len(cnt))]) if cnt.sum() else al
+    for f in ("score", "score_rev", "corrected", "pass_evalue", "accepted", "aln_len", "idents"):
+        assert np.array_equal(al[f], ra[f]), (f, ostr, eng)
+    pe = al["pass_evalue"] == 1
+    for f in ("qstart", "qend", "tstart", "tend"):
+        assert np.array_equal(al[f][pe], ra[f][pe]), (f, ostr, eng)
+    assert np.array_equal(e.setcover(e.edges()), ref["assign"]), (ostr, eng)
