@@ -169,7 +169,7 @@ class OracleDb:
         return [self.db.names[i].decode() for i in range(self.n)]
 
     def __del__(self):
-        if getattr(self, "_owned", False):
+        if getattr(self, "_owned", False) and lib is not None and C is not None:   # module globals are gone at interpreter exit
             lib().uco_db_free(C.byref(self.db))
 
 
