@@ -307,6 +307,7 @@ __global__ void __launch_bounds__(256) expand_kernel(const DeviceDb db, uint32_t
 // query reserved with one atomic (sized by its hit total) and are compacted afterwards.
 constexpr int FB_LOG2 = 19;            // bits per bitmap: 2 x 64 KiB of the CU's 160 KiB LDS
 constexpr int FT = 1024;               // threads per workgroup = runs per tile
+constexpr int KPT = 4;                 // consecutive keys per thread and binary search
 constexpr size_t FILTER_LDS = 2 * ((size_t)1 << FB_LOG2) / 8 + (FT + 1) * 8 + FT * 8 + 16 * 8 + 64;
 
 __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t qbegin, uint32_t p0, const uint32_t *rpidx,
@@ -362,15 +363,32 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
         if (tid == FT - 1) s_pref[FT] = woff + inc;
         __syncthreads();
     };
-    // key k of the current tile: (target << dbits | diagonal + dbias)
-    auto key_at = [&](uint64_t k) -> uint64_t {
+    // keys k4 .. k4+KPT-1 of the current tile, (target << dbits | diagonal + dbias) each: one binary search finds the run
+    // of the first key, the others walk forward from it, and the (up to) KPT index loads are in flight together —
+    // the kernel is bound by the latency of search + load, not by LDS or HBM throughput.  Returns the number of keys.
+    auto keys_at = [&](uint64_t k4, uint64_t T, uint64_t (&td)[KPT]) -> int {
         int lo = 0, hi = FT;
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (s_pref[mid] <= k) lo = mid; else hi = mid;
+            if (s_pref[mid] <= k4) lo = mid; else hi = mid;
         }
-        const uint64_t e = ent[s_e0[lo] + (uint32_t)(k - s_pref[lo])];
-        return ((e >> 16) << fmt.dbits) | (uint64_t)(s_i[lo] - (int32_t)(e & 0xFFFF));
+        const int n = T - k4 < KPT ? (int)(T - k4) : KPT;
+        uint32_t idx[KPT];
+        int32_t si[KPT];
+#pragma unroll
+        for (int i = 0; i < KPT; i++) {
+            if (i < n) {
+                while (s_pref[lo + 1] <= k4 + i) lo++;      // s_pref[FT] = T > k4 + i ends the walk
+                idx[i] = s_e0[lo] + (uint32_t)(k4 + i - s_pref[lo]);
+                si[i] = s_i[lo];
+            } else { idx[i] = idx[0]; si[i] = si[0]; }
+        }
+        uint64_t e[KPT];
+#pragma unroll
+        for (int i = 0; i < KPT; i++) e[i] = ent[idx[i]];
+#pragma unroll
+        for (int i = 0; i < KPT; i++) td[i] = ((e[i] >> 16) << fmt.dbits) | (uint64_t)(si[i] - (int32_t)(e[i] & 0xFFFF));
+        return n;
     };
     // two independent hash positions per (target, diagonal): a key survives only if BOTH were seen twice (a Bloom
     // filter with k = 2: collisions let ~2 % of the single hits through instead of ~11 %, which is what the sort pays for)
@@ -384,13 +402,19 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
     for (uint64_t tile = r0; tile < r1; tile += FT) {
         load_tile(tile);
         const uint64_t T = s_pref[FT];
-        for (uint64_t k = tid; k < T; k += FT) {
-            uint32_t g;
-            const uint32_t h = slot_of(key_at(k), g), bit = 1u << (h & 31), gbit = 1u << (g & 31);
-            const uint32_t old = atomicOr(&B1[h >> 5], bit);
-            if (old & bit) atomicOr(&B2[h >> 5], bit);
-            const uint32_t gold = atomicOr(&B1[g >> 5], gbit);
-            if (gold & gbit) atomicOr(&B2[g >> 5], gbit);
+        for (uint64_t k4 = (uint64_t)KPT * tid; k4 < T; k4 += (uint64_t)KPT * FT) {
+            uint64_t td[KPT];
+            const int n = keys_at(k4, T, td);
+#pragma unroll
+            for (int i = 0; i < KPT; i++) {
+                if (i >= n) break;
+                uint32_t g;
+                const uint32_t h = slot_of(td[i], g), bit = 1u << (h & 31), gbit = 1u << (g & 31);
+                const uint32_t old = atomicOr(&B1[h >> 5], bit);
+                if (old & bit) atomicOr(&B2[h >> 5], bit);
+                const uint32_t gold = atomicOr(&B1[g >> 5], gbit);
+                if (gold & gbit) atomicOr(&B2[g >> 5], gbit);
+            }
         }
         total += T;
         __syncthreads();
@@ -405,23 +429,34 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
     for (uint64_t tile = r0; tile < r1; tile += FT) {
         load_tile(tile);
         const uint64_t T = s_pref[FT];
-        const uint64_t Tr = (T + 63) & ~63ull;       // whole waves stay in the loop (ballot)
-        for (uint64_t k = tid; k < Tr; k += FT) {
-            uint64_t td = 0;
-            bool keep = false;
-            if (k < T) {
-                td = key_at(k);
-                uint32_t g;
-                const uint32_t h = slot_of(td, g);
-                keep = ((B2[h >> 5] >> (h & 31)) & (B2[g >> 5] >> (g & 31))) & 1u;
+        const uint64_t Tr = (T + 64 * KPT - 1) / (64 * KPT) * (64 * KPT);     // whole waves stay in the loop: 64 lanes x KPT keys
+        for (uint64_t k4 = (uint64_t)KPT * tid; k4 < Tr; k4 += (uint64_t)KPT * FT) {
+            uint64_t td[KPT] = {};
+            uint32_t keep = 0;                      // bit i: key i survives
+            if (k4 < T) {
+                const int n = keys_at(k4, T, td);
+#pragma unroll
+                for (int i = 0; i < KPT; i++) {
+                    uint32_t g;
+                    const uint32_t h = slot_of(td[i], g);
+                    if (i < n) keep |= (((B2[h >> 5] >> (h & 31)) & (B2[g >> 5] >> (g & 31))) & 1u) << i;
+                }
             }
-            const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
-            if (m) {
+            const uint32_t mine = (uint32_t)__popc(keep);
+            uint32_t inc = mine;                    // inclusive scan of the survivors inside the wave
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)inc, o, 64);
+                if (lane >= o) inc += up;
+            }
+            const uint32_t wave_total = (uint32_t)__shfl((int)inc, 63, 64);
+            if (wave_total) {
                 uint32_t s0 = 0;
-                if (lane == 0) s0 = atomicAdd(cur, (uint32_t)__popcll(m));
+                if (lane == 0) s0 = atomicAdd(cur, wave_total);
                 s0 = (uint32_t)__shfl((int)s0, 0, 64);
-                const uint64_t w = base + s0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (keep && w < key_cap) keys[w] = qbits | td;
+                uint64_t w = base + s0 + (inc - mine);
+#pragma unroll
+                for (int i = 0; i < KPT; i++)
+                    if ((keep >> i) & 1u) { if (w < key_cap) keys[w] = qbits | td[i]; w++; }
             }
         }
         __syncthreads();
