@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
             E[r] = pk_max(esub, t);
             f = pk_max(fsub, t);
             if constexpr (TRACK && !KNOWN) rowbest[r] = pk_max(rowbest[r], h);
-            colmax = pk_max(colmax, h);
+            if (r & 1) colmax = pk_max3(colmax, H[r - 1], h);   // two rows per instruction (R is even)
         }
         if constexpr (TBB) {   // bytes of 4 rows -> one dword per pair; step-major matrix: G*RB contiguous bytes per group and step
             constexpr int RB = 4 * RW;
