@@ -206,7 +206,8 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
         fetch_profile();
     };
 
-    auto do_step = [&](const int st) __attribute__((always_inline)) {
+    // ODD = second step of the 2-step loop trip: the per-row maxima take this step's and the previous step's H in one max3
+    auto do_step = [&](const int st, const bool ODD) __attribute__((always_inline)) {
         uint32_t sA[RW], sB[RW];
 #pragma unroll
         for (int k = 0; k < RW; k++) {
@@ -230,7 +231,8 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
             const uint32_t x = pk_sub_sat(pk_add_sat(diag, ub), bias2);
             const uint32_t e = E[r];                          // max(E - ext, H - open) of the previous column
             const uint32_t h = pk_max3(x, e, f);
-            diag = H[r];
+            const uint32_t hprev = H[r];                      // this row one column earlier
+            diag = hprev;
             H[r] = h;
             const uint32_t t = pk_sub_sat(h, open2);
             const uint32_t esub = pk_sub_sat(e, ext2), fsub = pk_sub_sat(f, ext2);
@@ -246,7 +248,7 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
             }
             E[r] = pk_max(esub, t);
             f = pk_max(fsub, t);
-            if constexpr (TRACK && !KNOWN) rowbest[r] = pk_max(rowbest[r], h);
+            if constexpr (TRACK && !KNOWN) { if (ODD) rowbest[r] = pk_max3(rowbest[r], hprev, h); }
             if (r & 1) colmax = pk_max3(colmax, H[r - 1], h);   // two rows per instruction (R is even)
         }
         if constexpr (TBB) {   // bytes of 4 rows -> one dword per pair; step-major matrix: G*RB contiguous bytes per group and step
@@ -374,8 +376,8 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
     start_slot();
     while (__builtin_amdgcn_ballot_w64(active) != 0) {
         if (active) {
-            do_step(lst);
-            do_step(lst + 1);
+            do_step(lst, false);
+            do_step(lst + 1, true);
             lst += 2;
             if (lst >= nst) {
                 finish_slot();
