@@ -36,6 +36,7 @@ constexpr int SW_PK_OVF = 0x7C00 - 256;   // scores at or above this are recompu
 typedef uint16_t u16x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned wide stores (MODE 7)
 typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+typedef const uint32_t __attribute__((address_space(4))) *sw_cu32p;         // constant address space: uniform loads become s_load_dword
 __device__ __forceinline__ u16x2_t pk_v(uint32_t x) { return __builtin_bit_cast(u16x2_t, x); }
 __device__ __forceinline__ uint32_t pk_u(u16x2_t v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b) { return pk_u(__builtin_elementwise_add_sat(pk_v(a), pk_v(b))); }
@@ -125,7 +126,16 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
         const uint32_t pa = toffA + (uint32_t)(REVT ? max(tlenA - 1 - ia, 0) : ia);
         const uint32_t pb_ = toffB + (uint32_t)(REVT ? max(tlenB - 1 - ib, 0) : ib);
         RawLetters r;
-        r.a3 = a.db.s3[pa]; r.aa = a.db.sa[pa]; r.b3 = a.db.s3[pb_]; r.ba = a.db.sa[pb_];
+        if constexpr (G == 64) {   // one group per wave: the slot state is wave-uniform, so the letters come through the scalar
+                                   // cache (aligned dword + shift on the SALU) and cost no VALU issue slots at all
+            auto ld = [&](const uint8_t *base, uint32_t p) -> uint32_t {
+                const sw_cu32p w = (sw_cu32p)(uintptr_t)(base + (p & ~3u));
+                return (*w >> (8u * (p & 3u))) & 0xffu;
+            };
+            r.a3 = ld(a.db.s3, pa); r.aa = ld(a.db.sa, pa); r.b3 = ld(a.db.s3, pb_); r.ba = ld(a.db.sa, pb_);
+        } else {
+            r.a3 = a.db.s3[pa]; r.aa = a.db.sa[pa]; r.b3 = a.db.s3[pb_]; r.ba = a.db.sa[pb_];
+        }
         return r;
     };
     auto pack_letters = [&](const RawLetters &r, int st) -> uint32_t {
@@ -144,7 +154,8 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
     auto start_slot = [&]() {
         uint32_t idx = 0;
         if (g == 0) idx = atomicAdd(slot_ctr, 1u);
-        idx = (uint32_t)__shfl((int)idx, lane - g, 64);
+        if constexpr (G == 64) idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);   // wave-uniform from here on (SGPRs)
+        else idx = (uint32_t)__shfl((int)idx, lane - g, 64);
         active = idx < nslots;
         if (!active) return;
         const uint32_t iA = 2 * idx, iB = iA + 1;
