@@ -143,9 +143,14 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
         const uint32_t cb_ = st < tlenB ? (r.b3 | (r.ba << 8)) : SW_PADPACK;
         return ca_ | (cb_ << 16);
     };
+    uint32_t off3 = (uint32_t)(g * BW) * 4u, offa = (uint32_t)(SW_NLET * RSW + g * BW) * 4u;
+    asm volatile("" : "+v"(off3), "+v"(offa));
     auto fetch_profile = [&]() __attribute__((always_inline)) {
-        const uint32_t *pA3 = P3 + (cin & 0xff) * RSW + g * BW, *pAa = PA + ((cin >> 8) & 0xff) * RSW + g * BW;
-        const uint32_t *pB3 = P3 + ((cin >> 16) & 0xff) * RSW + g * BW, *pBa = PA + (cin >> 24) * RSW + g * BW;
+        // byte offsets: letter * row-set stride + this lane's base in P3 / PA (two opaque registers, so that the PA base is
+        // the addend of the multiply-add instead of a separate add per load)
+        const char *l8 = (const char *)lds;
+        const uint32_t *pA3 = (const uint32_t *)(l8 + (cin & 0xff) * (RSW * 4) + off3), *pAa = (const uint32_t *)(l8 + ((cin >> 8) & 0xff) * (RSW * 4) + offa);
+        const uint32_t *pB3 = (const uint32_t *)(l8 + ((cin >> 16) & 0xff) * (RSW * 4) + off3), *pBa = (const uint32_t *)(l8 + (cin >> 24) * (RSW * 4) + offa);
 #pragma unroll
         for (int k = 0; k < RW; k++) { nA3[k] = pA3[k]; nAa[k] = pAa[k]; nB3[k] = pB3[k]; nBa[k] = pBa[k]; }
     };
@@ -213,6 +218,11 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
         nst = (max(tlenA, tlenB) + G) & ~1;      // Lt + G - 1 steps, rounded up to the 2-step loop trip
         c1 = pack_letters(issue_letters(1), 1);
         r2 = issue_letters(2);
+        if constexpr (G == 64) {   // keep the letter pipeline in SGPRs across the loop back edge
+            c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c1);
+            r2.a3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r2.a3); r2.aa = (uint32_t)__builtin_amdgcn_readfirstlane((int)r2.aa);
+            r2.b3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r2.b3); r2.ba = (uint32_t)__builtin_amdgcn_readfirstlane((int)r2.ba);
+        }
         cin = (uint32_t)shift_from_prev_lane<G>((int)(SW_PADPACK * 0x10001u), (int)pack_letters(issue_letters(0), 0), g);
         fetch_profile();
     };
