@@ -196,7 +196,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: %d synthetic proteomes, %d seqs, %d residues, options '%s', gen_synth seed %#x"
                                    % (args.proteomes, n, int(lens.sum()), args.options, seed),
                        "alignments_per_step": n_aln // steps, "clusters": int((assign == np.arange(n)).sum()) if assign is not None else None,
-                       "parallelism": "target-shard x%d + RCCL hit all-gather (device-resident), pair-hash partition of the gapped stage" % world if world > 1 else "single GPU"},
+                       "parallelism": ("%d query groups x %d target shards (unicore_amd.dist.grid_shape) + RCCL hit all-gather (device-resident), "
+                                       "pair-hash partition of the gapped stage" % ucdist.grid_shape(lens, world)) if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "sw_pk_kernel + sw_group_kernel (gapped 3Di+AA SW, all classes and passes)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic_per_launch(),

@@ -29,6 +29,26 @@ def test_shard_and_query_ranges_are_partitions():
         assert r[0][0] == 0 and r[-1][1] == len(lens) and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
 
 
+def test_grid_shape_and_ranges():
+    """query groups x target shards: T = 1 while the DB fits one prefilter chunk, target shards where they save whole chunks"""
+    small = np.full(1000, 300)                                   # 300 k residues: one chunk
+    for w in (1, 2, 4, 8):
+        assert ucdist.grid_shape(small, w) == (w, 1)
+        g = ucdist.grid_ranges(small, w)
+        assert len(g) == w and all(x[:2] == (0, 1000) for x in g)
+        assert g[0][2] == 0 and g[-1][3] == 1000 and all(g[i][3] == g[i + 1][2] for i in range(w - 1))
+    big = np.full(1_000_000, 192)                                # 192 M residues: two chunks unsharded, one per half
+    assert ucdist.grid_shape(big, 8) == (4, 2)                   # cost 2 for T = 1 and T = 2: the larger T wins the tie
+    assert ucdist.grid_shape(big, 8, target_shards=8) == (1, 8)
+    g = ucdist.grid_ranges(big, 8)
+    cover = np.zeros((8, 8), int)                                # every (query octile, target octile) cell exactly once
+    for tb, te, qb, qe in g:
+        cover[qb // 125000: -(-qe // 125000), tb // 125000: -(-te // 125000)] += 1
+    assert (cover == 1).all()
+    with pytest.raises(ValueError):
+        ucdist.grid_shape(small, 8, target_shards=3)
+
+
 def test_virtual_shards_merge_equals_unsharded_oracle():
     """G virtual shards processed one after the other and merged == the G=1 list (determinism requirement)"""
     s3, sa = util.family_db(17, n_fam=8, members=5, lmin=40, lmax=140)
@@ -47,7 +67,7 @@ def test_virtual_shards_merge_equals_unsharded_oracle():
         assert np.array_equal(mh["target"], flat1["target"]) and np.array_equal(mh["score"], flat1["score"]) and np.array_equal(mh["diag"], flat1["diag"])
 
 
-def _rank_main(rank, world, port, tmpdir):
+def _rank_main(rank, world, port, tmpdir, target_shards):
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
@@ -55,8 +75,9 @@ def _rank_main(rank, world, port, tmpdir):
         odb = O.OracleDb(s3=s3, sa=sa)
         p = util.oracle_params(O, "-c 0.8 --max-seqs 5")
         lens = np.array([len(x) for x in s3])
-        tb, te = ucdist.shard_ranges(lens, world)[rank]
+        tb, te, qb0, qe0 = ucdist.grid_ranges(lens, world, target_shards)[rank]
         c, h = O.prefilter_shard(odb, p, tb, te)                      # this rank's shard (stands in for the HIP prefilter)
+        c[:qb0] = 0; c[qe0:] = 0                                      # ... restricted to its query group
         flat = np.concatenate([h[q, : c[q]] for q in range(odb.n)]).astype(U.HIT_DTYPE)
         parts = ucdist.exchange_hits(c, flat, device="cpu")           # the collective
         mc, mh = ucdist.merged_hits(parts, odb.n, p.max_seqs)
@@ -79,10 +100,11 @@ def _rank_main(rank, world, port, tmpdir):
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_exchange_matches_single_rank(tmp_path):
+@pytest.mark.parametrize("target_shards", [2, 1])      # two target shards / two query groups
+def test_two_rank_gloo_exchange_matches_single_rank(tmp_path, target_shards):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_rank_main, args=(2, port, str(tmp_path), target_shards), nprocs=2, join=True)
     s3, sa = util.family_db(23, n_fam=7, members=5, lmin=40, lmax=120)
     odb = O.OracleDb(s3=s3, sa=sa)
     p = util.oracle_params(O, "-c 0.8 --max-seqs 5")

@@ -229,8 +229,9 @@ def test_long_query_pipeline_with_seqid(O):
     assert np.array_equal(U.setcover(e.n, e.edges()), ref["assign"])
 
 
-def test_device_exchange_virtual_ranks(O):
-    """multi-GPU layout on one GPU: W virtual target shards -> device-side export, union, merge (== unsharded lists),
+@pytest.mark.parametrize("target_shards", [3, 1, 2])
+def test_device_exchange_virtual_ranks(O, target_shards):
+    """multi-GPU layout on one GPU: W virtual ranks (query groups x target shards) -> device-side export, union, merge (== unsharded lists),
     pair-hash partition over W virtual ranks: every pair is aligned exactly once, mutual hits meet on one rank, and
     the union of the ranks' accepted edges equals the single-GPU edge set."""
     import torch
@@ -247,10 +248,11 @@ def test_device_exchange_virtual_ranks(O):
     e.align()
     edges_ref = set(map(tuple, e.edges().tolist()))
     assert len(edges_ref) > 50
-    W = 3
+    W = 3 if target_shards != 2 else 4
     bufs = []
-    for tb, te in ucdist.shard_ranges(lens, W):
-        e.prefilter(tb, te)
+    assert ucdist.grid_shape(lens, W, target_shards) == (W // target_shards, target_shards)
+    for tb, te, qb, qe in ucdist.grid_ranges(lens, W, target_shards):
+        e.prefilter(tb, te, qb, qe)
         n = e.hits_size()
         t = torch.empty((4, max(n, 1)), dtype=torch.int32, device="cuda")
         e.hits_export_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr())
@@ -260,6 +262,8 @@ def test_device_exchange_virtual_ranks(O):
     ptrs = [allh[i].data_ptr() for i in range(4)]
     ntot = int(allh.shape[1])
     assert ntot >= len(hits_ref)                      # per-shard top-M lists: the union is a superset
+    if target_shards == 1:
+        assert ntot == len(hits_ref)                  # query groups alone: the rank lists partition the unsharded lists
     assert e.hits_import_dev(ntot, *ptrs, 0, 1) == len(hits_ref)
     cnt, hits = e.hits()
     assert np.array_equal(cnt, cnt_ref) and hits.tobytes() == hits_ref.tobytes()

@@ -1,6 +1,7 @@
 """unicore_amd.dist — the multi-GPU layout of the cluster path, one process per GPU.
 
-    rank g:  index target shard g  ->  match ALL queries against it (E1-E4)  ->  per-shard hit lists
+    rank r:  index target shard r % T  ->  match query group r // T against it (E1-E4)  ->  per-rank hit lists
+             (Q x T = world; grid_shape picks T: 1 while the DB fits one prefilter chunk, see there)
     exchange: all-gather of the ragged hit lists (torch.distributed; backend "nccl" is RCCL over xGMI on
               ROCm, "gloo" on CPU for the tests) — the ONE collective of the path
     every rank: merge the shard lists per query under the frozen order (score desc, target asc), keep
@@ -32,6 +33,44 @@ def shard_ranges(lens, world):
     for i in range(1, len(bounds)):
         bounds[i] = max(bounds[i], bounds[i - 1])
     return [(bounds[g], bounds[g + 1]) for g in range(world)]
+
+
+PREFILTER_CHUNK_RESIDUES = 96_000_000      # the engine's target chunk (uc_engine.h prefilter_chunk_residues)
+
+
+def grid_shape(lens, world, target_shards=None):
+    """(query groups Q, target shards T) with Q * T == world.
+
+    Rank r matches query group r // T against target shard r % T.  The similar-k-mer generation of a rank is paid once
+    per (query of its group) x (target chunk of its shard: the engine walks a shard in chunks of PREFILTER_CHUNK_RESIDUES),
+    so the plan minimises  queries_per_rank x chunks_per_shard = ceil(R / T / chunk) * T / world;  ties go to the larger T
+    (smaller index per rank).  A database that fits one chunk (BASELINE configs[1]) therefore runs T = 1 — every rank
+    indexes all targets (a few ms) and range-partitions the DB on the query side; the target range partition takes over
+    where a shard saves whole chunks.  UC_TARGET_SHARDS (or `target_shards`) forces T."""
+    import os
+    if target_shards is None and os.environ.get("UC_TARGET_SHARDS"):
+        target_shards = int(os.environ["UC_TARGET_SHARDS"])
+    if target_shards is not None:
+        if target_shards < 1 or world % target_shards:
+            raise ValueError("target shards (%d) must divide the world size (%d)" % (target_shards, world))
+        return world // target_shards, target_shards
+    total = int(np.asarray(lens, np.int64).sum())
+    best = None
+    for t in range(1, world + 1):
+        if world % t:
+            continue
+        chunks = max(1, -(-total // (t * PREFILTER_CHUNK_RESIDUES)))
+        cost = chunks * t          # x queries / world, common to all t
+        if best is None or cost < best[0] or (cost == best[0] and t > best[1]):
+            best = (cost, t)
+    return world // best[1], best[1]
+
+
+def grid_ranges(lens, world, target_shards=None):
+    """Per rank (tb, te, qb, qe): target shard and query group, both contiguous ranges with ~equal residue counts."""
+    q, t = grid_shape(lens, world, target_shards)
+    tr, qr = shard_ranges(lens, t), shard_ranges(lens, q)
+    return [tr[r % t] + qr[r // t] for r in range(world)]
 
 
 def query_ranges(lens, counts, hits, world):
@@ -178,8 +217,8 @@ def cluster_step(engine, lens, rank, world, max_seqs, device="cpu", group=None, 
             timing[name] = timing.get(name, 0.0) + t[-1] - t[-2]
 
     n = len(lens)
-    tb, te = shard_ranges(lens, world)[rank]
-    engine.prefilter(tb, te)
+    tb, te, qb0, qe0 = grid_ranges(lens, world)[rank]
+    engine.prefilter(tb, te, qb0, qe0)
     lap("prefilter")
     if world > 1 and gpu_device is not None:
         # device-resident exchange; every rank then aligns the pairs it owns (unordered-pair hash) over all queries
