@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 39.3e12     # int32 VALU: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz — measured: every int32 VALU
                                  # instruction of the SW kernel occupies its SIMD for 4 cycles (profiles/r1b_pmc_sw.txt)
-VALU_OPS_PER_CELL = {"fwd": 6.3, "rev": 5.6, "start": 6.7, "mean": 6.3}    # static ISA counts of the packed kernel's step loop (two cells per
+VALU_OPS_PER_CELL = {"fwd": 5.9, "rev": 5.5, "start": 6.2, "mean": 5.9}    # static ISA counts of the packed kernel's step loop at r1v (two cells per
                                  # lane-op; the int32 classes need 9.7/8.7/9.95).  valu_frac = USEFUL cell updates x ops / peak: it
                                  # excludes row padding, pipeline fill/drain and A/B length mismatch (issue utilisation is ~0.94,
                                  # profiles/r1f_pmc_sw.txt)
