@@ -24,6 +24,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # the engine's 8 streams need 8 hardware queues; read when HIP initialises
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 39.3e12     # int32 VALU: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz — measured: every int32 VALU
@@ -204,7 +205,7 @@ def main():
                          "algorithmic_bytes_per_launch": st["sw_algorithmic_bytes"] / max(st["sw_kernel_launches"], 1),
                          "avg_launch_ms": st["sw_kernel_ms"] / max(st["sw_kernel_launches"], 1),
                          "launches": st["sw_kernel_launches"],
-                         "launch_overlap": "the length classes of a pass run concurrently on 4 HIP streams; avg_launch_ms = wall time of the "
+                         "launch_overlap": "the length classes of a pass run concurrently on 8 HIP streams; avg_launch_ms = wall time of the "
                                            "fork/join regions (HIP events on the engine stream) / launches, so the per-kernel durations "
                                            "of a rocprofv3 trace sum to more than launches x avg_launch_ms",
                          "note": "integer-VALU-bound by design (SURVEY.md 8d): see valu_*",

@@ -3,12 +3,23 @@
 #include "uc_engine.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
 #include <thread>
 
 namespace uc {
+
+// The class kernels of a pass are spread over 1 + N_AUX = 8 streams.  The HIP runtime maps streams onto
+// GPU_MAX_HW_QUEUES hardware queues (default 4) when it initialises, so the library asks for 8 when it is loaded;
+// a value the host process has set, or a runtime that is already initialised, is left alone (4 queues are correct,
+// only less concurrent: the gapped stage of a 1/8 share took 105 ms instead of 88 ms).
+namespace {
+struct HwQueues {
+    HwQueues() { setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); }
+} g_hw_queues;
+}  // namespace
 
 Engine::Engine(const Params &pp, int dev) : p(pp) {
     int ndev = 0;

@@ -58,9 +58,9 @@ struct Engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // the length classes of one SW pass are independent kernels: they are spread over these streams (forked from /
     // joined to `stream`) so that the tail of one class overlaps the start of the next
-    static constexpr int N_AUX = 3;
-    hipStream_t aux[N_AUX] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[N_AUX] = {nullptr, nullptr, nullptr};
+    static constexpr int N_AUX = 7;
+    hipStream_t aux[N_AUX] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[N_AUX] = {};
 
     // host view of the DB
     HostDb hdb;
