@@ -194,8 +194,9 @@ def main():
             "value": n_aln / dt, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d synthetic proteomes, %d seqs, %d residues, options '%s', gen_synth seed %#x"
-                                   % (args.proteomes, n, int(lens.sum()), args.options, seed),
+            "config": {"workload": "%s: %d synthetic proteomes, %d seqs, %d residues, options '%s', gen_synth seed %#x"
+                                   % ("BASELINE configs[1]" if (args.proteomes, args.families, args.len_scale, args.options) == (50, 6000, 1.0, "-c 0.8") else "custom size",
+                                      args.proteomes, n, int(lens.sum()), args.options, seed),
                        "alignments_per_step": n_aln // steps, "clusters": int((assign == np.arange(n)).sum()) if assign is not None else None,
                        "parallelism": ("%d query groups x %d target shards (unicore_amd.dist.grid_shape) + RCCL hit all-gather (device-resident), "
                                        "pair-hash partition of the gapped stage" % ucdist.grid_shape(lens, world)) if world > 1 else "single GPU"},
