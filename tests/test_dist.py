@@ -115,3 +115,25 @@ def test_two_rank_gloo_exchange_matches_single_rank(tmp_path, target_shards):
     assert np.array_equal(h0["target"], flat["t"]) and np.array_equal(h0["score"], flat["score"])
     assert np.array_equal(np.load(tmp_path / "rank1.npy"), ref["hit_cnt"])
     assert np.array_equal(np.load(tmp_path / "rank0.npy"), ref["assign"])                  # same clusters as 1 rank
+
+
+def _gather_main(rank, world, port, tmpdir, limit):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        ucdist.GATHER_ALL_LIMIT = limit
+        mine = (np.arange(2 * (3 + 5 * rank), dtype=np.uint32) + 1000 * rank).reshape(-1, 2)
+        got = ucdist.gather_edges(mine, device="cpu")
+        np.save(os.path.join(tmpdir, "g%d.npy" % rank), got)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("limit", [1 << 20, 0])          # all-gather path / gather-to-rank-0 path
+def test_gather_edges_two_ranks(tmp_path, limit):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_gather_main, args=(2, port, str(tmp_path), limit), nprocs=2, join=True)
+    want = np.concatenate([(np.arange(2 * (3 + 5 * r), dtype=np.uint32) + 1000 * r).reshape(-1, 2) for r in range(2)])
+    assert np.array_equal(np.load(tmp_path / "g0.npy"), want)
+    assert len(np.load(tmp_path / "g1.npy")) == 0

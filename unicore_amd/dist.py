@@ -119,9 +119,35 @@ def exchange_hits(counts, hits, device="cpu", group=None):
     return [(ci.view(np.uint32), hi.view(HIT_DTYPE)) for ci, hi in zip(c, h)]
 
 
-def gather_edges(edges, device="cpu", group=None):
-    parts = _allgather_ragged(np.ascontiguousarray(edges, np.uint32).reshape(-1).view(np.uint8), device, group)
-    return np.concatenate([p.view(np.uint32).reshape(-1, 2) for p in parts]) if parts else np.zeros((0, 2), np.uint32)
+GATHER_ALL_LIMIT = 256 << 20            # bytes of padded edge buffers up to which every rank receives all lists
+
+
+def gather_edges(edges, device="cpu", group=None, dst=0):
+    """Accepted edges of every rank -> rank `dst` (the one that runs the set cover); the other ranks get an empty array.
+    Beyond GATHER_ALL_LIMIT a gather, not an all-gather: at BASELINE configs[2] scale the edge lists are gigabytes and
+    only one rank needs them."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    e = np.ascontiguousarray(edges, np.uint32).reshape(-1)
+    n = torch.tensor([e.size], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(x.item()) for x in sizes]
+    m = max(max(sizes), 1)
+    buf = torch.zeros(m, dtype=torch.int32, device=device)
+    if e.size:
+        buf[: e.size] = torch.from_numpy(e.view(np.int32)).to(device)
+    if 4 * m * world <= GATHER_ALL_LIMIT:      # small lists: the all-gather is the better-tuned collective (and far faster on gloo)
+        outs = [torch.empty(m, dtype=torch.int32, device=device) for _ in range(world)]
+        dist.all_gather(outs, buf, group=group)
+    else:
+        outs = [torch.empty(m, dtype=torch.int32, device=device) for _ in range(world)] if rank == dst else None
+        dist.gather(buf, outs, dst=dst, group=group)
+    if rank != dst:
+        return np.zeros((0, 2), np.uint32)
+    return np.concatenate([o[:k].cpu().numpy().view(np.uint32).reshape(-1, 2) for o, k in zip(outs, sizes)])
 
 
 EXCHANGE_ONE_SHOT_LIMIT = 256 << 20     # hit records in the union above which the exchange is merged shard by shard
