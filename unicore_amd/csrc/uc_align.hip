@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256) cells_kernel(uint32_t n, const uint32_t *
 // The start pass of (q,t) with end cell (qe,te) and the one of its mirror (t,q) with end cell (te,qe) are transposed
 // DPs.  If the packed kernel saw exactly ONE row of the representative's DP reach the optimum, both tie-break orders
 // select the same cell, so the mirror's result is the representative's with the roles swapped; otherwise the mirror
-// is computed on its own (second round, together with the representatives whose end row was ambiguous).
+// is computed on its own (second round).
 __global__ void __launch_bounds__(256) sm_flag_kernel(uint32_t n2, const uint32_t *link, const uint32_t *mirror, const uint32_t *gflag,
                                                       const uint32_t *gpos, const int32_t *qe2, const int32_t *te2, const int32_t *qe0,
                                                       const int32_t *te0, uint32_t *keep, uint32_t *partner) {
@@ -293,14 +293,17 @@ __global__ void __launch_bounds__(256) sm_gather_kernel(uint32_t n2, const uint3
         qa[w] = q2[i]; ta[w] = t2[i]; qea[w] = qe2[i]; tea[w] = te2[i]; map[w] = i;
     }
 }
-// results of a sub-plan (plan order k) -> natural order of the gate-passer list; uniq = packed class, exactly one row
+// results of a sub-plan (plan order k) -> natural order of the gate-passer list; uniq = the packed known-score kernel
+// found every optimal cell in one row (SW_TE_UNIQUE on the column output; results of the int32 kernel never carry it)
 __global__ void __launch_bounds__(256) sm_scatter_kernel(uint32_t na, const uint32_t *idx, const uint32_t *map, const int32_t *s,
-                                                         const int32_t *qo, const int32_t *to, uint32_t n_pk, int ovf, int32_t *s2,
+                                                         const int32_t *qo, const int32_t *to, int32_t *s2,
                                                          int32_t *q2o, int32_t *t2o, uint32_t *uniq) {
     for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < na; k += gridDim.x * 256) {
         const uint32_t i = map ? map[idx[k]] : idx[k];
-        s2[i] = s[k]; q2o[i] = qo[k]; t2o[i] = to[k];
-        if (uniq) uniq[i] = (k < n_pk && qo[k] >= 0 && s[k] < ovf) ? 1u : 0u;
+        const int32_t te = to[k];
+        const bool u = te >= 0 && (te & SW_TE_UNIQUE) != 0;
+        s2[i] = s[k]; q2o[i] = qo[k]; t2o[i] = te >= 0 ? (te & ~SW_TE_UNIQUE) : te;
+        if (uniq) uniq[i] = (u && qo[k] >= 0) ? 1u : 0u;
     }
 }
 __global__ void __launch_bounds__(256) sm_resolve_kernel(uint32_t n2, const uint32_t *partner, const uint32_t *uniq, int32_t *s2,
@@ -1021,19 +1024,16 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                     q2a.reserve(n2a); t2a.reserve(n2a); qe2a.reserve(n2a); te2a.reserve(n2a); mapa.reserve(n2a);
                     hipLaunchKernelGGL(sm_gather_kernel, grid_for(n2), dim3(256), 0, s, n2, smkeep.p, smpos.p, q2.p, t2.p, qe2.p, te2.p,
                                        q2a.p, t2a.p, qe2a.p, te2a.p, mapa.p);
-                    build_plan(*this, P2, tmp, n2a, q2a.p, t2a.p, qe2a.p, te2a.p, tab);
-                    run_plan(*this, P2, 2, s2s.p, q2os.p, t2os.p, work, tmp, /*ovf_only=*/true);
-                    uint32_t n_pk2 = 0;
-                    {
-                        const ClassTable &ct = h_tab[P2.tab];
-                        int npk = 0;
-                        while (npk < ct.n && ct.pk[npk]) npk++;
-                        n_pk2 = P2.pair_base[npk];
-                    }
-                    hipLaunchKernelGGL(sm_scatter_kernel, grid_for(n2a), dim3(256), 0, s, n2a, P2.idx.p, mapa.p, s2s.p, q2os.p, t2os.p, n_pk2,
-                                       SW_PK_OVF_HOST, s2.p, q2o.p, t2o.p, uniq.p);
+                    // round 1: known-score start pass (packed MODE 6; the optimum of the start pass is the forward score) - exact
+                    // in one pass, and it reports whether a single row holds every optimal cell
+                    sknown.reserve(n2a);
+                    hipLaunchKernelGGL(sm_score_kernel, grid_for(n2a), dim3(256), 0, s, n2a, mapa.p, link.p, s0.p, sknown.p);
+                    build_plan(*this, P2, tmp, n2a, q2a.p, t2a.p, qe2a.p, te2a.p, tab, nullptr, nullptr, sknown.p);
+                    run_plan(*this, P2, 6, s2s.p, q2os.p, t2os.p, work, tmp);
+                    hipLaunchKernelGGL(sm_scatter_kernel, grid_for(n2a), dim3(256), 0, s, n2a, P2.idx.p, mapa.p, s2s.p, q2os.p, t2os.p,
+                                       s2.p, q2o.p, t2o.p, uniq.p);
                     hipLaunchKernelGGL(sm_resolve_kernel, grid_for(n2), dim3(256), 0, s, n2, partner.p, uniq.p, s2.p, q2o.p, t2o.p);
-                    // second round (int32, exact): ambiguous end rows + the mirrors that could not take their partner's result
+                    // round 2: the mirrors that could not take their partner's result
                     hipLaunchKernelGGL(amb_flag_kernel, grid_for(n2), dim3(256), 0, s, n2, q2o.p, smkeep.p);
                     scan_u32(*this, tmp, smkeep.p, smpos.p, n2, false);
                     const uint32_t n2b = scan_total(*this, smkeep.p, smpos.p, n2);
@@ -1045,15 +1045,15 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                         hipLaunchKernelGGL(sm_score_kernel, grid_for(n2b), dim3(256), 0, s, n2b, mapa.p, link.p, s0.p, sknown.p);
                         build_plan(*this, P2b, tmp, n2b, q2a.p, t2a.p, qe2a.p, te2a.p, 1, nullptr, nullptr, sknown.p);
                         run_plan(*this, P2b, 6, s2s.p, q2os.p, t2os.p, work, tmp);   // known-score start pass (packed MODE 6)
-                        hipLaunchKernelGGL(sm_scatter_kernel, grid_for(n2b), dim3(256), 0, s, n2b, P2b.idx.p, mapa.p, s2s.p, q2os.p, t2os.p, 0u,
-                                           0, s2.p, q2o.p, t2o.p, (uint32_t *)nullptr);
+                        hipLaunchKernelGGL(sm_scatter_kernel, grid_for(n2b), dim3(256), 0, s, n2b, P2b.idx.p, mapa.p, s2s.p, q2os.p, t2os.p,
+                                           s2.p, q2o.p, t2o.p, (uint32_t *)nullptr);
                         stats.n_pk_reruns += n2b;
                     }
                 } else {
                     build_plan(*this, P2, tmp, n2, q2.p, t2.p, qe2.p, te2.p, tab);
                     run_plan(*this, P2, 2, s2s.p, q2os.p, t2os.p, work, tmp);
                     hipLaunchKernelGGL(sm_scatter_kernel, grid_for(n2), dim3(256), 0, s, n2, P2.idx.p, (const uint32_t *)nullptr, s2s.p, q2os.p,
-                                       t2os.p, 0u, 0, s2.p, q2o.p, t2o.p, (uint32_t *)nullptr);
+                                       t2os.p, s2.p, q2o.p, t2o.p, (uint32_t *)nullptr);
                 }
                 {
                     unsigned long long hc = 0;

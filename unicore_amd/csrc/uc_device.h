@@ -22,6 +22,10 @@ struct DeviceDb {
 // one workgroup of the gapped kernel = one query + a contiguous run of its pairs
 struct SwTask { uint32_t q, begin, count; };
 
+// flag on the column output of the packed known-score start pass (MODE 6): one row holds every optimal cell, so the
+// mirror of the pair may take the result with the roles swapped (uc_sw_pk_impl.hpp finish_slot, uc_align.hip sm_scatter_kernel)
+constexpr int SW_TE_UNIQUE = 1 << 30;
+
 struct SwArgs {
     DeviceDb db;
     const SwTask *tasks;

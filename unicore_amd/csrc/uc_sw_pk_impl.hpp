@@ -56,9 +56,11 @@ __device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) 
 
 template <int G, int R, int MODE, int NW>
 __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
-    // MODE 4 / 6 = MODE 0 / 2 with the optimum score of every pair KNOWN (a.pscore): the exact re-run of the pairs whose
-    // end row was ambiguous.  No per-row maxima: the first step at which a lane's column maximum equals the known score
-    // is its first optimal column, and only then (a rare, wave-level branch) the lane looks for its first optimal row.
+    // MODE 4 / 6 = MODE 0 / 2 with the optimum score of every pair KNOWN (a.pscore).  MODE 4 is the exact re-run of the
+    // pairs whose end row was ambiguous; MODE 6 is THE start pass of the packed path (its optimum is the forward score).
+    // No per-row maxima: the first step at which a lane's column maximum equals the known score is its first optimal
+    // column, and only at such steps (a rare, wave-level branch) the lane looks at its rows: first optimal row, and
+    // whether a single row holds all optimal cells (the condition under which a mutual hit may share the result).
     // MODE 7 = traceback bytes: the forward DP on the box [qs..qe] x [ts..te] of an accepted pair; instead of tracking an
     // end position every cell stores one byte of decisions (bit 0 H != diagonal candidate, 1 H != F, 2 H != E, 3 H != 0,
     // 4 F of the next row extends (not opened from this H), 5 E of the next column extends) into a per-pair matrix in
@@ -108,6 +110,7 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
     uint32_t best = 0, Hlast = 0, prevHup = 0, fout = 0;
     int colA = -1, colB = -1;
     [[maybe_unused]] int rowA = 0, rowB = 0;
+    [[maybe_unused]] bool multA = false, multB = false;   // KNOWN: this lane saw the optimum in more than one of its rows
     [[maybe_unused]] uint32_t knownA = 0, knownB = 0;
     uint32_t gA = 0, gB = 0, toffA = 0, toffB = 0;
     [[maybe_unused]] unsigned long long tbA = 0, tbB = 0;
@@ -211,7 +214,7 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
         if constexpr (KNOWN) {
             knownA = (uint32_t)a.pscore[gA];
             knownB = vB ? (uint32_t)a.pscore[gB] : 0u;
-            rowA = 0; rowB = 0;
+            rowA = 0; rowB = 0; multA = false; multB = false;
         }
         best = 0; colA = -1; colB = -1; Hlast = 0; prevHup = 0; fout = 0;
         lst = 0;
@@ -312,18 +315,24 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
             colB = cmB > (best >> 16) ? st - g : colB;
         }
         if constexpr (KNOWN) {
-            const bool evA = colA < 0 && knownA != 0 && (colmax & 0xffffu) == knownA;
-            const bool evB = colB < 0 && knownB != 0 && (colmax >> 16) == knownB;
+            // every column of this lane that holds the optimum is an event (a handful per alignment: wave-level branch);
+            // the first one gives (column, row); all of them together tell whether ONE row holds every optimal cell
+            const bool evA = knownA != 0 && (colmax & 0xffffu) == knownA;
+            const bool evB = knownB != 0 && (colmax >> 16) == knownB;
             if (__builtin_amdgcn_ballot_w64(evA || evB) != 0) {
                 if (evA) {
-                    colA = st - g;
+                    int first = 0, cnt = 0;
 #pragma unroll
-                    for (int r = R - 1; r >= 0; r--) rowA = (H[r] & 0xffffu) == knownA ? r : rowA;
+                    for (int r = R - 1; r >= 0; r--) { const bool hit = (H[r] & 0xffffu) == knownA; first = hit ? r : first; cnt += hit ? 1 : 0; }
+                    if (colA < 0) { colA = st - g; rowA = first; }
+                    multA |= cnt > 1 || first != rowA;
                 }
                 if (evB) {
-                    colB = st - g;
+                    int first = 0, cnt = 0;
 #pragma unroll
-                    for (int r = R - 1; r >= 0; r--) rowB = (H[r] >> 16) == knownB ? r : rowB;
+                    for (int r = R - 1; r >= 0; r--) { const bool hit = (H[r] >> 16) == knownB; first = hit ? r : first; cnt += hit ? 1 : 0; }
+                    if (colB < 0) { colB = st - g; rowB = first; }
+                    multB |= cnt > 1 || first != rowB;
                 }
             }
         }
@@ -341,8 +350,13 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
             for (int half = 0; half < 2; half++) {
                 const int col = half ? colB : colA, row = half ? rowB : rowA;
                 int key = col < 0 ? 0x7fffffff : ((col << 11) | (g * R + row));      // (first optimal column, then first row)
+                // lanes that saw the optimum, + G if one of them saw it in two rows: exactly 1 <=> one row holds every optimal cell
+                int nrows = (col < 0 ? 0 : 1) + ((half ? multB : multA) ? G : 0);
 #pragma unroll
-                for (int m = 1; m < G; m <<= 1) key = min(key, __shfl_xor(key, m, 64));
+                for (int m = 1; m < G; m <<= 1) {
+                    key = min(key, __shfl_xor(key, m, 64));
+                    nrows += __shfl_xor(nrows, m, 64);
+                }
                 const bool valid = half ? vB : true;
                 const uint32_t gp = half ? gB : gA;
                 if (g == 0 && valid) {
@@ -350,7 +364,8 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
                     const bool found = key != 0x7fffffff;
                     a.oscore[gp] = (int)(half ? knownB : knownA);
                     a.oqe[gp] = found ? (key & 2047) - rowoff : -2;
-                    a.ote[gp] = found ? (key >> 11) : -2;
+                    // MODE 6 marks "one row only" in the column output (SW_TE_UNIQUE): the mirror of such a pair shares its result
+                    a.ote[gp] = found ? ((key >> 11) | ((MODE == 6 && nrows == 1) ? SW_TE_UNIQUE : 0)) : -2;
                 }
             }
             return;
