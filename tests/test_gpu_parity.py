@@ -197,6 +197,41 @@ def test_cascade_end_to_end_tsv_bytes(O, tmp_path, opts, steps, sens):
     assert ref["counts"]["n_alignments"] != single["counts"]["n_alignments"]   # and the cascade is not the single step
 
 
+def test_sw_long_query_row_blocks(O):
+    """queries of several 2048-row blocks through the row-blocked kernel (uc_sw_long.hip): boundaries between blocks,
+    optimum in a later block, start pass whose masked prefix skips whole blocks"""
+    rng = np.random.default_rng(31)
+    base3, basea = rng.integers(0, 20, 6500, dtype=np.uint8), rng.integers(0, 20, 6500, dtype=np.uint8)
+    s3 = [base3, base3[300:6400].copy(), base3[:4200].copy(), rng.integers(0, 20, 300, dtype=np.uint8), base3[2000:4500].copy(),
+          np.concatenate([base3[5000:6400], base3[100:900]])]
+    sa = [basea, basea[300:6400].copy(), basea[:4200].copy(), rng.integers(0, 20, 300, dtype=np.uint8), basea[2000:4500].copy(),
+          np.concatenate([basea[5000:6400], basea[100:900]])]
+    for k in (1, 2, 4):
+        mut = rng.random(len(s3[k])) < 0.15
+        s3[k][mut] = rng.integers(0, 20, int(mut.sum()), dtype=np.uint8)
+        cut = int(rng.integers(500, len(s3[k]) - 500))           # one deletion: the path crosses block boundaries in a gap state too
+        s3[k] = np.delete(s3[k], slice(cut, cut + 7)); sa[k] = np.delete(sa[k], slice(cut, cut + 7))
+    off, c3, ca = util.flat(s3, sa)
+    import unicore_amd as U
+    e = U.Engine("-c 0.8", verbosity=1)
+    e.set_db(off, c3, ca)
+    q = np.array([0, 0, 0, 0, 0, 1, 2, 4, 1, 2, 4, 1, 0], np.uint32); t = np.array([1, 2, 3, 4, 5, 0, 0, 0, 2, 1, 1, 3, 0], np.uint32)
+    p = O.default_params()
+    s, qe, te = e.sw(0, q, t)
+    s1, _, _ = e.sw(1, q, t)
+    for i in range(len(q)):
+        assert (s[i], qe[i], te[i]) == O.sw(s3[q[i]], sa[q[i]], s3[t[i]], sa[t[i]], p), i
+        assert s1[i] == O.sw(s3[q[i]], sa[q[i]], s3[t[i]], sa[t[i]], p, rev_q=1)[0], i
+    assert (qe > 4096).any() and ((qe > 2048) & (qe < 4096)).any()
+    keep = s > 0
+    s2, q2, t2 = e.sw(2, q[keep], t[keep], qe[keep], te[keep])
+    lens = np.array([len(x) for x in s3])
+    assert ((lens[q[keep]] - 1 - qe[keep]) >= 2048).any()         # a start pass that skips at least one whole block
+    for k, i in enumerate(np.nonzero(keep)[0]):
+        exp = O.sw(s3[q[i]][: qe[i] + 1], sa[q[i]][: qe[i] + 1], s3[t[i]][: te[i] + 1], sa[t[i]][: te[i] + 1], p, rev_q=1, rev_t=1)
+        assert (s2[k], q2[k], t2[k]) == exp, i
+
+
 def test_long_query_pipeline_with_seqid(O):
     """queries beyond the largest systolic class go through the generic kernel in every pass, including the
     traceback-statistics pass of --min-seq-id"""

@@ -73,7 +73,7 @@ __device__ __forceinline__ int class_of(int lq, int tab) {
     while (c < c_tab[tab].n && c_tab[tab].cap[c] < lq) c++;
     return c;
 }
-__device__ __forceinline__ uint32_t task_cap(int c, int tab) { return c < c_tab[tab].n ? c_tab[tab].tcap[c] : 256u; }
+__device__ __forceinline__ uint32_t task_cap(int c, int tab) { return c < c_tab[tab].n ? c_tab[tab].tcap[c] : SW_LONG_TASK_PAIRS; }   // long queries: one pair per wave (uc_sw_long.hip)
 
 inline dim3 grid_for(uint64_t n, uint32_t cap = 16384) {
     const uint64_t b = (n + 255) / 256;
@@ -660,10 +660,22 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
     if ((mode == 4 || mode == 6) && !P.has_aux) fail(UC_ERR_GENERIC, "known-score pass without scores");
     a.tbm = P.tbm; a.tboff = P.tboff;
     uint64_t launches = 0;
+    const uint32_t gb = P.pair_base[tab.n], ngen = P.n - gb;
+    const bool long_blocked = ngen && imode != 3;    // queries beyond the largest systolic class: row-blocked kernel (MODE 3: generic)
+    uint32_t long_stride = 0;
+    if (long_blocked) work.reserve(sw_long_work_ints(ngen, E.max_len, &long_stride));
     // fork: the classes run concurrently on the auxiliary streams, largest classes first on distinct streams
     UC_HIP(hipEventRecord(E.ev_fork, E.stream));
     for (int i = 0; i < Engine::N_AUX; i++) UC_HIP(hipStreamWaitEvent(E.aux[i], E.ev_fork, 0));
     int slot = 0;
+    if (long_blocked && !only_generic) {             // the longest-running launch goes first
+        SwArgs al = a;
+        al.tasks = P.tasks.p + P.task_base[tab.n];
+        launch_sw_long(imode, al, P.task_base[tab.n + 1] - P.task_base[tab.n], gb, work.p, long_stride, E.stream);
+        UC_HIP(hipGetLastError());
+        slot++;
+        launches++;
+    }
     for (int c = tab.n - 1; c >= 0 && !only_generic; c--) {
         const uint32_t nt = P.task_base[c + 1] - P.task_base[c];
         if (!nt) continue;
@@ -680,8 +692,7 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
         UC_HIP(hipEventRecord(E.ev_join[i], E.aux[i]));
         UC_HIP(hipStreamWaitEvent(E.stream, E.ev_join[i], 0));
     }
-    const uint32_t gb = P.pair_base[tab.n], ngen = P.n - gb;
-    if (ngen) {   // queries longer than the largest systolic class
+    if (ngen && !long_blocked) {   // traceback statistics of queries longer than the largest systolic class
         const size_t lanes = (size_t)((ngen + 63) / 64) * 64;
         work.reserve((imode == 3 ? 4 : 2) * (size_t)E.max_len * lanes);
         SwArgs ag = a;
