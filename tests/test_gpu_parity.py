@@ -264,6 +264,41 @@ def test_long_query_pipeline_with_seqid(O):
     assert np.array_equal(U.setcover(e.n, e.edges()), ref["assign"])
 
 
+def test_search_long_queries_m8_bytes(O, tmp_path):
+    """search path on sequences of several row blocks: both traceback-statistics passes (alignment length / identities and
+    the gap count) run through the row-blocked kernel; the BLAST-tab file equals the oracle's byte for byte"""
+    import unicore_amd as U
+    rng = np.random.default_rng(23)
+    base3, basea = rng.integers(0, 20, 5200, dtype=np.uint8), rng.integers(0, 20, 5200, dtype=np.uint8)
+    s3, sa = [], []
+    for m in range(5):
+        lo, hi = int(rng.integers(0, 400)), int(rng.integers(4700, 5200))
+        a3, aa = base3[lo:hi].copy(), basea[lo:hi].copy()
+        for _ in range(3):                                    # a few indels
+            cut = int(rng.integers(300, len(a3) - 300)); w = int(rng.integers(1, 9))
+            a3 = np.delete(a3, slice(cut, cut + w)); aa = np.delete(aa, slice(cut, cut + w))
+        mut = rng.random(len(a3)) < 0.15
+        a3[mut] = rng.integers(0, 20, int(mut.sum()), dtype=np.uint8)
+        muta = rng.random(len(aa)) < 0.3
+        aa[muta] = rng.integers(0, 20, int(muta.sum()), dtype=np.uint8)
+        s3.append(a3); sa.append(aa)
+    s3.append(base3[1000:1900].copy()); sa.append(basea[1000:1900].copy())
+    qdbp, tdbp = str(tmp_path / "q"), str(tmp_path / "t")
+    util.write_db(qdbp, s3[:3], sa[:3], ["q_%d" % i for i in range(3)])
+    util.write_db(tdbp, s3[2:], sa[2:], ["t_%d" % i for i in range(4)])
+    out = str(tmp_path / "res")
+    opts = "-c 0.5"
+    U.search(qdbp, tdbp, out + "_aln", str(tmp_path / "tmp"), opts, threads=4)
+    U.convertalis(qdbp, tdbp, out + "_aln", out + ".m8")
+    qdb, tdb = O.OracleDb(qdbp), O.OracleDb(tdbp)
+    po = util.oracle_params(O, "-e 10 --max-seqs 1000 " + opts)
+    O.write_m8(str(tmp_path / "ref.m8"), qdb, tdb, po, O.search(qdb, tdb, po, threads=8))
+    got, exp = open(out + ".m8", "rb").read(), open(str(tmp_path / "ref.m8"), "rb").read()
+    assert got == exp
+    rows = [l.split("\t") for l in got.decode().splitlines()]
+    assert len(rows) >= 8 and any(int(r[3]) > 4096 for r in rows) and any(int(r[5]) > 0 for r in rows)
+
+
 @pytest.mark.parametrize("target_shards", [3, 1, 2])
 def test_device_exchange_virtual_ranks(O, target_shards):
     """multi-GPU layout on one GPU: W virtual ranks (query groups x target shards) -> device-side export, union, merge (== unsharded lists),

@@ -26,7 +26,7 @@ for sfx in ("_fetch", "_write", "_sq", "_sq2"):
         continue
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if not ("sw_pk_kernel" in n or "sw_group_kernel" in n or "sw_generic" in n):
+        if not ("sw_pk_kernel" in n or "sw_group_kernel" in n or "sw_long" in n):
             continue
         tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         if sfx == "_fetch":

@@ -25,7 +25,7 @@ def main():
     for k, (c, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print("%-46s %7d %12.3f %12.4f %6.2f%%" % (k, c, ns / 1e6, ns / 1e6 / c, 100.0 * ns / tot))
     print("%-46s %7s %12.3f" % ("TOTAL", "", tot / 1e6))
-    sw = [(k, v) for k, v in agg.items() if "sw_group_kernel" in k or "sw_pk_kernel" in k or "sw_generic" in k]
+    sw = [(k, v) for k, v in agg.items() if "sw_group_kernel" in k or "sw_pk_kernel" in k or "sw_long" in k]
     c = sum(v[0] for _, v in sw); ns = sum(v[1] for _, v in sw)
     if c: print("\nsw kernels (all classes, all passes): %d launches, %.3f ms total, %.4f ms avg" % (c, ns / 1e6, ns / 1e6 / c))
     for sfx, label in (("_fetch", "FETCH_SIZE"), ("_write", "WRITE_SIZE"), ("_sq", None), ("_sq2", None)):

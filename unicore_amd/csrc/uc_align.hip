@@ -34,11 +34,11 @@ static unsigned long long tb_budget_bytes(size_t already_held) {
 
 namespace {
 
-// Length classes.  Table 0: int32 kernel for everything (16 systolic classes + generic).  Table 1: the packed
+// Length classes.  Table 0: int32 kernel for everything (16 systolic classes + the row-blocked long-query kernel).  Table 1: the packed
 // 16-bit kernel for all systolic classes: queries <= 2048 rows in 28 classes with even R (~6R + 60 live registers).
 constexpr int MAXCLS = 28;
 struct ClassTable {
-    int n;                 // systolic classes; index n = generic fallback (queries > cap[n-1])
+    int n;                 // systolic classes; index n = long queries (> cap[n-1] rows): uc_sw_long.hip
     int cap[MAXCLS], G[MAXCLS], R[MAXCLS], pk[MAXCLS];
     uint32_t tcap[MAXCLS]; // pairs per workgroup task
 };
@@ -648,7 +648,7 @@ static void build_plan(Engine &E, SwPlan &P, DevBuf<char> &tmp, uint32_t n, cons
 
 // one launch per populated class; outputs are in the plan's sorted order.  Returns the number of launches.
 static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t *oqe, int32_t *ote, DevBuf<int32_t> &work,
-                            const uint32_t *tb = nullptr, bool only_generic = false) {
+                            const uint32_t *tb = nullptr, bool only_long = false) {
     const ClassTable &tab = h_tab[P.tab];
     SwArgs a;
     a.db = E.ddb; a.tasks = P.tasks.p; a.pt = P.st.p; a.pqe = P.sqe.p; a.pte = P.ste.p;
@@ -656,19 +656,18 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
     a.oscore = os; a.oqe = oqe; a.ote = ote; a.open = E.p.gap_open; a.ext = E.p.gap_ext;
     if (tb) { a.tb_diag = tb[0]; a.tb_ident = tb[1]; a.tb_open = tb[2]; a.tb_ext = tb[3]; }
     a.pscore = P.has_aux ? P.saux.p : nullptr;
-    const int imode = mode >= 4 ? mode - 4 : mode;   // the int32 and generic kernels have no known-score variant (they are exact anyway)
+    const int imode = mode >= 4 ? mode - 4 : mode;   // the int32 and long-query kernels have no known-score variant (they are exact anyway)
     if ((mode == 4 || mode == 6) && !P.has_aux) fail(UC_ERR_GENERIC, "known-score pass without scores");
     a.tbm = P.tbm; a.tboff = P.tboff;
     uint64_t launches = 0;
     const uint32_t gb = P.pair_base[tab.n], ngen = P.n - gb;
-    const bool long_blocked = ngen && imode != 3;    // queries beyond the largest systolic class: row-blocked kernel (MODE 3: generic)
-    uint32_t long_stride = 0;
-    if (long_blocked) work.reserve(sw_long_work_ints(ngen, E.max_len, &long_stride));
+    uint32_t long_stride = 0;                        // queries beyond the largest systolic class: row-blocked kernel (uc_sw_long.hip)
+    if (ngen) work.reserve(sw_long_work_ints(imode, ngen, E.max_len, &long_stride));
     // fork: the classes run concurrently on the auxiliary streams, largest classes first on distinct streams
     UC_HIP(hipEventRecord(E.ev_fork, E.stream));
     for (int i = 0; i < Engine::N_AUX; i++) UC_HIP(hipStreamWaitEvent(E.aux[i], E.ev_fork, 0));
     int slot = 0;
-    if (long_blocked && !only_generic) {             // the longest-running launch goes first
+    if (ngen) {                                      // the longest-running launch goes first
         SwArgs al = a;
         al.tasks = P.tasks.p + P.task_base[tab.n];
         launch_sw_long(imode, al, P.task_base[tab.n + 1] - P.task_base[tab.n], gb, work.p, long_stride, E.stream);
@@ -676,7 +675,7 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
         slot++;
         launches++;
     }
-    for (int c = tab.n - 1; c >= 0 && !only_generic; c--) {
+    for (int c = tab.n - 1; c >= 0 && !only_long; c--) {
         const uint32_t nt = P.task_base[c + 1] - P.task_base[c];
         if (!nt) continue;
         SwArgs ac = a;
@@ -691,22 +690,6 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
     for (int i = 0; i < Engine::N_AUX; i++) {   // join
         UC_HIP(hipEventRecord(E.ev_join[i], E.aux[i]));
         UC_HIP(hipStreamWaitEvent(E.stream, E.ev_join[i], 0));
-    }
-    if (ngen && !long_blocked) {   // traceback statistics of queries longer than the largest systolic class
-        const size_t lanes = (size_t)((ngen + 63) / 64) * 64;
-        work.reserve((imode == 3 ? 4 : 2) * (size_t)E.max_len * lanes);
-        SwArgs ag = a;
-        ag.pt = P.st.p + gb;
-        ag.pqe = P.has_ends ? P.sqe.p + gb : nullptr;
-        ag.pte = P.has_ends ? P.ste.p + gb : nullptr;
-        ag.pqs = P.has_starts ? P.sqs.p + gb : nullptr;
-        ag.pts = P.has_starts ? P.sts.p + gb : nullptr;
-        ag.oscore = os + gb;
-        ag.oqe = oqe ? oqe + gb : nullptr;
-        ag.ote = ote ? ote + gb : nullptr;
-        launch_sw_generic(imode, ag, ngen, P.sq.p + gb, work.p, E.max_len, E.stream);
-        UC_HIP(hipGetLastError());
-        launches++;
     }
     return launches;
 }
@@ -1129,9 +1112,9 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                             }
                             P3.tbm = tbm.p; P3.tboff = tboff.p;
                             timed_ms_begin();
-                            launches = launch_plan(*this, P3, 7, pack3.p, nullptr, nullptr, work);        // generic part: int32 MODE 3
+                            launches = launch_plan(*this, P3, 7, pack3.p, nullptr, nullptr, work);        // long queries: int32 MODE 3
                             if (p.want_tb && P3.n > n_pk3)
-                                launches += launch_plan(*this, P3, 3, gaps3.p, nullptr, nullptr, work, tb_gaps, /*only_generic=*/true);
+                                launches += launch_plan(*this, P3, 3, gaps3.p, nullptr, nullptr, work, tb_gaps, /*only_long=*/true);
                             if (n_pk3)
                                 hipLaunchKernelGGL(tb_walk_kernel, grid_for(n_pk3), dim3(256), 0, s, n_pk3, ddb, P3.key2.p, P3.st.p, P3.sqs.p, P3.sqe.p,
                                                    P3.sts.p, P3.ste.p, 1, tbm.p, tboff.p, pack3.p, gaps3.p);

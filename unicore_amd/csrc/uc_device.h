@@ -47,11 +47,10 @@ constexpr int SW_MAX_ROWS = 2048;   // largest single-strip class (G=64, R=32)
 // host launchers (uc_sw.hip / uc_prefilter.hip)
 void launch_sw_class(int G, int R, int mode, const SwArgs &a, uint32_t n_tasks, hipStream_t s);
 void launch_sw_pk_class(int G, int R, int mode, const SwArgs &a, uint32_t n_tasks, hipStream_t s);
-void launch_sw_generic(int mode, const SwArgs &a, uint32_t n_pairs, const uint32_t *pq, int32_t *work, uint32_t max_lq, hipStream_t s);
-// queries beyond the systolic classes, MODE 0 / 1 / 2: row-blocked systolic kernel (uc_sw_long.hip); a.tasks = the long-query
-// tasks (<= SW_LONG_TASK_PAIRS pairs each), pair_base = plan index of the first long-query pair, work = 2 x stride ints per pair
+// queries beyond the systolic classes, MODE 0 / 1 / 2 / 3: row-blocked systolic kernel (uc_sw_long.hip); a.tasks = the long-query
+// tasks (<= SW_LONG_TASK_PAIRS pairs each), pair_base = plan index of the first long-query pair, work = 2 (MODE 3: 4) x stride ints per pair
 constexpr uint32_t SW_LONG_TASK_PAIRS = 8;
-size_t sw_long_work_ints(uint32_t n_pairs, uint32_t max_len, uint32_t *stride);
+size_t sw_long_work_ints(int mode, uint32_t n_pairs, uint32_t max_len, uint32_t *stride);
 void launch_sw_long(int mode, const SwArgs &a, uint32_t n_tasks, uint32_t pair_base, int32_t *work, uint32_t stride, hipStream_t s);
 void launch_ungapped(const DeviceDb &db, uint64_t n, const uint32_t *q, const uint32_t *t, const int32_t *diag,
                      int32_t *score, unsigned long long *overlap_sum /* nullable */, hipStream_t s);

@@ -1,4 +1,4 @@
-// uc_sw.hip — dispatch for the gapped DP kernel classes, the long-query fallback, and stage E3
+// uc_sw.hip — dispatch for the gapped DP kernel classes, and stage E3
 // (ungapped diagonal score).
 #include "uc_sw_impl.hpp"
 
@@ -40,16 +40,6 @@ void launch_sw_pk_class(int G, int R, int mode, const SwArgs &a, uint32_t n_task
     else if (mode == 4) launch_sw_pk_class_m4(G, R, a, n_tasks, s);
     else if (mode == 6) launch_sw_pk_class_m6(G, R, a, n_tasks, s);
     else launch_sw_pk_class_m7(G, R, a, n_tasks, s);
-}
-
-void launch_sw_generic(int mode, const SwArgs &a, uint32_t n_pairs, const uint32_t *pq, int32_t *work,
-                       uint32_t max_lq, hipStream_t s) {
-    if (n_pairs == 0) return;
-    const dim3 grid((n_pairs + 63) / 64), block(64);
-    if (mode == 0) hipLaunchKernelGGL(sw_generic_kernel<0>, grid, block, 0, s, a, n_pairs, pq, work, max_lq);
-    else if (mode == 1) hipLaunchKernelGGL(sw_generic_kernel<1>, grid, block, 0, s, a, n_pairs, pq, work, max_lq);
-    else if (mode == 2) hipLaunchKernelGGL(sw_generic_kernel<2>, grid, block, 0, s, a, n_pairs, pq, work, max_lq);
-    else hipLaunchKernelGGL(sw_generic_kernel<3>, grid, block, 0, s, a, n_pairs, pq, work, max_lq);
 }
 
 // ---- stage E3: ungapped diagonal score (MMseqs2 UngappedAlignment on the 3Di track) ----

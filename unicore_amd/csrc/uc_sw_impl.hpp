@@ -275,73 +275,6 @@ __global__ void __launch_bounds__(NW * 64) sw_group_kernel(const SwArgs a) {
     }
 }
 
-// Fallback for queries longer than SW_MAX_ROWS: one lane per pair, column-major sweep with the H/E
-// column in a global workspace ([row][pair] so a wave's accesses coalesce).  Slow, rare, same spec.
-template <int MODE>
-__global__ void __launch_bounds__(64) sw_generic_kernel(const SwArgs a, uint32_t n_pairs, const uint32_t *pq,
-                                                        int32_t *work, uint32_t max_lq) {
-    constexpr bool TB = MODE == 3, TRACK = MODE == 0 || MODE == 2, REVT = MODE == 2;
-    const uint32_t p = blockIdx.x * 64 + threadIdx.x;
-    if (p >= n_pairs) return;
-    const uint32_t q = pq[p], t = a.pt[p];
-    const int qs = TB ? a.pqs[p] : 0, ts = TB ? a.pts[p] : 0;
-    const uint32_t qoff = a.db.off[q] + (uint32_t)qs, toff = a.db.off[t] + (uint32_t)ts;
-    const int lq = TB ? a.pqe[p] - qs + 1 : (REVT ? a.pqe[p] + 1 : (int)a.db.len[q]);
-    const int lt = TB ? a.pte[p] - ts + 1 : (REVT ? a.pte[p] + 1 : (int)a.db.len[t]);
-    const int qfull = (int)a.db.len[q];
-    const int open = a.open, ext = a.ext;
-    const size_t stride = (size_t)gridDim.x * 64;
-    int32_t *H = work + p, *E = work + (size_t)max_lq * stride + p;
-    int32_t *HP = work + 2 * (size_t)max_lq * stride + p, *EP = work + 3 * (size_t)max_lq * stride + p;   // TB only
-    for (int i = 0; i < lq; i++) {
-        H[(size_t)i * stride] = 0; E[(size_t)i * stride] = 0;
-        if constexpr (TB) { HP[(size_t)i * stride] = 0; EP[(size_t)i * stride] = 0; }
-    }
-    int best = 0, bq = -1, bt = -1;
-    uint32_t cap = 0;
-    for (int j = 0; j < lt; j++) {
-        const uint32_t tp = toff + (uint32_t)(REVT ? lt - 1 - j : j);
-        const int t3 = a.db.s3[tp], ta = a.db.sa[tp];
-        int hdiag = 0, hup = 0, f = 0, colbest = 0, colrow = -1;
-        uint32_t dhp = 0, fp = 0;
-        for (int i = 0; i < lq; i++) {
-            // MODE 1 reverses the whole query; MODE 2 reads the prefix [0..qend] backwards
-            const int qi = MODE == 1 ? qfull - 1 - i : (MODE == 2 ? lq - 1 - i : i);
-            const int qa = a.db.sa[qoff + qi];
-            const int s = a.db.S3[a.db.s3[qoff + qi] * 21 + t3] + a.db.SA[qa * 21 + ta];
-            const int hleft = H[(size_t)i * stride];
-            const int esub = max(E[(size_t)i * stride] - ext, 0);
-            const int e = max(esub, hleft - open);
-            const int fsub = max(f - ext, 0);
-            const int fcur = max(fsub, hup - open);        // F(i,j)
-            const int x = hdiag + s;
-            const int h = max(max(x, e), max(fcur, 0));
-            if constexpr (TB) {
-                const uint32_t hpleft = (uint32_t)HP[(size_t)i * stride], epleft = (uint32_t)EP[(size_t)i * stride];
-                const uint32_t ep = hleft - open >= esub ? hpleft + a.tb_open : epleft + a.tb_ext;
-                const uint32_t fpc = i == 0 ? a.tb_open : fp;    // fp already holds the pack of F(i,j)
-                const uint32_t tie = (x != h && fcur == h && e == h) ? 0x80000000u : 0u;
-                const uint32_t hp = h == 0 ? 0u : (x == h ? dhp + a.tb_diag + (qa == ta ? a.tb_ident : 0u) : (fcur == h ? (fpc | tie) : ep));
-                dhp = hpleft;
-                HP[(size_t)i * stride] = (int32_t)hp;
-                EP[(size_t)i * stride] = (int32_t)ep;
-                // pack of F(i+1,j): open from H(i,j) preferred over extending F(i,j)
-                fp = h - open >= max(fcur - ext, 0) ? hp + a.tb_open : fpc + a.tb_ext;
-                if (j == lt - 1 && i == lq - 1) cap = hp;
-            }
-            hdiag = hleft;
-            H[(size_t)i * stride] = h;
-            E[(size_t)i * stride] = e;
-            hup = h;
-            f = fcur;
-            if (h > colbest) { colbest = h; colrow = i; }
-        }
-        if (colbest > best) { best = colbest; bq = colrow; bt = j; }
-    }
-    a.oscore[p] = TB ? (int32_t)cap : best;
-    if constexpr (TRACK) { a.oqe[p] = bq; a.ote[p] = bt; }
-}
-
 template <int MODE>
 void launch_sw_class_mode(int G, int R, const SwArgs &a, uint32_t n_tasks, hipStream_t s) {
 #define UC_SW_CASE(GG, RR)                                                                              \
