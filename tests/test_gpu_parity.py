@@ -598,15 +598,24 @@ def test_linclust_workflow_tsv_bytes(O, tmp_path, opts, steps, m):
     assert len(pr) > 20 and (pr[:, 0] != pr[:, 1]).all()
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
+@pytest.mark.parametrize("seed", list(range(16)))
 def test_random_option_sets_against_the_oracle(O, seed):
     """property test: random small databases x random option strings (gates, gap costs, sensitivity, truncation, execution
-    variants): accepted pairs and the cluster assignment equal the oracle's"""
+    variants): accepted pairs and the cluster assignment equal the oracle's.  Seeds >= 12 add sequences beyond 2048
+    residues with a mutated copy each (row-blocked kernel in every pass)."""
     import unicore_amd as U
     rng = np.random.default_rng(1000 + seed)
+    extra = tuple(int(x) for x in rng.integers(300, 1900, int(rng.integers(0, 3))))
+    if seed >= 12:
+        extra = extra + tuple(int(x) for x in rng.integers(2049, 5200, int(rng.integers(1, 3))))
     s3, sa = util.family_db(500 + seed, n_fam=int(rng.integers(4, 12)), members=int(rng.integers(2, 8)), lmin=int(rng.integers(20, 60)),
                             lmax=int(rng.integers(80, 400)), sub3=float(rng.uniform(0.05, 0.3)), suba=float(rng.uniform(0.1, 0.5)),
-                            indel=float(rng.uniform(0.0, 0.05)), extra=tuple(int(x) for x in rng.integers(300, 1900, int(rng.integers(0, 3)))))
+                            indel=float(rng.uniform(0.0, 0.05)), extra=extra)
+    if seed >= 12:
+        k = int(np.argmax([len(x) for x in s3])); a3, aa = s3[k].copy(), sa[k].copy()
+        m = rng.random(len(a3)) < 0.1; a3[m] = rng.integers(0, 20, int(m.sum()), dtype=np.uint8)
+        cut = int(rng.integers(100, len(a3) - 100)); a3 = np.delete(a3, slice(cut, cut + 5)); aa = np.delete(aa, slice(cut, cut + 5))
+        s3.append(a3); sa.append(aa)
     opts = ["-c %.2f" % rng.choice([0.3, 0.5, 0.8, 0.9]), "--cov-mode %d" % rng.integers(0, 3), "-e %g" % rng.choice([1e-3, 1e-6, 10.0]),
             "--max-seqs %d" % rng.choice([3, 20, 300])]
     if rng.random() < 0.5: opts.append("-s %g" % rng.choice([2.0, 4.0, 6.0]))
