@@ -461,7 +461,54 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
         }
         __syncthreads();
     }
-    if (tid == 0) { qbase[blockIdx.x] = base; qsurv[blockIdx.x] = *cur; }
+    // ---- second level: the same once / twice test over the SURVIVORS only, with independent hash functions ----
+    // Long queries load the bitmaps so heavily that most first-level survivors are single hits whose two positions were
+    // set by other keys (C2: 0.55 G survivors for ~0.03 G keys of real double-hit diagonals).  Every key of a diagonal with
+    // >= 2 hits survives level 1 together with its twins, so repeating the test over the ~10x shorter survivor list (a
+    // coalesced read of the query's own region, no index lookups) keeps all of them and drops nearly all the rest; the
+    // region is compacted in place.
+    const uint32_t n1 = min(*cur, (uint32_t)min<uint64_t>(key_cap > base ? key_cap - base : 0, 0xFFFFFFFFull));
+    __threadfence_block();
+    __syncthreads();
+    for (int w = tid; w < 2 * BW; w += FT) f_lds[w] = 0;
+    uint32_t *cur2 = cur + 1;
+    if (tid == 0) *cur2 = 0;
+    __syncthreads();
+    auto slot2_of = [&](uint64_t key, uint32_t &h2) -> uint32_t {
+        const uint32_t x = (uint32_t)key * 0xC2B2AE35u ^ (uint32_t)(key >> 32) * 0x27D4EB2Fu;
+        h2 = ((x ^ (x >> 13)) * 0x165667B1u) >> (32 - FB_LOG2);
+        return (x * 0x9E3779B1u) >> (32 - FB_LOG2);
+    };
+    for (uint32_t k = tid; k < n1; k += FT) {
+        uint32_t g;
+        const uint32_t h = slot2_of(keys[base + k], g), bit = 1u << (h & 31), gbit = 1u << (g & 31);
+        const uint32_t old = atomicOr(&B1[h >> 5], bit);
+        if (old & bit) atomicOr(&B2[h >> 5], bit);
+        const uint32_t gold = atomicOr(&B1[g >> 5], gbit);
+        if (gold & gbit) atomicOr(&B2[g >> 5], gbit);
+    }
+    __syncthreads();
+    for (uint32_t tile = 0; tile < n1; tile += FT) {
+        const uint32_t k = tile + tid;
+        uint64_t key = 0;
+        bool keep = false;
+        if (k < n1) {
+            key = keys[base + k];
+            uint32_t g;
+            const uint32_t h = slot2_of(key, g);
+            keep = ((B2[h >> 5] >> (h & 31)) & (B2[g >> 5] >> (g & 31))) & 1u;
+        }
+        __syncthreads();                                  // the whole tile is in registers before a survivor of it is stored
+        const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+        if (m) {
+            uint32_t s0 = 0;
+            if (lane == 0) s0 = atomicAdd(cur2, (uint32_t)__popcll(m));
+            s0 = (uint32_t)__shfl((int)s0, 0, 64);
+            if (keep) keys[base + s0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key;   // s0 + rank <= k: in place
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { qbase[blockIdx.x] = base; qsurv[blockIdx.x] = *cur2; }
 }
 
 // moves every query's surviving keys from its region to a dense array
