@@ -1219,13 +1219,17 @@ __global__ void __launch_bounds__(256) edge_off_kernel(uint32_t n, const uint64_
 void Engine::set_cover_device(uint32_t n, const uint32_t *h_edges, uint64_t n_edges, uint32_t *assign) {
     if (n_edges >= (1ull << 31)) { set_cover(n, h_edges, n_edges, assign); return; }   // 32-bit scan positions below
     UC_HIP(hipSetDevice(device));
-    std::vector<uint64_t> off((size_t)n + 1, 0);
-    std::vector<uint32_t> adj;
+    Timer t_graph;
+    static PinnedBuf<uint64_t> off;                  // host side of the CSR graph, kept between calls
+    static PinnedBuf<uint32_t> adj;
+    off.reserve((size_t)n + 1);
+    adj.reserve(1);
+    if (!n_edges) memset(off.p, 0, ((size_t)n + 1) * 8);
     if (n_edges) {
         const uint64_t m = 2 * n_edges;
-        DevBuf<uint32_t> d_e, flag, pos, d_adj, bad;
-        DevBuf<uint64_t> key, key2, ukey, d_off;
-        DevBuf<char> tmp;
+        static DevBuf<uint32_t> d_e, flag, pos, d_adj, bad;      // kept between calls like the other work buffers of this file
+        static DevBuf<uint64_t> key, key2, ukey, d_off;
+        static DevBuf<char> tmp;
         d_e.reserve(m); key.reserve(m); key2.reserve(m); flag.reserve(m); pos.reserve(m); bad.reserve(1); d_off.reserve((size_t)n + 1);
         UC_HIP(hipMemcpyAsync(d_e.p, h_edges, m * 4, hipMemcpyHostToDevice, stream));
         UC_HIP(hipMemsetAsync(bad.p, 0, 4, stream));
@@ -1243,14 +1247,17 @@ void Engine::set_cover_device(uint32_t n, const uint32_t *h_edges, uint64_t n_ed
         ukey.reserve(std::max<uint32_t>(mu, 1)); d_adj.reserve(std::max<uint32_t>(mu, 1));
         hipLaunchKernelGGL(edge_adj_kernel, grid_for(m), dim3(256), 0, stream, m, key2.p, flag.p, pos.p, ukey.p, d_adj.p);
         hipLaunchKernelGGL(edge_off_kernel, grid_for((uint64_t)n + 1), dim3(256), 0, stream, n, ukey.p, (uint64_t)mu, d_off.p);
-        adj.resize(std::max<uint32_t>(mu, 1));
-        UC_HIP(hipMemcpyAsync(off.data(), d_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, stream));
-        if (mu) UC_HIP(hipMemcpyAsync(adj.data(), d_adj.p, (size_t)mu * 4, hipMemcpyDeviceToHost, stream));
+        adj.reserve(std::max<uint32_t>(mu, 1));
+        UC_HIP(hipMemcpyAsync(off.p, d_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, stream));
+        if (mu) UC_HIP(hipMemcpyAsync(adj.p, d_adj.p, (size_t)mu * 4, hipMemcpyDeviceToHost, stream));
         UC_HIP(hipStreamSynchronize(stream));
         UC_HIP(hipGetLastError());
     }
-    if (adj.empty()) adj.resize(1);
-    set_cover_csr(n, off.data(), adj.data(), assign);
+    const bool timing = getenv("UC_SETCOVER_TIMING") != nullptr;
+    if (timing) fprintf(stderr, "set_cover_device: graph on the GPU %.2f ms\n", t_graph.seconds() * 1e3);
+    Timer t_greedy;
+    set_cover_csr(n, off.p, adj.p, assign);
+    if (timing) fprintf(stderr, "set_cover_device: greedy on the host %.2f ms\n", t_greedy.seconds() * 1e3);
 }
 
 }  // namespace uc

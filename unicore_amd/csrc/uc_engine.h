@@ -45,6 +45,24 @@ struct DevBuf {   // plain owning device allocation (hipMalloc), grows geometric
     }
 };
 
+template <typename T>
+struct PinnedBuf {   // page-locked host staging buffer (hipHostMalloc): D2H copies run at link speed and skip the page faults of a fresh vector
+    T *p = nullptr;
+    size_t cap = 0;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    void reserve(size_t n) {   // contents are NOT preserved
+        if (n <= cap) return;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        const size_t want = n + n / 8 + 64;
+        UC_HIP(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
+        cap = want;
+    }
+};
+
 struct PairIn { uint32_t q, t; int32_t qe, te; };
 struct PrefilterScratch;                                  // uc_prefilter.hip
 void free_prefilter_scratch(PrefilterScratch *p);

@@ -24,36 +24,53 @@ namespace uc {
 
 // the greedy cover on a CSR graph (deg[i] entries of node i start at off[i])
 static void greedy_cover(uint32_t n, const uint64_t *off, const uint32_t *adj, const uint32_t *deg, uint32_t *assign) {
+    // Monotone bucket queue with lazy move-down.  Counts only ever decrease and a pick never raises another node's count, so
+    // when the sweep reaches bucket c its content is final: it is sorted once (ascending id = the tie-break) and scanned;
+    // a node whose count dropped since it was filed is re-filed in its current (lower) bucket when it is met.
     constexpr uint32_t NONE = UINT32_MAX;
     std::vector<uint32_t> cnt(n);
     uint32_t maxc = 1;
     for (uint32_t i = 0; i < n; i++) { cnt[i] = deg[i] + 1; maxc = std::max(maxc, cnt[i]); assign[i] = NONE; }
-    using MinHeap = std::priority_queue<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>>;
-    std::vector<MinHeap> bucket((size_t)maxc + 1);
+    std::vector<uint32_t> fill((size_t)maxc + 2, 0);
+    for (uint32_t i = 0; i < n; i++) fill[cnt[i] + 1]++;
+    for (uint32_t c = 0; c <= maxc; c++) fill[c + 1] += fill[c];
+    std::vector<uint32_t> init(n);                       // counting sort: ascending ids inside every bucket
     {
-        std::vector<std::vector<uint32_t>> init((size_t)maxc + 1);
-        for (uint32_t i = 0; i < n; i++) init[cnt[i]].push_back(i);     // ascending ids: already a valid heap
-        for (uint32_t c = 0; c <= maxc; c++) bucket[c] = MinHeap(std::greater<uint32_t>(), std::move(init[c]));
+        std::vector<uint32_t> cur(fill.begin(), fill.end() - 1);
+        for (uint32_t i = 0; i < n; i++) init[cur[cnt[i]]++] = i;
     }
-    std::vector<uint32_t> newly;
-    for (uint32_t c = maxc; c >= 1;) {
-        if (bucket[c].empty()) { c--; continue; }
-        const uint32_t u = bucket[c].top();
-        bucket[c].pop();
-        if (assign[u] != NONE) continue;
-        if (cnt[u] != c) { bucket[cnt[u]].push(u); continue; }   // stale: move down lazily
-        newly.clear();
-        assign[u] = u;
-        newly.push_back(u);
-        for (uint64_t k = off[u]; k < off[u] + deg[u]; k++) {
-            const uint32_t v = adj[k];
-            if (assign[v] == NONE) { assign[v] = u; newly.push_back(v); }
+    std::vector<std::vector<uint32_t>> moved((size_t)maxc + 1);   // nodes re-filed into a bucket (arbitrary order)
+    std::vector<uint32_t> cand, newly;
+    for (uint32_t c = maxc; c >= 1; c--) {
+        const uint32_t *ib = init.data() + fill[c], *ie = init.data() + fill[c + 1];
+        std::vector<uint32_t> &mv = moved[c];
+        const uint32_t *list = ib;
+        size_t len = (size_t)(ie - ib);
+        if (!mv.empty()) {                               // merge the re-filed nodes in
+            std::sort(mv.begin(), mv.end());
+            cand.resize(len + mv.size());
+            std::merge(ib, ie, mv.begin(), mv.end(), cand.begin());
+            list = cand.data();
+            len = cand.size();
         }
-        for (uint32_t v : newly)
-            for (uint64_t k = off[v]; k < off[v] + deg[v]; k++) {
-                const uint32_t w = adj[k];
-                if (assign[w] == NONE) cnt[w]--;
+        for (size_t k = 0; k < len; k++) {
+            const uint32_t u = list[k];
+            if (assign[u] != NONE) continue;
+            if (cnt[u] != c) { moved[cnt[u]].push_back(u); continue; }   // stale: cnt[u] < c
+            newly.clear();
+            assign[u] = u;
+            newly.push_back(u);
+            for (uint64_t e = off[u]; e < off[u] + deg[u]; e++) {
+                const uint32_t v = adj[e];
+                if (assign[v] == NONE) { assign[v] = u; newly.push_back(v); }
             }
+            for (uint32_t v : newly)
+                for (uint64_t e = off[v]; e < off[v] + deg[v]; e++) {
+                    const uint32_t w = adj[e];
+                    if (assign[w] == NONE) cnt[w]--;
+                }
+        }
+        std::vector<uint32_t>().swap(mv);
     }
     for (uint32_t i = 0; i < n; i++)
         if (assign[i] == NONE) assign[i] = i;   // unreachable: every node has cnt >= 1
