@@ -36,5 +36,5 @@ for world in (1, 2, 4, 8):
     e.reset_stats(); t0 = time.perf_counter(); e.align(); t_aln = time.perf_counter() - t0
     swk = e.stats()["sw_kernel_ms"]
     ed = e.edges()
-    print("N=%d (Q%d x T%d) rank %d: prefilter(cell) %.0f ms | merge+ownership %.0f ms | gapped stage on %d of %d pairs %.0f ms (SW kernels %.0f ms) | sum %.0f ms (+ exchange, + set cover ~25 ms on rank 0)"
+    print("N=%d (Q%d x T%d) rank %d: prefilter(cell) %.0f ms | merge+ownership %.0f ms | gapped stage on %d of %d pairs %.0f ms (SW kernels %.0f ms) | sum %.0f ms (+ exchange, + set cover ~9 ms on rank 0)"
           % ((world,) + ucdist.grid_shape(lens, world) + (rank, t_pre * 1e3, t_imp * 1e3, kept, 14107485, t_aln * 1e3, swk, (t_pre + t_imp + t_aln) * 1e3)))
