@@ -85,9 +85,18 @@ void Engine::upload_db() {
     }
     h_poff[n] = (uint32_t)tot;
     std::vector<uint8_t> p3(tot + 64, 20), pa(tot + 64, 20);
-    for (uint32_t i = 0; i < n; i++) {
-        memcpy(p3.data() + h_poff[i], hdb.s3.data() + hdb.off[i], h_len[i]);
-        memcpy(pa.data() + h_poff[i], hdb.sa.data() + hdb.off[i], h_len[i]);
+    {
+        auto pad_copy = [&](uint32_t b, uint32_t e) {
+            for (uint32_t i = b; i < e; i++) {
+                memcpy(p3.data() + h_poff[i], hdb.s3.data() + hdb.off[i], h_len[i]);
+                memcpy(pa.data() + h_poff[i], hdb.sa.data() + hdb.off[i], h_len[i]);
+            }
+        };
+        const unsigned T = tot < (1u << 22) ? 1u : std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; t++) th.emplace_back(pad_copy, (uint32_t)((uint64_t)n * t / T), (uint32_t)((uint64_t)n * (t + 1) / T));
+        pad_copy(0, (uint32_t)((uint64_t)n / T));
+        for (auto &x : th) x.join();
     }
     d_s3.reserve(tot + 64);
     d_sa.reserve(tot + 64);
