@@ -19,6 +19,24 @@ inline uint64_t lc_hash(uint32_t v) {   // SplitMix64 finaliser of the k-mer val
 }
 struct Cand { uint64_t h; uint32_t v, pos; };
 struct Ent { uint32_t v, seq; };
+
+void radix_sort_u64(std::vector<uint64_t> &a) {   // LSD, 11 bits per pass, passes whose digit is constant are skipped
+    if (a.size() < 2) return;
+    uint64_t all_or = 0, all_and = ~0ull;
+    for (uint64_t x : a) { all_or |= x; all_and &= x; }
+    const uint64_t varying = all_or ^ all_and;
+    std::vector<uint64_t> b(a.size());
+    std::vector<size_t> cnt(2048);
+    for (int sh = 0; sh < 64; sh += 11) {
+        if (((varying >> sh) & 2047ull) == 0) continue;
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (uint64_t x : a) cnt[(x >> sh) & 2047]++;
+        size_t run = 0;
+        for (size_t &c : cnt) { const size_t k = c; c = run; run += k; }
+        for (uint64_t x : a) b[cnt[(x >> sh) & 2047]++] = x;
+        a.swap(b);
+    }
+}
 }  // namespace
 
 std::vector<uint32_t> linclust_pairs(const HostDb &db, const Params &p, int threads) {
@@ -56,22 +74,30 @@ std::vector<uint32_t> linclust_pairs(const HostDb &db, const Params &p, int thre
         for (unsigned t = 0; t < T; t++) th.emplace_back(work, t);
         for (auto &x : th) x.join();
     }
-    std::vector<Ent> ent;
-    for (auto &v : part) ent.insert(ent.end(), v.begin(), v.end());
-    std::sort(ent.begin(), ent.end(), [](const Ent &a, const Ent &b) { return a.v != b.v ? a.v < b.v : a.seq < b.seq; });
+    // group by k-mer value: entries as (value << 32 | sequence) keys, LSD radix sort (the comparison sorts of these two
+    // lists were most of this function's time)
+    std::vector<uint64_t> ent;
+    {
+        size_t tot = 0;
+        for (auto &v : part) tot += v.size();
+        ent.reserve(tot);
+        for (auto &v : part)
+            for (const Ent &x : v) ent.push_back(((uint64_t)x.v << 32) | x.seq);
+    }
+    radix_sort_u64(ent);
     std::vector<uint64_t> pr;   // (centre << 32 | member)
     for (size_t b = 0; b < ent.size();) {
         size_t e = b;
-        while (e < ent.size() && ent[e].v == ent[b].v) e++;
-        uint32_t c = ent[b].seq;               // centre: longest sequence of the group, ties: smallest id
+        while (e < ent.size() && (ent[e] >> 32) == (ent[b] >> 32)) e++;
+        uint32_t c = (uint32_t)ent[b];         // centre: longest sequence of the group, ties: smallest id
         uint64_t lc = db.len(c);
         for (size_t k = b + 1; k < e; k++)
-            if (db.len(ent[k].seq) > lc) { c = ent[k].seq; lc = db.len(c); }
+            if (db.len((uint32_t)ent[k]) > lc) { c = (uint32_t)ent[k]; lc = db.len(c); }
         for (size_t k = b; k < e; k++)
-            if (ent[k].seq != c && (k == b || ent[k].seq != ent[k - 1].seq)) pr.push_back(((uint64_t)c << 32) | ent[k].seq);
+            if ((uint32_t)ent[k] != c && (k == b || ent[k] != ent[k - 1])) pr.push_back(((uint64_t)c << 32) | (uint32_t)ent[k]);
         b = e;
     }
-    std::sort(pr.begin(), pr.end());
+    radix_sort_u64(pr);
     pr.erase(std::unique(pr.begin(), pr.end()), pr.end());
     std::vector<uint32_t> out(2 * pr.size());
     for (size_t k = 0; k < pr.size(); k++) { out[2 * k] = (uint32_t)(pr[k] >> 32); out[2 * k + 1] = (uint32_t)pr[k]; }
