@@ -106,45 +106,6 @@ __device__ void build_sim_tables(SimTables &t, const int8_t *S3) {
     }
 }
 
-// calls f(kmer_value) for every k-mer with sum_m S3[c[m]][c'[m]] >= thr
-template <typename F>
-__device__ __forceinline__ void for_each_similar(const SimTables &t, const uint32_t c[K], int thr, F &&f) {
-    int rest[K + 1];
-    rest[K] = 0;
-#pragma unroll
-    for (int m = K - 1; m >= 0; m--) rest[m] = rest[m + 1] + t.rowmax[c[m]];
-    if (rest[0] < thr) return;
-    for (int k0 = 0; k0 < KA; k0++) {
-        const int s0 = t.sc[c[0]][k0];
-        if (s0 + rest[1] < thr) break;
-        const uint32_t v0 = t.ord[c[0]][k0];
-        for (int k1 = 0; k1 < KA; k1++) {
-            const int s1 = s0 + t.sc[c[1]][k1];
-            if (s1 + rest[2] < thr) break;
-            const uint32_t v1 = v0 + t.ord[c[1]][k1] * 20u;
-            for (int k2 = 0; k2 < KA; k2++) {
-                const int s2 = s1 + t.sc[c[2]][k2];
-                if (s2 + rest[3] < thr) break;
-                const uint32_t v2 = v1 + t.ord[c[2]][k2] * 400u;
-                for (int k3 = 0; k3 < KA; k3++) {
-                    const int s3 = s2 + t.sc[c[3]][k3];
-                    if (s3 + rest[4] < thr) break;
-                    const uint32_t v3 = v2 + t.ord[c[3]][k3] * 8000u;
-                    for (int k4 = 0; k4 < KA; k4++) {
-                        const int s4 = s3 + t.sc[c[4]][k4];
-                        if (s4 + rest[5] < thr) break;
-                        const uint32_t v4 = v3 + t.ord[c[4]][k4] * 160000u;
-                        for (int k5 = 0; k5 < KA; k5++) {
-                            if (s4 + t.sc[c[5]][k5] < thr) break;
-                            f(v4 + t.ord[c[5]][k5] * 3200000u);
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
 // shared by the count and the emit pass: decode the query position handled by this thread
 __device__ __forceinline__ bool query_kmer_at(const DeviceDb &db, const KmerCfg &cfg, uint32_t qbegin, uint32_t qend,
                                               uint32_t p, uint32_t *q, uint32_t *i, uint32_t c[K]) {
@@ -159,11 +120,20 @@ __device__ __forceinline__ bool query_kmer_at(const DeviceDb &db, const KmerCfg 
     return ok;
 }
 
-// ---- E2 pass 1: enumerate similar k-mers, keep the non-empty index ranges ("runs") ----
-// A run is (first index entry, entry count, query position inside the batch).  Threads enumerate divergently, so
-// runs are staged per wave in LDS and drained to global memory in blocks: whichever lanes are active when the
-// buffer is nearly full copy it out behind ONE global atomic.  Run order is irrelevant (keys get sorted).
-constexpr int RUN_STAGE = 256;    // staged runs per wave (12 KB of LDS per workgroup: 8 workgroups = 32 waves per CU hide the offset-table latency)
+// ---- E2 pass 1: enumerate similar k-mers (sorted-letter DFS with score bound), keep the non-empty index ranges ("runs") ----
+// A run is (first index entry, entry count, query position inside the batch); run order is irrelevant (keys get sorted).
+// A lane per query position running its own nested loops leaves most lanes idle: the number of similar k-mers per
+// position is heavy-tailed (mean ~20, maximum > 1000), a wave lasts as long as its worst position (~0.18 SIMD
+// efficiency).  Here the DFS is an explicit state machine (level, index per level and the six letters packed into
+// registers; score and value so far kept incrementally): every wave step advances every lane by ONE node, and a lane that
+// finishes its position takes the next one of the wave's region at once, so all lanes stay busy until the region is
+// exhausted — which pays once a lane works through many positions, hence one contiguous region per wave and query
+// batches as large as the key buffer allows.  Positions are decoded 64 at a time into a small pool (the sequence search
+// and letter loads are ~10 us of dependent loads that must not sit in front of every hand-out).  Leaves (k-mer value,
+// position) are appended to a wave queue by ballot rank — no per-lane atomics under divergence — and the offset-table
+// lookups are done 64 at a time when the queue fills, fully parallel and off the enumeration's critical path; the
+// non-empty ranges are staged per wave and written out behind ONE global atomic per RUN_STAGE runs.
+constexpr int RUN_STAGE = 256;      // staged runs per wave
 
 struct RunList {
     uint32_t *pidx;     // query position inside the batch
@@ -172,61 +142,183 @@ struct RunList {
 };
 
 // counters: [0] similar k-mers, [1] kept candidates, [2] ungapped overlap, [3] run cursor, [4] k-mer hits, [5] key cursor
+constexpr int LEAFQ = 256;          // leaf queue entries per wave
+constexpr int POSQ = 128;           // decoded positions per wave (ring)
+constexpr int SIM_MIN_WAVE_POS = 256;   // fewer positions per wave than this: fewer workgroups
+constexpr int SIM_MAX_BLOCKS = 1280;     // 256 CUs x 5 resident workgroups (29 KB of LDS each)
+
 __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCfg cfg, uint32_t qbegin, uint32_t qend,
-                                                       uint32_t p0, uint32_t p1, const uint32_t *koff, RunList out,
-                                                       unsigned long long *counters) {
+                                                            uint32_t p0, uint32_t p1, const uint32_t *koff, RunList out,
+                                                            unsigned long long *counters) {
     __shared__ SimTables tab;
+    __shared__ uint32_t s_mul[K];
     __shared__ uint32_t s_n[4];
     __shared__ uint64_t s_val[4][RUN_STAGE];
     __shared__ uint32_t s_pi[4][RUN_STAGE];
+    __shared__ uint32_t s_qv[4][LEAFQ], s_qp[4][LEAFQ];
+    __shared__ uint32_t s_pc[4][POSQ], s_pp[4][POSQ];
+    __shared__ uint64_t s_pr[4][POSQ];
     build_sim_tables(tab, db.S3);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < K) { uint32_t m = 1; for (int i = 0; i < (int)threadIdx.x; i++) m *= KA; s_mul[threadIdx.x] = m; }
     if (lane == 0) s_n[wv] = 0;
     __syncthreads();
     volatile uint32_t *vn = &s_n[wv];
     volatile uint64_t *vval = s_val[wv];
     volatile uint32_t *vpi = s_pi[wv];
+    volatile uint32_t *qv = s_qv[wv], *qp = s_qp[wv];
+    volatile uint32_t *pc = s_pc[wv], *pp = s_pp[wv];
+    volatile uint64_t *pr = s_pr[wv];
+    const int thr = cfg.thr;
 
-    auto drain = [&]() {   // runs on whatever subset of the wave is active at the call site
-        const uint64_t act = __builtin_amdgcn_ballot_w64(true);
-        const int nact = __popcll(act), rank = __popcll(act & ((1ull << lane) - 1ull)), leader = __ffsll((long long)act) - 1;
+    auto flush_runs = [&]() {   // whole wave
         const uint32_t n = *vn;
         uint32_t blo = 0, bhi = 0;
-        if (lane == leader) {
+        if (lane == 0) {
             const unsigned long long b = atomicAdd(counters + 3, (unsigned long long)n);
             blo = (uint32_t)b; bhi = (uint32_t)(b >> 32);
         }
-        blo = (uint32_t)__shfl((int)blo, leader, 64);
-        bhi = (uint32_t)__shfl((int)bhi, leader, 64);
+        blo = (uint32_t)__shfl((int)blo, 0, 64);
+        bhi = (uint32_t)__shfl((int)bhi, 0, 64);
         const uint64_t base = ((uint64_t)bhi << 32) | blo;
-        for (uint32_t k = rank; k < n; k += nact) {
+        for (uint32_t k = lane; k < n; k += 64) {
             const uint64_t w = base + k;
             if (w < out.cap) { out.pidx[w] = vpi[k]; out.val[w] = vval[k]; }
         }
         __builtin_amdgcn_wave_barrier();
-        if (lane == leader) *vn = 0;
+        if (lane == 0) *vn = 0;
         __builtin_amdgcn_wave_barrier();
     };
-
-    unsigned long long nsim = 0, nhit = 0;
-    for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < p1 - p0; idx += (uint64_t)gridDim.x * 256) {
-        uint32_t q, i, c[K];
-        if (!query_kmer_at(db, cfg, qbegin, qend, p0 + (uint32_t)idx, &q, &i, c)) continue;
-        for_each_similar(tab, c, cfg.thr, [&](uint32_t v) {
-            nsim++;
-            const uint32_t e0 = koff[v], n = koff[v + 1] - e0;
-            if (n == 0) return;
+    unsigned long long nhit = 0;
+    // look the queued leaves up, 64 at a time (whole wave), and stage the non-empty index ranges
+    auto drain_leaves = [&](uint32_t qn) {
+        for (uint32_t b = 0; b < qn; b += 64) {
+            const uint32_t i = b + lane;
+            uint32_t e0 = 0, n = 0, pi = 0;
+            if (i < qn) {
+                const uint32_t v = qv[i];
+                pi = qp[i];
+                e0 = koff[v];
+                n = koff[v + 1] - e0;
+            }
             nhit += n;
-            // append first, check afterwards: at most 64 lanes append between two checks, so a buffer that is drained as
-            // soon as a slot >= RUN_STAGE - 64 was handed out never overflows (one LDS round trip less per run than
-            // reading the fill level before the atomic)
-            const uint32_t slot = atomicAdd(&s_n[wv], 1u);
-            vval[slot] = ((uint64_t)n << 32) | e0; vpi[slot] = (uint32_t)idx;
-            if (__builtin_amdgcn_ballot_w64(slot >= RUN_STAGE - 64) != 0) drain();
-        });
+            const uint64_t m = __builtin_amdgcn_ballot_w64(n != 0);
+            if (m) {
+                if (*vn + 64 > RUN_STAGE) flush_runs();
+                const uint32_t slot = *vn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (n) { vval[slot] = ((uint64_t)n << 32) | e0; vpi[slot] = pi; }
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) *vn = *vn + (uint32_t)__popcll(m);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    };
+
+    unsigned long long nsim = 0;
+    const uint64_t npos = (uint64_t)p1 - p0;
+    // one contiguous region per wave: the more positions a lane works through, the less the heaviest single position weighs
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4, region = (npos + nwaves - 1) / nwaves;
+    {
+        const uint64_t rg = (uint64_t)blockIdx.x * 4 + wv;
+        const uint64_t rbeg = min(rg * region, npos), rend = min(rbeg + region, npos);
+        uint64_t next = rbeg;                      // wave-uniform cursor into the region
+        uint32_t qn = 0;                           // wave-uniform fill of the leaf queue
+        uint32_t head = 0, tail = 0;               // wave-uniform: pool of decoded positions (ring of POSQ entries)
+        // per-lane DFS state
+        bool idle = true, out_of_work = false;
+        uint32_t cpack = 0, kpack = 0, pidx = 0, vcur = 0;
+        int L = 0, scur = 0;
+        uint64_t restpack = 0;                     // rest[m] (m = 1..6) in 8-bit fields, biased by 64
+        for (;;) {
+            // ---- decode the next 64 positions together (sequence search + letter loads: ~10 us of dependent loads that
+            //      must not sit in front of every single hand-out) ----
+            if (tail - head <= POSQ - 64 && next < rend) {
+                const uint64_t mine = next + lane;
+                bool ok = false;
+                uint32_t cp = 0;
+                uint64_t rp = 0;
+                if (mine < rend) {
+                    uint32_t q, i, c[K];
+                    if (query_kmer_at(db, cfg, qbegin, qend, p0 + (uint32_t)mine, &q, &i, c)) {
+                        int rest = 0;
+#pragma unroll
+                        for (int m = K - 1; m >= 0; m--) {
+                            rp |= (uint64_t)(uint32_t)(rest + 64) << (8 * m);       // field m holds rest[m + 1]
+                            rest += tab.rowmax[c[m]];
+                            cp |= c[m] << (5 * m);
+                        }
+                        ok = rest >= thr;
+                    }
+                }
+                const uint64_t om = __builtin_amdgcn_ballot_w64(ok);
+                if (ok) {
+                    const uint32_t slot = (tail + (uint32_t)__popcll(om & ((1ull << lane) - 1ull))) % POSQ;
+                    pc[slot] = cp; pr[slot] = rp; pp[slot] = (uint32_t)mine;
+                }
+                tail += (uint32_t)__popcll(om);
+                next = min(next + 64, rend);
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
+            // ---- hand out decoded positions ----
+            const uint64_t want = __builtin_amdgcn_ballot_w64(idle && !out_of_work);
+            if (want) {
+                const uint32_t take = head + (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
+                if (idle && !out_of_work) {
+                    if (take < tail) {
+                        const uint32_t slot = take % POSQ;
+                        cpack = pc[slot]; restpack = pr[slot]; pidx = pp[slot];
+                        kpack = 0; L = 0; scur = 0; vcur = 0; idle = false;
+                    } else if (next >= rend) out_of_work = true;       // pool empty and nothing left to decode
+                }
+                head = min(head + (uint32_t)__popcll(want), tail);
+            }
+            if (__builtin_amdgcn_ballot_w64(!idle) == 0) {
+                if (next >= rend && head == tail) break;                       // region exhausted
+                continue;
+            }
+            // ---- one DFS node per lane ----
+            bool leaf = false;
+            uint32_t leafv = 0;
+            if (!idle) {
+                const uint32_t a = (cpack >> (5 * L)) & 31u, k = (kpack >> (5 * L)) & 31u;
+                const int restn = (int)((restpack >> (8 * L)) & 0xffu) - 64;
+                const int cand = scur + (k < (uint32_t)KA ? (int)tab.sc[a][k < (uint32_t)KA ? k : 0] : -100000);
+                if (k < (uint32_t)KA && cand + restn >= thr) {
+                    const uint32_t o = tab.ord[a][k];
+                    if (L == K - 1) {
+                        leaf = true;
+                        leafv = vcur + o * s_mul[K - 1];
+                        kpack += 1u << (5 * (K - 1));
+                    } else {
+                        scur = cand;
+                        vcur += o * s_mul[L];
+                        L++;
+                        kpack &= ~(31u << (5 * L));
+                    }
+                } else if (L == 0) {
+                    idle = true;
+                } else {
+                    L--;
+                    const uint32_t a2 = (cpack >> (5 * L)) & 31u, k2 = (kpack >> (5 * L)) & 31u;
+                    scur -= tab.sc[a2][k2];
+                    vcur -= tab.ord[a2][k2] * s_mul[L];
+                    kpack += 1u << (5 * L);
+                }
+            }
+            const uint64_t lm = __builtin_amdgcn_ballot_w64(leaf);
+            if (lm) {
+                if (leaf) { const uint32_t slot = qn + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull)); qv[slot] = leafv; qp[slot] = pidx; }
+                qn += (uint32_t)__popcll(lm);
+                nsim += (lane == 0) ? (unsigned long long)__popcll(lm) : 0ull;
+                if (qn > LEAFQ - 64) { __builtin_amdgcn_wave_barrier(); drain_leaves(qn); qn = 0; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        drain_leaves(qn);
     }
     __builtin_amdgcn_wave_barrier();
-    drain();
+    flush_runs();
     for (int o = 32; o > 0; o >>= 1) { nsim += __shfl_down(nsim, o, 64); nhit += __shfl_down(nhit, o, 64); }
     if (lane == 0) {
         if (nsim) atomicAdd(counters + 0, nsim);
@@ -794,8 +886,8 @@ void Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
     stats.stage_seconds[UC_ST_INDEX] += t_index.seconds();
 
     // ------------------------------------------------------------ E2-E4 over query batches
-    const uint64_t HIT_CAP = 1ull << 30;       // keys per batch (8 GiB + 8 GiB sort double buffer)
-    const uint64_t RUN_MAX = 1ull << 28;       // runs per batch (3 GiB)
+    const uint64_t HIT_CAP = 1ull << 32;       // keys per batch (32 GiB; the filter path needs < 2^32 per batch)
+    const uint64_t RUN_MAX = 1ull << 30;       // runs per batch (12 GiB + 12 GiB sort double buffer)
     double hits_per_res = 64.0;                // adaptive estimates
     uint64_t run_cap = 1ull << 20;
     KeyFmt fmt;
@@ -837,7 +929,7 @@ void Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
             UC_HIP(hipMemsetAsync(d_counters.p + 3, 0, 32, stream));   // run cursor, batch hits, key cursor, candidate cursor
             UC_HIP(hipMemsetAsync(d_counters.p, 0, 8, stream));
             const RunList rl{d_rpidx.p, d_rval.p, run_cap};
-            hipLaunchKernelGGL(sim_runs_kernel, grid_for(nq_res), dim3(256), 0, stream, ddb, cfg, qa, qb, qp0, qp1, d_koff.p, rl, d_counters.p);
+            hipLaunchKernelGGL(sim_runs_kernel, dim3((uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (nq_res + 4 * SIM_MIN_WAVE_POS - 1) / (4 * SIM_MIN_WAVE_POS)), SIM_MAX_BLOCKS)), dim3(256), 0, stream, ddb, cfg, qa, qb, qp0, qp1, d_koff.p, rl, d_counters.p);
             unsigned long long c5[5];
             UC_HIP(hipMemcpyAsync(c5, d_counters.p, 40, hipMemcpyDeviceToHost, stream));
             UC_HIP(hipStreamSynchronize(stream));
