@@ -886,8 +886,8 @@ void Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
     stats.stage_seconds[UC_ST_INDEX] += t_index.seconds();
 
     // ------------------------------------------------------------ E2-E4 over query batches
-    const uint64_t HIT_CAP = 1ull << 32;       // keys per batch (32 GiB; the filter path needs < 2^32 per batch)
-    const uint64_t RUN_MAX = 1ull << 30;       // runs per batch (12 GiB + 12 GiB sort double buffer)
+    const uint64_t HIT_CAP = 1ull << 31;       // keys per batch (16 GiB)
+    const uint64_t RUN_MAX = 1ull << 29;       // runs per batch (6 GiB + 6 GiB sort double buffer)
     double hits_per_res = 64.0;                // adaptive estimates
     uint64_t run_cap = 1ull << 20;
     KeyFmt fmt;
