@@ -277,34 +277,33 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
                 if (next >= rend && head == tail) break;                       // region exhausted
                 continue;
             }
-            // ---- one DFS node per lane ----
+            // ---- one DFS node per lane, branch-free: probe (L, k[L]); descend, emit a leaf, or step back to level L-1 ----
+            // (three divergent paths would run one after the other in nearly every step; selects cost fewer issue slots)
             bool leaf = false;
             uint32_t leafv = 0;
-            if (!idle) {
+            {
+                const int Lm = L > 0 ? L - 1 : 0;
                 const uint32_t a = (cpack >> (5 * L)) & 31u, k = (kpack >> (5 * L)) & 31u;
+                const uint32_t a2 = (cpack >> (5 * Lm)) & 31u, k2 = (kpack >> (5 * Lm)) & 31u;
+                const uint32_t kk = k < (uint32_t)KA ? k : 0u, kk2 = k2 < (uint32_t)KA ? k2 : 0u;
+                const int sc1 = tab.sc[a][kk], sc2 = tab.sc[a2][kk2];
+                const uint32_t o1 = tab.ord[a][kk], o2 = tab.ord[a2][kk2];
+                const uint32_t mulL = s_mul[L], mulM = s_mul[Lm];
                 const int restn = (int)((restpack >> (8 * L)) & 0xffu) - 64;
-                const int cand = scur + (k < (uint32_t)KA ? (int)tab.sc[a][k < (uint32_t)KA ? k : 0] : -100000);
-                if (k < (uint32_t)KA && cand + restn >= thr) {
-                    const uint32_t o = tab.ord[a][k];
-                    if (L == K - 1) {
-                        leaf = true;
-                        leafv = vcur + o * s_mul[K - 1];
-                        kpack += 1u << (5 * (K - 1));
-                    } else {
-                        scur = cand;
-                        vcur += o * s_mul[L];
-                        L++;
-                        kpack &= ~(31u << (5 * L));
-                    }
-                } else if (L == 0) {
-                    idle = true;
-                } else {
-                    L--;
-                    const uint32_t a2 = (cpack >> (5 * L)) & 31u, k2 = (kpack >> (5 * L)) & 31u;
-                    scur -= tab.sc[a2][k2];
-                    vcur -= tab.ord[a2][k2] * s_mul[L];
-                    kpack += 1u << (5 * L);
-                }
+                const int cand = scur + sc1;
+                const bool act = !idle;
+                const bool ok = act && k < (uint32_t)KA && cand + restn >= thr;
+                const bool push = ok && L < K - 1, pop = act && !ok && L > 0;
+                leaf = ok && L == K - 1;
+                leafv = vcur + o1 * mulL;
+                idle = idle || (act && !ok && L == 0);
+                scur = push ? cand : (pop ? scur - sc2 : scur);
+                vcur = push ? leafv : (pop ? vcur - o2 * mulM : vcur);
+                const uint32_t kp_leaf = kpack + (1u << (5 * (K - 1)));
+                const uint32_t kp_push = kpack & ~(31u << (5 * (L + 1)));       // L + 1 <= 5 when push
+                const uint32_t kp_pop = kpack + (1u << (5 * Lm));
+                kpack = leaf ? kp_leaf : (push ? kp_push : (pop ? kp_pop : kpack));
+                L = push ? L + 1 : (pop ? L - 1 : L);
             }
             const uint64_t lm = __builtin_amdgcn_ballot_w64(leaf);
             if (lm) {
