@@ -7,6 +7,7 @@
 // Work that is never launched: the reversed-query pass of pairs below the E-value threshold (UC-1.1),
 // and one of the two DPs of a mutual hit (q,t)/(t,q) in the forward, reversed-query, start and traceback passes
 // whenever the result of the other orientation is provably the transposed one.
+#include <mutex>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -829,6 +830,28 @@ struct AlignScratch {
 };
 void free_align_scratch(AlignScratch *p) { delete p; }
 
+// parked between engines like the prefilter's work buffers (uc_prefilter.hip)
+namespace {
+std::mutex g_park_mutex_aln;
+AlignScratch *g_parked_aln[16] = {};
+}  // namespace
+void park_align_scratch(AlignScratch *p, int device) {
+    if (!p) return;
+    const char *e = getenv("UC_KEEP_SCRATCH");
+    if (!(e && e[0] == '0') && device >= 0 && device < 16) {
+        std::lock_guard<std::mutex> g(g_park_mutex_aln);
+        if (!g_parked_aln[device]) { g_parked_aln[device] = p; return; }
+    }
+    delete p;
+}
+AlignScratch *take_align_scratch(int device) {
+    if (device >= 0 && device < 16) {
+        std::lock_guard<std::mutex> g(g_park_mutex_aln);
+        if (AlignScratch *p = g_parked_aln[device]) { g_parked_aln[device] = nullptr; return p; }
+    }
+    return new AlignScratch;
+}
+
 // ---- kernel-level entry point: arbitrary pair list from the host -----------------------------------
 void Engine::sw_batch(int mode, const std::vector<PairIn> &pairs, int32_t *score, int32_t *qe, int32_t *te) {
     if (!have_db) fail(UC_ERR_ARGS, "no database loaded");
@@ -890,7 +913,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
         if (m < 0) m = min_score_for(p, (int)h_len[q], dbres);
         h_ms[q - qbegin] = m;
     }
-    if (!aln) aln = new AlignScratch;
+    if (!aln) aln = take_align_scratch(device);
     AlignScratch &A = *aln;
     DevBuf<int32_t> &d_ms = A.d_ms, &s0 = A.s0, &qe0 = A.qe0, &te0 = A.te0, &s1 = A.s1, &s1c = A.s1c, &qe2 = A.qe2, &te2 = A.te2, &s2 = A.s2,
                     &q2o = A.q2o, &t2o = A.t2o, &work = A.work;

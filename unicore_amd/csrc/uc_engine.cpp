@@ -53,9 +53,9 @@ Engine::~Engine() {
         if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
         if (aux[i]) (void)hipStreamDestroy(aux[i]);
     }
-    free_prefilter_scratch(pre);
+    park_prefilter_scratch(pre, device);
     pre = nullptr;
-    free_align_scratch(aln);
+    park_align_scratch(aln, device);
     aln = nullptr;
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (stream) (void)hipStreamDestroy(stream);

@@ -66,8 +66,12 @@ struct PinnedBuf {   // page-locked host staging buffer (hipHostMalloc): D2H cop
 struct PairIn { uint32_t q, t; int32_t qe, te; };
 struct PrefilterScratch;                                  // uc_prefilter.hip
 void free_prefilter_scratch(PrefilterScratch *p);
+void park_prefilter_scratch(PrefilterScratch *p, int device);   // keeps one set per device for the next engine of the process
+PrefilterScratch *take_prefilter_scratch(int device);
 struct AlignScratch;                                      // uc_align.hip
 void free_align_scratch(AlignScratch *p);
+void park_align_scratch(AlignScratch *p, int device);
+AlignScratch *take_align_scratch(int device);
 
 struct Engine {
     Params p;

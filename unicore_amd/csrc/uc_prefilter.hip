@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include <rocprim/rocprim.hpp>
 
@@ -773,6 +774,30 @@ struct PrefilterScratch {
 };
 void free_prefilter_scratch(PrefilterScratch *p) { delete p; }
 
+// A destroyed engine parks its work buffers here (one set per device) and the next engine of the process takes them
+// over: freeing and re-allocating tens of GB between two uc_cluster calls is usually free, but now and then the next
+// hipMalloc then takes 1-3 s (measured: 1 in ~5 calls).  UC_KEEP_SCRATCH=0 releases them with the engine instead.
+namespace {
+std::mutex g_park_mutex;
+PrefilterScratch *g_parked_pre[16] = {};
+bool keep_scratch() { const char *e = getenv("UC_KEEP_SCRATCH"); return !(e && e[0] == '0'); }
+}  // namespace
+void park_prefilter_scratch(PrefilterScratch *p, int device) {
+    if (!p) return;
+    if (keep_scratch() && device >= 0 && device < 16) {
+        std::lock_guard<std::mutex> g(g_park_mutex);
+        if (!g_parked_pre[device]) { g_parked_pre[device] = p; return; }
+    }
+    delete p;
+}
+PrefilterScratch *take_prefilter_scratch(int device) {
+    if (device >= 0 && device < 16) {
+        std::lock_guard<std::mutex> g(g_park_mutex);
+        if (PrefilterScratch *p = g_parked_pre[device]) { g_parked_pre[device] = nullptr; return p; }
+    }
+    return new PrefilterScratch;
+}
+
 // E1-E4 for a target range.  Large ranges are processed as several index chunks whose per-query top-M lists are
 // merged on the device (lossless, same argument as the multi-GPU shards): the double-hit filter keeps one query's
 // (target, diagonal) hashes in 2 x 2^19 LDS bits, which only works while a query has well under ~500 k k-mer hits,
@@ -844,7 +869,7 @@ void Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
     if (n > (1u << 24)) fail(UC_ERR_GENERIC, "prefilter: %u sequences exceed the 2^24 limit of the hit keys", n);
     // counters: [0] similar k-mers, [1] kept candidates, [2] ungapped overlap residues, [3] run cursor,
     //           [4] k-mer hits of the batch, [5] key cursor, [6] candidate cursor
-    if (!pre) pre = new PrefilterScratch;
+    if (!pre) pre = take_prefilter_scratch(device);
     PrefilterScratch &S = *pre;
     DevBuf<unsigned long long> &d_counters = S.d_counters;
     d_counters.reserve(8);
