@@ -238,17 +238,44 @@ void write_aln_db(const std::string &prefix, const std::vector<uint64_t> &qkeys,
     std::string tmpd = prefix + ".tmp_data", tmpi = prefix + ".tmp_index";
     FILE *fd = fopen(tmpd.c_str(), "wb"), *fi = fopen(tmpi.c_str(), "wb");
     if (!fd || !fi) { if (fd) fclose(fd); if (fi) fclose(fi); fail(UC_ERR_IO, "cannot write alignment DB %s", prefix.c_str()); }
-    uint64_t off = 0;
-    for (size_t q = 0; q < qkeys.size(); q++) {
-        uint64_t len = 0;
-        for (const AlnRow &r : rows[q]) {
-            const int k = fprintf(fd, "%llu\t%d\t%.3f\t%.3E\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n", (unsigned long long)r.tkey, r.bits, r.fident,
-                                  r.evalue, r.qstart, r.qend, r.qlen, r.tstart, r.tend, r.tlen, r.aln_len, r.idents, r.gap_opens, r.corrected);
-            if (k > 0) len += (uint64_t)k;
+    // records are formatted by a few threads (contiguous query ranges, one text buffer each) and written in order: the
+    // 14-field printf per row was most of uc_search's host time
+    const size_t nq = qkeys.size();
+    size_t nrows = 0;
+    for (const auto &v : rows) nrows += v.size();
+    const unsigned T = nrows < 20000 ? 1u : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::string> text(T);
+    std::vector<std::vector<uint64_t>> lens(T);
+    auto format = [&](unsigned t) {
+        const size_t qb = nq * t / T, qe = nq * (t + 1) / T;
+        std::string &out = text[t];
+        lens[t].resize(qe - qb);
+        char buf[256];
+        for (size_t q = qb; q < qe; q++) {
+            const size_t start = out.size();
+            for (const AlnRow &r : rows[q]) {
+                const int k = snprintf(buf, sizeof buf, "%llu\t%d\t%.3f\t%.3E\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n", (unsigned long long)r.tkey, r.bits,
+                                       r.fident, r.evalue, r.qstart, r.qend, r.qlen, r.tstart, r.tend, r.tlen, r.aln_len, r.idents, r.gap_opens, r.corrected);
+                if (k > 0) out.append(buf, (size_t)std::min<int>(k, (int)sizeof buf - 1));
+            }
+            out.push_back('\0');
+            lens[t][q - qb] = out.size() - start;
         }
-        fputc(0, fd); len += 1;
-        fprintf(fi, "%llu\t%llu\t%llu\n", (unsigned long long)qkeys[q], (unsigned long long)off, (unsigned long long)len);
-        off += len;
+    };
+    if (T == 1) format(0);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; t++) th.emplace_back(format, t);
+        for (auto &x : th) x.join();
+    }
+    uint64_t off = 0;
+    for (unsigned t = 0; t < T; t++) {
+        if (!text[t].empty()) fwrite(text[t].data(), 1, text[t].size(), fd);
+        const size_t qb = nq * t / T;
+        for (size_t k = 0; k < lens[t].size(); k++) {
+            fprintf(fi, "%llu\t%llu\t%llu\n", (unsigned long long)qkeys[qb + k], (unsigned long long)off, (unsigned long long)lens[t][k]);
+            off += lens[t][k];
+        }
     }
     bool bad = ferror(fd) || ferror(fi);
     bad |= fclose(fd) != 0;
@@ -279,43 +306,62 @@ void convert_alis(const std::string &query_db, const std::string &target_db, con
     std::vector<IndexEntry> ia = read_index(aln_db + ".index");
     std::string da = read_whole_file(aln_db);
     std::string tmp = out_m8 + ".tmp";
+    // rows are converted by a few threads (contiguous ranges of query records, one text buffer each) and written in order
+    const size_t nrec = ia.size();
+    const unsigned T = da.size() < (1u << 20) ? 1u : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::string> text(T), err(T);
+    auto convert = [&](unsigned t) {
+        std::string &out = text[t];
+        char buf[512];
+        for (size_t r = nrec * t / T; r < nrec * (t + 1) / T; r++) {
+            const IndexEntry &e = ia[r];
+            auto qit = qname.find(e.key);
+            if (qit == qname.end()) { err[t] = "alignment DB query key " + std::to_string(e.key) + " not in " + query_db + "_h"; return; }
+            size_t p = e.off;
+            const size_t end = std::min<size_t>(e.off + e.len, da.size());
+            while (p < end && da[p]) {
+                size_t eol = p;
+                while (eol < end && da[eol] && da[eol] != '\n') eol++;
+                // 14 tab-separated fields; fields 2 and 3 (fident, evalue) are passed through as text
+                const char *fld[14];
+                size_t flen[14];
+                int nf = 0;
+                for (size_t b = p; nf < 14;) {
+                    size_t x = b;
+                    while (x < eol && da[x] != '\t') x++;
+                    fld[nf] = da.data() + b; flen[nf] = x - b; nf++;
+                    if (x >= eol) break;
+                    b = x + 1;
+                }
+                if (nf != 14) { err[t] = "malformed row in alignment DB " + aln_db + ": '" + da.substr(p, eol - p) + "'"; return; }
+                auto num = [&](int k) { return strtoll(fld[k], nullptr, 10); };
+                const unsigned long long tkey = strtoull(fld[0], nullptr, 10);
+                const int bits = (int)num(1), qs = (int)num(4), qe = (int)num(5), ts = (int)num(7), te = (int)num(8), alen = (int)num(10),
+                          idents = (int)num(11), gaps = (int)num(12);
+                p = eol < end && da[eol] == '\n' ? eol + 1 : eol;
+                auto tit = tname.find(tkey);
+                if (tit == tname.end()) { err[t] = "alignment DB target key " + std::to_string(tkey) + " not in " + target_db + "_h"; return; }
+                const int pairs = (qe - qs + 1) + (te - ts + 1) - alen;
+                out.append(qit->second).push_back('\t');
+                out.append(tit->second);
+                const int k = snprintf(buf, sizeof buf, "\t%.*s\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%.*s\t%d\n", (int)std::min<size_t>(flen[2], 64), fld[2], alen,
+                                       pairs - idents, gaps, qs + 1, qe + 1, ts + 1, te + 1, (int)std::min<size_t>(flen[3], 64), fld[3], bits);
+                if (k > 0) out.append(buf, (size_t)std::min<int>(k, (int)sizeof buf - 1));
+            }
+        }
+    };
+    if (T == 1) convert(0);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; t++) th.emplace_back(convert, t);
+        for (auto &x : th) x.join();
+    }
+    for (unsigned t = 0; t < T; t++)
+        if (!err[t].empty()) fail(UC_ERR_IO, "%s", err[t].c_str());
     FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) fail(UC_ERR_IO, "cannot write %s", out_m8.c_str());
-    for (const IndexEntry &e : ia) {
-        auto qit = qname.find(e.key);
-        if (qit == qname.end()) { fclose(f); fail(UC_ERR_IO, "alignment DB query key %llu not in %s_h", (unsigned long long)e.key, query_db.c_str()); }
-        size_t p = e.off;
-        const size_t end = std::min<size_t>(e.off + e.len, da.size());
-        while (p < end && da[p]) {
-            size_t eol = p;
-            while (eol < end && da[eol] && da[eol] != '\n') eol++;
-            // 14 tab-separated fields; fields 2 and 3 (fident, evalue) are passed through as text
-            const char *fld[14];
-            size_t flen[14];
-            int nf = 0;
-            for (size_t b = p; nf < 14;) {
-                size_t x = b;
-                while (x < eol && da[x] != '\t') x++;
-                fld[nf] = da.data() + b; flen[nf] = x - b; nf++;
-                if (x >= eol) break;
-                b = x + 1;
-            }
-            if (nf != 14) {
-                fclose(f);
-                fail(UC_ERR_IO, "malformed row in alignment DB %s: '%s'", aln_db.c_str(), da.substr(p, eol - p).c_str());
-            }
-            auto num = [&](int k) { return strtoll(fld[k], nullptr, 10); };
-            const unsigned long long tkey = strtoull(fld[0], nullptr, 10);
-            const int bits = (int)num(1), qs = (int)num(4), qe = (int)num(5), ts = (int)num(7), te = (int)num(8), alen = (int)num(10),
-                      idents = (int)num(11), gaps = (int)num(12);
-            p = eol < end && da[eol] == '\n' ? eol + 1 : eol;
-            auto tit = tname.find(tkey);
-            if (tit == tname.end()) { fclose(f); fail(UC_ERR_IO, "alignment DB target key %llu not in %s_h", tkey, target_db.c_str()); }
-            const int pairs = (qe - qs + 1) + (te - ts + 1) - alen;
-            fprintf(f, "%s\t%s\t%.*s\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%.*s\t%d\n", qit->second.c_str(), tit->second.c_str(), (int)flen[2], fld[2], alen,
-                    pairs - idents, gaps, qs + 1, qe + 1, ts + 1, te + 1, (int)flen[3], fld[3], bits);
-        }
-    }
+    for (unsigned t = 0; t < T; t++)
+        if (!text[t].empty()) fwrite(text[t].data(), 1, text[t].size(), f);
     bool bad = ferror(f);
     bad |= fclose(f) != 0;
     if (bad || rename(tmp.c_str(), out_m8.c_str()) != 0) fail(UC_ERR_IO, "write error on %s", out_m8.c_str());
