@@ -41,7 +41,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 unicore_amd/libunicore_cluster.so: $(HOSTOBJ) $(HIPOBJ)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -pthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -pthread -L/opt/rocm/lib -lrccl
 
 bin/unicore: $(CSRC)/cli/unicore_main.cpp unicore_amd/libunicore_cluster.so $(HDRS)
 	@mkdir -p bin

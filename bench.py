@@ -24,6 +24,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("UC_ALLOW_SYNTHETIC", "1")    # the benchmark runs on the seeded stand-in 3Di matrix (no real mat3di.out can be shipped)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # the engine's 8 streams need 8 hardware queues; read when HIP initialises
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec

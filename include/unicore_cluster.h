@@ -35,9 +35,12 @@ typedef struct uc_opts {
     uint32_t struct_size;        /* = sizeof(uc_opts) */
     int32_t threads;             /* host threads, >=1 (cluster.rs:46 "--threads") */
     int32_t verbosity;           /* 0..3, Foldseek scale after the 4->3,3->2 mapping of cluster.rs:18 */
-    int32_t device;              /* HIP device ordinal, -1 = current */
+    int32_t device;              /* HIP device ordinal of a single-GPU run / of an engine, -1 = current */
+    int32_t num_gpus;            /* uc_cluster only: GPUs the run is spread over: 0 = all visible, 1 = `device`,
+                                    N = devices 0..N-1; "--gpus N" inside cluster_options overrides it */
     const char *cluster_options; /* may be NULL == "" */
-    const char *data_dir;        /* directory holding mat3di*.out / blosum62.out; NULL = <lib dir>/data */
+    const char *data_dir;        /* directory holding mat3di.out / blosum62.out; NULL = <lib dir>/data.  Without a real
+                                    mat3di.out the call fails unless UC_ALLOW_SYNTHETIC=1 opts into the seeded stand-in */
 } uc_opts;
 
 #define UC_NSTAGE 8
@@ -62,6 +65,11 @@ typedef struct uc_stats {
     uint64_t n_filtered_hits;                            /* k-mer hits that survive the double-hit filter and get sorted */
     uint64_t n_sw_runs;                                  /* DP problems actually executed over all passes (mutual hits share one, re-runs add) */
     uint64_t cells_run;                                  /* DP cell updates actually executed (cells_* above are the algorithmic counts) */
+    /* multi-GPU exchange: wall seconds of the hit-list all-gather + device merge + edge gather on this rank,
+     * and the bytes this rank received through the collective */
+    double exchange_seconds;
+    uint64_t exchange_bytes;
+    uint32_t n_gpus, target_shards;                      /* the Q x T grid the run used: Q = n_gpus / target_shards */
 } uc_stats;
 
 /* ---- the three calls of cluster.rs ------------------------------------------------------------ */
@@ -84,6 +92,14 @@ const char *uc_last_error(void);
 const char *uc_version(void);
 /* validates a Foldseek-style option string without running anything (0 or UC_ERR_ARGS) */
 int uc_check_options(const char *cluster_options);
+/* how the engine's flag table reads one flag: 1 = takes a value, 2 = switch with an optional 0/1, -1 = unknown.  The argv
+ * shim uses it to split Foldseek-style command lines with flags anywhere. */
+int uc_option_arity(const char *flag);
+/* Work buffers (tens of GB of HBM at bench scale) are parked per device when an engine is destroyed, so that the next
+ * uc_cluster / engine of the process does not pay hipMalloc again (UC_KEEP_SCRATCH=0 disables parking).  An in-process
+ * host that is done with the engine for now calls this to give the memory back.  Loading the library also sets
+ * GPU_MAX_HW_QUEUES=8 in the process environment if the variable is unset (the class kernels of a pass run on 8 streams). */
+void uc_release_scratch(void);
 
 /* ---- staged engine API (multi-GPU driver, bench, parity tests) -------------------------------- */
 typedef struct uc_engine uc_engine;
@@ -138,6 +154,21 @@ int uc_hits_merge(uint32_t n_seqs, int32_t max_seqs, int n_parts, const uint32_t
 int uc_engine_hits_export_dev(const uc_engine *e, uint32_t *d_query, uint32_t *d_target, int32_t *d_score, int32_t *d_diag);
 int uc_engine_hits_import_dev(uc_engine *e, uint64_t n, const uint32_t *d_query, const uint32_t *d_target, const int32_t *d_score,
                               const int32_t *d_diag, uint32_t rank, uint32_t world, uint64_t *n_kept);
+
+/* ---- one process per GPU: the same sharded pass driven from outside (bench.py under torch.distributed.run) ----------
+ * The data path stays inside the library: RCCL all-gather of the hit lists, device merge, point-to-point edge gather.
+ * Rank 0 creates an id and ships its 128 bytes to the other ranks by any means (a file, torch.distributed's store);
+ * uc_comm_create is collective (ncclCommInitRank) and binds the communicator to HIP device `device`. */
+typedef struct uc_comm uc_comm;
+#define UC_COMM_ID_BYTES 128
+int uc_comm_unique_id(uint8_t id[UC_COMM_ID_BYTES]);
+int uc_comm_create(const uint8_t id[UC_COMM_ID_BYTES], int32_t rank, int32_t world, int32_t device, uc_comm **out);
+void uc_comm_destroy(uc_comm *c);
+/* One pass of the hot path on this rank: E1-E4 on the rank's cell of the Q x T grid (target_shards = T, 0 = one target
+ * shard per GPU: the north-star layout) -> hit-list all-gather + merge + ownership -> E5/E6 on the rank's pairs -> edges
+ * to rank 0 -> set cover on rank 0.  comm == NULL runs the single-GPU pass.  assign[n_seqs] is written on rank 0 only
+ * (may be NULL elsewhere); *n_alignments = gapped alignments of THIS rank. */
+int uc_engine_cluster_step(uc_engine *e, uc_comm *comm, int32_t target_shards, uint32_t *assign, uint64_t *n_alignments);
 
 /* E5-E6 for queries [qbegin,qend) of the engine's hit lists; results are kept per hit */
 int uc_engine_align(uc_engine *e, uint32_t qbegin, uint32_t qend);

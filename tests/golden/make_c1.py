@@ -5,7 +5,7 @@ written in the format `unicore createdb` leaves on disk (names unicore_<md5(aa)[
 "name\\tspecies\\toriginal header", src/modules/createdb.rs:86-108).  ProstT5 weights are not obtainable offline, so the
 3Di track is a DOCUMENTED STAND-IN derived deterministically from the AA track - the fixture pins
 the plumbing and the engine on real protein lengths / compositions, not real structures.  Expected output: the oracle's
-clust.tsv for `-c 0.8`.   Run from the repo root:  python tests/golden/make_c1.py
+clust.tsv for `-c 0.8 --single-step-clustering` and clust_workflow.tsv for a bare `-c 0.8` (pre-step + 3-step cascade).   Run from the repo root:  python tests/golden/make_c1.py
 """
 import hashlib
 import os
@@ -70,6 +70,10 @@ def main():
     p = util.oracle_params(O, "-c 0.8")
     r = O.cluster(odb, p, threads=4, dumps=False)
     O.write_tsv(os.path.join(HERE, "c1", "clust.tsv"), odb, r["assign"])
+    # what a bare "-c 0.8" runs by default: linear-time pre-step (20 k-mers per sequence) + 3-step cascade
+    rw = O.cluster_workflow(odb, p, O.cascade_thresholds(p, 4.0, 3), linclust_m=20, threads=4)
+    O.write_tsv(os.path.join(HERE, "c1", "clust_workflow.tsv"), odb, rw["assign"])
+    print("default workflow:", rw["round_sizes"].tolist(), "sequences per round,", rw["counts"]["n_clusters"], "clusters")
     print(len(files), "proteomes,", odb.n, "sequences,", r["counts"]["n_alignments"], "alignments,", r["counts"]["n_clusters"], "clusters")
 
 

@@ -61,7 +61,7 @@ def test_hip_path_reproduces_golden(name, tmp_path):
         assert np.array_equal(al[f][pe], z["aln"][f][pe]), f
     assert np.array_equal(U.setcover(e.n, e.edges()), z["assign"])
     out = str(tmp_path / "clust")
-    U.cluster(os.path.join(GOLD, "db"), out + "_cluster", str(tmp_path / "tmp"), opts)
+    U.cluster(os.path.join(GOLD, "db"), out + "_cluster", str(tmp_path / "tmp"), opts + " --single-step-clustering")
     U.createtsv(os.path.join(GOLD, "db"), out + "_cluster", out + ".tsv")
     assert open(out + ".tsv", "rb").read() == open(os.path.join(GOLD, "clust_%s.tsv" % name), "rb").read()
 
@@ -86,12 +86,16 @@ def test_oracle_reproduces_golden_cascade_and_search(tmp_path):
 def test_hip_path_reproduces_golden_cascade_and_search(tmp_path):
     import unicore_amd as U
     db = os.path.join(GOLD, "db")
-    U.cluster(db, str(tmp_path / "c_cluster"), str(tmp_path / "tmp"), "-c 0.8 --cluster-steps 3")
+    U.cluster(db, str(tmp_path / "c_cluster"), str(tmp_path / "tmp"), "-c 0.8 --cluster-steps 3 --linclust 0")
     U.createtsv(db, str(tmp_path / "c_cluster"), str(tmp_path / "c.tsv"))
     assert open(tmp_path / "c.tsv", "rb").read() == open(os.path.join(GOLD, "clust_cascade3.tsv"), "rb").read()
     U.cluster(db, str(tmp_path / "w_cluster"), str(tmp_path / "tmp"), "-c 0.8 --linclust 1 --cluster-steps 3")
     U.createtsv(db, str(tmp_path / "w_cluster"), str(tmp_path / "w.tsv"))
     assert open(tmp_path / "w.tsv", "rb").read() == open(os.path.join(GOLD, "clust_linclust_cascade3.tsv"), "rb").read()
+    # a bare "-c 0.8" - all that Unicore ever passes (arg_parser.rs:238-239) - runs that same default workflow
+    U.cluster(db, str(tmp_path / "d_cluster"), str(tmp_path / "tmp"), "-c 0.8")
+    U.createtsv(db, str(tmp_path / "d_cluster"), str(tmp_path / "d.tsv"))
+    assert open(tmp_path / "d.tsv", "rb").read() == open(os.path.join(GOLD, "clust_linclust_cascade3.tsv"), "rb").read()
     U.search(db, db, str(tmp_path / "s_aln"), str(tmp_path / "tmp"), "-c 0.8")
     U.convertalis(db, db, str(tmp_path / "s_aln"), str(tmp_path / "s.m8"))
     assert open(tmp_path / "s.m8", "rb").read() == open(os.path.join(GOLD, "search_self.m8"), "rb").read()
@@ -114,15 +118,23 @@ def test_c1_example_data_oracle_and_consumer_contract(tmp_path):
     species = {l.split("\t")[1] for l in open(os.path.join(C1, "db.map"))}
     assert {r_[1] for r_ in rows} <= mapped and len(species) == 5
     assert len({r_[0] for r_ in rows}) < len(names)          # orthologs of different species were clustered
+    # the default workflow (what a bare "-c 0.8" runs: pre-step + 3-step cascade) has its own committed result
+    rw = O.cluster_workflow(odb, util.oracle_params(O, "-c 0.8"), O.cascade_thresholds(util.oracle_params(O, "-c 0.8"), 4.0, 3), linclust_m=20, threads=4)
+    O.write_tsv(str(tmp_path / "w.tsv"), odb, rw["assign"])
+    assert open(tmp_path / "w.tsv", "rb").read() == open(os.path.join(C1, "clust_workflow.tsv"), "rb").read()
+    util.tsv_invariants(os.path.join(C1, "clust_workflow.tsv"), names)
 
 
 @pytest.mark.gpu
 def test_c1_example_data_hip_path(tmp_path):
     import unicore_amd as U
     db = os.path.join(C1, "db")
-    U.cluster(db, str(tmp_path / "c_cluster"), str(tmp_path / "tmp"), "-c 0.8")
+    U.cluster(db, str(tmp_path / "c_cluster"), str(tmp_path / "tmp"), "-c 0.8 --single-step-clustering")
     U.createtsv(db, str(tmp_path / "c_cluster"), str(tmp_path / "c.tsv"))
     assert open(tmp_path / "c.tsv", "rb").read() == open(os.path.join(C1, "clust.tsv"), "rb").read()
+    U.cluster(db, str(tmp_path / "w_cluster"), str(tmp_path / "tmp"), "-c 0.8")      # the default workflow (pre-step + cascade)
+    U.createtsv(db, str(tmp_path / "w_cluster"), str(tmp_path / "w.tsv"))
+    assert open(tmp_path / "w.tsv", "rb").read() == open(os.path.join(C1, "clust_workflow.tsv"), "rb").read()
 
 
 @pytest.mark.gpu
@@ -141,7 +153,7 @@ def test_real_foldseek_conformance(tmp_path):
     subprocess.check_call([fs, "cluster", "--threads", "4", "-v", "1", db, str(tmp_path / "f_cluster"), str(tmp_path / "ftmp"), "-c", "0.8",
                            "--single-step-clustering"])
     subprocess.check_call([fs, "createtsv", "--threads", "4", "-v", "1", db, db, str(tmp_path / "f_cluster"), str(tmp_path / "f.tsv")])
-    U.cluster(db, str(tmp_path / "c_cluster"), str(tmp_path / "tmp"), "-c 0.8")
+    U.cluster(db, str(tmp_path / "c_cluster"), str(tmp_path / "tmp"), "-c 0.8 --single-step-clustering")
     U.createtsv(db, str(tmp_path / "c_cluster"), str(tmp_path / "c.tsv"))
     assert open(tmp_path / "c.tsv", "rb").read() == open(tmp_path / "f.tsv", "rb").read(), \
         "clust.tsv differs from real Foldseek: the spec's EXT-UNVERIFIED constants (matrix, thresholds, E-value model) need the real data files"

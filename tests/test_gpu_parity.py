@@ -163,7 +163,7 @@ def test_cluster_end_to_end_tsv_bytes(O, tmp_path):
     db = util.gen_synth_db(str(tmp_path / "db"), 6, 0x5EED0001, 48, 0.6)
     out = str(tmp_path / "clu" / "clust")
     os.makedirs(os.path.dirname(out))
-    st = U.cluster(db, out + "_cluster", str(tmp_path / "tmp"), "-c 0.8", threads=4)
+    st = U.cluster(db, out + "_cluster", str(tmp_path / "tmp"), "-c 0.8 --single-step-clustering", threads=4)
     U.createtsv(db, out + "_cluster", out + ".tsv")
     odb = O.OracleDb(db)
     ref = O.cluster(odb, util.oracle_params(O, "-c 0.8"), threads=8, dumps=False)
@@ -181,7 +181,7 @@ def test_cascade_end_to_end_tsv_bytes(O, tmp_path, opts, steps, sens):
     import unicore_amd as U
     db = util.gen_synth_db(str(tmp_path / "db"), 6, 0x5EED0003, 40, 0.6)
     out = str(tmp_path / "clust")
-    st = U.cluster(db, out + "_cluster", str(tmp_path / "tmp"), opts, threads=4)
+    st = U.cluster(db, out + "_cluster", str(tmp_path / "tmp"), opts + " --linclust 0", threads=4)
     U.createtsv(db, out + "_cluster", out + ".tsv")
     odb = O.OracleDb(db)
     p = util.oracle_params(O, opts.replace(" --cluster-steps %d" % steps, ""))
@@ -492,7 +492,7 @@ def test_degenerate_databases(O, tmp_path):
         db = str(tmp_path / name)
         util.write_db(db, s3, sa)
         odb = O.OracleDb(db)
-        for opts in ("-c 0.8", "-c 0.8 --cluster-steps 2"):
+        for opts in ("-c 0.8 --single-step-clustering", "-c 0.8 --cluster-steps 2 --linclust 0"):
             out = str(tmp_path / (name + "_c"))
             U.cluster(db, out + "_cluster", str(tmp_path / "tmp"), opts)
             U.createtsv(db, out + "_cluster", out + ".tsv")
@@ -575,7 +575,7 @@ def test_traceback_bytes_in_several_batches(O, small):
     assert (al["aln_len"] > 0).sum() > 50
 
 
-@pytest.mark.parametrize("opts,steps,m", [("-c 0.8 --linclust 1", 1, 20), ("-c 0.8 --linclust 1 --cluster-steps 3", 3, 20),
+@pytest.mark.parametrize("opts,steps,m", [("-c 0.8 --linclust 1 --cluster-steps 1", 1, 20), ("-c 0.8 --linclust 1 --cluster-steps 3", 3, 20),
                                           ("-c 0.5 --linclust 1 --kmer-per-seq 5 --cluster-steps 2", 2, 5)])
 def test_linclust_workflow_tsv_bytes(O, tmp_path, opts, steps, m):
     """E8a: linear-time pre-step (minimum-hash k-mer groups, centre = longest member, candidate pairs

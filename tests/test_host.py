@@ -158,29 +158,35 @@ def test_cluster_db_createtsv_rmdb_roundtrip(tmp_path):
 
 
 def test_cli_surface_and_checkpoint_contract(tmp_path):
-    """`unicore cluster` mirrors src/util/arg_parser.rs:225-246 + src/modules/cluster.rs: arg errors exit 0x40,
-    the checkpoint is written as "0" before the engine runs, engine failure -> exit 1 with 'Error: ...'"""
+    """`unicore cluster` mirrors src/util/arg_parser.rs:225-246 + src/modules/cluster.rs: no arguments -> the help text
+    (clap's arg_required_else_help, arg_parser.rs:8,226), clap usage errors exit 2, the checkpoint is written as "0"
+    before the engine runs, engine failure -> exit 1 with 'Error: ...'"""
     exe = os.path.join(ROOT, "bin", "unicore")
-    r = subprocess.run([exe, "cluster"], capture_output=True, text=True)
-    assert r.returncode == 0x40 and "Argument parsing error" in r.stderr
+    for argv in ([exe], [exe, "cluster"]):
+        r = subprocess.run(argv, capture_output=True, text=True)
+        assert r.returncode == 2 and "Usage: unicore cluster [OPTIONS] <INPUT> <OUTPUT> <TMP>" in r.stderr and "--keep-cluster-db" in r.stderr
+    r = subprocess.run([exe, "cluster", "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Usage: unicore cluster" in r.stdout
+    r = subprocess.run([exe, "cluster", "a", "b"], capture_output=True, text=True)
+    assert r.returncode == 2 and "required arguments were not provided" in r.stderr
     r = subprocess.run([exe, "cluster", "a", "b", "c", "--nope"], capture_output=True, text=True)
-    assert r.returncode == 0x40
+    assert r.returncode == 2 and "unexpected argument '--nope'" in r.stderr
     r = subprocess.run([exe, "version"], capture_output=True, text=True)
     assert r.returncode == 0 and "unicore-cluster" in r.stdout
     out = tmp_path / "res" / "clust"
     r = subprocess.run([exe, "cluster", str(tmp_path / "missing_db"), str(out), str(tmp_path / "tmp"), "-c", "-c 0.8", "-v", "1"],
                        capture_output=True, text=True)
-    assert r.returncode == 1 and r.stderr.startswith("Error: ")
+    assert r.returncode == 1 and "\nError: " in "\n" + r.stderr
     assert open(tmp_path / "res" / "cluster.chk").read() == "0"      # started, never finished
     r = subprocess.run([exe, "cluster", "db", str(out), "tmp", "-c", "--frobnicate 3"], capture_output=True, text=True)
     assert r.returncode == 1 and "unknown or unsupported cluster option" in r.stderr
     # `unicore search` (arg_parser.rs:247-270, search.rs): same contract, its own checkpoint file
     r = subprocess.run([exe, "search", "a", "b", "c"], capture_output=True, text=True)
-    assert r.returncode == 0x40
+    assert r.returncode == 2
     sout = tmp_path / "sres" / "hits"
     r = subprocess.run([exe, "search", str(tmp_path / "missing_q"), str(tmp_path / "missing_t"), str(sout), str(tmp_path / "tmp"), "-s", "-c 0.8", "-v", "1"],
                        capture_output=True, text=True)
-    assert r.returncode == 1 and r.stderr.startswith("Error: ")
+    assert r.returncode == 1 and "\nError: " in "\n" + r.stderr
     assert open(tmp_path / "sres" / "search.chk").read() == "0"
     shim = os.path.join(ROOT, "bin", "foldseek")
     assert subprocess.run([shim, "version"], capture_output=True).returncode == 0      # config.rs:49-66 handshake
@@ -189,3 +195,39 @@ def test_cli_surface_and_checkpoint_contract(tmp_path):
     assert subprocess.run([shim, "easy-search"], capture_output=True).returncode != 0
     r = subprocess.run([shim, "rmdb", str(tmp_path / "nothing_cluster"), "-v", "2"], capture_output=True)
     assert r.returncode == 0
+
+
+def test_shim_accepts_flags_anywhere(tmp_path):
+    """`foldseek cluster` flags may stand before, between or after the positionals; whether a flag takes
+    a value comes from the engine's flag table (uc_option_arity), not from its position.  Without a GPU every well-formed
+    command line reaches the engine and fails there (status 3: the DB does not exist / 4: no device), a malformed one
+    fails in the parser (status 2)."""
+    shim = os.path.join(ROOT, "bin", "foldseek")
+    db, out, tmp = str(tmp_path / "nodb"), str(tmp_path / "o_cluster"), str(tmp_path / "t")
+    L = U.lib()
+    assert L.uc_option_arity(b"-c") == 1 and L.uc_option_arity(b"--single-step-clustering") == 2 and L.uc_option_arity(b"--nope") == -1
+    for argv in (["cluster", "--threads", "2", "-v", "1", db, out, tmp, "-c", "0.8"],                 # cluster.rs:45-49 order
+                 ["cluster", "-c", "0.8", db, out, tmp],                                             # valued flag first
+                 ["cluster", db, "-c", "0.8", "--threads", "2", out, "--min-seq-id", "0.3", tmp, "-v", "1"],
+                 ["cluster", "--single-step-clustering", db, out, tmp, "-e", "1e-3"],                # switch before a positional
+                 ["cluster", "--single-step-clustering", "1", db, out, tmp]):
+        r = subprocess.run([shim] + argv, capture_output=True, text=True)
+        assert r.returncode in (3, 4) and ("cannot" in r.stderr or "HIP" in r.stderr or "device" in r.stderr), (argv, r.returncode, r.stderr)
+    for argv in (["cluster", db, out], ["cluster", db, out, tmp, "extra"], ["cluster", db, out, tmp, "-c"],
+                 ["cluster", db, out, tmp, "--frobnicate", "3"]):
+        r = subprocess.run([shim] + argv, capture_output=True, text=True)
+        assert r.returncode == 2, (argv, r.returncode, r.stderr)
+
+
+def test_synthetic_matrix_needs_an_explicit_opt_in(tmp_path):
+    """the shipped 3Di matrix is a seeded stand-in: without UC_ALLOW_SYNTHETIC=1 (or a real mat3di.out /
+    --mat3di) the engine refuses to run instead of clustering with a meaningless matrix"""
+    shim = os.path.join(ROOT, "bin", "foldseek")
+    env = {k: v for k, v in os.environ.items() if k != "UC_ALLOW_SYNTHETIC"}
+    r = subprocess.run([shim, "cluster", "db", "out", str(tmp_path / "t")], capture_output=True, text=True, env=env)
+    assert r.returncode == 2 and "UC_ALLOW_SYNTHETIC=1" in r.stderr
+    r = subprocess.run([shim, "version"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "synthetic stand-in" in r.stdout
+    mat = os.path.join(ROOT, "unicore_amd", "data", "mat3di_synthetic.out")
+    r = subprocess.run([shim, "cluster", "db", "out", str(tmp_path / "t"), "--mat3di", mat], capture_output=True, text=True, env=env)
+    assert r.returncode in (3, 4)          # an explicit matrix is accepted; the run then fails on the missing DB / device

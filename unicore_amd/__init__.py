@@ -20,7 +20,7 @@ STAGES = ("load", "index", "kmer", "ungapped", "select", "gapped", "setcover", "
 
 class UcOpts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("threads", C.c_int32), ("verbosity", C.c_int32), ("device", C.c_int32),
-                ("cluster_options", C.c_char_p), ("data_dir", C.c_char_p)]
+                ("num_gpus", C.c_int32), ("cluster_options", C.c_char_p), ("data_dir", C.c_char_p)]
 
 
 class UcStats(C.Structure):
@@ -30,7 +30,8 @@ class UcStats(C.Structure):
         ("algorithmic_bytes", C.c_uint64 * NSTAGE), ("stage_seconds", C.c_double * NSTAGE),
         ("sw_kernel_ms", C.c_double), ("sw_kernel_launches", C.c_uint64), ("sw_algorithmic_bytes", C.c_uint64),
         ("prefilter_kernel_ms", C.c_double), ("n_filtered_hits", C.c_uint64), ("n_sw_runs", C.c_uint64),
-        ("cells_run", C.c_uint64)]
+        ("cells_run", C.c_uint64), ("exchange_seconds", C.c_double), ("exchange_bytes", C.c_uint64),
+        ("n_gpus", C.c_uint32), ("target_shards", C.c_uint32)]
 
     def as_dict(self):
         d = {}
@@ -47,6 +48,7 @@ ALN_DTYPE = np.dtype([(n, "<i4") for n in ("score", "score_rev", "corrected", "q
 # every symbol include/unicore_cluster.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "uc_cluster", "uc_createtsv", "uc_rmdb", "uc_search", "uc_convertalis", "uc_last_error", "uc_version", "uc_check_options",
+    "uc_option_arity", "uc_release_scratch", "uc_comm_unique_id", "uc_comm_create", "uc_comm_destroy", "uc_engine_cluster_step",
     "uc_engine_create", "uc_engine_destroy", "uc_engine_load_db", "uc_engine_set_db", "uc_engine_num_seqs",
     "uc_engine_prefilter", "uc_engine_prefilter_range", "uc_engine_hits_size", "uc_engine_hits_get", "uc_engine_hits_set", "uc_engine_hits_merge",
     "uc_engine_hits_export_dev", "uc_engine_hits_import_dev", "uc_engine_setcover",
@@ -75,6 +77,13 @@ def lib():
     L.uc_last_error.restype = C.c_char_p
     L.uc_version.restype = C.c_char_p
     L.uc_check_options.argtypes = [C.c_char_p]
+    L.uc_option_arity.argtypes = [C.c_char_p]
+    L.uc_release_scratch.restype = None
+    L.uc_comm_unique_id.argtypes = [vp]
+    L.uc_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    L.uc_comm_destroy.argtypes = [vp]
+    L.uc_comm_destroy.restype = None
+    L.uc_engine_cluster_step.argtypes = [vp, vp, i32, vp, C.POINTER(u64)]
     L.uc_cluster.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(UcOpts), C.POINTER(UcStats)]
     L.uc_createtsv.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(UcOpts)]
     L.uc_search.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(UcOpts), C.POINTER(UcStats)]
@@ -117,12 +126,13 @@ def _check(rc):
         raise UcError(rc, lib().uc_last_error().decode(errors="replace"))
 
 
-def make_opts(cluster_options="", threads=1, verbosity=1, device=-1, data_dir=None):
+def make_opts(cluster_options="", threads=1, verbosity=1, device=-1, data_dir=None, num_gpus=1):
     o = UcOpts()
     o.struct_size = C.sizeof(UcOpts)
     o.threads = threads
     o.verbosity = verbosity
     o.device = device
+    o.num_gpus = num_gpus
     o.cluster_options = cluster_options.encode()
     o.data_dir = data_dir.encode() if data_dir else None
     return o
@@ -136,9 +146,9 @@ def check_options(s):
     return lib().uc_check_options(s.encode())
 
 
-def cluster(db, out_cluster_db, tmp, cluster_options="-c 0.8", threads=1, verbosity=1, device=-1):
-    """== `foldseek cluster` (cluster.rs:45-56).  Returns the stats dict."""
-    o, st = make_opts(cluster_options, threads, verbosity, device), UcStats()
+def cluster(db, out_cluster_db, tmp, cluster_options="-c 0.8", threads=1, verbosity=1, device=-1, num_gpus=1):
+    """== `foldseek cluster` (cluster.rs:45-56).  Returns the stats dict.  num_gpus: 0 = all visible GPUs."""
+    o, st = make_opts(cluster_options, threads, verbosity, device, num_gpus=num_gpus), UcStats()
     _check(lib().uc_cluster(db.encode(), out_cluster_db.encode(), tmp.encode(), C.byref(o), C.byref(st)))
     return st.as_dict()
 
@@ -183,6 +193,28 @@ def hits_merge(n_seqs, max_seqs, parts):
     oc, oh, on = np.zeros(n_seqs, np.uint32), np.zeros(max(cap, 1), HIT_DTYPE), C.c_uint64()
     _check(lib().uc_hits_merge(n_seqs, max_seqs, k, cp, hp, oc.ctypes.data, oh.ctypes.data, cap, C.byref(on)))
     return oc, oh[: on.value].copy()
+
+
+class Comm:
+    """RCCL communicator of the one-process-per-GPU layout (uc_comm_* of the C ABI).  Rank 0 calls Comm.unique_id()
+    and ships the 128 bytes to the other ranks; creating the communicator is collective."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        _check(lib().uc_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, uid, rank, world, device=-1):
+        self._h = C.c_void_p()
+        self.rank, self.world = rank, world
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        _check(lib().uc_comm_create(buf, rank, world, device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().uc_comm_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 class Engine:
@@ -261,6 +293,16 @@ class Engine:
 
     def align(self, qbegin=0, qend=None):
         _check(lib().uc_engine_align(self._h, qbegin, self.n if qend is None else qend))
+
+    def cluster_step(self, comm=None, target_shards=0):
+        """One pass of the (sharded) hot path inside the library: prefilter of this rank's grid cell -> RCCL hit all-gather +
+        device merge -> E5/E6 -> edges to rank 0 -> set cover there.  Returns (assign or None, gapped alignments of this rank)."""
+        rank0 = comm is None or comm.rank == 0
+        assign = np.zeros(self.n, np.uint32) if rank0 else None
+        k = C.c_uint64()
+        _check(lib().uc_engine_cluster_step(self._h, comm._h if comm is not None else None, target_shards,
+                                            assign.ctypes.data if rank0 else None, C.byref(k)))
+        return assign, int(k.value)
 
     def alns(self, qbegin=0, qend=None):
         qend = self.n if qend is None else qend

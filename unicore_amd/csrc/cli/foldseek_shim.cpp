@@ -26,22 +26,29 @@ int main(int argc, char **argv) {
     if (argc < 2) { fprintf(stderr, "usage: foldseek <cluster|createtsv|search|convertalis|rmdb|version> ...\n"); return 2; }
     const std::string cmd = argv[1];
     if (cmd == "version") { puts(uc_version()); return 0; }
-    // flags may appear anywhere; --threads / -v are consumed here, everything else that starts with '-'
-    // (plus its value, validated by the engine) is forwarded as the cluster option string
+    // Flags may appear anywhere (the reference puts them after the positionals, cluster.rs:45-49, but
+    // `foldseek cluster -c 0.8 db out tmp` is just as valid).  Whether a flag takes a value is decided by the engine's
+    // flag table (uc_option_arity), never by position; --threads / -v are consumed here, the other flags are forwarded
+    // verbatim as the option string and validated by the engine (unknown flags are rejected there, not ignored).
     std::vector<std::string> pos;
     std::string opts;
     int threads = 1, verbosity = 3;
+    auto is_flag = [](const char *a) { return a[0] == '-' && a[1] != 0 && !((a[1] >= '0' && a[1] <= '9') || a[1] == '.'); };
     for (int i = 2; i < argc; i++) {
-        std::string a = argv[i];
-        if (a == "--threads" && i + 1 < argc) threads = atoi(argv[++i]);
-        else if (a == "-v" && i + 1 < argc) verbosity = atoi(argv[++i]);
-        else if (a.size() > 1 && a[0] == '-' && !(a[1] >= '0' && a[1] <= '9')) {
-            opts += (opts.empty() ? "" : " ") + a;
-            // a following token that is not itself a flag is this flag's value
-            if (i + 1 < argc && !(argv[i + 1][0] == '-' && !(argv[i + 1][1] >= '0' && argv[i + 1][1] <= '9')) && pos.size() >= (cmd == "cluster" ? 3u : cmd == "search" ? 4u : 99u))
-                opts += std::string(" ") + argv[++i];
-        } else if ((cmd == "cluster" && pos.size() >= 3) || (cmd == "search" && pos.size() >= 4)) opts += (opts.empty() ? "" : " ") + a;
-        else pos.push_back(a);
+        const std::string a = argv[i];
+        if (!is_flag(argv[i])) { pos.push_back(a); continue; }
+        const int ar = uc_option_arity(a.c_str());
+        std::string val;
+        bool has_val = false;
+        if (ar == 1) {
+            if (i + 1 >= argc) { fprintf(stderr, "Error: option %s needs a value\n", a.c_str()); return 2; }
+            val = argv[++i]; has_val = true;
+        } else if (ar == 2 && i + 1 < argc && (!strcmp(argv[i + 1], "0") || !strcmp(argv[i + 1], "1"))) {
+            val = argv[++i]; has_val = true;
+        }
+        if (a == "--threads") threads = atoi(val.c_str());
+        else if (a == "-v") verbosity = atoi(val.c_str());
+        else opts += (opts.empty() ? "" : " ") + a + (has_val ? " " + val : "");
     }
     uc_opts o;
     memset(&o, 0, sizeof o);
@@ -49,6 +56,7 @@ int main(int argc, char **argv) {
     o.threads = threads > 0 ? threads : 1;
     o.verbosity = verbosity;
     o.device = -1;
+    o.num_gpus = 0;   // all visible GPUs (north star); `--gpus N` in the options narrows it
     o.cluster_options = opts.c_str();
     if (cmd == "cluster") {
         if (pos.size() != 3) { fprintf(stderr, "Error: cluster expects <db> <out_cluster_db> <tmp>\n"); return 2; }

@@ -48,8 +48,8 @@ void create_dir_all(const std::string &path) {
     }
 }
 
-void usage() {
-    puts("Usage: unicore cluster [OPTIONS] <INPUT> <OUTPUT> <TMP>\n\n"
+void usage(FILE *to) {
+    fputs("Usage: unicore cluster [OPTIONS] <INPUT> <OUTPUT> <TMP>\n\n"
          "Arguments:\n"
          "  <INPUT>   Input database (createdb output)\n"
          "  <OUTPUT>  Output prefix; the result will be saved as OUTPUT.tsv\n"
@@ -59,7 +59,7 @@ void usage() {
          "  -c, --cluster-options <STRING>   Arguments for foldseek-style options in string e.g. -c \"-c 0.8\" [default: \"-c 0.8\"]\n"
          "      --threads <THREADS>          Number of threads to use; 0 to use all [default: 0]\n"
          "  -v, --verbosity <VERBOSITY>      Verbosity (0: quiet, 1: +errors, 2: +warnings, 3: +info, 4: +debug) [default: 3]\n"
-         "  -h, --help                       Print help");
+         "  -h, --help                       Print help\n", to);
 }
 
 // modules::cluster::run (cluster.rs:9-84)
@@ -80,6 +80,7 @@ int cluster_run(const std::string &input, const std::string &output, const std::
     o.threads = threads;
     o.verbosity = engine_verbosity;
     o.device = -1;
+    o.num_gpus = 0;   // all visible GPUs; "--gpus N" inside the option string narrows it
     o.cluster_options = cluster_options.c_str();
 
     print_message("Running cluster on the MI355X engine...", 3);   // cluster.rs:52
@@ -97,8 +98,8 @@ int cluster_run(const std::string &input, const std::string &output, const std::
     return 0;
 }
 
-void usage_search() {
-    puts("Usage: unicore search [OPTIONS] <INPUT> <TARGET> <OUTPUT> <TMP>\n\n"
+void usage_search(FILE *to) {
+    fputs("Usage: unicore search [OPTIONS] <INPUT> <TARGET> <OUTPUT> <TMP>\n\n"
          "Arguments:\n"
          "  <INPUT>   Input database\n"
          "  <TARGET>  Target database to search against\n"
@@ -109,7 +110,7 @@ void usage_search() {
          "  -s, --search-options <STRING>    Arguments for foldseek-style options in string e.g. -s \"-c 0.8\" [default: \"-c 0.8\"]\n"
          "      --threads <THREADS>          Number of threads to use; 0 to use all [default: 0]\n"
          "  -v, --verbosity <VERBOSITY>      Verbosity (0: quiet, 1: +errors, 2: +warnings, 3: +info, 4: +debug) [default: 3]\n"
-         "  -h, --help                       Print help");
+         "  -h, --help                       Print help\n", to);
 }
 
 // modules::search::run (search.rs:8-84)
@@ -127,6 +128,7 @@ int search_run(const std::string &input, const std::string &target, const std::s
     o.threads = threads;
     o.verbosity = engine_verbosity;
     o.device = -1;
+    o.num_gpus = 0;   // all visible GPUs; "--gpus N" inside the option string narrows it
     o.cluster_options = search_options.c_str();
     print_message("Running search on the MI355X engine...", 3);
     if (g_verbosity >= 3) putchar('\n');
@@ -144,13 +146,26 @@ int search_run(const std::string &input, const std::string &target, const std::s
     return 0;
 }
 
+// clap's own failures (missing positional, unknown flag, bad value) print "error: ..." + a usage hint on stderr and exit
+// with status 2; `arg_required_else_help = true` (arg_parser.rs:8,226) prints the HELP text — also status 2 — when the
+// (sub)command gets no argument at all.  ERR_ARGPARSE (0x40) is reserved for cluster.rs:11-15's unwrap_or_else arms, which
+// clap's required positionals make unreachable.
+constexpr int CLAP_USAGE = 2;
+[[noreturn]] void clap_error(bool is_search, const std::string &what) {
+    fprintf(stderr, "error: %s\n\nUsage: unicore %s\n\nFor more information, try '--help'.\n", what.c_str(),
+            is_search ? "search [OPTIONS] <INPUT> <TARGET> <OUTPUT> <TMP>" : "cluster [OPTIONS] <INPUT> <OUTPUT> <TMP>");
+    exit(CLAP_USAGE);
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
-    if (argc < 2 || !strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) { usage(); return argc < 2 ? 2 : 0; }
+    if (argc < 2) { usage(stderr); return CLAP_USAGE; }
+    if (!strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) { usage(stdout); return 0; }
     if (!strcmp(argv[1], "version") || !strcmp(argv[1], "--version")) { puts(uc_version()); return 0; }
     const bool is_search = !strcmp(argv[1], "search");
     if (strcmp(argv[1], "cluster") != 0 && !is_search) error(0x30 /* ERR_MODULE_NOT_IMPLEMENTED */, argv[1]);
+    if (argc == 2) { if (is_search) usage_search(stderr); else usage(stderr); return CLAP_USAGE; }   // arg_required_else_help
     std::vector<std::string> pos;
     bool keep = false;
     std::string copts = "-c 0.8";   // arg_parser.rs:238-239 (cluster), :262-263 (search)
@@ -158,7 +173,7 @@ int main(int argc, char **argv) {
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i];
         auto value = [&]() -> std::string {
-            if (i + 1 >= argc) error(ERR_ARGPARSE, "cluster - missing value for " + a);
+            if (i + 1 >= argc) clap_error(is_search, "a value is required for '" + a + "' but none was supplied");
             return argv[++i];
         };
         if (a == "-k" || a == (is_search ? "--keep-aln-db" : "--keep-cluster-db")) keep = true;
@@ -168,13 +183,14 @@ int main(int argc, char **argv) {
         else if (is_search && a.rfind("--search-options=", 0) == 0) copts = a.substr(17);
         else if (a == "--threads") threads = atoi(value().c_str());
         else if (a == "-v" || a == "--verbosity") verbosity = atoi(value().c_str());
-        else if (a == "-h" || a == "--help") { if (is_search) usage_search(); else usage(); return 0; }
-        else if (a.size() > 1 && a[0] == '-') error(ERR_ARGPARSE, "cluster - unexpected argument " + a);
+        else if (a == "-h" || a == "--help") { if (is_search) usage_search(stdout); else usage(stdout); return 0; }
+        else if (a.size() > 1 && a[0] == '-') clap_error(is_search, "unexpected argument '" + a + "' found");
         else pos.push_back(a);
     }
-    if (is_search && pos.size() != 4) { usage_search(); error(ERR_ARGPARSE, "search - expected <INPUT> <TARGET> <OUTPUT> <TMP>"); }
-    if (!is_search && pos.size() != 3) { usage(); error(ERR_ARGPARSE, "cluster - expected <INPUT> <OUTPUT> <TMP>"); }
-    if (verbosity < 0 || verbosity > 4) error(ERR_ARGPARSE, "cluster - verbosity");
+    const size_t want = is_search ? 4 : 3;
+    if (pos.size() < want) clap_error(is_search, "the following required arguments were not provided");
+    if (pos.size() > want) clap_error(is_search, "unexpected argument '" + pos[want] + "' found");
+    if (verbosity < 0 || verbosity > 4) clap_error(is_search, "invalid value for '--verbosity <VERBOSITY>'");
     g_verbosity = verbosity;
     // set_threads (variables.rs:155-166): 0 -> all CPUs, clamp to the CPU count
     int cpus = (int)std::thread::hardware_concurrency();

@@ -596,8 +596,15 @@ static uint32_t scan_total(Engine &E, const uint32_t *flag, const uint32_t *pos,
 static void build_plan(Engine &E, SwPlan &P, DevBuf<char> &tmp, uint32_t n, const uint32_t *q, const uint32_t *t,
                        const int32_t *qe, const int32_t *te, int tab, const int32_t *qs = nullptr, const int32_t *ts = nullptr,
                        const int32_t *aux = nullptr /* one value per pair carried into plan order (known scores) */) {
-    static bool tables_uploaded = false;
-    if (!tables_uploaded) { UC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), h_tab, sizeof h_tab)); tables_uploaded = true; }
+    {   // a __constant__ symbol exists once per DEVICE: upload the class tables to every device an engine plans on
+        static std::mutex mu;
+        static bool uploaded[64] = {};
+        std::lock_guard<std::mutex> g(mu);
+        if (E.device < 0 || E.device >= 64 || !uploaded[E.device]) {
+            UC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), h_tab, sizeof h_tab));
+            if (E.device >= 0 && E.device < 64) uploaded[E.device] = true;
+        }
+    }
     P.n = n; P.ntasks = 0; P.alg_bytes = 0; P.cells = 0; P.has_ends = qe != nullptr; P.has_starts = qs != nullptr; P.tab = tab;
     P.has_aux = aux != nullptr;
     memset(P.task_base, 0, sizeof P.task_base);
@@ -681,7 +688,7 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
         if (!nt) continue;
         SwArgs ac = a;
         ac.tasks = P.tasks.p + P.task_base[c];
-        hipStream_t st = slot % (Engine::N_AUX + 1) == 0 ? E.stream : E.aux[slot % (Engine::N_AUX + 1) - 1];
+        hipStream_t st = slot % E.n_streams == 0 ? E.stream : E.aux[slot % E.n_streams - 1];
         slot++;
         if (tab.pk[c]) launch_sw_pk_class(tab.G[c], tab.R[c], mode, ac, nt, st);
         else launch_sw_class(tab.G[c], tab.R[c], imode, ac, nt, st);
@@ -742,10 +749,45 @@ __global__ void __launch_bounds__(256) pk_putback_kernel(uint32_t n2, const uint
     }
 }
 
+
 struct RerunBufs {
     DevBuf<uint32_t> flag, pos, q2, t2, link;
     DevBuf<int32_t> qe2, te2, s, qe, te, sin;
 };
+
+// Work buffers of the gapped stage and of the set-cover graph build.  ONE set per engine (parked per device between
+// engines): nothing in this file is process-wide, so engines on different devices - or several engines on one device,
+// each driven by its own host thread as uc_cluster does for num_gpus > 1 - never share or race on a buffer.
+struct AlignScratch {
+    DevBuf<int32_t> d_ms, s0, qe0, te0, s1, s1c, qe2, te2, s2, q2o, t2o, work;
+    DevBuf<uint32_t> gflag, gpos, q1, t1, link1, q2, t2, link, eflag, epos, mism, d_e;
+    DevBuf<uint64_t> ukey, ukey2;
+    DevBuf<uint32_t> uidx_in, uidx, fq, ft, mirror, rep, rpos, qr, tr, jrep, rcopy;
+    DevBuf<int32_t> su, qeu, teu, s2s, q2os, t2os, qe2a, te2a, sknown;
+    DevBuf<uint32_t> iota2, smkeep, smpos, partner, uniq, q2a, t2a, mapa;
+    DevBuf<unsigned long long> d_cells;
+    DevBuf<char> tmp;
+    SwPlan P0, P1, P2, P2b;
+    // packed-range / ambiguous-end re-runs (run_plan, fix_ambiguous_ends)
+    RerunBufs rr_B, amb_B;
+    SwPlan rr_P2, amb_P3;
+    // traceback statistics (align: --min-seq-id / search)
+    DevBuf<uint32_t> tb_q3, tb_t3, tb_src3, tb_trun, tb_tpos, tb_tpart, tb_ttie, tb_tlo, tb_thi, tb_tchunk, tb_tcpos;
+    DevBuf<unsigned long long> tb_tbsize, tb_tboff;
+    DevBuf<uint8_t> tb_tbm;
+    DevBuf<int32_t> tb_qs3, tb_qe3, tb_ts3, tb_te3, tb_pack3, tb_gaps3;
+    SwPlan tb_P3;
+    // set-cover graph build (set_cover_device)
+    PinnedBuf<uint64_t> sc_off;
+    PinnedBuf<uint32_t> sc_adj;
+    DevBuf<uint32_t> sc_e, sc_flag, sc_pos, sc_dadj, sc_bad;
+    DevBuf<uint64_t> sc_key, sc_key2, sc_ukey, sc_doff;
+    DevBuf<char> sc_tmp;
+};
+static AlignScratch &scratch_of(Engine &E) {
+    if (!E.aln) E.aln = take_align_scratch(E.device);
+    return *E.aln;
+}
 
 // ovf_only: re-run immediately only what saturated; ambiguous end rows (qe == -2) are left for the caller
 static void run_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t *oqe, int32_t *ote, DevBuf<int32_t> &work,
@@ -759,8 +801,8 @@ static void run_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t *oqe, 
     while (npk < tab.n && tab.pk[npk]) npk++;
     const uint32_t n_pk = P.pair_base[npk];   // packed classes form a prefix of the sorted pair list
     if (n_pk) {
-        static RerunBufs B;
-        static SwPlan P2;
+        RerunBufs &B = scratch_of(E).rr_B;
+        SwPlan &P2 = scratch_of(E).rr_P2;
         hipStream_t s = E.stream;
         B.flag.reserve(n_pk); B.pos.reserve(n_pk);
         hipLaunchKernelGGL(pk_flag_kernel, grid_for(n_pk), dim3(256), 0, s, n_pk, os, oqe, SW_PK_OVF_HOST, ovf_only ? 1 : 0, B.flag.p);
@@ -798,8 +840,8 @@ static void run_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t *oqe, 
 static void fix_ambiguous_ends(Engine &E, uint32_t n2, const uint32_t *q2, const uint32_t *t2, int32_t *qe2, int32_t *te2,
                                const uint32_t *link, const int32_t *s0, int32_t *qe0, int32_t *te0, DevBuf<int32_t> &work,
                                DevBuf<char> &tmp) {
-    static RerunBufs B;
-    static SwPlan P3;
+    RerunBufs &B = scratch_of(E).amb_B;
+    SwPlan &P3 = scratch_of(E).amb_P3;
     hipStream_t s = E.stream;
     B.flag.reserve(n2); B.pos.reserve(n2);
     hipLaunchKernelGGL(amb_flag_kernel, grid_for(n2), dim3(256), 0, s, n2, qe2, B.flag.p);
@@ -816,18 +858,6 @@ static void fix_ambiguous_ends(Engine &E, uint32_t n2, const uint32_t *q2, const
     UC_HIP(hipGetLastError());
 }
 
-// work buffers of the gapped stage, kept by the engine between calls
-struct AlignScratch {
-    DevBuf<int32_t> d_ms, s0, qe0, te0, s1, s1c, qe2, te2, s2, q2o, t2o, work;
-    DevBuf<uint32_t> gflag, gpos, q1, t1, link1, q2, t2, link, eflag, epos, mism, d_e;
-    DevBuf<uint64_t> ukey, ukey2;
-    DevBuf<uint32_t> uidx_in, uidx, fq, ft, mirror, rep, rpos, qr, tr, jrep, rcopy;
-    DevBuf<int32_t> su, qeu, teu, s2s, q2os, t2os, qe2a, te2a, sknown;
-    DevBuf<uint32_t> iota2, smkeep, smpos, partner, uniq, q2a, t2a, mapa;
-    DevBuf<unsigned long long> d_cells;
-    DevBuf<char> tmp;
-    SwPlan P0, P1, P2, P2b;
-};
 void free_align_scratch(AlignScratch *p) { delete p; }
 
 // parked between engines like the prefilter's work buffers (uc_prefilter.hip)
@@ -843,6 +873,13 @@ void park_align_scratch(AlignScratch *p, int device) {
         if (!g_parked_aln[device]) { g_parked_aln[device] = p; return; }
     }
     delete p;
+}
+AlignScratch *take_parked_align_scratch(int device) {   // nullptr if nothing is parked (uc_release_scratch)
+    if (device < 0 || device >= 16) return nullptr;
+    std::lock_guard<std::mutex> g(g_park_mutex_aln);
+    AlignScratch *p = g_parked_aln[device];
+    g_parked_aln[device] = nullptr;
+    return p;
 }
 AlignScratch *take_align_scratch(int device) {
     if (device >= 0 && device < 16) {
@@ -902,10 +939,10 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
     Timer tm;
     hipStream_t s = stream;
     const uint64_t dbres = evalue_residues ? evalue_residues : hdb.residues();
-    if (d_alns.cap < std::max<uint64_t>(n_hits, 1)) {
-        d_alns.reserve(std::max<uint64_t>(n_hits, 1));
-        UC_HIP(hipMemsetAsync(d_alns.p, 0, n_hits * sizeof(uc_aln), s));
-    }
+    // records of queries outside [qbegin,qend) must read as "not aligned" (all zero), never as leftovers of an earlier hit
+    // list: the array is cleared whenever the hit lists changed since the last align (0.2 ms at 14 M records)
+    d_alns.reserve(std::max<uint64_t>(n_hits, 1));
+    if (!alns_valid && n_hits) UC_HIP(hipMemsetAsync(d_alns.p, 0, n_hits * sizeof(uc_aln), s));
     // E-value gate as an integer threshold per query length (host; exp() evaluated once per distinct length)
     std::vector<int32_t> ms_by_len(65536, -1), h_ms(qend - qbegin);
     for (uint32_t q = qbegin; q < qend; q++) {
@@ -1085,11 +1122,12 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                 if ((p.min_seq_id > 0.0f || p.want_tb) && ne) {
                     // sequence-identity gate / BLAST-tab statistics: (alignment length, identities[, gaps]) of the traceback on
                     // the box, computed by the MODE 3 pass of the int32 kernel for the pairs that passed the coverage gate
-                    static DevBuf<uint32_t> q3, t3, src3, trun, tpos, tpart, ttie, tlo, thi, tchunk, tcpos;
-                    static DevBuf<unsigned long long> tbsize, tboff;
-                    static DevBuf<uint8_t> tbm;
-                    static DevBuf<int32_t> qs3, qe3, ts3, te3, pack3, gaps3;
-                    static SwPlan P3;
+                    DevBuf<uint32_t> &q3 = A.tb_q3, &t3 = A.tb_t3, &src3 = A.tb_src3, &trun = A.tb_trun, &tpos = A.tb_tpos, &tpart = A.tb_tpart,
+                                     &ttie = A.tb_ttie, &tlo = A.tb_tlo, &thi = A.tb_thi, &tchunk = A.tb_tchunk, &tcpos = A.tb_tcpos;
+                    DevBuf<unsigned long long> &tbsize = A.tb_tbsize, &tboff = A.tb_tboff;
+                    DevBuf<uint8_t> &tbm = A.tb_tbm;
+                    DevBuf<int32_t> &qs3 = A.tb_qs3, &qe3 = A.tb_qe3, &ts3 = A.tb_ts3, &te3 = A.tb_te3, &pack3 = A.tb_pack3, &gaps3 = A.tb_gaps3;
+                    SwPlan &P3 = A.tb_P3;
                     trun.reserve(n2); tpos.reserve(n2); tpart.reserve(n2); ttie.reserve(n2);
                     UC_HIP(hipMemsetAsync(ttie.p, 0, (size_t)n2 * 4, s));
                     // one batch: gather the flagged entries, plan, run, apply.  pk: packed MODE 7 (decision bytes) + walk kernel;
@@ -1243,16 +1281,17 @@ void Engine::set_cover_device(uint32_t n, const uint32_t *h_edges, uint64_t n_ed
     if (n_edges >= (1ull << 31)) { set_cover(n, h_edges, n_edges, assign); return; }   // 32-bit scan positions below
     UC_HIP(hipSetDevice(device));
     Timer t_graph;
-    static PinnedBuf<uint64_t> off;                  // host side of the CSR graph, kept between calls
-    static PinnedBuf<uint32_t> adj;
+    AlignScratch &A = scratch_of(*this);
+    PinnedBuf<uint64_t> &off = A.sc_off;             // host side of the CSR graph, kept between calls
+    PinnedBuf<uint32_t> &adj = A.sc_adj;
     off.reserve((size_t)n + 1);
     adj.reserve(1);
     if (!n_edges) memset(off.p, 0, ((size_t)n + 1) * 8);
     if (n_edges) {
         const uint64_t m = 2 * n_edges;
-        static DevBuf<uint32_t> d_e, flag, pos, d_adj, bad;      // kept between calls like the other work buffers of this file
-        static DevBuf<uint64_t> key, key2, ukey, d_off;
-        static DevBuf<char> tmp;
+        DevBuf<uint32_t> &d_e = A.sc_e, &flag = A.sc_flag, &pos = A.sc_pos, &d_adj = A.sc_dadj, &bad = A.sc_bad;
+        DevBuf<uint64_t> &key = A.sc_key, &key2 = A.sc_key2, &ukey = A.sc_ukey, &d_off = A.sc_doff;
+        DevBuf<char> &tmp = A.sc_tmp;
         d_e.reserve(m); key.reserve(m); key2.reserve(m); flag.reserve(m); pos.reserve(m); bad.reserve(1); d_off.reserve((size_t)n + 1);
         UC_HIP(hipMemcpyAsync(d_e.p, h_edges, m * 4, hipMemcpyHostToDevice, stream));
         UC_HIP(hipMemsetAsync(bad.p, 0, 4, stream));

@@ -4,15 +4,21 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <thread>
 
 #include "uc_engine.h"
+#include "uc_multi.h"
 
 using namespace uc;
 
 struct uc_engine {
     std::unique_ptr<Engine> e;
+};
+struct uc_comm {
+    Comm c;
 };
 
 namespace {
@@ -41,6 +47,7 @@ Params params_from(const uc_opts *o, bool search = false) {
         if (o->struct_size != sizeof(uc_opts)) fail(UC_ERR_ARGS, "uc_opts.struct_size mismatch (%u != %zu)", o->struct_size, sizeof(uc_opts));
         p.threads = o->threads > 0 ? o->threads : 1;
         p.verbosity = o->verbosity;
+        p.num_gpus = o->num_gpus;
         if (o->cluster_options) parse_cluster_options(o->cluster_options, p);
     }
     g_verbosity = p.verbosity;
@@ -70,7 +77,24 @@ void require(const void *p, const char *what) {
 extern "C" {
 
 const char *uc_last_error(void) { return last_error_cstr(); }
-const char *uc_version(void) { return "unicore-cluster-mi355x 0.1.0 (spec UC-1, gfx950)"; }
+const char *uc_version(void) {
+    // says which 3Di matrix a run without --mat3di would use: results with the stand-in are not Foldseek's
+    static thread_local std::string v;
+    struct stat st;
+    const bool real = stat((default_data_dir() + "/mat3di.out").c_str(), &st) == 0;
+    v = std::string("unicore-cluster-mi355x 0.2.0 (spec UC-1.1, gfx950; default workflow: linclust pre-step + 3-step cascade; 3Di matrix: ") +
+        (real ? "data/mat3di.out" : "MISSING - only the synthetic stand-in is shipped, runs need UC_ALLOW_SYNTHETIC=1 or --mat3di") + ")";
+    return v.c_str();
+}
+
+int uc_option_arity(const char *flag) { return flag ? option_arity(flag) : -1; }
+
+void uc_release_scratch(void) {
+    for (int d = 0; d < 16; d++) {
+        free_prefilter_scratch(take_parked_prefilter_scratch(d));
+        free_align_scratch(take_parked_align_scratch(d));
+    }
+}
 
 int uc_check_options(const char *cluster_options) {
     return guard([&] { Params p; parse_cluster_options(cluster_options ? cluster_options : "", p); });
@@ -203,6 +227,7 @@ int uc_engine_alns_get(const uc_engine *e, uint32_t qbegin, uint32_t qend, uc_al
     return guard([&] {
         require(e, "engine");
         const Engine &E = *e->e;
+        if (!E.have_db) fail(UC_ERR_ARGS, "alns_get: no database loaded");
         if (qbegin > qend || qend > E.hdb.n) fail(UC_ERR_ARGS, "alns_get: bad query range");
         const uint64_t b = E.hit_off[qbegin], n = E.hit_off[qend] - b;
         if (n) { require(out, "out"); E.get_alns(b, n, out); }
@@ -283,6 +308,48 @@ int uc_engine_sw_batch(uc_engine *e, int mode, uint64_t n, const uint32_t *q, co
     });
 }
 
+}  // extern "C"
+
+namespace {
+
+// counters add up over the ranks of a run; times are the slowest rank's (the ranks run side by side)
+void merge_stats(uc_stats &d, const uc_stats &s) {
+    d.n_index_entries += s.n_index_entries; d.n_sim_kmers += s.n_sim_kmers; d.n_kmer_hits += s.n_kmer_hits;
+    d.n_candidates += s.n_candidates; d.n_prefilter_hits += s.n_prefilter_hits; d.n_gapped_alignments += s.n_gapped_alignments;
+    d.n_start_alignments += s.n_start_alignments; d.n_pk_reruns += s.n_pk_reruns;
+    d.cells_fwd += s.cells_fwd; d.cells_rev += s.cells_rev; d.cells_start += s.cells_start;
+    d.sw_kernel_launches += s.sw_kernel_launches; d.sw_algorithmic_bytes += s.sw_algorithmic_bytes;
+    d.n_filtered_hits += s.n_filtered_hits; d.n_sw_runs += s.n_sw_runs; d.cells_run += s.cells_run; d.exchange_bytes += s.exchange_bytes;
+    for (int k = 0; k < UC_NSTAGE; k++) {
+        if (k != UC_ST_SETCOVER && k != UC_ST_OUTPUT && k != UC_ST_LOAD) d.algorithmic_bytes[k] += s.algorithmic_bytes[k];
+        d.stage_seconds[k] = std::max(d.stage_seconds[k], s.stage_seconds[k]);
+    }
+    d.sw_kernel_ms = std::max(d.sw_kernel_ms, s.sw_kernel_ms);
+    d.prefilter_kernel_ms = std::max(d.prefilter_kernel_ms, s.prefilter_kernel_ms);
+    d.exchange_seconds = std::max(d.exchange_seconds, s.exchange_seconds);
+}
+
+// the sub-database of the current representatives (createsubdb)
+HostDb sub_db(const HostDb &full, const std::vector<uint32_t> &cur) {
+    HostDb sub;
+    sub.n = (uint32_t)cur.size();
+    sub.off.resize((size_t)sub.n + 1);
+    uint64_t tot = 0;
+    for (uint32_t i = 0; i < sub.n; i++) { sub.off[i] = tot; tot += full.len(cur[i]); }
+    sub.off[sub.n] = tot;
+    sub.s3.resize(tot); sub.sa.resize(tot); sub.keys.resize(sub.n);
+    for (uint32_t i = 0; i < sub.n; i++) {
+        memcpy(sub.s3.data() + sub.off[i], full.s3.data() + full.off[cur[i]], full.len(cur[i]));
+        memcpy(sub.sa.data() + sub.off[i], full.sa.data() + full.off[cur[i]], full.len(cur[i]));
+        sub.keys[i] = full.keys[cur[i]];
+    }
+    return sub;
+}
+
+}  // namespace
+
+extern "C" {
+
 // ---- the three calls of /root/reference/src/modules/cluster.rs:45-76 ----------------------------
 
 int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, const uc_opts *o, uc_stats *stats_out) {
@@ -290,74 +357,190 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
         require(db, "db"); require(out_cluster_db, "out_cluster_db");
         Params p = params_from(o);
         if (tmp && *tmp) mkdir_p(tmp);   // callee owns <tmp>; nothing is spilled there yet
-        Engine E(p, o ? o->device : -1);
+        if (p.mat3di_synthetic)
+            logf(1, "Warning: clustering with the SYNTHETIC 3Di matrix %s (UC_ALLOW_SYNTHETIC=1): results are not Foldseek's\n", p.mat3di_path.c_str());
+
+        // ---- devices (one engine + one host thread per GPU, hit lists all-gathered with RCCL)
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+            fail(UC_ERR_DEVICE, "no HIP device available; this engine has no CPU fallback");
+        int W = p.num_gpus == 0 ? ndev : p.num_gpus;
+        std::vector<int> devices;
+        bool virtual_gpus = false;
+        if (W == 1) {
+            int d = o ? o->device : -1;
+            if (d < 0) UC_HIP(hipGetDevice(&d));
+            devices.push_back(d);
+        } else {
+            if (W > ndev) {
+                // several ranks per physical GPU: only to exercise the N > 1 path on a single-GPU box (tests); RCCL refuses
+                // two ranks on one device, so these ranks exchange with plain device copies
+                const char *v = getenv("UC_VIRTUAL_GPUS");
+                if (!v || strcmp(v, "1") != 0) fail(UC_ERR_DEVICE, "%d GPUs requested but only %d visible", W, ndev);
+                virtual_gpus = true;
+            }
+            for (int r = 0; r < W; r++) devices.push_back(r % ndev);
+        }
+        int gQ = 1, gT = 1;
+        grid_shape(W, p.target_shards, &gQ, &gT);
+
         Timer tl;
         logf(3, "unicore-cluster: reading %s\n", db);
-        read_seq_db(db, E.hdb, false);
-        E.stats.stage_seconds[UC_ST_LOAD] += tl.seconds();
-        const HostDb full = E.hdb;            // round 0 runs on the whole DB; later rounds on representatives (createsubdb)
+        HostDb full;
+        read_seq_db(db, full, false);
+        const double t_load = tl.seconds();
         const uint32_t n = full.n;
-        logf(3, "unicore-cluster: %u sequences, %llu residues, device %d, %d clustering step(s)\n", n, (unsigned long long)full.residues(),
-             E.device, p.cluster_steps);
+        const int pre = p.linclust ? 1 : 0;     // E8a: one linear-time pre-clustering round in front of the cascade rounds
+        logf(3, "unicore-cluster: %u sequences, %llu residues, %d GPU(s)%s [%d query group(s) x %d target shard(s)], %s%d clustering step(s)\n", n,
+             (unsigned long long)full.residues(), W, virtual_gpus ? " (virtual: several ranks per device)" : "", gQ, gT,
+             pre ? "linear-time pre-step + " : "", p.cluster_steps);
+
+        // ---- state shared by the rank threads (host memory; rank 0 owns the workflow, the others follow its rounds)
         std::vector<uint32_t> assign(n), cur(n), posmap(n);
         for (uint32_t i = 0; i < n; i++) { assign[i] = i; cur[i] = i; }
-        const int pre = p.linclust ? 1 : 0;     // E8a: one linear-time pre-clustering round in front of the cascade rounds
-        for (int rr = 0; rr < p.cluster_steps + pre; rr++) {
-            const int r = rr - pre;             // cascade round index (-1 = the pre-step)
-            if (rr > 0) {   // sub-database of the current representatives
-                HostDb sub;
-                sub.n = (uint32_t)cur.size();
-                sub.off.resize((size_t)sub.n + 1);
-                uint64_t tot = 0;
-                for (uint32_t i = 0; i < sub.n; i++) { sub.off[i] = tot; tot += full.len(cur[i]); }
-                sub.off[sub.n] = tot;
-                sub.s3.resize(tot); sub.sa.resize(tot); sub.keys.resize(sub.n);
-                for (uint32_t i = 0; i < sub.n; i++) {
-                    memcpy(sub.s3.data() + sub.off[i], full.s3.data() + full.off[cur[i]], full.len(cur[i]));
-                    memcpy(sub.sa.data() + sub.off[i], full.sa.data() + full.off[cur[i]], full.len(cur[i]));
-                    sub.keys[i] = full.keys[cur[i]];
-                }
-                E.hdb = std::move(sub);
-            }
-            if (r >= 0 && p.cluster_steps > 1 && !p.kmer_thr_explicit)   // sensitivity rises linearly from 1 to the target (spec UC-1 E8)
-                E.p.kmer_thr = kmer_thr_for(p, 1.0 + (p.sensitivity - 1.0) * r / (p.cluster_steps - 1));
-            E.upload_db();
-            if (r < 0) {   // E8a: candidate pairs (centre, member) from shared minimum-hash k-mers, the centre is the query
-                const std::vector<uint32_t> pr = linclust_pairs(E.hdb, p, p.threads);
-                std::vector<uint32_t> cnt(E.hdb.n, 0);
-                std::vector<uc_hit> hl(pr.size() / 2);
-                for (size_t k = 0; k < pr.size() / 2; k++) { cnt[pr[2 * k]]++; hl[k].target = pr[2 * k + 1]; hl[k].score = 0; hl[k].diag = 0; }
-                E.set_hits(cnt.data(), hl.data(), /*check_max_seqs=*/false);
-                E.stats.n_prefilter_hits += pr.size() / 2;
-                logf(3, "unicore-cluster: pre-step: %u sequences, %zu candidate pairs (%d k-mers per sequence)\n", E.hdb.n, pr.size() / 2, p.kmer_per_seq);
-            } else {
-                E.prefilter(0, E.hdb.n);
-                logf(3, "unicore-cluster: step %d: %u sequences, prefilter kept %llu pairs (k-score %d, max-seqs %d)\n", r + 1, E.hdb.n,
-                     (unsigned long long)E.n_hits, E.p.kmer_thr, p.max_seqs);
-            }
-            E.align(0, E.hdb.n);
-            Timer tc;
-            std::vector<uint32_t> sa(E.hdb.n);
-            E.set_cover_device(E.hdb.n, E.edges.data(), E.edges.size() / 2, sa.data());
-            // mergeclusters: the representative of a sequence is the representative of its representative
-            for (uint32_t i = 0; i < cur.size(); i++) posmap[cur[i]] = i;
-            for (uint32_t x = 0; x < n; x++) assign[x] = cur[sa[posmap[assign[x]]]];
-            std::vector<uint32_t> next;
-            for (uint32_t i = 0; i < cur.size(); i++) if (sa[i] == i) next.push_back(cur[i]);
-            E.stats.algorithmic_bytes[UC_ST_SETCOVER] += 8ull * (E.edges.size() / 2) + 4ull * E.hdb.n;
-            E.stats.stage_seconds[UC_ST_SETCOVER] += tc.seconds();
-            logf(3, "unicore-cluster: step %d: %llu accepted pairs, %zu representatives\n", r + 1, (unsigned long long)(E.edges.size() / 2), next.size());
-            cur.swap(next);
+        HostDb round_db;                       // sub-database of the round (rounds > 0)
+        std::vector<uint32_t> pre_pairs;       // candidate pairs of the pre-step
+        int round_kmer_thr = p.kmer_thr;
+        LocalGroup grp(W);
+        std::vector<std::unique_ptr<Comm>> comms;
+        for (int r = 0; r < W; r++) {
+            comms.emplace_back(new Comm);
+            comms.back()->rank = r; comms.back()->world = W; comms.back()->grp = W > 1 ? &grp : nullptr;
         }
-        E.stats.n_clusters = cur.size();
-        E.stats.n_seqs = n;
-        E.stats.n_residues = full.residues();
-        const uint64_t ncl = cur.size();
+        uint8_t nccl_id[UC_COMM_ID_BYTES] = {0};
+        if (W > 1 && !virtual_gpus) comm_unique_id(nccl_id);
+        std::vector<uc_stats> rank_stats((size_t)W);
+        uint64_t n_clusters = 0;
+
+        auto rank_main = [&](int r) {
+            Engine E(p, devices[(size_t)r]);
+            Comm &C = *comms[(size_t)r];
+            if (W > 1 && !virtual_gpus) comm_init_rank(C, nccl_id, r, W, devices[(size_t)r]);
+            for (int rr = 0; rr < p.cluster_steps + pre; rr++) {
+                const int rd = rr - pre;             // cascade round index (-1 = the pre-step)
+                if (r == 0) {
+                    if (rr > 0) round_db = sub_db(full, cur);
+                    round_kmer_thr = p.kmer_thr;
+                    if (rd >= 0 && p.cluster_steps > 1 && !p.kmer_thr_explicit)   // sensitivity rises linearly from 1 to the target (spec UC-1 E8)
+                        round_kmer_thr = kmer_thr_for(p, 1.0 + (p.sensitivity - 1.0) * rd / (p.cluster_steps - 1));
+                }
+                C.barrier(E);
+                E.hdb = rr == 0 ? full : round_db;
+                E.p.kmer_thr = round_kmer_thr;
+                E.upload_db();
+                const uint32_t m = E.hdb.n;
+                if (rd < 0) {   // E8a: candidate pairs (centre, member) from shared minimum-hash k-mers, the centre is the query
+                    if (r == 0) pre_pairs = linclust_pairs(E.hdb, p, p.threads);
+                    C.barrier(E);
+                    // a rank aligns the pairs of the centres it owns (centre mod world): whole queries stay together
+                    std::vector<uint32_t> cnt(m, 0);
+                    std::vector<uc_hit> hl;
+                    hl.reserve(pre_pairs.size() / 2 / (size_t)W + 16);
+                    for (size_t k = 0; k < pre_pairs.size() / 2; k++) {
+                        const uint32_t c = pre_pairs[2 * k];
+                        if ((int)(c % (uint32_t)W) != r) continue;
+                        cnt[c]++;
+                        uc_hit h; h.target = pre_pairs[2 * k + 1]; h.score = 0; h.diag = 0;
+                        hl.push_back(h);
+                    }
+                    E.set_hits(cnt.data(), hl.data(), /*check_max_seqs=*/false);
+                    E.stats.n_prefilter_hits += hl.size();
+                    if (r == 0)
+                        logf(3, "unicore-cluster: pre-step: %u sequences, %zu candidate pairs (%d k-mers per sequence)\n", m, pre_pairs.size() / 2, p.kmer_per_seq);
+                } else {
+                    const GridCell g = grid_cell(E.h_len, W, p.target_shards, r);
+                    E.prefilter(g.tb, g.te, g.qb, g.qe);
+                    if (W > 1) exchange_hits(E, C);
+                    if (r == 0)
+                        logf(3, "unicore-cluster: step %d: %u sequences, prefilter kept %llu pairs%s (k-score %d, max-seqs %d)\n", rd + 1, m,
+                             (unsigned long long)E.n_hits, W > 1 ? " on rank 0" : "", E.p.kmer_thr, p.max_seqs);
+                }
+                E.align(0, m);
+                std::vector<uint32_t> all;
+                Timer te;
+                C.gather_edges(E, all);
+                if (W > 1) E.stats.exchange_seconds += te.seconds();
+                if (r == 0) {
+                    Timer tc;
+                    std::vector<uint32_t> sa(m);
+                    E.set_cover_device(m, all.data(), all.size() / 2, sa.data());
+                    // mergeclusters: the representative of a sequence is the representative of its representative
+                    for (uint32_t i = 0; i < cur.size(); i++) posmap[cur[i]] = i;
+                    for (uint32_t x = 0; x < n; x++) assign[x] = cur[sa[posmap[assign[x]]]];
+                    std::vector<uint32_t> next;
+                    for (uint32_t i = 0; i < cur.size(); i++) if (sa[i] == i) next.push_back(cur[i]);
+                    E.stats.algorithmic_bytes[UC_ST_SETCOVER] += 8ull * (all.size() / 2) + 4ull * m;
+                    E.stats.stage_seconds[UC_ST_SETCOVER] += tc.seconds();
+                    logf(3, "unicore-cluster: step %d: %llu accepted pairs, %zu representatives\n", rd + 1, (unsigned long long)(all.size() / 2), next.size());
+                    cur.swap(next);
+                    E.stats.n_edges = all.size() / 2;
+                }
+            }
+            C.barrier(E);
+            if (r == 0) n_clusters = cur.size();
+            rank_stats[(size_t)r] = E.stats;
+        };
+
+        if (W == 1) rank_main(0);
+        else {
+            std::vector<std::string> err((size_t)W);
+            std::vector<int> code((size_t)W, 0);
+            std::vector<std::thread> th;
+            for (int r = 0; r < W; r++)
+                th.emplace_back([&, r] {
+                    try { rank_main(r); }
+                    catch (const Error &e) { code[(size_t)r] = e.code; err[(size_t)r] = e.what(); grp.fail_all(); }
+                    catch (const std::exception &e) { code[(size_t)r] = UC_ERR_GENERIC; err[(size_t)r] = e.what(); grp.fail_all(); }
+                });
+            for (auto &t : th) t.join();
+            // report the rank that failed first-hand, not the ones that were released from a barrier because of it
+            int bad = -1;
+            for (int r = 0; r < W; r++)
+                if (code[(size_t)r] && (bad < 0 || err[(size_t)bad].find("another GPU rank") != std::string::npos)) bad = r;
+            if (bad >= 0) fail(code[(size_t)bad], "GPU rank %d: %s", bad, err[(size_t)bad].c_str());
+        }
+
+        uc_stats st = rank_stats[0];
+        for (int r = 1; r < W; r++) merge_stats(st, rank_stats[(size_t)r]);
+        st.stage_seconds[UC_ST_LOAD] += t_load;
+        st.n_clusters = n_clusters;
+        st.n_seqs = n;
+        st.n_residues = full.residues();
+        st.n_gpus = (uint32_t)W;
+        st.target_shards = (uint32_t)gT;
         Timer to;
         write_cluster_db(out_cluster_db, full.keys, assign.data(), n);
-        E.stats.stage_seconds[UC_ST_OUTPUT] += to.seconds();
-        logf(3, "unicore-cluster: %llu clusters -> %s\n", (unsigned long long)ncl, out_cluster_db);
-        if (stats_out) *stats_out = E.stats;
+        st.stage_seconds[UC_ST_OUTPUT] += to.seconds();
+        logf(3, "unicore-cluster: %llu clusters -> %s\n", (unsigned long long)n_clusters, out_cluster_db);
+        if (stats_out) *stats_out = st;
+    });
+}
+
+int uc_comm_unique_id(uint8_t id[UC_COMM_ID_BYTES]) {
+    return guard([&] { require(id, "id"); comm_unique_id(id); });
+}
+
+int uc_comm_create(const uint8_t id[UC_COMM_ID_BYTES], int32_t rank, int32_t world, int32_t device, uc_comm **out) {
+    return guard([&] {
+        require(id, "id"); require(out, "out");
+        *out = nullptr;
+        if (world < 1 || rank < 0 || rank >= world) fail(UC_ERR_ARGS, "uc_comm_create: rank %d outside world %d", rank, world);
+        auto h = std::make_unique<uc_comm>();
+        if (device < 0) UC_HIP(hipGetDevice(&device));
+        comm_init_rank(h->c, id, rank, world, device);
+        *out = h.release();
+    });
+}
+
+void uc_comm_destroy(uc_comm *c) { delete c; }
+
+int uc_engine_cluster_step(uc_engine *e, uc_comm *comm, int32_t target_shards, uint32_t *assign, uint64_t *n_alignments) {
+    return guard([&] {
+        require(e, "engine");
+        Comm solo;
+        Comm &C = comm ? comm->c : solo;
+        const uint64_t k = cluster_step(*e->e, C, target_shards, assign);
+        if (n_alignments) *n_alignments = k;
     });
 }
 

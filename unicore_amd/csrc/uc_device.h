@@ -7,9 +7,23 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 
 namespace uc {
+
+// Function attributes (dynamic LDS beyond 64 KB) live per DEVICE: a launcher keeps one bit per device ordinal and sets
+// the attribute the first time it launches on that device (two threads racing on one device both set it: harmless).
+struct PerDeviceOnce {
+    std::atomic<uint64_t> mask{0};
+    template <typename F>
+    void operator()(F &&f) {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        const uint64_t bit = 1ull << (d & 63);
+        if (!(mask.load(std::memory_order_acquire) & bit)) { f(); mask.fetch_or(bit, std::memory_order_release); }
+    }
+};
 
 struct DeviceDb {
     uint32_t n = 0;

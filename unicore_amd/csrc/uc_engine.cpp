@@ -39,6 +39,7 @@ Engine::Engine(const Params &pp, int dev) : p(pp) {
         UC_HIP(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
         UC_HIP(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
     }
+    if (const char *ns = getenv("UC_STREAMS")) n_streams = std::max(1, std::min(N_AUX + 1, atoi(ns)));
     d_S3.reserve(A * A);
     d_SA.reserve(A * A);
     UC_HIP(hipMemcpy(d_S3.p, p.S3, A * A, hipMemcpyHostToDevice));

@@ -68,10 +68,12 @@ struct PrefilterScratch;                                  // uc_prefilter.hip
 void free_prefilter_scratch(PrefilterScratch *p);
 void park_prefilter_scratch(PrefilterScratch *p, int device);   // keeps one set per device for the next engine of the process
 PrefilterScratch *take_prefilter_scratch(int device);
+PrefilterScratch *take_parked_prefilter_scratch(int device);
 struct AlignScratch;                                      // uc_align.hip
 void free_align_scratch(AlignScratch *p);
 void park_align_scratch(AlignScratch *p, int device);
 AlignScratch *take_align_scratch(int device);
+AlignScratch *take_parked_align_scratch(int device);
 
 struct Engine {
     Params p;
@@ -83,6 +85,7 @@ struct Engine {
     static constexpr int N_AUX = 7;
     hipStream_t aux[N_AUX] = {};
     hipEvent_t ev_fork = nullptr, ev_join[N_AUX] = {};
+    int n_streams = N_AUX + 1;   // UC_STREAMS=1 serializes the class kernels on the engine stream (profiling: per-kernel durations then add up to the event time)
 
     // host view of the DB
     HostDb hdb;

@@ -77,6 +77,20 @@ static int to_int(const std::string &flag, const std::string &v) {
     return (int)d;
 }
 
+// 1 = takes a value, 2 = MMseqs-style switch with an optional 0/1, -1 = not a flag of this engine.
+// The shim uses the same table to split Foldseek's argv into positionals and options (flags may come anywhere).
+int option_arity(const std::string &f) {
+    static const char *const valued[] = {
+        "-c", "--cov-mode", "--min-seq-id", "-e", "-s", "--max-seqs", "--k-score", "--min-ungapped-score", "--min-diag-hits",
+        "--gap-open", "--gap-extend", "--spaced-kmer-pattern", "--rev-correction", "--linclust", "--kmer-per-seq", "--sym-dedup",
+        "--sw-kernel", "--evalue-lambda", "--evalue-k", "--mat3di", "--mat-aa", "--cluster-mode", "--cluster-steps",
+        "--alignment-type", "--alignment-mode", "--threads", "-v", "--remove-tmp-files", "--db-load-mode", "--compressed",
+        "--gpus", "--target-shards"};
+    for (const char *v : valued) if (f == v) return 1;
+    if (f == "--single-step-clustering") return 2;
+    return -1;
+}
+
 void parse_cluster_options(const std::string &opts, Params &p) {
     std::istringstream ss(opts);
     std::vector<std::string> tok;
@@ -104,7 +118,7 @@ void parse_cluster_options(const std::string &opts, Params &p) {
         else if (f == "--gap-extend") { p.gap_ext = to_int(f, value()); if (p.gap_ext < 0 || p.gap_ext > 31) fail(UC_ERR_ARGS, "--gap-extend must be in [0,31]"); }
         else if (f == "--spaced-kmer-pattern") { p.pattern = value(); }
         else if (f == "--rev-correction") { p.rev_correction = to_int(f, value()) != 0; }
-        else if (f == "--linclust") { p.linclust = to_int(f, value()) != 0; }
+        else if (f == "--linclust") { p.linclust = to_int(f, value()) != 0; p.linclust_given = true; }
         else if (f == "--kmer-per-seq") { p.kmer_per_seq = to_int(f, value()); if (p.kmer_per_seq < 1 || p.kmer_per_seq > 1000) fail(UC_ERR_ARGS, "--kmer-per-seq must be in [1,1000]"); }
         else if (f == "--sym-dedup") { p.sym_dedup = to_int(f, value()) != 0; }
         else if (f == "--sw-kernel") { const std::string &v = value(); if (v == "pk16") p.sw_pk = 1; else if (v == "i32") p.sw_pk = 0; else fail(UC_ERR_ARGS, "--sw-kernel must be pk16 or i32"); }
@@ -114,7 +128,9 @@ void parse_cluster_options(const std::string &opts, Params &p) {
         else if (f == "--mat-aa") { p.mataa_path = value(); }
         else if (f == "--cluster-mode") { p.cluster_mode = to_int(f, value()); if (p.cluster_mode != 0) fail(UC_ERR_ARGS, "--cluster-mode %d unsupported (only 0 = greedy set cover)", p.cluster_mode); }
         else if (f == "--single-step-clustering") { p.single_step = opt_bool(); p.single_step_given = true; }
-        else if (f == "--cluster-steps") { p.cluster_steps = to_int(f, value()); }
+        else if (f == "--cluster-steps") { p.cluster_steps = to_int(f, value()); p.cluster_steps_given = true; }
+        else if (f == "--gpus") { p.num_gpus = to_int(f, value()); if (p.num_gpus < 0 || p.num_gpus > 64) fail(UC_ERR_ARGS, "--gpus must be in [0,64] (0 = all visible)"); }
+        else if (f == "--target-shards") { p.target_shards = to_int(f, value()); if (p.target_shards < 0 || p.target_shards > 64) fail(UC_ERR_ARGS, "--target-shards must be in [0,64] (0 = one shard per GPU)"); }
         else if (f == "--alignment-type") { int v = to_int(f, value()); if (v != 2) fail(UC_ERR_ARGS, "--alignment-type %d unsupported (only 2 = 3Di+AA)", v); }
         else if (f == "--alignment-mode") { int v = to_int(f, value()); if (v < 0 || v > 3) fail(UC_ERR_ARGS, "--alignment-mode %d unsupported", v); }
         else if (f == "--threads") { p.threads = to_int(f, value()); }
@@ -138,7 +154,20 @@ static bool exists(const std::string &p) { struct stat st; return stat(p.c_str()
 
 void finalize_params(Params &p, const std::string &data_dir_in) {
     std::string dd = data_dir_in.empty() ? default_data_dir() : data_dir_in;
-    if (p.mat3di_path.empty()) p.mat3di_path = exists(dd + "/mat3di.out") ? dd + "/mat3di.out" : dd + "/mat3di_synthetic.out";
+    if (p.mat3di_path.empty()) {
+        if (exists(dd + "/mat3di.out")) p.mat3di_path = dd + "/mat3di.out";
+        else {
+            // Foldseek's mat3di.out cannot be authored here; the shipped stand-in is a seeded random matrix.
+            // Clustering real proteomes with it would look valid and mean nothing, so it needs an explicit opt-in.
+            const char *allow = getenv("UC_ALLOW_SYNTHETIC");
+            if (!allow || strcmp(allow, "1") != 0)
+                fail(UC_ERR_ARGS, "no mat3di.out in %s: copy Foldseek's data/mat3di.out there (or pass --mat3di <path>). The shipped "
+                                  "mat3di_synthetic.out is a seeded STAND-IN for tests and benchmarks; set UC_ALLOW_SYNTHETIC=1 to use it",
+                     dd.c_str());
+            p.mat3di_path = dd + "/mat3di_synthetic.out";
+            p.mat3di_synthetic = true;
+        }
+    }
     if (p.mataa_path.empty()) p.mataa_path = dd + "/blosum62.out";
     load_matrix(p.mat3di_path, p.S3);
     load_matrix(p.mataa_path, p.SA);
@@ -157,12 +186,18 @@ void finalize_params(Params &p, const std::string &data_dir_in) {
     if (n != K || p.pattern.front() != '1' || p.pattern.back() != '1') fail(UC_ERR_ARGS, "--spaced-kmer-pattern needs exactly 6 ones and 1 at both ends");
     p.kmer_thr_explicit = p.kmer_thr >= 0;
     if (p.kmer_thr < 0) p.kmer_thr = kmer_thr_for(p, p.sensitivity);
+    // Workflow (E8).  Unicore forwards only "-c 0.8" (arg_parser.rs:238-239), so what runs is Foldseek's DEFAULT `cluster`
+    // workflow: a linear-time pre-step + a 3-step cascade.  --single-step-clustering selects the plain
+    // all-vs-all step; --cluster-steps / --linclust override the two halves individually.
+    if (p.single_step_given && p.single_step) {
+        p.cluster_steps = 1;
+        if (!p.linclust_given) p.linclust = 0;
+    } else {
+        if (!p.cluster_steps_given) p.cluster_steps = 3;
+        if (!p.linclust_given) p.linclust = 1;
+    }
     if (p.cluster_steps < 1 || p.cluster_steps > 16) fail(UC_ERR_ARGS, "--cluster-steps must be in [1,16]");
-    // rounds of the clustering workflow: Foldseek cascades by default (3 steps); THIS build runs a single step unless
-    // asked (--cluster-steps N > 1, or --single-step-clustering 0 => 3 steps) — DESIGN.md 2, deviation kept on purpose
-    if (p.single_step_given && p.single_step) p.cluster_steps = 1;
-    else if (p.single_step_given && !p.single_step && p.cluster_steps == 1) p.cluster_steps = 3;
-    p.single_step = p.cluster_steps == 1;
+    p.single_step = p.cluster_steps == 1 && !p.linclust;
     if (p.threads < 1) p.threads = 1;
 }
 

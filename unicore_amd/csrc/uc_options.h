@@ -46,7 +46,12 @@ struct Params {
     int kmer_per_seq = 20;      // k-mers every sequence keeps in the pre-step
     bool kmer_thr_explicit = false;   // --k-score given: every cascade round uses it
     bool single_step = true;
-    bool single_step_given = false;
+    bool single_step_given = false, cluster_steps_given = false, linclust_given = false;
+    bool mat3di_synthetic = false;    // the stand-in matrix is in use (UC_ALLOW_SYNTHETIC=1)
+    // multi-GPU: devices uc_cluster spreads over (0 = all visible) and the target-shard count of the
+    // Q x T grid (0 = one target shard per GPU, the north-star layout)
+    int num_gpus = 1;
+    int target_shards = 0;
     // runtime
     int threads = 1;
     int verbosity = 3;
@@ -57,6 +62,8 @@ int letter_code(char c);
 void load_matrix(const std::string &path, int8_t out[A * A]);
 // parse `opts` (Foldseek flag names) into p; throws Error(UC_ERR_ARGS) on unknown flags / bad values
 void parse_cluster_options(const std::string &opts, Params &p);
+// 1 = flag with a value, 2 = switch with an optional 0/1, -1 = unknown
+int option_arity(const std::string &flag);
 // resolve data files + derived values (pattern offsets, kmer_thr from sensitivity); loads matrices
 void finalize_params(Params &p, const std::string &data_dir);
 std::string default_data_dir();

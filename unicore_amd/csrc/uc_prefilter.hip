@@ -790,6 +790,13 @@ void park_prefilter_scratch(PrefilterScratch *p, int device) {
     }
     delete p;
 }
+PrefilterScratch *take_parked_prefilter_scratch(int device) {   // nullptr if nothing is parked (uc_release_scratch)
+    if (device < 0 || device >= 16) return nullptr;
+    std::lock_guard<std::mutex> g(g_park_mutex);
+    PrefilterScratch *p = g_parked_pre[device];
+    g_parked_pre[device] = nullptr;
+    return p;
+}
 PrefilterScratch *take_prefilter_scratch(int device) {
     if (device >= 0 && device < 16) {
         std::lock_guard<std::mutex> g(g_park_mutex);
@@ -996,11 +1003,8 @@ void Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
                 temp_reserve(tb);
                 UC_HIP(rocprim::radix_sort_pairs(d_temp.p, tb, d_rpidx.p, d_rpidx2.p, d_rval.p, d_rval2.p, (size_t)n_runs, 0u, pbits, stream));
                 d_qbase.reserve(nq); d_qsurv.reserve(nq); d_soff.reserve((size_t)nq + 1);
-                static bool attr_set = false;
-                if (!attr_set) {
-                    UC_HIP(hipFuncSetAttribute((const void *)filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FILTER_LDS));
-                    attr_set = true;
-                }
+                static PerDeviceOnce once;
+                once([&] { UC_HIP(hipFuncSetAttribute((const void *)filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FILTER_LDS)); });
                 hipLaunchKernelGGL(filter_kernel, dim3(nq), dim3(FT), FILTER_LDS, stream, ddb, qa, qp0, d_rpidx2.p, d_rval2.p, n_runs, d_ent.p, fmt,
                                    d_counters.p + 5, d_keys.p, total_hits, d_qbase.p, d_qsurv.p);
                 auto sin = rocprim::make_transform_iterator(d_qsurv.p, WidenU32());

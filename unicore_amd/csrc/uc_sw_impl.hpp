@@ -282,12 +282,10 @@ void launch_sw_class_mode(int G, int R, const SwArgs &a, uint32_t n_tasks, hipSt
         constexpr int BW = ((RR / 4) | 1);                                                              \
         constexpr int NW = MODE == 3 ? (GG == 64 ? 8 : 4) : sw_waves_per_group(GG, RR);               \
         const size_t lds = (size_t)2 * SW_NLET * GG * BW * 4;                                           \
-        static bool attr_set = false;                                                                   \
-        if (!attr_set && lds > 64 * 1024) {                                                             \
-            (void)hipFuncSetAttribute((const void *)sw_group_kernel<GG, RR, MODE, NW>,                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
-            attr_set = true;                                                                            \
-        }                                                                                               \
+        static PerDeviceOnce once;                                                                      \
+        if (lds > 64 * 1024)                                                                            \
+            once([&] { (void)hipFuncSetAttribute((const void *)sw_group_kernel<GG, RR, MODE, NW>,           \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
         hipLaunchKernelGGL((sw_group_kernel<GG, RR, MODE, NW>), dim3(n_tasks), dim3(NW * 64), lds, s, a); \
         return;                                                                                         \
     }

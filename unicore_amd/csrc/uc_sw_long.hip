@@ -294,11 +294,9 @@ template <int MODE>
 static void launch_long_mode(const SwArgs &a, uint32_t n_tasks, uint32_t pair_base, int32_t *work, uint32_t stride, hipStream_t s) {
     constexpr int BW = ((long_rows_per_lane(MODE) / 4) | 1);
     const size_t lds = (size_t)2 * SW_NLET * LONG_G * BW * 4;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)sw_long_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    if (lds > 64 * 1024)
+        once([&] { (void)hipFuncSetAttribute((const void *)sw_long_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     hipLaunchKernelGGL(sw_long_kernel<MODE>, dim3(n_tasks), dim3(LONG_NW * 64), lds, s, a, pair_base, work, stride);
 }
 

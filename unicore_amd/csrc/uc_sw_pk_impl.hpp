@@ -430,12 +430,10 @@ void launch_sw_pk_class_mode(int G, int R, const SwArgs &a, uint32_t n_tasks, hi
         constexpr int BW = (((RR + 3) / 4) | 1);                                                        \
         constexpr int NW = GG == 16 ? 2 : (GG == 32 ? 4 : 8);   /* small workgroups share one LDS profile */ \
         const size_t lds = (size_t)2 * SW_NLET * GG * BW * 4 + 16;                                      \
-        static bool attr_set = false;                                                                   \
-        if (!attr_set && lds > 64 * 1024) {                                                             \
-            (void)hipFuncSetAttribute((const void *)sw_pk_kernel<GG, RR, MODE, NW>,                     \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
-            attr_set = true;                                                                            \
-        }                                                                                               \
+        static PerDeviceOnce once;                                                                      \
+        if (lds > 64 * 1024)                                                                            \
+            once([&] { (void)hipFuncSetAttribute((const void *)sw_pk_kernel<GG, RR, MODE, NW>,           \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
         hipLaunchKernelGGL((sw_pk_kernel<GG, RR, MODE, NW>), dim3(n_tasks), dim3(NW * 64), lds, s, a);  \
         return;                                                                                         \
     }
