@@ -13,8 +13,9 @@ all: oracle tools product
 
 # ---------------------------------------------------------------- oracle (plain C, OpenMP)
 oracle: oracle/liboracle.so
-oracle/liboracle.so: oracle/uc_oracle.c oracle/uc_oracle.h
-	$(CC) -std=c11 $(OPT) -fopenmp -fPIC -shared -Wall -Wextra -o $@ oracle/uc_oracle.c -lm
+# -march=x86-64-v3 (AVX2), not -march=native: the .so is built in the dev container and runs on the GPU box's host CPU
+oracle/liboracle.so: oracle/uc_oracle.c oracle/uc_simd.c oracle/uc_oracle.h
+	$(CC) -std=c11 $(OPT) -march=x86-64-v3 -fopenmp -fPIC -shared -Wall -Wextra -D_POSIX_C_SOURCE=200809L -o $@ oracle/uc_oracle.c oracle/uc_simd.c -lm
 
 # ---------------------------------------------------------------- tools
 tools: bin/gen_synth

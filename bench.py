@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the `unicore cluster` hot path on MI355X.
 
-metric  : 3Di alignments/sec on the cluster path (BASELINE.json) = gapped 3Di+AA alignments handed to stage
-          E5 divided by the wall time of one full pass (k-mer index -> similar-k-mer match -> ungapped ->
-          top-M -> 3-pass gapped SW -> coverage/E-value gate -> host set cover), sequence DB already
-          resident in HBM when the timed region starts.
-workload: BASELINE.json configs[1] — 50 synthetic proteomes (~150k sequences, mean length ~300), seeded
-          generator tools/gen_synth.c (seed 0x5EED0002), options "-c 0.8".
-N > 1   : one process per GPU (torchrun); target DB range-partitioned, per-shard hit lists all-gathered with
-          torch.distributed "nccl" (= RCCL over xGMI), queries re-partitioned for the gapped stage, edges
-          gathered to rank 0 for the host set cover (unicore_amd/dist.py).  Total work is fixed -> "strong".
+metric  : 3Di alignments/sec on the cluster path (BASELINE.json) = gapped 3Di+AA alignments handed to stage E5 divided
+          by wall time.
+step    : one full pass of the all-vs-all path (k-mer index -> similar-k-mer match -> ungapped -> top-M -> 3-pass gapped
+          SW -> coverage/E-value gate -> set cover) through ONE C entry point, uc_engine_cluster_step, with the sequence
+          DB already resident in HBM when the timed region starts.  `value` is that rate.
+also    : `value_disk_to_tsv` — SURVEY.md 8(d)'s definition: wall of uc_cluster + uc_createtsv, DB on disk (page cache
+          warm) -> clust.tsv written, same workload, measured after the timed region (best and mean of 3);
+          `workflow_default` — what a bare "-c 0.8" runs (Foldseek's default: linear-time pre-step + 3-step cascade).
+workload: --config c2 (default) = BASELINE.json configs[1]: 50 synthetic proteomes (~150 k sequences), tools/gen_synth.c
+          seed 0x5EED0002, "-c 0.8", the plain all-vs-all step (`--single-step-clustering` semantics);
+          --config c3 = configs[2] (500 proteomes, seed 0x5EED0003); --config c4-lite = configs[3]'s options
+          ("-c 0.8 --min-seq-id 0.3 -s 7.5") on 500 proteomes (seed 0x5EED0004).
+N > 1   : one process per GPU (torch.distributed.run).  The data path is inside the library: the target DB is range-
+          partitioned across the ranks (Q x T grid, T = N by default = the north-star layout), the per-shard hit lists are
+          all-gathered with RCCL over xGMI from C (uc_comm_*), merged on the device, every rank aligns the pairs it owns,
+          edges go to rank 0 for the host set cover.  torch.distributed (gloo) only carries the 128-byte RCCL id, the
+          barriers and the max-over-ranks of the timing.  Total work is fixed -> "strong".
 
-A "step" = one such pass.  Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import shutil
 import subprocess
 import sys
 import time
@@ -28,21 +37,22 @@ os.environ.setdefault("UC_ALLOW_SYNTHETIC", "1")    # the benchmark runs on the 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # the engine's 8 streams need 8 hardware queues; read when HIP initialises
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_LANE_OPS = 39.3e12     # int32 VALU: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz — measured: every int32 VALU
-                                 # instruction of the SW kernel occupies its SIMD for 4 cycles (profiles/r1b_pmc_sw.txt)
-VALU_OPS_PER_CELL = {"fwd": 5.9, "rev": 5.5, "start": 6.2, "mean": 5.9}    # static ISA counts of the packed kernel's step loop at r1v (two cells per
-                                 # lane-op; the int32 classes need 9.7/8.7/9.95).  valu_frac = USEFUL cell updates x ops / peak: it
-                                 # excludes row padding, pipeline fill/drain and A/B length mismatch (issue utilisation is ~0.94,
-                                 # profiles/r1f_pmc_sw.txt)
+HBM_COPY_GBS = 6290.0            # ... and the measured copy bandwidth of the same guide
+VALU_PEAK_LANE_OPS = 39.3e12     # int32/packed VALU: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz — measured: every VALU instruction of the
+                                 # SW kernel occupies its SIMD for 4 cycles (profiles/r1b_pmc_sw.txt, tools/ubench/valu_rate.hip)
+VALU_OPS_PER_CELL = 5.9          # static ISA count of the packed kernel's step loop at C2's class mix
+
+CONFIGS = {
+    # name: (proteomes, families, len_scale, seed, options, label)
+    "c2": (50, 6000, 1.0, 0x5EED0002, "-c 0.8", "BASELINE configs[1]"),
+    "c3": (500, 6000, 1.0, 0x5EED0003, "-c 0.8", "BASELINE configs[2] on the GPUs given"),
+    "c4-lite": (500, 6000, 1.0, 0x5EED0004, "-c 0.8 --min-seq-id 0.3 -s 7.5", "BASELINE configs[3] options on 500 proteomes"),
+}
 
 
-def pmc_traffic_per_launch():
-    """HBM bytes per SW launch from the committed rocprofv3 PMC passes (bench.py cannot read PMCs itself)."""
-    f = os.path.join(ROOT, "profiles", "sw_traffic.json")
-    if not os.path.exists(f):
-        return None
-    d = json.load(open(f))
-    return (d["fetch_size_kib"] + d["write_size_kib"]) * 1024.0 / d["sw_launches"]
+def pmc_json(name):
+    f = os.path.join(ROOT, "profiles", name)
+    return json.load(open(f)) if os.path.exists(f) else None
 
 
 def gen_db(workdir, proteomes, families, scale, seed):
@@ -65,9 +75,28 @@ def read_lens(prefix):
     return (idx[:, 2] - 2).astype(np.int64)
 
 
-def cpu_baseline(prefix, opts, n_seqs, target_seconds=15.0):
-    """Oracle (plain-C restatement, OpenMP over queries) on a bounded sample of the same workload:
-    E2-E6 for evenly spaced queries against the full k-mer index, index build charged pro rata."""
+def real_foldseek():
+    """a real Foldseek on PATH (never this repo's shim) — SURVEY.md 8(d) asks for it to be timed if present"""
+    for d in os.environ.get("PATH", "").split(os.pathsep):
+        f = os.path.join(d, "foldseek")
+        if os.path.isfile(f) and os.access(f, os.X_OK) and os.path.realpath(f) != os.path.realpath(os.path.join(ROOT, "bin", "foldseek")):
+            try:
+                v = subprocess.run([f, "version"], capture_output=True, text=True, timeout=20).stdout.strip()
+            except Exception:
+                continue
+            if "unicore-cluster" not in v:
+                return f, v
+    return None, None
+
+
+def cpu_baseline(prefix, opts, n_seqs, target_seconds=20.0):
+    """CPU legs timed on this host's cores, on a bounded random query sample of the same workload (E2-E6 of the sampled
+    queries against the FULL k-mer index; index build charged pro rata):
+      kind "port": the oracle — the plain-C restatement of the spec (scalar DP), OpenMP, dynamic schedule over (query,
+                   target) pairs;
+      kind "simd": the same pipeline with the gapped stage as inter-sequence SIMD (16 targets of one query per AVX2
+                   register, int16, query profile) — what a competent CPU implementation does (oracle/uc_simd.c).
+    Both process the identical pair list, so alignments/s compare one to one with the GPU figure."""
     from oracle import oracle_py as O
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import util
@@ -77,21 +106,34 @@ def cpu_baseline(prefix, opts, n_seqs, target_seconds=15.0):
     t0 = time.time()
     ix = O.build_index(odb, p)
     t_index = time.time() - t0
-    rng = np.random.default_rng(12345)
-    order = rng.permutation(n_seqs).astype(np.uint32)
-    n1 = min(n_seqs, max(64, 4 * cores))
-    a1, tp1, ta1 = O.sample_run(odb, ix, p, order[:n1], threads=cores)
-    rate = (tp1 + ta1) / max(n1, 1)
-    n2 = int(min(n_seqs - n1, max(0, (target_seconds - (tp1 + ta1)) / max(rate, 1e-9))))
-    a2, tp2, ta2 = (0, 0.0, 0.0)
-    if n2 > 0:
-        a2, tp2, ta2 = O.sample_run(odb, ix, p, order[n1:n1 + n2], threads=cores)
+    order = np.random.default_rng(12345).permutation(n_seqs).astype(np.uint32)
+    fs_path, fs_version = real_foldseek()
+    out = []
+    for kind in ("port", "simd"):
+        if kind == "simd" and not hasattr(O, "simd_sample_run"):
+            continue
+        run = O.sample_run if kind == "port" else O.simd_sample_run
+        n1 = min(n_seqs, max(64, 2 * cores))                               # calibration sample
+        a1, tp1, ta1 = run(odb, ix, p, order[:n1], threads=cores)
+        rate = (tp1 + ta1) / max(n1, 1)
+        # fill the time budget, but never fewer than 20 queries per thread (a smaller sample is tail-dominated)
+        n2 = int(max(0, (target_seconds - (tp1 + ta1)) / max(rate, 1e-9)))
+        n2 = max(n2, 20 * cores - n1)
+        n2 = max(0, min(n2, n_seqs - n1))
+        a2, tp2, ta2 = (0, 0.0, 0.0)
+        if n2 > 0:
+            a2, tp2, ta2 = run(odb, ix, p, order[n1:n1 + n2], threads=cores)
+        # rate from the large sample alone (the calibration run also pays thread start-up and cold caches)
+        nq, aln, tp, ta = (n2, a2, tp2, ta2) if n2 > 0 else (n1, a1, tp1, ta1)
+        t = tp + ta + t_index * nq / n_seqs
+        out.append({"value": aln / t if t > 0 else 0.0, "unit": "alignments/s", "cores": cores, "kind": kind,
+                    "implementation": ("oracle/uc_oracle.c (scalar C restatement of the spec, gcc -O3 -march=x86-64-v3, OpenMP dynamic)" if kind == "port" else
+                                       "oracle/uc_simd.c (AVX2 inter-sequence int16 Smith-Waterman, 16 targets per register, + the oracle's prefilter; OpenMP dynamic)"),
+                    "foldseek": ("%s (%s)" % (fs_path, fs_version)) if fs_path else "not available — the CPU baseline is this repository's own code, not Foldseek",
+                    "sample": "%d of %d queries (random, seed 12345, %.1f per thread): %d gapped alignments; prefilter %.2fs + gapped %.2fs "
+                              "+ pro-rata index build %.3fs of %.2fs" % (nq, n_seqs, nq / cores, aln, tp, ta, t_index * nq / n_seqs, t_index)})
     O.free_index(ix)
-    nq, aln = n1 + n2, a1 + a2
-    t = tp1 + ta1 + tp2 + ta2 + t_index * nq / n_seqs
-    return {"value": aln / t if t > 0 else 0.0, "unit": "alignments/s", "cores": cores, "kind": "port",
-            "sample": "%d of %d queries (random, seed 12345): %d gapped alignments; prefilter %.2fs + gapped %.2fs "
-                      "+ pro-rata index build %.2fs of %.2fs" % (nq, n_seqs, aln, tp1 + tp2, ta1 + ta2, t_index * nq / n_seqs, t_index)}
+    return out
 
 
 def main():
@@ -99,18 +141,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--proteomes", type=int, default=50)
-    ap.add_argument("--families", type=int, default=6000)
-    ap.add_argument("--len-scale", type=float, default=1.0)
-    ap.add_argument("--options", default="-c 0.8")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--proteomes", type=int)
+    ap.add_argument("--families", type=int)
+    ap.add_argument("--len-scale", type=float)
+    ap.add_argument("--options")
+    ap.add_argument("--target-shards", type=int, default=int(os.environ.get("UC_TARGET_SHARDS", "0")),
+                    help="T of the Q x T grid for N > 1 (0 = one target shard per GPU, the north-star layout)")
     ap.add_argument("--workdir", default=os.environ.get("UC_BENCH_DIR", "/tmp/uc_bench"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the disk-to-TSV and default-workflow legs")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
+    proteomes, families, len_scale, seed, options, label = CONFIGS[args.config]
+    custom = any(v is not None for v in (args.proteomes, args.families, args.len_scale, args.options))
+    proteomes = args.proteomes if args.proteomes is not None else proteomes
+    families = args.families if args.families is not None else families
+    len_scale = args.len_scale if args.len_scale is not None else len_scale
+    options = args.options if args.options is not None else options
 
     import torch
     import unicore_amd as U
-    from unicore_amd import dist as ucdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -119,53 +170,39 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    # UC_DIST_BACKEND=gloo + UC_SHARE_GPU=1: debugging aid to exercise the N>1 code path on a single-GPU box
-    # (all ranks on cuda:0, exchange through gloo); the real multi-GPU run uses one GPU per rank and RCCL.
-    backend = os.environ.get("UC_DIST_BACKEND", "nccl")
-    if os.environ.get("UC_SHARE_GPU") == "1":
-        local_rank = 0
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    xdev = dev if backend == "nccl" else torch.device("cpu")      # where the exchanged buffers live
+    comm = None
     if world > 1:
         import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("gloo")                     # control plane only: RCCL id, barriers, max of the timing
+        uid = [U.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = U.Comm(uid[0], rank, world, device=local_rank)   # collective: ncclCommInitRank inside the library
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    seed = 0x5EED0000 + 2
-    workdir = os.path.join(args.workdir, "p%d_f%d_s%g_%x" % (args.proteomes, args.families, args.len_scale, seed))
+    workdir = os.path.join(args.workdir, "p%d_f%d_s%g_%x" % (proteomes, families, len_scale, seed))
     if rank == 0:
-        gen_db(workdir, args.proteomes, args.families, args.len_scale, seed)
+        gen_db(workdir, proteomes, families, len_scale, seed)
     barrier()
     prefix = os.path.join(workdir, "db")
     lens = read_lens(prefix)
     n = len(lens)
 
-    eng = U.Engine(args.options, threads=max(1, (os.cpu_count() or 1) // world), verbosity=1, device=local_rank)
+    threads = max(1, (os.cpu_count() or 1) // world)
+    eng = U.Engine(options, threads=threads, verbosity=1, device=local_rank)
     eng.load_db(prefix)                      # H2D upload: outside the timed region (inputs resident in HBM)
-    max_seqs = 300
-    tok = args.options.split()
-    if "--max-seqs" in tok:
-        max_seqs = int(tok[tok.index("--max-seqs") + 1])
-
-    phase = {}
 
     def step():
-        return ucdist.cluster_step(eng, lens, rank, world, max_seqs, device=xdev if world > 1 else "cpu",
-                                   gpu_device=dev if (world > 1 and not os.environ.get("UC_HOST_EXCHANGE")) else None, timing=phase)
+        return eng.cluster_step(comm, args.target_shards)
 
     assign = None
     for _ in range(args.warmup):
         assign, _ = step()
     eng.reset_stats()
-    phase.clear()
     barrier()
     t0 = time.perf_counter()
     n_aln = 0
@@ -176,58 +213,110 @@ def main():
     dt = time.perf_counter() - t0
     st = eng.stats()
     if world > 1:
-        v = torch.tensor([dt], dtype=torch.float64, device=xdev)
+        v = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(v, op=dist.ReduceOp.MAX)
         dt = float(v.item())
-        c = torch.tensor([n_aln], dtype=torch.int64, device=xdev)
+        c = torch.tensor([n_aln, st["exchange_bytes"]], dtype=torch.int64)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        n_aln = int(c.item())
+        n_aln, xbytes = int(c[0].item()), int(c[1].item())
+    else:
+        xbytes = 0
 
     if rank == 0:
         steps = max(args.steps, 1)
         sw_s = st["sw_kernel_ms"] / 1e3
+        pre_s = st["prefilter_kernel_ms"] / 1e3
         achieved = st["sw_algorithmic_bytes"] / sw_s / 1e9 if sw_s > 0 else 0.0
         cells_alg = st["cells_fwd"] + st["cells_rev"] + st["cells_start"]     # what the spec asks for (oracle counts)
-        cells_run = st["cells_run"]                                            # what the kernels executed (mutual hits
-                                                                               # share a DP, flagged pairs run twice)
+        cells_run = st["cells_run"]                                            # what the kernels executed (mutual hits share a DP, flagged pairs run twice)
+        ab = dict(zip(U.STAGES, st["algorithmic_bytes"]))
+        pre_bytes = ab["index"] + ab["kmer"] + ab["ungapped"] + ab["select"]
+        all_bytes = pre_bytes + ab["gapped"] + ab["setcover"]
+        swt, pft = pmc_json("sw_traffic.json"), pmc_json("prefilter_traffic.json")
+        n_streams = int(os.environ.get("UC_STREAMS", "8"))
+        Q, T = (world // (args.target_shards or world), args.target_shards or world) if world > 1 else (1, 1)
         out = {
             "metric": "3Di alignments/sec (cluster path)",
             "value": n_aln / dt, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
-            "config": {"workload": "%s: %d synthetic proteomes, %d seqs, %d residues, options '%s', gen_synth seed %#x"
-                                   % ("BASELINE configs[1]" if (args.proteomes, args.families, args.len_scale, args.options) == (50, 6000, 1.0, "-c 0.8") else "custom size",
-                                      args.proteomes, n, int(lens.sum()), args.options, seed),
+            "config": {"workload": "%s: %d synthetic proteomes, %d seqs, %d residues, options '%s', plain all-vs-all step (--single-step-clustering "
+                                   "semantics), gen_synth seed %#x, synthetic stand-in 3Di matrix" % (label if not custom else "custom size", proteomes, n, int(lens.sum()), options, seed),
                        "alignments_per_step": n_aln // steps, "clusters": int((assign == np.arange(n)).sum()) if assign is not None else None,
-                       "parallelism": ("%d query groups x %d target shards (unicore_amd.dist.grid_shape) + RCCL hit all-gather (device-resident), "
-                                       "pair-hash partition of the gapped stage" % ucdist.grid_shape(lens, world)) if world > 1 else "single GPU"},
+                       "parallelism": ("%d query groups x %d target shards, RCCL all-gather of the hit lists from the C library (uc_comm_*), device merge, "
+                                       "pair-ownership partition of the gapped stage, edges to rank 0" % (Q, T)) if world > 1 else "single GPU"},
+            "value_definition": "DB resident in HBM at the start of the timed region; see value_disk_to_tsv for SURVEY.md 8(d)'s disk -> clust.tsv wall",
+            # dominant kernel: the gapped SW (all classes and passes)
             "roofline": {"bound": "hbm", "kernel": "sw_pk_kernel + sw_group_kernel (gapped 3Di+AA SW, all classes and passes)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_per_launch(),
+                         "traffic": ((swt["fetch_size_kib"] + swt["write_size_kib"]) * 1024.0 / swt["sw_launches"]) if swt else None,
                          "algorithmic_bytes_per_launch": st["sw_algorithmic_bytes"] / max(st["sw_kernel_launches"], 1),
                          "avg_launch_ms": st["sw_kernel_ms"] / max(st["sw_kernel_launches"], 1),
-                         "launches": st["sw_kernel_launches"],
-                         "launch_overlap": "the length classes of a pass run concurrently on 8 HIP streams; avg_launch_ms = wall time of the "
-                                           "fork/join regions (HIP events on the engine stream) / launches, so the per-kernel durations "
-                                           "of a rocprofv3 trace sum to more than launches x avg_launch_ms",
-                         "note": "integer-VALU-bound by design (SURVEY.md 8d): see valu_*",
+                         "launches": st["sw_kernel_launches"], "streams": n_streams,
+                         "launch_overlap": ("the length classes of a pass run concurrently on %d HIP streams; avg_launch_ms = HIP-event time of the fork/join regions on the engine "
+                                            "stream / launches.  With UC_STREAMS=1 the launches are serialized and the per-kernel durations of a rocprofv3 trace add up to that event "
+                                            "time (profiles/r3*_serial_*)" % n_streams),
+                         "note": "integer-VALU-bound by design (SURVEY.md 8d): the meaningful fraction is valu_frac",
                          "valu_gcups": cells_run / sw_s / 1e9 if sw_s > 0 else 0.0,
                          "valu_gcups_algorithmic": cells_alg / sw_s / 1e9 if sw_s > 0 else 0.0,
-                         "valu_peak_lane_ops": VALU_PEAK_LANE_OPS,
-                         "valu_frac": (cells_run * VALU_OPS_PER_CELL["mean"] / sw_s / VALU_PEAK_LANE_OPS) if sw_s > 0 else 0.0},
+                         "valu_peak_lane_ops": VALU_PEAK_LANE_OPS, "valu_ops_per_cell": VALU_OPS_PER_CELL,
+                         "valu_frac": (cells_run * VALU_OPS_PER_CELL / sw_s / VALU_PEAK_LANE_OPS) if sw_s > 0 else 0.0},
+            # the HBM-bound stages E1-E4 (index, similar-k-mer match + double-hit filter, ungapped, top-M)
+            "roofline_prefilter": {"bound": "hbm", "kernels": "kmer_extract, sim_runs, filter, compact, diag_select, ungapped, select/rank/scatter + rocPRIM sorts",
+                                   "algorithmic_bytes_per_step": pre_bytes / steps, "kernel_ms_per_step": 1e3 * pre_s / steps,
+                                   "achieved": pre_bytes / pre_s / 1e9 if pre_s > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": (pre_bytes / pre_s / 1e9 / HBM_PEAK_GBS) if pre_s > 0 else 0.0,
+                                   "frac_of_measured_copy_bw": (pre_bytes / pre_s / 1e9 / HBM_COPY_GBS) if pre_s > 0 else 0.0,
+                                   "traffic_per_step": pft["bytes_per_step"] if pft else None,
+                                   "traffic_source": pft["source"] if pft else None},
+            "roofline_end_to_end": {"bound": "hbm", "algorithmic_bytes_per_step": all_bytes / steps,
+                                    "bytes_per_alignment": all_bytes / max(n_aln, 1) if world == 1 else None,
+                                    "achieved": all_bytes / dt / 1e9, "peak": HBM_COPY_GBS, "unit": "GB/s", "frac": all_bytes / dt / 1e9 / HBM_COPY_GBS,
+                                    "note": "SURVEY.md 8(d): sum of per-stage algorithmic bytes / (wall x 6.29 TB/s); rank 0's bytes when N > 1"},
+            "algorithmic_bytes_per_step": {k: v / steps for k, v in ab.items()},
             "stages_s_per_step": {k: v / steps for k, v in zip(U.STAGES, st["stage_seconds"])},
             "prefilter_kernel_ms_per_step": st["prefilter_kernel_ms"] / steps,
             "sw_kernel_ms_per_step": st["sw_kernel_ms"] / steps,
             "sw_dp_runs_per_step": st["n_sw_runs"] // steps,
-            "phases_rank0_s_per_step": {k: v / steps for k, v in phase.items()},
+            "exchange_rank0_s_per_step": st["exchange_seconds"] / steps, "exchange_bytes_per_step_all_ranks": xbytes // steps,
             "counts_rank0_per_step": {k: st[k] // steps for k in ("n_sim_kmers", "n_kmer_hits", "n_filtered_hits", "n_candidates", "n_prefilter_hits",
                                                                   "n_gapped_alignments", "n_start_alignments", "n_pk_reruns", "n_edges")},
         }
+        if world == 1 and not args.no_extra_legs:
+            # uc_cluster + uc_createtsv, DB on disk (page cache warm) -> clust.tsv
+            eng.close()
+            eng = None
+            outp = os.path.join(workdir, "bench_clust")
+            walls = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                s1 = U.cluster(prefix, outp + "_cluster", os.path.join(workdir, "tmp"), options + " --single-step-clustering", threads=threads)
+                U.createtsv(prefix, outp + "_cluster", outp + ".tsv")
+                walls.append(time.perf_counter() - t1)
+            tsv_ok = s1["n_clusters"] == out["config"]["clusters"] and sum(1 for _ in open(outp + ".tsv")) == n
+            out["value_disk_to_tsv"] = {"value": s1["n_gapped_alignments"] / min(walls), "unit": "alignments/s", "wall_s_best": min(walls),
+                                        "wall_s_mean": sum(walls) / len(walls), "value_mean": s1["n_gapped_alignments"] / (sum(walls) / len(walls)),
+                                        "alignments": s1["n_gapped_alignments"], "clusters": s1["n_clusters"], "tsv_rows": n, "same_clusters_as_steps": bool(tsv_ok),
+                                        "what": "uc_cluster('%s --single-step-clustering') + uc_createtsv from the DB files to clust.tsv (SURVEY.md 8d), 3 runs" % options}
+            walls = []
+            for _ in range(2):
+                t1 = time.perf_counter()
+                s2 = U.cluster(prefix, outp + "_cluster", os.path.join(workdir, "tmp"), options, threads=threads)
+                U.createtsv(prefix, outp + "_cluster", outp + ".tsv")
+                walls.append(time.perf_counter() - t1)
+            out["workflow_default"] = {"what": "uc_cluster('%s') + uc_createtsv: Foldseek's default workflow (linear-time pre-step + 3-step cascade), disk -> clust.tsv" % options,
+                                       "wall_s_best": min(walls), "alignments": s2["n_gapped_alignments"], "clusters": s2["n_clusters"],
+                                       "value": s2["n_gapped_alignments"] / min(walls), "unit": "alignments/s"}
+            U.rmdb(outp + "_cluster")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(prefix, args.options, n, args.cpu_seconds)
+            cb = cpu_baseline(prefix, options, n, args.cpu_seconds)
+            best = max(cb, key=lambda d: d["value"])
+            out["cpu_baseline"] = best                       # the faster CPU leg is THE baseline ...
+            out["cpu_baselines"] = cb                        # ... both are reported
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
+        comm.close()
         dist.destroy_process_group()
 
 

@@ -96,6 +96,13 @@ def lib():
     L.uco_write_m8.argtypes = [C.c_char_p, C.POINTER(Db), C.POINTER(Db), C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]
     L.uco_sample_run.argtypes = [C.POINTER(Db), C.POINTER(Index), C.POINTER(Params), C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
     L.uco_sample_run.restype = C.c_uint64
+    L.uco_simd_sample_run.argtypes = [C.POINTER(Db), C.POINTER(Index), C.POINTER(Params), C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_double),
+                                      C.c_void_p, C.c_void_p, C.c_void_p]
+    L.uco_simd_sample_run.restype = C.c_uint64
+    L.uco_align_pair.argtypes = [C.POINTER(Db), C.c_uint32, C.c_uint32, C.POINTER(Params), C.c_int32, C.c_void_p]
+    L.uco_align_pair.restype = None
+    L.uco_min_score.argtypes = [C.POINTER(Params), C.c_int, C.c_uint64]
+    L.uco_min_score.restype = C.c_int32
     _lib = L
     return L
 
@@ -309,6 +316,33 @@ def sample_run(odb, ix, p, queries, threads=0):
     sec = (C.c_double * 2)()
     n = lib().uco_sample_run(C.byref(odb.db), C.byref(ix), C.byref(p), threads, q.ctypes.data, len(q), sec)
     return int(n), sec[0], sec[1]
+
+
+def simd_sample_run(odb, ix, p, queries, threads=0, records=False):
+    """sample_run with the gapped stage as AVX2 inter-sequence SW (oracle/uc_simd.c).  records=True also returns
+    (counts, hits[nq, max_seqs], alns[nq, max_seqs])."""
+    q = np.ascontiguousarray(queries, np.uint32)
+    sec = (C.c_double * 2)()
+    if not records:
+        n = lib().uco_simd_sample_run(C.byref(odb.db), C.byref(ix), C.byref(p), threads, q.ctypes.data, len(q), sec, None, None, None)
+        return int(n), sec[0], sec[1]
+    M = p.max_seqs
+    cnt, hits, alns = np.zeros(len(q), np.uint32), np.zeros((len(q), M), HIT_DTYPE), np.zeros((len(q), M), ALN_DTYPE)
+    n = lib().uco_simd_sample_run(C.byref(odb.db), C.byref(ix), C.byref(p), threads, q.ctypes.data, len(q), sec,
+                                  hits.ctypes.data, cnt.ctypes.data, alns.ctypes.data)
+    return int(n), sec[0], sec[1], cnt, hits, alns
+
+
+def align_pair(odb, p, q, t, min_score):
+    """the scalar oracle's E5/E6 record for one pair"""
+    out = np.zeros(1, ALN_DTYPE)
+    lib().uco_align_pair(C.byref(odb.db), int(q), int(t), C.byref(p), int(min_score), out.ctypes.data)
+    return out[0]
+
+
+def min_score(odb, p, q):
+    lq = int(odb.db.off[q + 1] - odb.db.off[q])
+    return int(lib().uco_min_score(C.byref(p), lq, int(odb.db.off[odb.n])))
 
 
 def prefilter_shard(odb, p, tbegin=0, tend=None):

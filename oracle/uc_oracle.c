@@ -459,6 +459,11 @@ static void traceback(const uco_db *db, uint32_t q, uint32_t t, const uco_params
     *aln_len = len; *idents = id; *gap_opens = gaps;
 }
 
+void uco_traceback(const uco_db *db, uint32_t q, uint32_t t, const uco_params *p, int qs, int qe, int ts, int te,
+                   int32_t *aln_len, int32_t *idents, int32_t *gap_opens) {
+    traceback(db, q, t, p, qs, qe, ts, te, aln_len, idents, gap_opens);
+}
+
 /* Foldseek structurealign for one (query, target) pair (call site cluster.rs:45-49). */
 void uco_align_pair(const uco_db *db, uint32_t q, uint32_t t, const uco_params *p, int32_t min_score, uco_aln *o) {
     memset(o, 0, sizeof *o);

@@ -201,6 +201,19 @@ int  uco_write_m8(const char *path, const uco_db *qdb, const uco_db *tdb, const 
 uint64_t uco_sample_run(const uco_db *db, const uco_index *ix, const uco_params *p, int threads,
                         const uint32_t *queries, uint32_t n_queries, double seconds[2]);
 
+/* traceback statistics of the box [qs..qe] x [ts..te] (spec E6) */
+void uco_traceback(const uco_db *db, uint32_t q, uint32_t t, const uco_params *p, int qs, int qe, int ts, int te,
+                   int32_t *aln_len, int32_t *idents, int32_t *gap_opens);
+
+/* ---- vectorised CPU leg (uc_simd.c; bench.py cpu_baseline "kind": "simd") -------------------------------------------
+   E5/E6 of one query against its hit list with inter-sequence AVX2 Smith-Waterman: results identical to uco_align_pair */
+void uco_simd_align_query(const uco_db *db, uint32_t q, const uint32_t *targets, uint32_t nh, const uco_params *p, int32_t min_score,
+                          uco_aln *out);
+/* uco_sample_run with that gapped stage; hit_out / cnt_out / aln_out (optional: n_queries * max_seqs, n_queries) */
+uint64_t uco_simd_sample_run(const uco_db *db, const uco_index *ix, const uco_params *p, int threads,
+                             const uint32_t *queries, uint32_t n_queries, double seconds[2],
+                             uco_hit *hit_out, uint32_t *cnt_out, uco_aln *aln_out);
+
 #ifdef __cplusplus
 }
 #endif

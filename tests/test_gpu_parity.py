@@ -430,6 +430,34 @@ def test_chunked_prefilter_equals_unchunked(O, small):
     assert st1["n_candidates"] - st0["n_candidates"] > 0
 
 
+def test_prefilter_wide_and_compact_key_forms_agree(O, small):
+    """index entries and the per-query (target, diagonal) keys of the double-hit filter are u32 when target and diagonal
+    fit 32 bits together (compact, the common case) and u64 otherwise (wide; forced here with UC_PREFILTER_WIDE): same
+    hit lists and the same stage counters, whole DB, target sub-range (relative target ids) and chunked"""
+    e = small["eng"]
+    res = []
+    for wide in (False, True):
+        if wide:
+            os.environ["UC_PREFILTER_WIDE"] = "1"
+        try:
+            e.reset_stats()
+            e.prefilter()
+            c0, h0 = e.hits()
+            st = e.stats()
+            e.prefilter(7, 70, 3, 90)
+            c1, h1 = e.hits()
+            os.environ["UC_PREFILTER_CHUNK_RES"] = "2500"
+            e.prefilter()
+            c2, h2 = e.hits()
+        finally:
+            os.environ.pop("UC_PREFILTER_WIDE", None)
+            os.environ.pop("UC_PREFILTER_CHUNK_RES", None)
+        res.append((c0.tobytes(), h0.tobytes(), c1.tobytes(), h1.tobytes(), c2.tobytes(), h2.tobytes(),
+                    st["n_sim_kmers"], st["n_kmer_hits"], st["n_candidates"], st["n_filtered_hits"]))
+    assert res[0] == res[1]
+    assert res[0][0] == res[0][4] and res[0][1] == res[0][5]           # chunked == unchunked
+
+
 def _scaled_matrix(src, dst, factor):
     out = []
     for line in open(src):
@@ -550,7 +578,15 @@ def test_bench_line_contract(tmp_path):
         assert k in d["roofline"], k
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
-    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert d["cpu_baseline"]["kind"] in ("port", "simd") and d["cpu_baseline"]["value"] > 0
+    assert {b["kind"] for b in d["cpu_baselines"]} == {"port", "simd"} and all("not available" in b["foldseek"] for b in d["cpu_baselines"])
+    # SURVEY.md 8(d)'s own definition (disk -> clust.tsv) and the default workflow are measured beside the headline value
+    assert d["value_disk_to_tsv"]["value"] > 0 and d["value_disk_to_tsv"]["same_clusters_as_steps"]
+    assert d["workflow_default"]["clusters"] > 0
+    for blk in ("roofline_prefilter", "roofline_end_to_end"):
+        for k in ("bound", "achieved", "peak", "unit", "frac"):
+            assert k in d[blk], (blk, k)
+    assert sum(d["algorithmic_bytes_per_step"].values()) > 0
 
 
 def test_traceback_bytes_in_several_batches(O, small):

@@ -297,3 +297,35 @@ def test_cascade_oracle_invariants():
     # round 1 alone (highest threshold) is a refinement of the merged result
     r1 = O.cluster_cascade(odb, p, thr[:1], threads=4)["assign"]
     assert all(a[r1[i]] == a[i] for i in range(odb.n))
+
+
+@pytest.mark.parametrize("opts", ["-c 0.8", "-c 0.5 -e 1e-2 --min-seq-id 0.3 --gap-open 7 --gap-extend 2 --cov-mode 1", "-c 0.8 --rev-correction 0 --max-seqs 9"])
+def test_simd_cpu_leg_equals_the_scalar_oracle(opts, tmp_path):
+    """oracle/uc_simd.c (bench.py's cpu_baseline "simd": AVX2 inter-sequence Smith-Waterman, 16 targets per register)
+    must give the scalar oracle's record for every pair - score, reversed-query score, ends, starts, gates, traceback
+    statistics - including sequences of very different lengths in one batch, X residues and 1-residue sequences."""
+    import util
+    s3, sa = util.family_db(11, n_fam=14, members=7, lmin=12, lmax=420, extra=(700, 33, 1500))
+    db = str(tmp_path / "db")
+    util.write_db(db, s3, sa)
+    odb = O.OracleDb(db)
+    p = util.oracle_params(O, opts)
+    ix = O.build_index(odb, p)
+    queries = np.arange(odb.n, dtype=np.uint32)[::-1].copy()
+    n, _, _, cnt, hits, alns = O.simd_sample_run(odb, ix, p, queries, threads=4, records=True)
+    n_ref, _, _ = O.sample_run(odb, ix, p, queries, threads=4)
+    O.free_index(ix)
+    assert n == n_ref == int(cnt.sum()) and n > 200
+    checked = 0
+    for k, q in enumerate(queries):
+        ms = O.min_score(odb, p, int(q))
+        for h in range(cnt[k]):
+            ref = O.align_pair(odb, p, int(q), int(hits[k, h]["t"]), ms)
+            got = alns[k, h]
+            for f in ("score", "score_rev", "corrected", "pass_evalue", "accepted", "aln_len", "idents", "gap_opens"):
+                assert got[f] == ref[f], (opts, int(q), int(hits[k, h]["t"]), f, got, ref)
+            if ref["pass_evalue"]:
+                for f in ("qstart", "qend", "tstart", "tend"):
+                    assert got[f] == ref[f], (opts, int(q), int(hits[k, h]["t"]), f, got, ref)
+            checked += 1
+    assert checked == n

@@ -7,5 +7,5 @@ cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
 d=gpurun_out/prof_${TAG}
 mkdir -p "$d"
-rocprofv3 --kernel-trace --stats -d "$d" -o out --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > "$d/bench.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$d" -o out --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra-legs "$@" > "$d/bench.log" 2>&1
 echo "rc=$?"; tail -c 300 "$d/bench.log"

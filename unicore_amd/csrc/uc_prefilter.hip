@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 
 #include <rocprim/rocprim.hpp>
 
@@ -48,7 +49,8 @@ __device__ __forceinline__ uint32_t find_seq(const uint32_t *off, uint32_t lo, u
 
 // ---------------------------------------------------------------- E1: index build
 __global__ void __launch_bounds__(256) kmer_extract_kernel(const DeviceDb db, uint32_t tbegin, uint32_t tend, KmerCfg cfg,
-                                                           uint32_t p0, uint32_t p1, uint32_t *keys, uint64_t *vals) {
+                                                           uint32_t p0, uint32_t p1, uint32_t *keys, uint64_t *vals,
+                                                           uint32_t *vals32 /* compact entries instead of vals */, int pshift) {
     for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < p1 - p0; idx += (uint64_t)gridDim.x * 256) {
         const uint32_t p = p0 + (uint32_t)idx;
         const uint32_t s = find_seq(db.off, tbegin, tend, p);
@@ -67,7 +69,8 @@ __global__ void __launch_bounds__(256) kmer_extract_kernel(const DeviceDb db, ui
             if (ok) key = v;
         }
         keys[idx] = key;
-        vals[idx] = ((uint64_t)s << 16) | j;
+        if (vals32) vals32[idx] = ((s - tbegin) << pshift) | (j & ((1u << pshift) - 1u));
+        else vals[idx] = ((uint64_t)s << 16) | j;
     }
 }
 
@@ -331,14 +334,33 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
 struct KeyFmt {
     int dbits, tbits;
     int dbias;
+    // compact mode (the common case): when (target - tbase) and the diagonal fit 32 bits together, index entries are
+    // u32 [target - tbase | position : dbits - 1] and the per-query (target, diagonal) keys of the double-hit filter are
+    // u32 [target - tbase | diagonal + dbias : dbits] - half the bytes of the wide u64 forms on every gather and stream
+    int compact;
+    uint32_t tbase;
 };
+
+// one index entry -> (global target id, position)
+template <bool C>
+__device__ __forceinline__ void ent_decode(const void *ent, uint32_t idx, const KeyFmt &fmt, uint32_t &t, uint32_t &pos) {
+    if (C) {
+        const uint32_t e = ((const uint32_t *)ent)[idx];
+        t = (e >> (fmt.dbits - 1)) + fmt.tbase;
+        pos = e & ((1u << (fmt.dbits - 1)) - 1u);
+    } else {
+        const uint64_t e = ((const uint64_t *)ent)[idx];
+        t = (uint32_t)(e >> 16);
+        pos = (uint32_t)(e & 0xFFFF);
+    }
+}
 
 // ---- E2 pass 2: expand runs into hit keys, load-balanced ----
 // A workgroup takes 256 runs, scans their lengths, reserves the tile's key range with one atomic and then lets
 // thread k write key k of the tile (binary search in the LDS prefix): loads of index entries touch a handful of
 // lines per wave and the key stores are fully coalesced.
 __global__ void __launch_bounds__(256) expand_kernel(const DeviceDb db, uint32_t qbegin, uint32_t qend, uint32_t p0, RunList runs,
-                                                     uint64_t n_runs, const uint64_t *ent, KeyFmt fmt,
+                                                     uint64_t n_runs, const void *ent, KeyFmt fmt,
                                                      unsigned long long *key_cursor, uint64_t *keys, uint64_t key_cap) {
     __shared__ uint64_t s_pref[257];
     __shared__ uint64_t s_qb[256];
@@ -382,8 +404,10 @@ __global__ void __launch_bounds__(256) expand_kernel(const DeviceDb db, uint32_t
                 const int mid = (lo + hi) >> 1;
                 if (s_pref[mid] <= k) lo = mid; else hi = mid;
             }
-            const uint64_t e = ent[s_e0[lo] + (uint32_t)(k - s_pref[lo])];
-            const uint64_t key = s_qb[lo] | ((e >> 16) << fmt.dbits) | (uint64_t)(s_i[lo] - (int32_t)(e & 0xFFFF));
+            uint32_t et, epos;
+            if (fmt.compact) ent_decode<true>(ent, s_e0[lo] + (uint32_t)(k - s_pref[lo]), fmt, et, epos);
+            else ent_decode<false>(ent, s_e0[lo] + (uint32_t)(k - s_pref[lo]), fmt, et, epos);
+            const uint64_t key = s_qb[lo] | ((uint64_t)et << fmt.dbits) | (uint64_t)(s_i[lo] - (int32_t)epos);
             if (base + k < key_cap) keys[base + k] = key;
         }
         __syncthreads();
@@ -392,95 +416,144 @@ __global__ void __launch_bounds__(256) expand_kernel(const DeviceDb db, uint32_t
 
 // ---- E2 pass 2 (min_diag_hits >= 2): expand + double-hit filter, one workgroup per query ----
 // Only hits that share (target, diagonal) with another hit of the same query can make a candidate, and they are a
-// few percent of all hits.  With the runs sorted by query position a workgroup owns one query: sweep 1 expands the
-// query's runs and records every (target, diagonal) hash in two LDS bitmaps (seen once / seen twice); sweep 2
-// expands again and keeps the keys whose hash was seen twice — every key of a real multi-hit diagonal plus a
-// few collisions, which the exact diagonal count after the sort discards again.  Survivors go to a region the
-// query reserved with one atomic (sized by its hit total) and are compacted afterwards.
+// few percent of all hits.  With the runs sorted by query position a workgroup owns one query:
+//   sweep 1 expands the query's runs (load-balanced: thread k takes KPT consecutive keys of the tile by one binary
+//           search in the LDS prefix of the run lengths), records every (target, diagonal) hash in two LDS bitmaps
+//           (seen once / seen twice, two hash positions per key) and STREAMS the (target, diagonal) keys it computed
+//           into the query's region of the key buffer (coalesced 16-byte stores);
+//   sweep 2 reads that stream back — a coalesced scan instead of a second round of binary searches and index gathers
+//           (the gathers were the kernel's critical path: 69 % of its cycles waited on them, profiles/r2b) — keeps the
+//           keys whose two hash positions were both seen twice, and compacts them in place;
+//   level 2 repeats the once/twice test over the survivors alone with independent hash functions (below).
+// Every key of a real multi-hit diagonal survives, plus a few collisions which the exact diagonal count after the sort
+// discards again.  The region is sized by the query's exact hit total (from sim_runs), so nothing can overflow.
 constexpr int FB_LOG2 = 19;            // bits per bitmap: 2 x 64 KiB of the CU's 160 KiB LDS
 constexpr int FT = 1024;               // threads per workgroup = runs per tile
 constexpr int KPT = 4;                 // consecutive keys per thread and binary search
-constexpr size_t FILTER_LDS = 2 * ((size_t)1 << FB_LOG2) / 8 + (FT + 1) * 8 + FT * 8 + 16 * 8 + 64;
+constexpr size_t FILTER_LDS = 2 * ((size_t)1 << FB_LOG2) / 8 + (FT + 1) * 4 + FT * 4 + FT * 4 + 16 * 4 + 64;
 
+// first run of every query of the batch (runs are sorted by query position): qr[i] = lower_bound(rpidx, off[qbegin + i] - p0),
+// i = 0..nq.  One thread per query here instead of two serial ~25-step searches at the head of every filter workgroup
+// (those cost ~20 us of the ~100 us a query spends in the filter kernel).
+__global__ void __launch_bounds__(256) run_range_kernel(const DeviceDb db, uint32_t qbegin, uint32_t nq, uint32_t p0, const uint32_t *rpidx,
+                                                        uint64_t n_runs, uint64_t *qr) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i <= nq; i += gridDim.x * 256) {
+        const uint32_t want = db.off[qbegin + i] - p0;
+        uint64_t lo = 0, hi = n_runs;
+        while (lo < hi) { const uint64_t m = (lo + hi) >> 1; if (rpidx[m] < want) lo = m + 1; else hi = m; }
+        qr[i] = lo;
+    }
+}
+
+// launch order of the filter workgroups: queries with the most runs first (longest-processing-time-first: a batch then ends
+// with many short queries instead of a few long ones; the tail was ~20 % of the kernel)
+__global__ void __launch_bounds__(256) run_order_key_kernel(uint32_t nq, const uint64_t *qr, uint32_t *key, uint32_t *idx) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
+        const uint64_t c = qr[i + 1] - qr[i];
+        key[i] = 0xFFFFFFFFu - (uint32_t)min<uint64_t>(c, 0xFFFFFFFFull);
+        idx[i] = i;
+    }
+}
+
+template <bool C> struct TdType { using type = uint64_t; };
+template <> struct TdType<true> { using type = uint32_t; };
+
+template <bool C>
 __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t qbegin, uint32_t p0, const uint32_t *rpidx,
-                                                    const uint64_t *rval, uint64_t n_runs, const uint64_t *ent, KeyFmt fmt,
-                                                    unsigned long long *region_cursor, uint64_t *keys, uint64_t key_cap,
-                                                    uint64_t *qbase, uint32_t *qsurv) {
+                                                    const uint64_t *rval, const uint64_t *qr, const uint32_t *order, const void *ent, KeyFmt fmt,
+                                                    unsigned long long *region_cursor, void *region_v, uint64_t region_cap,
+                                                    uint64_t *qbase, uint32_t *qsurv, unsigned long long *prof /* UC_FILTER_PROF: cycles per phase */) {
+    using TD = typename TdType<C>::type;
+    struct __attribute__((aligned(4))) TD4 { TD v[KPT]; };
+    unsigned long long t_prev = prof ? wall_clock64() : 0;
+    auto lap = [&](int k) {
+        if (prof && threadIdx.x == 0) { const unsigned long long t = wall_clock64(); atomicAdd(prof + k, t - t_prev); t_prev = t; }
+    };        // KPT keys of one thread: dword-aligned vector access
+    TD *region = (TD *)region_v;
     extern __shared__ __attribute__((aligned(16))) uint32_t f_lds[];
     constexpr int BW = 1 << (FB_LOG2 - 5);          // words per bitmap
     uint32_t *B1 = f_lds, *B2 = f_lds + BW;
-    uint64_t *s_pref = (uint64_t *)(f_lds + 2 * BW);            // FT + 1
-    uint32_t *s_e0 = (uint32_t *)(s_pref + FT + 1);             // FT
+    uint32_t *s_pref = f_lds + 2 * BW;                          // FT + 1 (hits of one query < 2^32: checked by the host)
+    uint32_t *s_e0 = s_pref + FT + 1;                           // FT
     int32_t *s_i = (int32_t *)(s_e0 + FT);                      // FT
-    uint64_t *s_wsum = (uint64_t *)(s_i + FT);                  // 16
-    uint64_t *s_misc = s_wsum + 16;                             // [0] r0, [1] r1, [2] region base, [3] survivor cursor (u32)
+    uint32_t *s_wsum = (uint32_t *)(s_i + FT);                  // 16
+    uint64_t *s_misc = (uint64_t *)(((uintptr_t)(s_wsum + 16) + 7) & ~(uintptr_t)7);   // [0] r0, [1] r1, [2] region base, [3] cursors (2 x u32)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t q = qbegin + blockIdx.x;
-    const uint32_t plo = db.off[q] - p0, phi = db.off[q + 1] - p0;
-    if (tid < 2) {
-        const uint32_t want = tid ? phi : plo;
-        uint64_t lo = 0, hi = n_runs;
-        while (lo < hi) { const uint64_t m = (lo + hi) >> 1; if (rpidx[m] < want) lo = m + 1; else hi = m; }
-        s_misc[tid] = lo;
-    }
+    const uint32_t qi = order[blockIdx.x];                      // query of this workgroup (index inside the batch)
+    const uint32_t q = qbegin + qi;
+    const uint32_t plo = db.off[q] - p0;
+    const uint64_t r0 = qr[qi], r1 = qr[qi + 1];
+    TD *surv = region + region_cap;                             // second area of the same size: survivors of sweep 2
     for (int w = tid; w < 2 * BW; w += FT) f_lds[w] = 0;
-    __syncthreads();
-    const uint64_t r0 = s_misc[0], r1 = s_misc[1];
     if (r0 == r1) {
-        if (tid == 0) { qbase[blockIdx.x] = 0; qsurv[blockIdx.x] = 0; }
+        if (tid == 0) { qbase[qi] = 0; qsurv[qi] = 0; }
         return;
     }
-    const uint64_t qbits = (uint64_t)blockIdx.x << (fmt.tbits + fmt.dbits);
 
     // loads one tile of runs, leaves the exclusive prefix of their lengths in s_pref[0..FT] (s_pref[FT] = total)
+    // the run of the NEXT tile is fetched while the current one is expanded (the loads' latency would otherwise sit between
+    // two barriers with nothing else to run: one workgroup per CU)
+    uint64_t pf_rv = 0;
+    uint32_t pf_pi = 0;
+    auto prefetch_tile = [&](uint64_t tile) {
+        const uint64_t r = tile + tid;
+        if (r < r1) { pf_rv = rval[r]; pf_pi = rpidx[r]; }
+    };
     auto load_tile = [&](uint64_t tile) {
         const uint64_t r = tile + tid;
-        uint64_t c = 0;
+        uint32_t c = 0;
         if (r < r1) {
-            const uint64_t rv = rval[r];
-            c = rv >> 32;
-            s_e0[tid] = (uint32_t)rv;
-            s_i[tid] = (int32_t)(rpidx[r] - plo) + fmt.dbias;
+            c = (uint32_t)(pf_rv >> 32);
+            s_e0[tid] = (uint32_t)pf_rv;
+            s_i[tid] = (int32_t)(pf_pi - plo) + fmt.dbias;
         }
-        uint64_t inc = c;
+        uint32_t inc = c;
         for (int o = 1; o < 64; o <<= 1) {
-            const uint64_t up = __shfl_up(inc, o, 64);
+            const uint32_t up = (uint32_t)__shfl_up((int)inc, o, 64);
             if (lane >= o) inc += up;
         }
         if (lane == 63) s_wsum[wv] = inc;
         __syncthreads();
-        uint64_t woff = 0;
+        uint32_t woff = 0;
         for (int w = 0; w < wv; w++) woff += s_wsum[w];
         s_pref[tid] = woff + inc - c;
         if (tid == FT - 1) s_pref[FT] = woff + inc;
         __syncthreads();
     };
-    // keys k4 .. k4+KPT-1 of the current tile, (target << dbits | diagonal + dbias) each: one binary search finds the run
-    // of the first key, the others walk forward from it, and the (up to) KPT index loads are in flight together —
-    // the kernel is bound by the latency of search + load, not by LDS or HBM throughput.  Returns the number of keys.
-    auto keys_at = [&](uint64_t k4, uint64_t T, uint64_t (&td)[KPT]) -> int {
-        int lo = 0, hi = FT;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (s_pref[mid] <= k4) lo = mid; else hi = mid;
-        }
-        const int n = T - k4 < KPT ? (int)(T - k4) : KPT;
-        uint32_t idx[KPT];
-        int32_t si[KPT];
+    // keys k4 .. k4+KPT-1 of the current tile: one binary search finds the run of the first key; every run holds at least
+    // one key, so each following key is in the same run or the next one (a branch-free step).  locate() is pure LDS work
+    // with a fixed trip count, so the two groups a thread handles per iteration interleave and their 2 x KPT index loads
+    // are in flight together (the kernel is bound by the latency of search -> gather -> mark, one workgroup per CU).
+    auto locate = [&](uint32_t k4, uint32_t T, uint32_t (&idx)[KPT], int32_t (&si)[KPT]) -> int {
+        int lo = 0;
+#pragma unroll
+        for (int step = FT / 2; step >= 1; step >>= 1)            // FT = 2^10: ten probes
+            if (s_pref[lo + step] <= k4) lo += step;
+        const int n = k4 >= T ? 0 : (T - k4 < (uint32_t)KPT ? (int)(T - k4) : KPT);
 #pragma unroll
         for (int i = 0; i < KPT; i++) {
-            if (i < n) {
-                while (s_pref[lo + 1] <= k4 + i) lo++;      // s_pref[FT] = T > k4 + i ends the walk
-                idx[i] = s_e0[lo] + (uint32_t)(k4 + i - s_pref[lo]);
-                si[i] = s_i[lo];
-            } else { idx[i] = idx[0]; si[i] = si[0]; }
+            if (i > 0 && i < n) lo += (s_pref[lo + 1] <= k4 + i) ? 1 : 0;
+            idx[i] = s_e0[lo] + (k4 + i - s_pref[lo]);
+            si[i] = s_i[lo];
         }
-        uint64_t e[KPT];
 #pragma unroll
-        for (int i = 0; i < KPT; i++) e[i] = ent[idx[i]];
-#pragma unroll
-        for (int i = 0; i < KPT; i++) td[i] = ((e[i] >> 16) << fmt.dbits) | (uint64_t)(si[i] - (int32_t)(e[i] & 0xFFFF));
+        for (int i = 1; i < KPT; i++) if (i >= n) { idx[i] = idx[0]; si[i] = si[0]; }
         return n;
+    };
+    auto gather = [&](const uint32_t (&idx)[KPT], typename std::conditional<C, uint32_t, uint64_t>::type (&e)[KPT]) {
+#pragma unroll
+        for (int i = 0; i < KPT; i++) {
+            if (C) e[i] = ((const uint32_t *)ent)[idx[i]];
+            else e[i] = ((const uint64_t *)ent)[idx[i]];
+        }
+    };
+    auto to_td = [&](const typename std::conditional<C, uint32_t, uint64_t>::type (&e)[KPT], const int32_t (&si)[KPT], TD (&td)[KPT]) {
+        const uint32_t pm = (1u << (fmt.dbits - 1)) - 1u;
+#pragma unroll
+        for (int i = 0; i < KPT; i++) {
+            if (C) td[i] = (TD)((((uint32_t)e[i] >> (fmt.dbits - 1)) << fmt.dbits) | (uint32_t)(si[i] - (int32_t)((uint32_t)e[i] & pm)));
+            else td[i] = (TD)((((uint64_t)e[i] >> 16) << fmt.dbits) | (uint64_t)(si[i] - (int32_t)((uint64_t)e[i] & 0xFFFF)));
+        }
     };
     // two independent hash positions per (target, diagonal): a key survives only if BOTH were seen twice (a Bloom
     // filter with k = 2: collisions let ~2 % of the single hits through instead of ~11 %, which is what the sort pays for)
@@ -490,81 +563,134 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
         return (x * 0x2C1B3C6Du) >> (32 - FB_LOG2);
     };
 
-    uint64_t total = 0;
+    // the query's region: its exact hit total is the sum of its run lengths; reserve it first (rounded up to KPT keys)
+    {
+        uint64_t part = 0;
+        for (uint64_t r = r0 + tid; r < r1; r += FT) part += rval[r] >> 32;
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+        uint64_t *s_part = (uint64_t *)s_pref;      // not in use yet
+        if (lane == 0) s_part[wv] = part;
+        __syncthreads();
+        if (tid == 0) {
+            uint64_t tot = 0;
+            for (int w = 0; w < FT / 64; w++) tot += s_part[w];
+            s_misc[2] = atomicAdd(region_cursor, (unsigned long long)((tot + KPT - 1) / KPT * KPT));
+            ((uint32_t *)&s_misc[3])[0] = 0;
+            ((uint32_t *)&s_misc[3])[1] = 0;
+        }
+        __syncthreads();
+    }
+    const uint64_t base = s_misc[2];
+    uint32_t *cur = (uint32_t *)&s_misc[3];
+    uint32_t total = 0;
+    lap(0);                                  // clear + region reservation
+    prefetch_tile(r0);
     for (uint64_t tile = r0; tile < r1; tile += FT) {
         load_tile(tile);
-        const uint64_t T = s_pref[FT];
-        for (uint64_t k4 = (uint64_t)KPT * tid; k4 < T; k4 += (uint64_t)KPT * FT) {
-            uint64_t td[KPT];
-            const int n = keys_at(k4, T, td);
+        lap(1);                              // tile loads + scan
+        prefetch_tile(tile + FT);
+        const uint32_t T = s_pref[FT];
+        using ET = typename std::conditional<C, uint32_t, uint64_t>::type;
+        auto mark_store = [&](TD4 &td, int n, uint32_t k4) {
 #pragma unroll
             for (int i = 0; i < KPT; i++) {
-                if (i >= n) break;
+                if (i >= n) { td.v[i] = td.v[0]; continue; }
                 uint32_t g;
-                const uint32_t h = slot_of(td[i], g), bit = 1u << (h & 31), gbit = 1u << (g & 31);
+                const uint32_t h = slot_of(td.v[i], g), bit = 1u << (h & 31), gbit = 1u << (g & 31);
                 const uint32_t old = atomicOr(&B1[h >> 5], bit);
                 if (old & bit) atomicOr(&B2[h >> 5], bit);
                 const uint32_t gold = atomicOr(&B1[g >> 5], gbit);
                 if (gold & gbit) atomicOr(&B2[g >> 5], gbit);
             }
+            const uint64_t w = base + total + k4;
+            if (n && w + KPT <= region_cap) {
+                if (n == KPT) *(TD4 *)(region + w) = td;
+                else {
+#pragma unroll
+                    for (int i = 0; i < KPT; i++) if (i < n) region[w + i] = td.v[i];     // (a runtime trip count would put td into scratch)
+                }
+            }
+        };
+        for (uint32_t k4 = (uint32_t)KPT * tid; k4 < T; k4 += 2u * KPT * FT) {
+            const uint32_t k4b = k4 + (uint32_t)KPT * FT;
+            uint32_t ia[KPT], ib[KPT];
+            int32_t sa[KPT], sb[KPT];
+            const int na = locate(k4, T, ia, sa);
+            const int nb = locate(k4b < T ? k4b : k4, T, ib, sb);
+            ET ea[KPT], eb[KPT];
+            gather(ia, ea);
+            gather(ib, eb);
+            TD4 ta, tb;
+            to_td(ea, sa, ta.v);
+            mark_store(ta, na, k4);
+            to_td(eb, sb, tb.v);
+            mark_store(tb, k4b < T ? nb : 0, k4b);
         }
         total += T;
         __syncthreads();
+        lap(2);                              // expansion + marks + key stream
     }
-    if (tid == 0) {
-        s_misc[2] = atomicAdd(region_cursor, (unsigned long long)total);
-        *(uint32_t *)&s_misc[3] = 0;
-    }
+    __threadfence_block();
     __syncthreads();
-    const uint64_t base = s_misc[2];
-    uint32_t *cur = (uint32_t *)&s_misc[3];
-    for (uint64_t tile = r0; tile < r1; tile += FT) {
-        load_tile(tile);
-        const uint64_t T = s_pref[FT];
-        const uint64_t Tr = (T + 64 * KPT - 1) / (64 * KPT) * (64 * KPT);     // whole waves stay in the loop: 64 lanes x KPT keys
-        for (uint64_t k4 = (uint64_t)KPT * tid; k4 < Tr; k4 += (uint64_t)KPT * FT) {
-            uint64_t td[KPT] = {};
-            uint32_t keep = 0;                      // bit i: key i survives
-            if (k4 < T) {
-                const int n = keys_at(k4, T, td);
+    // sweep 2: stream the keys back, keep those whose two positions were both seen twice and append them to the query's
+    // slice of the survivor area (same offsets as its region): no barrier and no in-place hazard, so the loads of successive
+    // iterations overlap.
+    const uint32_t n0 = (uint32_t)min<uint64_t>(total, region_cap > base ? region_cap - base : 0);
+    const uint32_t n0r = n0;                 // (a wave's lanes enter the loop together: their k4 differ by < 64 * KPT <= the loop stride; the ballots below only need the lanes that are in)
+    for (uint32_t k4 = (uint32_t)KPT * tid; k4 < n0r; k4 += 2u * KPT * FT) {
+        // two groups of KPT keys per thread and iteration: both loads are in flight before either is tested
+        TD4 td[2] = {};
+        int nn[2];
 #pragma unroll
-                for (int i = 0; i < KPT; i++) {
-                    uint32_t g;
-                    const uint32_t h = slot_of(td[i], g);
-                    if (i < n) keep |= (((B2[h >> 5] >> (h & 31)) & (B2[g >> 5] >> (g & 31))) & 1u) << i;
-                }
-            }
-            const uint32_t mine = (uint32_t)__popc(keep);
-            uint32_t inc = mine;                    // inclusive scan of the survivors inside the wave
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t up = (uint32_t)__shfl_up((int)inc, o, 64);
-                if (lane >= o) inc += up;
-            }
-            const uint32_t wave_total = (uint32_t)__shfl((int)inc, 63, 64);
-            if (wave_total) {
-                uint32_t s0 = 0;
-                if (lane == 0) s0 = atomicAdd(cur, wave_total);
-                s0 = (uint32_t)__shfl((int)s0, 0, 64);
-                uint64_t w = base + s0 + (inc - mine);
+        for (int g2 = 0; g2 < 2; g2++) {
+            const uint32_t k = k4 + (uint32_t)g2 * KPT * FT;
+            nn[g2] = k >= n0 ? 0 : (n0 - k < (uint32_t)KPT ? (int)(n0 - k) : KPT);
+            if (nn[g2] == KPT) td[g2] = *(const TD4 *)(region + base + k);
+            else {
 #pragma unroll
-                for (int i = 0; i < KPT; i++)
-                    if ((keep >> i) & 1u) { if (w < key_cap) keys[w] = qbits | td[i]; w++; }
+                for (int i = 0; i < KPT; i++) if (i < nn[g2]) td[g2].v[i] = region[base + k + i];
             }
         }
-        __syncthreads();
+        uint32_t keep = 0;                      // bit 4 * g2 + i: key i of group g2 survives
+#pragma unroll
+        for (int g2 = 0; g2 < 2; g2++)
+#pragma unroll
+            for (int i = 0; i < KPT; i++) {
+                uint32_t g;
+                const uint32_t h = slot_of(td[g2].v[i], g);
+                if (i < nn[g2]) keep |= (((B2[h >> 5] >> (h & 31)) & (B2[g >> 5] >> (g & 31))) & 1u) << (KPT * g2 + i);
+            }
+        // wave-level compaction by ballots (the order of the survivors is irrelevant: they get sorted): rank of key j of
+        // this lane = survivors of keys < j over the whole wave + survivors of key j in the lanes below
+        uint32_t rank[2 * KPT];
+        uint32_t wave_total = 0;
+#pragma unroll
+        for (int j = 0; j < 2 * KPT; j++) {
+            const uint64_t m = __builtin_amdgcn_ballot_w64((keep >> j) & 1u);
+            rank[j] = wave_total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            wave_total += (uint32_t)__popcll(m);
+        }
+        if (wave_total) {
+            uint32_t s0 = 0;
+            if (lane == 0) s0 = atomicAdd(cur, wave_total);
+            s0 = (uint32_t)__shfl((int)s0, 0, 64);
+#pragma unroll
+            for (int j = 0; j < 2 * KPT; j++)
+                if ((keep >> j) & 1u) surv[base + s0 + rank[j]] = td[j / KPT].v[j % KPT];
+        }
     }
     // ---- second level: the same once / twice test over the SURVIVORS only, with independent hash functions ----
     // Long queries load the bitmaps so heavily that most first-level survivors are single hits whose two positions were
     // set by other keys (C2: 0.55 G survivors for ~0.03 G keys of real double-hit diagonals).  Every key of a diagonal with
     // >= 2 hits survives level 1 together with its twins, so repeating the test over the ~10x shorter survivor list (a
-    // coalesced read of the query's own region, no index lookups) keeps all of them and drops nearly all the rest; the
-    // region is compacted in place.
-    const uint32_t n1 = min(*cur, (uint32_t)min<uint64_t>(key_cap > base ? key_cap - base : 0, 0xFFFFFFFFull));
+    // coalesced read of the query's own slice, no index lookups) keeps all of them and drops nearly all the rest; the final
+    // keys go back to the head of the query's region.
     __threadfence_block();
     __syncthreads();
+    lap(3);                                  // sweep 2
+    const uint32_t n1 = *cur;
     for (int w = tid; w < 2 * BW; w += FT) f_lds[w] = 0;
     uint32_t *cur2 = cur + 1;
-    if (tid == 0) *cur2 = 0;
     __syncthreads();
     auto slot2_of = [&](uint64_t key, uint32_t &h2) -> uint32_t {
         const uint32_t x = (uint32_t)key * 0xC2B2AE35u ^ (uint32_t)(key >> 32) * 0x27D4EB2Fu;
@@ -573,43 +699,52 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
     };
     for (uint32_t k = tid; k < n1; k += FT) {
         uint32_t g;
-        const uint32_t h = slot2_of(keys[base + k], g), bit = 1u << (h & 31), gbit = 1u << (g & 31);
+        const uint32_t h = slot2_of(surv[base + k], g), bit = 1u << (h & 31), gbit = 1u << (g & 31);
         const uint32_t old = atomicOr(&B1[h >> 5], bit);
         if (old & bit) atomicOr(&B2[h >> 5], bit);
         const uint32_t gold = atomicOr(&B1[g >> 5], gbit);
         if (gold & gbit) atomicOr(&B2[g >> 5], gbit);
     }
     __syncthreads();
-    for (uint32_t tile = 0; tile < n1; tile += FT) {
-        const uint32_t k = tile + tid;
-        uint64_t key = 0;
+    const uint32_t n1r = (n1 + 63) / 64 * 64;
+    for (uint32_t k = tid; k < n1r; k += FT) {
+        TD key = 0;
         bool keep = false;
         if (k < n1) {
-            key = keys[base + k];
+            key = surv[base + k];
             uint32_t g;
             const uint32_t h = slot2_of(key, g);
             keep = ((B2[h >> 5] >> (h & 31)) & (B2[g >> 5] >> (g & 31))) & 1u;
         }
-        __syncthreads();                                  // the whole tile is in registers before a survivor of it is stored
         const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
         if (m) {
             uint32_t s0 = 0;
             if (lane == 0) s0 = atomicAdd(cur2, (uint32_t)__popcll(m));
             s0 = (uint32_t)__shfl((int)s0, 0, 64);
-            if (keep) keys[base + s0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key;   // s0 + rank <= k: in place
+            if (keep) region[base + s0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
         }
     }
     __syncthreads();
-    if (tid == 0) { qbase[blockIdx.x] = base; qsurv[blockIdx.x] = *cur2; }
+    lap(4);                                  // level 2
+    if (tid == 0) { qbase[qi] = base; qsurv[qi] = *cur2; }
 }
 
-// moves every query's surviving keys from its region to a dense array
-__global__ void __launch_bounds__(256) compact_kernel(const uint64_t *keys, const uint64_t *qbase, const uint32_t *qsurv,
-                                                      const uint64_t *soff, uint32_t nq, uint64_t *out) {
+// moves every query's surviving (target, diagonal) keys from its region to a dense array of full sort keys
+// [ query - qbegin | target | diagonal + dbias ]
+template <bool C>
+__global__ void __launch_bounds__(256) compact_kernel(const void *region_v, const uint64_t *qbase, const uint32_t *qsurv,
+                                                      const uint64_t *soff, uint32_t nq, KeyFmt fmt, uint64_t *out) {
+    using TD = typename TdType<C>::type;
+    const TD *region = (const TD *)region_v;
+    const uint64_t dmask = (1ull << fmt.dbits) - 1;
     for (uint32_t b = blockIdx.x; b < nq; b += gridDim.x) {
         const uint64_t src = qbase[b], dst = soff[b];
         const uint32_t n = qsurv[b];
-        for (uint32_t k = threadIdx.x; k < n; k += 256) out[dst + k] = keys[src + k];
+        const uint64_t qbits = (uint64_t)b << (fmt.tbits + fmt.dbits);
+        for (uint32_t k = threadIdx.x; k < n; k += 256) {
+            const uint64_t td = region[src + k];
+            out[dst + k] = C ? (qbits | (((td >> fmt.dbits) + fmt.tbase) << fmt.dbits) | (td & dmask)) : (qbits | td);
+        }
     }
 }
 
@@ -764,12 +899,12 @@ struct WidenU32 {
 // work buffers of the prefilter, kept by the engine between calls (hipMalloc / hipFree of multi-GB buffers on every
 // call cost tens of ms per step and, now and then, seconds)
 struct PrefilterScratch {
-    DevBuf<unsigned long long> d_counters;
+    DevBuf<unsigned long long> d_counters, d_prof;
     DevBuf<char> d_temp;
-    DevBuf<uint32_t> d_koff, k_in, k_out;
+    DevBuf<uint32_t> d_koff, k_in, k_out, d_ent32, v_in32, d_okey, d_okey2, d_oidx, d_order;
     DevBuf<uint64_t> d_ent, v_in;
     DevBuf<uint32_t> d_cnt, d_flag, d_cq, d_ct, d_rpidx, d_rpidx2, d_qsurv;
-    DevBuf<uint64_t> d_keys, d_keys2, d_pos, d_skey, d_skey2, d_rval, d_rval2, d_qbase, d_soff;
+    DevBuf<uint64_t> d_keys, d_keys2, d_pos, d_skey, d_skey2, d_rval, d_rval2, d_qbase, d_soff, d_qr;
     DevBuf<int32_t> d_cd, d_cd2, d_score;
 };
 void free_prefilter_scratch(PrefilterScratch *p) { delete p; }
@@ -890,20 +1025,44 @@ void Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
     const uint32_t tp0 = h_poff[tbegin], tp1 = h_poff[tend];
     const uint32_t nres = tp1 - tp0;
     DevBuf<uint32_t> &d_koff = S.d_koff;
-    DevBuf<uint64_t> &d_ent = S.d_ent;      // index entries sorted by k-mer: [sequence : 32 | position : 16]
+    DevBuf<uint64_t> &d_ent = S.d_ent;      // wide index entries sorted by k-mer: [sequence : 32 | position : 16]
+    DevBuf<uint32_t> &d_ent32 = S.d_ent32;  // compact index entries: [sequence - tbegin | position : dbits - 1]
     d_koff.reserve((size_t)KSPACE + 1);
+    KeyFmt fmt;
+    {
+        const uint32_t m = std::min<uint32_t>(std::max<uint32_t>(max_len, 2), 65536u);
+        fmt.dbits = 1;
+        while ((1u << (fmt.dbits - 1)) < m) fmt.dbits++;
+        fmt.dbias = 1 << (fmt.dbits - 1);
+        fmt.tbits = 1;
+        while ((1u << fmt.tbits) < n) fmt.tbits++;
+        int rbits = 1;                                   // bits of a target id relative to this chunk
+        while ((1ull << rbits) < (uint64_t)std::max<uint32_t>(tend - tbegin, 1)) rbits++;
+        fmt.compact = rbits + fmt.dbits <= 32 && !getenv("UC_PREFILTER_WIDE");
+        fmt.tbase = tbegin;
+    }
+    const void *ent_p = nullptr;
     uint32_t n_entries = 0;
     {
-        DevBuf<uint32_t> &k_in = S.k_in, &k_out = S.k_out;
+        DevBuf<uint32_t> &k_in = S.k_in, &k_out = S.k_out, &v_in32 = S.v_in32;
         DevBuf<uint64_t> &v_in = S.v_in;
         const size_t cap = std::max<uint32_t>(nres, 1);
-        k_in.reserve(cap); k_out.reserve(cap); v_in.reserve(cap); d_ent.reserve(cap);
+        k_in.reserve(cap); k_out.reserve(cap);
+        if (fmt.compact) { v_in32.reserve(cap); d_ent32.reserve(cap); ent_p = d_ent32.p; }
+        else { v_in.reserve(cap); d_ent.reserve(cap); ent_p = d_ent.p; }
         if (nres) {
-            hipLaunchKernelGGL(kmer_extract_kernel, grid_for(nres), dim3(256), 0, stream, ddb, tbegin, tend, cfg, tp0, tp1, k_in.p, v_in.p);
+            hipLaunchKernelGGL(kmer_extract_kernel, grid_for(nres), dim3(256), 0, stream, ddb, tbegin, tend, cfg, tp0, tp1, k_in.p,
+                               fmt.compact ? nullptr : v_in.p, fmt.compact ? v_in32.p : nullptr, fmt.dbits - 1);
             size_t tb = 0;
-            UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, k_in.p, k_out.p, v_in.p, d_ent.p, (size_t)nres, 0u, 32u, stream));
-            temp_reserve(tb);
-            UC_HIP(rocprim::radix_sort_pairs(d_temp.p, tb, k_in.p, k_out.p, v_in.p, d_ent.p, (size_t)nres, 0u, 32u, stream));
+            if (fmt.compact) {
+                UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, k_in.p, k_out.p, v_in32.p, d_ent32.p, (size_t)nres, 0u, 32u, stream));
+                temp_reserve(tb);
+                UC_HIP(rocprim::radix_sort_pairs(d_temp.p, tb, k_in.p, k_out.p, v_in32.p, d_ent32.p, (size_t)nres, 0u, 32u, stream));
+            } else {
+                UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, k_in.p, k_out.p, v_in.p, d_ent.p, (size_t)nres, 0u, 32u, stream));
+                temp_reserve(tb);
+                UC_HIP(rocprim::radix_sort_pairs(d_temp.p, tb, k_in.p, k_out.p, v_in.p, d_ent.p, (size_t)nres, 0u, 32u, stream));
+            }
         }
         // number of valid entries = first index with key >= KSPACE: the offsets kernel's last slot
         hipLaunchKernelGGL(kmer_offsets_kernel, grid_for((uint64_t)KSPACE + 1), dim3(256), 0, stream, k_out.p, nres, d_koff.p);
@@ -921,15 +1080,6 @@ void Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
     const uint64_t RUN_MAX = 1ull << 29;       // runs per batch (6 GiB + 6 GiB sort double buffer)
     double hits_per_res = 64.0;                // adaptive estimates
     uint64_t run_cap = 1ull << 20;
-    KeyFmt fmt;
-    {
-        const uint32_t m = std::min<uint32_t>(std::max<uint32_t>(max_len, 2), 65536u);
-        fmt.dbits = 1;
-        while ((1u << (fmt.dbits - 1)) < m) fmt.dbits++;
-        fmt.dbias = 1 << (fmt.dbits - 1);
-        fmt.tbits = 1;
-        while ((1u << fmt.tbits) < n) fmt.tbits++;
-    }
     DevBuf<uint32_t> &d_cnt = S.d_cnt, &d_flag = S.d_flag, &d_cq = S.d_cq, &d_ct = S.d_ct, &d_rpidx = S.d_rpidx, &d_rpidx2 = S.d_rpidx2, &d_qsurv = S.d_qsurv;
     DevBuf<uint64_t> &d_keys = S.d_keys, &d_keys2 = S.d_keys2, &d_pos = S.d_pos, &d_skey = S.d_skey, &d_skey2 = S.d_skey2, &d_rval = S.d_rval, &d_rval2 = S.d_rval2,
                      &d_qbase = S.d_qbase, &d_soff = S.d_soff;
@@ -987,7 +1137,6 @@ void Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
         uint64_t n_cand = 0;
         if (total_hits) {
             // pass 2: expand runs into keys (filtered to double hits when the rule allows), sort them
-            d_keys.reserve(total_hits);
             unsigned qbits = 1;
             while ((1u << qbits) < qb - qa) qbits++;
             const unsigned kbits = (unsigned)(fmt.dbits + fmt.tbits) + qbits;
@@ -1003,10 +1152,37 @@ void Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
                 temp_reserve(tb);
                 UC_HIP(rocprim::radix_sort_pairs(d_temp.p, tb, d_rpidx.p, d_rpidx2.p, d_rval.p, d_rval2.p, (size_t)n_runs, 0u, pbits, stream));
                 d_qbase.reserve(nq); d_qsurv.reserve(nq); d_soff.reserve((size_t)nq + 1);
-                static PerDeviceOnce once;
-                once([&] { UC_HIP(hipFuncSetAttribute((const void *)filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FILTER_LDS)); });
-                hipLaunchKernelGGL(filter_kernel, dim3(nq), dim3(FT), FILTER_LDS, stream, ddb, qa, qp0, d_rpidx2.p, d_rval2.p, n_runs, d_ent.p, fmt,
-                                   d_counters.p + 5, d_keys.p, total_hits, d_qbase.p, d_qsurv.p);
+                // the query regions hold (target, diagonal) keys: u32 in compact mode (half of the u64 buffer stays unused),
+                // every region rounded up to KPT keys
+                const uint64_t region_cap = total_hits + (uint64_t)KPT * nq;
+                d_keys.reserve(fmt.compact ? region_cap : 2 * region_cap);       // regions + survivor area of the same size
+                S.d_qr.reserve((size_t)nq + 1);
+                unsigned long long *prof_p = nullptr;
+                if (getenv("UC_FILTER_PROF")) { S.d_prof.reserve(8); prof_p = S.d_prof.p; UC_HIP(hipMemsetAsync(prof_p, 0, 64, stream)); }
+                hipLaunchKernelGGL(run_range_kernel, grid_for((uint64_t)nq + 1), dim3(256), 0, stream, ddb, qa, nq, qp0, d_rpidx2.p, n_runs, S.d_qr.p);
+                S.d_okey.reserve(nq); S.d_okey2.reserve(nq); S.d_oidx.reserve(nq); S.d_order.reserve(nq);
+                hipLaunchKernelGGL(run_order_key_kernel, grid_for(nq), dim3(256), 0, stream, nq, S.d_qr.p, S.d_okey.p, S.d_oidx.p);
+                UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, S.d_okey.p, S.d_okey2.p, S.d_oidx.p, S.d_order.p, (size_t)nq, 0u, 32u, stream));
+                temp_reserve(tb);
+                UC_HIP(rocprim::radix_sort_pairs(d_temp.p, tb, S.d_okey.p, S.d_okey2.p, S.d_oidx.p, S.d_order.p, (size_t)nq, 0u, 32u, stream));
+                if (fmt.compact) {
+                    static PerDeviceOnce once;
+                    once([&] { UC_HIP(hipFuncSetAttribute((const void *)filter_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FILTER_LDS)); });
+                    hipLaunchKernelGGL(filter_kernel<true>, dim3(nq), dim3(FT), FILTER_LDS, stream, ddb, qa, qp0, d_rpidx2.p, d_rval2.p, S.d_qr.p, S.d_order.p, ent_p, fmt,
+                                       d_counters.p + 5, (void *)d_keys.p, region_cap, d_qbase.p, d_qsurv.p, prof_p);
+                } else {
+                    static PerDeviceOnce once;
+                    once([&] { UC_HIP(hipFuncSetAttribute((const void *)filter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FILTER_LDS)); });
+                    hipLaunchKernelGGL(filter_kernel<false>, dim3(nq), dim3(FT), FILTER_LDS, stream, ddb, qa, qp0, d_rpidx2.p, d_rval2.p, S.d_qr.p, S.d_order.p, ent_p, fmt,
+                                       d_counters.p + 5, (void *)d_keys.p, region_cap, d_qbase.p, d_qsurv.p, prof_p);
+                }
+                if (prof_p) {
+                    unsigned long long hp[8];
+                    UC_HIP(hipMemcpyAsync(hp, prof_p, 64, hipMemcpyDeviceToHost, stream));
+                    UC_HIP(hipStreamSynchronize(stream));
+                    fprintf(stderr, "filter phases (sum over %u workgroups, 100 MHz ticks): clear+reserve %llu, tile loads %llu, expand %llu, sweep2 %llu, level2 %llu\n",
+                            nq, hp[0], hp[1], hp[2], hp[3], hp[4]);
+                }
                 auto sin = rocprim::make_transform_iterator(d_qsurv.p, WidenU32());
                 UC_HIP(rocprim::exclusive_scan(nullptr, tb, sin, d_soff.p, (uint64_t)0, (size_t)nq, rocprim::plus<uint64_t>(), stream));
                 temp_reserve(tb);
@@ -1017,19 +1193,24 @@ void Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
                 UC_HIP(hipStreamSynchronize(stream));
                 n_sort = lo + ls;
                 if (n_sort) {
-                    d_keys2.reserve(n_sort);
-                    hipLaunchKernelGGL(compact_kernel, dim3(std::min<uint32_t>(nq, 65535u)), dim3(256), 0, stream, d_keys.p, d_qbase.p, d_qsurv.p,
-                                       d_soff.p, nq, d_keys2.p);
-                    UC_HIP(rocprim::radix_sort_keys(nullptr, tb, d_keys2.p, d_keys.p, (size_t)n_sort, 0u, kbits, stream));
+                    d_keys2.reserve(2 * n_sort);              // dense keys + the sort's output
+                    if (fmt.compact)
+                        hipLaunchKernelGGL(compact_kernel<true>, dim3(std::min<uint32_t>(nq, 65535u)), dim3(256), 0, stream, (const void *)d_keys.p, d_qbase.p,
+                                           d_qsurv.p, d_soff.p, nq, fmt, d_keys2.p);
+                    else
+                        hipLaunchKernelGGL(compact_kernel<false>, dim3(std::min<uint32_t>(nq, 65535u)), dim3(256), 0, stream, (const void *)d_keys.p, d_qbase.p,
+                                           d_qsurv.p, d_soff.p, nq, fmt, d_keys2.p);
+                    UC_HIP(rocprim::radix_sort_keys(nullptr, tb, d_keys2.p, d_keys2.p + n_sort, (size_t)n_sort, 0u, kbits, stream));
                     temp_reserve(tb);
-                    UC_HIP(rocprim::radix_sort_keys(d_temp.p, tb, d_keys2.p, d_keys.p, (size_t)n_sort, 0u, kbits, stream));
+                    UC_HIP(rocprim::radix_sort_keys(d_temp.p, tb, d_keys2.p, d_keys2.p + n_sort, (size_t)n_sort, 0u, kbits, stream));
                 }
-                sorted = d_keys.p;
+                sorted = d_keys2.p + n_sort;
                 stats.n_filtered_hits += n_sort;
             } else {
+                d_keys.reserve(total_hits);
                 d_keys2.reserve(total_hits);
                 const RunList rl{d_rpidx.p, d_rval.p, run_cap};
-                hipLaunchKernelGGL(expand_kernel, grid_for(n_runs), dim3(256), 0, stream, ddb, qa, qb, qp0, rl, n_runs, d_ent.p, fmt,
+                hipLaunchKernelGGL(expand_kernel, grid_for(n_runs), dim3(256), 0, stream, ddb, qa, qb, qp0, rl, n_runs, ent_p, fmt,
                                    d_counters.p + 5, d_keys.p, total_hits);
                 UC_HIP(rocprim::radix_sort_keys(nullptr, tb, d_keys.p, d_keys2.p, (size_t)total_hits, 0u, kbits, stream));
                 temp_reserve(tb);
