@@ -12,7 +12,7 @@ also    : `value_disk_to_tsv` — SURVEY.md 8(d)'s definition: wall of uc_cluste
 workload: --config c2 (default) = BASELINE.json configs[1]: 50 synthetic proteomes (~150 k sequences), tools/gen_synth.c
           seed 0x5EED0002, "-c 0.8", the plain all-vs-all step (`--single-step-clustering` semantics);
           --config c3 = configs[2] (500 proteomes, seed 0x5EED0003); --config c4-lite = configs[3]'s options
-          ("-c 0.8 --min-seq-id 0.3 -s 7.5") on 500 proteomes (seed 0x5EED0004).
+          ("-c 0.8 --min-seq-id 0.3 -s 7.5") on 50 proteomes (seed 0x5EED0004).
 N > 1   : one process per GPU (torch.distributed.run).  The data path is inside the library: the target DB is range-
           partitioned across the ranks (Q x T grid, T = N by default = the north-star layout), the per-shard hit lists are
           all-gathered with RCCL over xGMI from C (uc_comm_*), merged on the device, every rank aligns the pairs it owns,
@@ -46,7 +46,9 @@ CONFIGS = {
     # name: (proteomes, families, len_scale, seed, options, label)
     "c2": (50, 6000, 1.0, 0x5EED0002, "-c 0.8", "BASELINE configs[1]"),
     "c3": (500, 6000, 1.0, 0x5EED0003, "-c 0.8", "BASELINE configs[2] on the GPUs given"),
-    "c4-lite": (500, 6000, 1.0, 0x5EED0004, "-c 0.8 --min-seq-id 0.3 -s 7.5", "BASELINE configs[3] options on 500 proteomes"),
+    # configs[3]'s options at the size one GPU finishes in half a minute: k-mer hits grow with the square of the database and
+    # -s 7.5 already gives ~23x the hits of -s 4 (100 proteomes: 78 s per pass, 500: ~50 min; tools/c4_probe.py)
+    "c4-lite": (50, 6000, 1.0, 0x5EED0004, "-c 0.8 --min-seq-id 0.3 -s 7.5", "BASELINE configs[3] options (-s 7.5, --min-seq-id 0.3) on 50 proteomes"),
 }
 
 

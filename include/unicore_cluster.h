@@ -133,6 +133,9 @@ int uc_engine_prefilter_range(uc_engine *e, uint32_t tbegin, uint32_t tend, uint
 /* hit lists live in the engine: counts[n_seqs], hits flat, grouped by query in query order */
 int uc_engine_hits_size(const uc_engine *e, uint64_t *n_hits);
 int uc_engine_hits_get(const uc_engine *e, uint32_t *counts, uc_hit *hits);
+/* the same for the queries [qbegin,qend) only: counts may be NULL; hits must hold the sum of their counts (at BASELINE
+ * configs[2] scale the whole list is gigabytes, a sample of queries is not) */
+int uc_engine_hits_get_range(const uc_engine *e, uint32_t qbegin, uint32_t qend, uint32_t *counts, uc_hit *hits);
 /* replace the engine's hit lists (counts[n_seqs] + flat hits grouped by query) */
 int uc_engine_hits_set(uc_engine *e, const uint32_t *counts, const uc_hit *hits);
 /* replace the engine's hit lists by the merge of n_parts shard lists (each: counts[n_seqs] + flat hits),

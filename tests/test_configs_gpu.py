@@ -1,0 +1,129 @@
+"""BASELINE.json configs[2] and configs[3] AT SIZE on the GPU (the toy-size variants live in test_gpu_parity.py):
+
+  c3       500 synthetic proteomes (1.58 M sequences, 475 M residues, seed 0x5EED0003), "-c 0.8": the full HIP path once;
+  c4-lite  configs[3]'s options "-c 0.8 --min-seq-id 0.3 -s 7.5" (deep prefilter: ~23x the k-mer hits of -s 4, traceback
+           statistics for every pair that passes the coverage gate) on 50 proteomes (159 k sequences, seed 0x5EED0004).
+           k-mer hits grow with the square of the database: 100 proteomes take 78 s per pass on one MI355X, 500 would take
+           ~50 min, so the suite runs the size that finishes in half a minute (tools/c4_probe.py has the measurements).
+
+For each: (a) the whole pipeline runs; (b) a contiguous block of queries recomputed by the plain path (--sw-kernel i32
+--sym-dedup 0: every directed pair on its own, int32 kernel) gives byte-identical hit lists and alignment records; (c) hit
+lists and alignment records of 2,000 random queries equal the CPU oracle's, computed against the FULL database (the
+oracle only needs the index and those queries); (d) the cluster TSV satisfies the consumer contract of profile.rs."""
+import os
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    "c3": dict(proteomes=500, seed=0x5EED0003, opts="-c 0.8", min_aln=300_000_000),
+    "c4-lite": dict(proteomes=50, seed=0x5EED0004, opts="-c 0.8 --min-seq-id 0.3 -s 7.5", min_aln=30_000_000),
+}
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle_py
+    return oracle_py
+
+
+@pytest.mark.parametrize("name", ["c3", "c4-lite"])
+def test_config_at_size(name, O, tmp_path_factory):
+    import unicore_amd as U
+    cfg = CONFIGS[name]
+    d = tmp_path_factory.mktemp(name.replace("-", "_"))
+    db = util.gen_synth_db(str(d / "db"), cfg["proteomes"], cfg["seed"], 6000, 1.0)
+    opts = cfg["opts"]
+
+    # (a) the full HIP path
+    e = U.Engine(opts, threads=16, verbosity=1)
+    e.load_db(db)
+    n = e.n
+    e.prefilter()
+    e.align()
+    st = e.stats()
+    assert st["n_gapped_alignments"] >= cfg["min_aln"] and st["n_gapped_alignments"] == e.hits_size()
+    edges = e.edges()
+    assign = e.setcover(edges)
+    n_clusters = int((assign == np.arange(n)).sum())
+    assert 0 < n_clusters < n
+
+    # (c) 2,000 random queries against the oracle at full database size
+    odb = O.OracleDb(db)
+    assert odb.n == n
+    p = util.oracle_params(O, opts)
+    ix = O.build_index(odb, p)
+    rng = np.random.default_rng(20260928)
+    sample = np.sort(rng.choice(n, 2000, replace=False)).astype(np.uint32)
+    n_pairs, _, _, ocnt, ohits, oalns = O.simd_sample_run(odb, ix, p, sample, threads=0, records=True)
+    O.free_index(ix)
+    assert n_pairs > 100_000
+    scalar_checks = 0
+    for k, q in enumerate(sample):
+        q = int(q)
+        cnt, hits = e.hits_range(q, q + 1)
+        al = e.alns_range(q, q + 1)
+        c = int(ocnt[k])
+        assert int(cnt[0]) == c, (name, q)
+        assert np.array_equal(hits["target"], ohits[k, :c]["t"]) and np.array_equal(hits["score"], ohits[k, :c]["score"]) \
+            and np.array_equal(hits["diag"], ohits[k, :c]["diag"]), (name, q)
+        ref = oalns[k, :c]
+        for f in ("score", "score_rev", "corrected", "pass_evalue", "accepted"):
+            assert np.array_equal(al[f], ref[f]), (name, q, f)
+        pe = ref["pass_evalue"] == 1
+        for f in ("qstart", "qend", "tstart", "tend"):
+            assert np.array_equal(al[f][pe], ref[f][pe]), (name, q, f)
+        acc = ref["accepted"] == 1
+        if p.min_seq_id > 0:
+            covered = ref["aln_len"] > 0                    # traceback statistics exist for every pair that passed the coverage gate
+            for f in ("aln_len", "idents"):
+                assert np.array_equal(al[f][covered], ref[f][covered]), (name, q, f)
+        # the SIMD checker itself against the scalar oracle on a few pairs of this run (it is proven equal on the CPU suite)
+        if k % 100 == 0 and c:
+            ms = O.min_score(odb, p, q)
+            for h in range(min(c, 3)):
+                s_ref = O.align_pair(odb, p, q, int(ohits[k, h]["t"]), ms)
+                assert s_ref["score"] == ref[h]["score"] and s_ref["accepted"] == ref[h]["accepted"] and s_ref["corrected"] == ref[h]["corrected"]
+                scalar_checks += 1
+        assert acc.sum() == (al["accepted"] == 1).sum()
+    assert scalar_checks > 20
+
+    # (b) a block of queries through the plain path: int32 kernel, no sharing between mutual hits
+    qb = n // 3
+    qe = qb + (1500 if name == "c3" else 4000)
+    cnt0, hits0 = e.hits_range(qb, qe)
+    al0 = e.alns_range(qb, qe)
+    plain = U.Engine(opts + " --sw-kernel i32 --sym-dedup 0", threads=16, verbosity=1)
+    plain.load_db(db)
+    plain.prefilter(0, n, qb, qe)
+    plain.align(qb, qe)
+    cnt1, hits1 = plain.hits_range(qb, qe)
+    al1 = plain.alns_range(qb, qe)
+    assert np.array_equal(cnt0, cnt1) and hits0.tobytes() == hits1.tobytes()
+    assert len(al0) == len(al1) > 10_000
+    for f in al0.dtype.names:
+        if f in ("qstart", "qend", "tstart", "tend"):
+            m = al1["pass_evalue"] == 1
+            assert np.array_equal(al0[f][m], al1[f][m]), (name, f)
+        elif f in ("aln_len", "idents"):
+            m = al1["aln_len"] > 0
+            assert np.array_equal(al0[f][m], al1[f][m]), (name, f)
+        elif f == "gap_opens":
+            continue                                        # only filled on the search path (want_tb)
+        else:
+            assert np.array_equal(al0[f], al1[f]), (name, f)
+    plain.close()
+
+    # (d) the TSV the consumer reads (profile.rs:50-55,79-84)
+    out = str(d / "clust")
+    assert U.lib().uc_write_cluster_db((out + "_cluster").encode(), n, assign.ctypes.data) == 0
+    U.createtsv(db, out + "_cluster", out + ".tsv")
+    names = [l.split("\t")[1] for l in open(db + ".lookup")]
+    rows = util.tsv_invariants(out + ".tsv", names)
+    assert len(rows) == n and len({r[0] for r in rows}) == n_clusters
+    e.close()
+    U.lib().uc_release_scratch()

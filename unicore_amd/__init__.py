@@ -50,7 +50,7 @@ SYMBOLS = (
     "uc_cluster", "uc_createtsv", "uc_rmdb", "uc_search", "uc_convertalis", "uc_last_error", "uc_version", "uc_check_options",
     "uc_option_arity", "uc_release_scratch", "uc_comm_unique_id", "uc_comm_create", "uc_comm_destroy", "uc_engine_cluster_step",
     "uc_engine_create", "uc_engine_destroy", "uc_engine_load_db", "uc_engine_set_db", "uc_engine_num_seqs",
-    "uc_engine_prefilter", "uc_engine_prefilter_range", "uc_engine_hits_size", "uc_engine_hits_get", "uc_engine_hits_set", "uc_engine_hits_merge",
+    "uc_engine_prefilter", "uc_engine_prefilter_range", "uc_engine_hits_size", "uc_engine_hits_get", "uc_engine_hits_get_range", "uc_engine_hits_set", "uc_engine_hits_merge",
     "uc_engine_hits_export_dev", "uc_engine_hits_import_dev", "uc_engine_setcover",
     "uc_hits_merge", "uc_engine_align", "uc_engine_alns_get", "uc_engine_edges_size", "uc_engine_edges_get",
     "uc_engine_stats", "uc_engine_reset_stats", "uc_setcover", "uc_write_cluster_db",
@@ -100,6 +100,7 @@ def lib():
     L.uc_engine_prefilter.argtypes = [vp, u32, u32]
     L.uc_engine_hits_size.argtypes = [vp, C.POINTER(u64)]
     L.uc_engine_hits_get.argtypes = [vp, vp, vp]
+    L.uc_engine_hits_get_range.argtypes = [vp, u32, u32, vp, vp]
     L.uc_engine_hits_set.argtypes = [vp, vp, vp]
     L.uc_engine_hits_merge.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]
     L.uc_engine_hits_export_dev.argtypes = [vp, vp, vp, vp, vp]
@@ -268,6 +269,25 @@ class Engine:
         hits = np.zeros(max(nh.value, 1), HIT_DTYPE)
         _check(lib().uc_engine_hits_get(self._h, counts.ctypes.data, hits.ctypes.data))
         return counts, hits[: nh.value]
+
+    def hits_range(self, qbegin, qend):
+        """(counts, hits) of the queries [qbegin, qend) only"""
+        counts = np.zeros(max(qend - qbegin, 1), np.uint32)
+        _check(lib().uc_engine_hits_get_range(self._h, qbegin, qend, counts.ctypes.data, None))
+        counts = counts[: qend - qbegin]
+        k = int(counts.sum())
+        hits = np.zeros(max(k, 1), HIT_DTYPE)
+        _check(lib().uc_engine_hits_get_range(self._h, qbegin, qend, None, hits.ctypes.data))
+        return counts, hits[:k]
+
+    def alns_range(self, qbegin, qend):
+        """alignment records of the queries [qbegin, qend) only (one per hit, in hit order)"""
+        counts, _ = np.zeros(max(qend - qbegin, 1), np.uint32), None
+        _check(lib().uc_engine_hits_get_range(self._h, qbegin, qend, counts.ctypes.data, None))
+        k = int(counts[: qend - qbegin].sum())
+        out = np.zeros(max(k, 1), ALN_DTYPE)
+        _check(lib().uc_engine_alns_get(self._h, qbegin, qend, out.ctypes.data))
+        return out[:k]
 
     def set_hits(self, counts, hits):
         counts = np.ascontiguousarray(counts, np.uint32)

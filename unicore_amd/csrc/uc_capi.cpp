@@ -171,6 +171,18 @@ int uc_engine_hits_get(const uc_engine *e, uint32_t *counts, uc_hit *hits) {
     });
 }
 
+int uc_engine_hits_get_range(const uc_engine *e, uint32_t qbegin, uint32_t qend, uint32_t *counts, uc_hit *hits) {
+    return guard([&] {
+        require(e, "engine");
+        const Engine &E = *e->e;
+        if (!E.have_db) fail(UC_ERR_ARGS, "hits_get_range: no database loaded");
+        if (qbegin > qend || qend > E.hdb.n) fail(UC_ERR_ARGS, "hits_get_range: bad query range");
+        if (counts && qend > qbegin) memcpy(counts, E.hit_cnt.data() + qbegin, (size_t)(qend - qbegin) * 4);
+        const uint64_t b = E.hit_off[qbegin], k = E.hit_off[qend] - b;
+        if (hits && k) E.get_hits_range(b, k, hits);
+    });
+}
+
 int uc_hits_merge(uint32_t n_seqs, int32_t max_seqs, int n_parts, const uint32_t *const *counts, const uc_hit *const *hits,
                   uint32_t *out_counts, uc_hit *out_hits, uint64_t out_capacity, uint64_t *out_n) {
     return guard([&] {

@@ -171,15 +171,18 @@ void Engine::set_hits(const uint32_t *counts, const uc_hit *h, bool check_max_se
     edges.clear();
 }
 
-void Engine::get_hits(uc_hit *out) const {
-    if (!n_hits) return;
+void Engine::get_hits(uc_hit *out) const { get_hits_range(0, n_hits, out); }
+
+void Engine::get_hits_range(uint64_t begin, uint64_t k, uc_hit *out) const {
+    if (!k) return;
+    if (begin + k > n_hits) fail(UC_ERR_ARGS, "get_hits_range: range outside the hit lists");
     UC_HIP(hipSetDevice(device));
-    std::vector<uint32_t> ht(n_hits);
-    std::vector<int32_t> hs(n_hits), hd(n_hits);
-    UC_HIP(hipMemcpy(ht.data(), d_ht.p, n_hits * 4, hipMemcpyDeviceToHost));
-    UC_HIP(hipMemcpy(hs.data(), d_hs.p, n_hits * 4, hipMemcpyDeviceToHost));
-    UC_HIP(hipMemcpy(hd.data(), d_hd.p, n_hits * 4, hipMemcpyDeviceToHost));
-    for (uint64_t k = 0; k < n_hits; k++) { out[k].target = ht[k]; out[k].score = hs[k]; out[k].diag = hd[k]; }
+    std::vector<uint32_t> ht(k);
+    std::vector<int32_t> hs(k), hd(k);
+    UC_HIP(hipMemcpy(ht.data(), d_ht.p + begin, k * 4, hipMemcpyDeviceToHost));
+    UC_HIP(hipMemcpy(hs.data(), d_hs.p + begin, k * 4, hipMemcpyDeviceToHost));
+    UC_HIP(hipMemcpy(hd.data(), d_hd.p + begin, k * 4, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < k; i++) { out[i].target = ht[i]; out[i].score = hs[i]; out[i].diag = hd[i]; }
 }
 
 void Engine::get_alns(uint64_t begin, uint64_t n, uc_aln *out) const {

@@ -120,12 +120,14 @@ struct Engine {
     void upload_db();
     // E1-E4: index targets [tbegin,tend), match queries [qbegin,qend) (default: all) against it       (uc_prefilter.hip)
     void prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin = 0, uint32_t qend = UINT32_MAX);
-    void prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend, bool count_sims);   // one target chunk
+    bool prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend, bool count_sims, double density_limit = 0.0,
+                       double *density_out = nullptr);   // one target chunk
     PrefilterScratch *pre = nullptr;                       // work buffers kept between prefilter calls
     AlignScratch *aln = nullptr;                           // ... and between align calls
     uint64_t prefilter_chunk_residues = 96ull << 20;   // target residues per index chunk (keeps hits/query inside the LDS filter)
     void set_hits(const uint32_t *counts, const uc_hit *h, bool check_max_seqs = true);
     void get_hits(uc_hit *out) const;                        // D2H of the device hit arrays
+    void get_hits_range(uint64_t begin, uint64_t k, uc_hit *out) const;
     void export_hits_dev(uint32_t *dq, uint32_t *dt, int32_t *ds, int32_t *dd) const;
     uint64_t import_hits_dev(uint64_t n, const uint32_t *dq, const uint32_t *dt, const int32_t *ds, const int32_t *dd,
                              uint32_t rank, uint32_t world);

@@ -952,49 +952,71 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t
     if (qbegin > qend || qend > hdb.n) fail(UC_ERR_ARGS, "prefilter: bad query range");
     uint64_t chunk_res = prefilter_chunk_residues;
     if (const char *ev = getenv("UC_PREFILTER_CHUNK_RES")) chunk_res = std::max<uint64_t>(1, strtoull(ev, nullptr, 10));
-    std::vector<std::pair<uint32_t, uint32_t>> chunks;
-    for (uint32_t b = tbegin; b < tend;) {
-        uint32_t e = b;
-        uint64_t res = 0;
-        while (e < tend && (e == b || res + h_len[e] <= chunk_res)) res += h_len[e++];
-        chunks.emplace_back(b, e);
-        b = e;
-    }
-    if (chunks.size() <= 1) {
-        prefilter_one(tbegin, tend, qbegin, qend, true);
-        stats.n_prefilter_hits += n_hits;
-        return;
-    }
-    DevBuf<uint32_t> aq, at, tq, tt;
-    DevBuf<int32_t> as, ad, ts, td;
-    uint64_t acc_n = 0;
-    for (size_t c = 0; c < chunks.size(); c++) {
-        prefilter_one(chunks[c].first, chunks[c].second, qbegin, qend, c == 0);
-        if (c == 0 || acc_n == 0) {
-            aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd);
-            acc_n = n_hits;
-        } else if (n_hits) {
-            const uint64_t tot = acc_n + n_hits;
-            tq.reserve(tot); tt.reserve(tot); ts.reserve(tot); td.reserve(tot);
-            UC_HIP(hipMemcpyAsync(tq.p, aq.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
-            UC_HIP(hipMemcpyAsync(tt.p, at.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
-            UC_HIP(hipMemcpyAsync(ts.p, as.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
-            UC_HIP(hipMemcpyAsync(td.p, ad.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
-            UC_HIP(hipMemcpyAsync(tq.p + acc_n, d_hq.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-            UC_HIP(hipMemcpyAsync(tt.p + acc_n, d_ht.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-            UC_HIP(hipMemcpyAsync(ts.p + acc_n, d_hs.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-            UC_HIP(hipMemcpyAsync(td.p + acc_n, d_hd.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-            UC_HIP(hipStreamSynchronize(stream));
-            acc_n = import_hits_dev(tot, tq.p, tt.p, ts.p, td.p, 0, 1);      // merge + truncate to max_seqs
-            aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd);
+    // The chunk size that keeps a query's hits inside the LDS filter depends on how many k-mer hits a target residue
+    // attracts, i.e. on the sensitivity (-s 7.5 gives ~30x the hits of the default 4): prefilter_one measures the density
+    // (k-mer hits per query residue) of its first batch and gives up before expanding anything if the chunk is too dense;
+    // the range is then re-cut into proportionally smaller chunks (one wasted enumeration pass).
+    const double DENSITY_LIMIT = 400.0;           // hits per query residue and chunk (C2 whole DB at -s 4: 124)
+    for (int attempt = 0;; attempt++) {
+        std::vector<std::pair<uint32_t, uint32_t>> chunks;
+        for (uint32_t b = tbegin; b < tend;) {
+            uint32_t e = b;
+            uint64_t res = 0;
+            while (e < tend && (e == b || res + h_len[e] <= chunk_res)) res += h_len[e++];
+            chunks.emplace_back(b, e);
+            b = e;
         }
+        double density = 0;
+        const double limit = attempt < 6 ? DENSITY_LIMIT : 0.0;      // after 6 re-cuts: run with what we have
+        bool ok = true;
+        if (chunks.size() <= 1) {
+            ok = prefilter_one(tbegin, tend, qbegin, qend, true, limit, &density);
+            if (ok) { stats.n_prefilter_hits += n_hits; return; }
+        } else {
+            DevBuf<uint32_t> aq, at, tq, tt;
+            DevBuf<int32_t> as, ad, ts, td;
+            uint64_t acc_n = 0;
+            for (size_t c = 0; c < chunks.size() && ok; c++) {
+                ok = prefilter_one(chunks[c].first, chunks[c].second, qbegin, qend, c == 0, c == 0 ? limit : 0.0, &density);
+                if (!ok) break;
+                if (c == 0 || acc_n == 0) {
+                    aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd);
+                    acc_n = n_hits;
+                } else if (n_hits) {
+                    const uint64_t tot = acc_n + n_hits;
+                    tq.reserve(tot); tt.reserve(tot); ts.reserve(tot); td.reserve(tot);
+                    UC_HIP(hipMemcpyAsync(tq.p, aq.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipMemcpyAsync(tt.p, at.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipMemcpyAsync(ts.p, as.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipMemcpyAsync(td.p, ad.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipMemcpyAsync(tq.p + acc_n, d_hq.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipMemcpyAsync(tt.p + acc_n, d_ht.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipMemcpyAsync(ts.p + acc_n, d_hs.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipMemcpyAsync(td.p + acc_n, d_hd.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipStreamSynchronize(stream));
+                    acc_n = import_hits_dev(tot, tq.p, tt.p, ts.p, td.p, 0, 1);      // merge + truncate to max_seqs
+                    aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd);
+                }
+            }
+            if (ok) {
+                // install the accumulated lists (also rebuilds the per-query counts)
+                import_hits_dev(acc_n, aq.p, at.p, as.p, ad.p, 0, 1);
+                stats.n_prefilter_hits += n_hits;
+                return;
+            }
+        }
+        // too dense: smaller chunks, proportionally (and a little more)
+        const uint64_t cur = std::min<uint64_t>(chunk_res, std::max<uint64_t>(1, (uint64_t)h_poff[chunks[0].second] - h_poff[chunks[0].first]));
+        chunk_res = std::max<uint64_t>(1u << 16, (uint64_t)((double)cur * DENSITY_LIMIT / density * 0.75));
+        logf(3, "unicore-cluster: prefilter: %.0f k-mer hits per query residue in a chunk of %llu residues; re-cutting the targets into chunks of %llu\n",
+             density, (unsigned long long)cur, (unsigned long long)chunk_res);
     }
-    // install the accumulated lists (also rebuilds the per-query counts)
-    import_hits_dev(acc_n, aq.p, at.p, as.p, ad.p, 0, 1);
-    stats.n_prefilter_hits += n_hits;
 }
 
-void Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend, bool count_sims) {
+// returns false (nothing installed) if density_limit > 0 and the first query batch exceeds it; *density_out = k-mer hits
+// per query residue of that batch
+bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend, bool count_sims, double density_limit,
+                           double *density_out) {
     UC_HIP(hipSetDevice(device));
     const uint32_t n = hdb.n;
     KmerCfg cfg;
@@ -1101,7 +1123,7 @@ void Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
                 qb++;
             }
         }
-        uint64_t total_hits = 0, n_runs = 0;
+        uint64_t total_hits = 0, n_runs = 0, sims_this_batch = 0;
         uint32_t qp0 = 0, qp1 = 0, nq_res = 0;
         for (;;) {   // pass 1: runs + exact hit count; shrink the batch / grow the run list if it does not fit
             qp0 = h_poff[qa]; qp1 = h_poff[qb]; nq_res = qp1 - qp0;
@@ -1128,8 +1150,19 @@ void Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
                 qb = qa + std::max<uint32_t>(1, (qb - qa) / 2);
                 continue;
             }
+            sims_this_batch = count_sims ? c5[0] : 0;
             if (count_sims) stats.n_sim_kmers += c5[0];
             break;
+        }
+        if (density_out && qa == qbegin) *density_out = (double)total_hits / std::max<uint32_t>(1, nq_res);
+        if (density_limit > 0 && qa == qbegin && p.min_diag_hits >= 2 && tend - tbegin > 1 &&
+            (double)total_hits / std::max<uint32_t>(1, nq_res) > density_limit) {
+            // undo what this abandoned attempt counted
+            if (count_sims) stats.n_sim_kmers -= std::min<uint64_t>(stats.n_sim_kmers, sims_this_batch);
+            stats.n_index_entries -= n_entries;
+            stats.algorithmic_bytes[UC_ST_INDEX] -= 6ull * n_entries + 8ull * KSPACE;
+            stats.prefilter_kernel_ms += gpu_ms + timed_ms_end();
+            return false;
         }
         if (total_hits > (1ull << 34)) fail(UC_ERR_GENERIC, "query %u alone produces %llu k-mer hits", qa, (unsigned long long)total_hits);
         hits_per_res = std::max(1.0, (double)total_hits / std::max<uint32_t>(1, nq_res)) * 1.25;
@@ -1306,6 +1339,7 @@ void Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
     stats.stage_seconds[UC_ST_UNGAPPED] += t_ung;
     stats.stage_seconds[UC_ST_SELECT] += t_sel;
     stats.prefilter_kernel_ms += gpu_ms;
+    return true;
 }
 
 void Engine::export_hits_dev(uint32_t *dq, uint32_t *dt, int32_t *ds, int32_t *dd) const {
