@@ -88,6 +88,25 @@ int uc_search(const char *query_db, const char *target_db, const char *out_aln_d
 /* == `foldseek convertalis --threads T <queryDB> <targetDB> <out>_aln <out>.m8`    (search.rs:52-57) */
 int uc_convertalis(const char *query_db, const char *target_db, const char *aln_db, const char *out_m8, const uc_opts *o);
 
+/* ---- createdb's GPU stage (BASELINE configs[4]): ProstT5 AA -> 3Di on the matrix cores ---------------
+ * == `foldseek createdb <fasta> <db> --prostt5-model <dir> [--gpu 1]` (src/modules/createdb.rs:157-166).  `model` is the
+ * GGUF file or the directory holding prostt5-f16.gguf (createdb.rs:148).  Writes <db>, <db>_h, <db>_ss (predicted 3Di) with
+ * their .index / .dbtype and <db>.lookup: the files uc_cluster / uc_search read.  Several FASTA files: one path per entry. */
+typedef struct uc_t5_stats {
+    uint64_t n_seqs, n_tokens;       /* tokens = residues + 2 per sequence (<AA2fold> ... </s>) */
+    double flops;                    /* algorithmic FLOPs of the linear layers + attention */
+    double gpu_ms;                   /* HIP-event time of the encoder passes */
+} uc_t5_stats;
+int uc_createdb(const char *const *fasta_paths, int n_fasta, const char *out_db, const char *model, const uc_opts *o, uc_t5_stats *stats_out);
+/* the encoder alone (no disk round trip: the codes go straight into uc_engine_set_db): */
+typedef struct uc_t5 uc_t5;
+int uc_t5_load(const char *model, int32_t device, uc_t5 **out);
+void uc_t5_free(uc_t5 *m);
+/* n sequences as residue letters, off[n + 1] byte offsets into aa; codes (one 3Di state 0..19 per residue, same offsets);
+ * logits (nullable): 20 floats per residue */
+int uc_t5_encode(uc_t5 *m, uint32_t n, const uint64_t *off, const char *aa, uint8_t *codes, float *logits);
+int uc_t5_get_stats(const uc_t5 *m, uc_t5_stats *out);
+
 const char *uc_last_error(void);
 const char *uc_version(void);
 /* validates a Foldseek-style option string without running anything (0 or UC_ERR_ARGS) */

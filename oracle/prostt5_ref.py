@@ -1,0 +1,213 @@
+"""prostt5_ref.py — fp32 PyTorch restatement of the ProstT5 AA -> 3Di encoder + the GGUF reader/writer the tests use.
+TEST INFRASTRUCTURE (oracle/): nothing in the product imports it.
+
+PARITY UNPINNED.  The reference reaches this computation through `foldseek createdb --prostt5-model`
+(/root/reference/src/modules/createdb.rs:157-166); Foldseek and the ProstT5 weights (prostt5-f16.gguf, downloaded at run
+time, createdb.rs:148-155) are absent here, so what is restated is the PUBLISHED architecture:
+  * T5 encoder as in Raffel et al. 2020 / HuggingFace transformers `T5Stack` (ProtT5-XL-U50 geometry: 24 blocks,
+    d_model 1024, 32 heads x 128, d_ff 16384, ReLU, T5LayerNorm = RMS norm without bias, relative-position bias of block 0
+    shared by all blocks, 32 buckets / max distance 128, bidirectional, no 1/sqrt(d) scaling), Elnaggar et al. 2021;
+  * ProstT5's 3Di head (Heinzinger et al. 2023, github.com/mheinzinger/ProstT5 `CNN`): Conv(1024 -> 32, k = 7, pad 3),
+    ReLU, Conv(32 -> 20, k = 7, pad 3), argmax over the 20 classes = 3Di states in alphabetical letter order;
+  * input = "<AA2fold>" + residues + "</s>", the prediction of the residue positions is kept.
+The weights used by the tests and the benchmark are SEEDED SYNTHETIC ones written as GGUF by write_synthetic_gguf();
+a real prostt5-f16.gguf drops into the same loader (tensor names: llama.cpp's t5encoder convention, aliases in
+unicore_amd/csrc/uc_t5.cpp; the CNN head's tensor names inside Foldseek's file are EXT-UNVERIFIED).
+Tolerance of the HIP path against this fp32 restatement (f16 operands, fp32 accumulation): see tests/test_t5.py.
+"""
+import math
+import struct
+
+import numpy as np
+
+GGUF_MAGIC = 0x46554747
+AA_ORDER = "ALGVSREDTIPKFQNYMHWCXBOUZ"          # ProtT5 sentencepiece order, ids 3..27
+
+
+def default_config(**kw):
+    cfg = dict(vocab=150, d_model=1024, d_kv=128, n_heads=32, d_ff=16384, n_layers=24, rel_buckets=32, rel_max_dist=128, eps=1e-6,
+               cnn_hidden=32, cnn_kernel=7, n_out=20, prefix_token=149, eos_token=1)
+    cfg.update(kw)
+    return cfg
+
+
+# ---------------------------------------------------------------------------------------------- GGUF
+def _w_str(f, s):
+    b = s.encode()
+    f.write(struct.pack("<Q", len(b)))
+    f.write(b)
+
+
+def write_gguf(path, kv, tensors, alignment=32):
+    """kv: {key: int | float | str | [str]}; tensors: [(name, np.ndarray float16/float32 in torch (row-major) shape)]"""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<IIQQ", GGUF_MAGIC, 3, len(tensors), len(kv)))
+        for k, v in kv.items():
+            _w_str(f, k)
+            if isinstance(v, str):
+                f.write(struct.pack("<I", 8)); _w_str(f, v)
+            elif isinstance(v, list):
+                f.write(struct.pack("<IIQ", 9, 8, len(v)))
+                for s in v:
+                    _w_str(f, s)
+            elif isinstance(v, float):
+                f.write(struct.pack("<If", 6, v))
+            else:
+                f.write(struct.pack("<II", 4, int(v)))
+        off = 0
+        metas = []
+        for name, a in tensors:
+            a = np.ascontiguousarray(a)
+            t = 1 if a.dtype == np.float16 else 0
+            metas.append((name, a, t, off))
+            off += (a.nbytes + alignment - 1) // alignment * alignment
+        for name, a, t, o in metas:
+            _w_str(f, name)
+            f.write(struct.pack("<I", a.ndim))
+            for d in reversed(a.shape):                     # ggml: ne[0] is the contiguous dimension
+                f.write(struct.pack("<Q", d))
+            f.write(struct.pack("<IQ", t, o))
+        pos = f.tell()
+        f.write(b"\0" * ((pos + alignment - 1) // alignment * alignment - pos))
+        for name, a, t, o in metas:
+            f.write(a.tobytes())
+            f.write(b"\0" * ((a.nbytes + alignment - 1) // alignment * alignment - a.nbytes))
+
+
+def read_gguf(path):
+    """-> (kv, {name: np.ndarray in torch shape})"""
+    buf = open(path, "rb").read()
+    p = 0
+
+    def g(fmt):
+        nonlocal p
+        v = struct.unpack_from("<" + fmt, buf, p)
+        p += struct.calcsize("<" + fmt)
+        return v[0] if len(v) == 1 else v
+
+    def s():
+        nonlocal p
+        n = g("Q")
+        v = buf[p:p + n].decode()
+        p += n
+        return v
+    magic, ver, nt, nkv = g("IIQQ")
+    assert magic == GGUF_MAGIC
+    scal = {0: "B", 1: "b", 2: "H", 3: "h", 4: "I", 5: "i", 6: "f", 7: "B", 10: "Q", 11: "q", 12: "d"}
+    kv = {}
+    for _ in range(nkv):
+        k = s()
+        t = g("I")
+        if t == 8:
+            kv[k] = s()
+        elif t == 9:
+            et, cnt = g("I"), g("Q")
+            kv[k] = [s() if et == 8 else g(scal[et]) for _ in range(cnt)]
+        else:
+            kv[k] = g(scal[t])
+    metas = []
+    for _ in range(nt):
+        name = s()
+        nd = g("I")
+        ne = [g("Q") for _ in range(nd)]
+        t, o = g("I"), g("Q")
+        metas.append((name, ne, t, o))
+    al = kv.get("general.alignment", 32)
+    base = (p + al - 1) // al * al
+    out = {}
+    for name, ne, t, o in metas:
+        dt = np.float16 if t == 1 else np.float32
+        n = int(np.prod(ne))
+        out[name] = np.frombuffer(buf, dt, n, base + o).reshape(list(reversed(ne)))
+    return kv, out
+
+
+def write_synthetic_gguf(path, cfg, seed=0x5EED0005, f16=True, with_vocab=True):
+    """Seeded random-init weights of the given geometry in llama.cpp's t5encoder naming (+ cnn.* for the 3Di head).
+    Scales keep activations O(1) through the stack so that the argmax is not degenerate."""
+    rng = np.random.default_rng(seed)
+    D, HD, F = cfg["d_model"], cfg["n_heads"] * cfg["d_kv"], cfg["d_ff"]
+    wt = np.float16 if f16 else np.float32
+
+    def mat(rows, cols, scale):
+        return (rng.standard_normal((rows, cols), dtype=np.float32) * scale).astype(wt)
+    tensors = [("token_embd.weight", mat(cfg["vocab"], D, 1.0))]
+    for l in range(cfg["n_layers"]):
+        b = "enc.blk.%d." % l
+        tensors += [(b + "attn_norm.weight", (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32)),
+                    (b + "attn_q.weight", mat(HD, D, 0.3 / math.sqrt(D))), (b + "attn_k.weight", mat(HD, D, 1.0 / math.sqrt(D))),
+                    (b + "attn_v.weight", mat(HD, D, 1.0 / math.sqrt(D))), (b + "attn_o.weight", mat(D, HD, 1.0 / math.sqrt(HD))),
+                    (b + "ffn_norm.weight", (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32)),
+                    (b + "ffn_up.weight", mat(F, D, 1.0 / math.sqrt(D))), (b + "ffn_down.weight", mat(D, F, 1.0 / math.sqrt(F)))]
+        if l == 0:
+            tensors.append((b + "attn_rel_b.weight", (rng.standard_normal((cfg["rel_buckets"], cfg["n_heads"])) * 0.5).astype(np.float32)))
+    tensors += [("enc.output_norm.weight", (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32)),
+                ("cnn.conv1.weight", (rng.standard_normal((cfg["cnn_hidden"], D, cfg["cnn_kernel"])) / math.sqrt(D * cfg["cnn_kernel"])).astype(np.float32)),
+                ("cnn.conv1.bias", (0.1 * rng.standard_normal(cfg["cnn_hidden"])).astype(np.float32)),
+                ("cnn.conv2.weight", (rng.standard_normal((cfg["n_out"], cfg["cnn_hidden"], cfg["cnn_kernel"])) / math.sqrt(cfg["cnn_hidden"])).astype(np.float32)),
+                ("cnn.conv2.bias", (0.1 * rng.standard_normal(cfg["n_out"])).astype(np.float32))]
+    a = "t5encoder"
+    kv = {"general.architecture": a, a + ".embedding_length": D, a + ".feed_forward_length": F, a + ".block_count": cfg["n_layers"],
+          a + ".attention.head_count": cfg["n_heads"], a + ".attention.key_length": cfg["d_kv"], a + ".attention.relative_buckets_count": cfg["rel_buckets"],
+          a + ".attention.relative_max_distance": cfg["rel_max_dist"], a + ".attention.layer_norm_epsilon": float(cfg["eps"])}
+    if with_vocab:
+        toks = ["<pad>", "</s>", "<unk>"] + ["▁" + c for c in AA_ORDER]
+        toks += ["<extra_%d>" % i for i in range(cfg["vocab"] - len(toks) - 2)] + ["<fold2AA>", "<AA2fold>"]
+        assert len(toks) == cfg["vocab"]
+        kv["tokenizer.ggml.tokens"] = toks
+    write_gguf(path, kv, tensors)
+
+
+# ---------------------------------------------------------------------------------------------- the fp32 restatement
+def tokenize(seq, cfg):
+    ids = {c: 3 + i for i, c in enumerate(AA_ORDER)}
+    x = ids["X"]
+    return [cfg["vocab"] - 1 if cfg.get("prefix_token") is None else cfg["prefix_token"]] + [ids.get(c.upper(), x) for c in seq] + [cfg["eos_token"]]
+
+
+def relative_position_bucket(rel, num_buckets, max_distance):
+    """transformers T5Attention._relative_position_bucket(bidirectional=True), verbatim semantics (float32 log)"""
+    import torch
+    nb = num_buckets // 2
+    ret = (rel > 0).to(torch.long) * nb
+    n = torch.abs(rel)
+    max_exact = nb // 2
+    is_small = n < max_exact
+    large = max_exact + (torch.log(n.float() / max_exact) / math.log(max_distance / max_exact) * (nb - max_exact)).to(torch.long)
+    large = torch.min(large, torch.full_like(large, nb - 1))
+    return ret + torch.where(is_small, n, large)
+
+
+def forward(weights, cfg, seq, dtype=None, run_layers=None, part=3):
+    """fp32 (or `dtype`) forward of one sequence -> (logits [L, n_out] float32 numpy, codes uint8 [L])"""
+    import torch
+    dt = dtype or torch.float32
+    W = {k: torch.from_numpy(np.array(v, dtype=np.float32)).to(dt) for k, v in weights.items()}
+    tok = torch.tensor(tokenize(seq, cfg), dtype=torch.long)
+    L = len(tok)
+    H, dk = cfg["n_heads"], cfg["d_kv"]
+    h = W["token_embd.weight"][tok]
+
+    def rms(x, w):
+        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + cfg["eps"]) * w
+    pos = torch.arange(L)
+    bucket = relative_position_bucket(pos[None, :] - pos[:, None], cfg["rel_buckets"], cfg["rel_max_dist"])      # [query, key]: key - query
+    bias = W["enc.blk.0.attn_rel_b.weight"][bucket].permute(2, 0, 1)                                            # [H, L, L]
+    for l in range(cfg["n_layers"] if run_layers is None else run_layers):
+        b = "enc.blk.%d." % l
+        x = rms(h, W[b + "attn_norm.weight"])
+        q = (x @ W[b + "attn_q.weight"].T).view(L, H, dk).transpose(0, 1)
+        k = (x @ W[b + "attn_k.weight"].T).view(L, H, dk).transpose(0, 1)
+        v = (x @ W[b + "attn_v.weight"].T).view(L, H, dk).transpose(0, 1)
+        p = torch.softmax((q @ k.transpose(1, 2) + bias).float(), dim=-1).to(dt)
+        if part & 1:
+            h = h + (p @ v).transpose(0, 1).reshape(L, H * dk) @ W[b + "attn_o.weight"].T
+        x = rms(h, W[b + "ffn_norm.weight"])
+        if part & 2:
+            h = h + torch.relu(x @ W[b + "ffn_up.weight"].T) @ W[b + "ffn_down.weight"].T
+    x = rms(h, W["enc.output_norm.weight"])[1:]               # ProstT5 predict_3Di: the <AA2fold> prefix is sliced off BEFORE the CNN
+    pad = cfg["cnn_kernel"] // 2
+    y = torch.nn.functional.conv1d(x.T[None], W["cnn.conv1.weight"], W["cnn.conv1.bias"], padding=pad)
+    y = torch.nn.functional.conv1d(torch.relu(y), W["cnn.conv2.weight"], W["cnn.conv2.bias"], padding=pad)[0].T     # [L - 1, n_out]: residues + </s>
+    logits = y[:-1].float().numpy()                            # ... and the </s> position is dropped after it
+    return logits, logits.argmax(-1).astype(np.uint8)

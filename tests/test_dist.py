@@ -100,17 +100,18 @@ def _rank_main(rank, world, port, tmpdir, target_shards):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("target_shards", [2, 1])      # two target shards / two query groups
-def test_two_rank_gloo_exchange_matches_single_rank(tmp_path, target_shards):
+@pytest.mark.parametrize("world,target_shards", [(2, 2), (2, 1), (4, 2)])      # two target shards / two query groups / a Q2 x T2 grid
+def test_gloo_exchange_matches_single_rank(tmp_path, world, target_shards):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_rank_main, args=(2, port, str(tmp_path), target_shards), nprocs=2, join=True)
+    mp.spawn(_rank_main, args=(world, port, str(tmp_path), target_shards), nprocs=world, join=True)
     s3, sa = util.family_db(23, n_fam=7, members=5, lmin=40, lmax=120)
     odb = O.OracleDb(s3=s3, sa=sa)
     p = util.oracle_params(O, "-c 0.8 --max-seqs 5")
     ref = O.cluster(odb, p, threads=2)
-    h0, h1 = np.load(tmp_path / "hits0.npy"), np.load(tmp_path / "hits1.npy")
-    assert np.array_equal(h0, h1)                                                         # every rank holds the same merged lists
+    h0 = np.load(tmp_path / "hits0.npy")
+    for r in range(1, world):
+        assert np.array_equal(h0, np.load(tmp_path / ("hits%d.npy" % r)))                 # every rank holds the same merged lists
     flat = np.concatenate([ref["hits"][q, : ref["hit_cnt"][q]] for q in range(odb.n)])
     assert np.array_equal(h0["target"], flat["t"]) and np.array_equal(h0["score"], flat["score"])
     assert np.array_equal(np.load(tmp_path / "rank1.npy"), ref["hit_cnt"])

@@ -41,6 +41,10 @@ class UcStats(C.Structure):
         return d
 
 
+class UcT5Stats(C.Structure):
+    _fields_ = [("n_seqs", C.c_uint64), ("n_tokens", C.c_uint64), ("flops", C.c_double), ("gpu_ms", C.c_double)]
+
+
 HIT_DTYPE = np.dtype([("target", "<u4"), ("score", "<i4"), ("diag", "<i4")])
 ALN_DTYPE = np.dtype([(n, "<i4") for n in ("score", "score_rev", "corrected", "qstart", "qend", "tstart", "tend",
                                             "aln_len", "idents", "pass_evalue", "accepted", "gap_opens")])
@@ -48,7 +52,7 @@ ALN_DTYPE = np.dtype([(n, "<i4") for n in ("score", "score_rev", "corrected", "q
 # every symbol include/unicore_cluster.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "uc_cluster", "uc_createtsv", "uc_rmdb", "uc_search", "uc_convertalis", "uc_last_error", "uc_version", "uc_check_options",
-    "uc_option_arity", "uc_release_scratch", "uc_comm_unique_id", "uc_comm_create", "uc_comm_destroy", "uc_engine_cluster_step",
+    "uc_option_arity", "uc_release_scratch", "uc_createdb", "uc_t5_load", "uc_t5_free", "uc_t5_encode", "uc_t5_get_stats", "uc_comm_unique_id", "uc_comm_create", "uc_comm_destroy", "uc_engine_cluster_step",
     "uc_engine_create", "uc_engine_destroy", "uc_engine_load_db", "uc_engine_set_db", "uc_engine_num_seqs",
     "uc_engine_prefilter", "uc_engine_prefilter_range", "uc_engine_hits_size", "uc_engine_hits_get", "uc_engine_hits_get_range", "uc_engine_hits_set", "uc_engine_hits_merge",
     "uc_engine_hits_export_dev", "uc_engine_hits_import_dev", "uc_engine_setcover",
@@ -78,6 +82,12 @@ def lib():
     L.uc_version.restype = C.c_char_p
     L.uc_check_options.argtypes = [C.c_char_p]
     L.uc_option_arity.argtypes = [C.c_char_p]
+    L.uc_createdb.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.c_char_p, C.POINTER(UcOpts), C.POINTER(UcT5Stats)]
+    L.uc_t5_load.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+    L.uc_t5_free.argtypes = [vp]
+    L.uc_t5_free.restype = None
+    L.uc_t5_encode.argtypes = [vp, u32, vp, C.c_char_p, vp, vp]
+    L.uc_t5_get_stats.argtypes = [vp, C.POINTER(UcT5Stats)]
     L.uc_release_scratch.restype = None
     L.uc_comm_unique_id.argtypes = [vp]
     L.uc_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
@@ -194,6 +204,47 @@ def hits_merge(n_seqs, max_seqs, parts):
     oc, oh, on = np.zeros(n_seqs, np.uint32), np.zeros(max(cap, 1), HIT_DTYPE), C.c_uint64()
     _check(lib().uc_hits_merge(n_seqs, max_seqs, k, cp, hp, oc.ctypes.data, oh.ctypes.data, cap, C.byref(on)))
     return oc, oh[: on.value].copy()
+
+
+def createdb(fasta_paths, out_db, model, verbosity=1, device=-1):
+    """== `foldseek createdb <fasta...> <db> --prostt5-model <model>` (createdb.rs:157-166): ProstT5 AA -> 3Di on the GPU"""
+    if isinstance(fasta_paths, str):
+        fasta_paths = [fasta_paths]
+    arr = (C.c_char_p * len(fasta_paths))(*[p.encode() for p in fasta_paths])
+    o, st = make_opts("", 1, verbosity, device), UcT5Stats()
+    _check(lib().uc_createdb(arr, len(fasta_paths), out_db.encode(), model.encode(), C.byref(o), C.byref(st)))
+    return {k: getattr(st, k) for k, _ in UcT5Stats._fields_}
+
+
+class T5Encoder:
+    """the ProstT5 AA -> 3Di encoder (uc_t5_* of the C ABI)"""
+
+    def __init__(self, model, device=-1):
+        self._h = C.c_void_p()
+        _check(lib().uc_t5_load(model.encode(), device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().uc_t5_free(self._h)
+            self._h = C.c_void_p()
+
+    def encode(self, seqs, logits=False):
+        """seqs: list of residue strings -> list of uint8 arrays (3Di states 0..19) [, list of float32 [L, 20] logits]"""
+        off = np.zeros(len(seqs) + 1, np.uint64)
+        off[1:] = np.cumsum([len(s) for s in seqs])
+        aa = "".join(seqs).encode()
+        codes = np.zeros(max(int(off[-1]), 1), np.uint8)
+        lg = np.zeros((max(int(off[-1]), 1), 20), np.float32) if logits else None
+        _check(lib().uc_t5_encode(self._h, len(seqs), off.ctypes.data, aa, codes.ctypes.data, lg.ctypes.data if logits else None))
+        out = [codes[int(off[i]):int(off[i + 1])].copy() for i in range(len(seqs))]
+        if logits:
+            return out, [lg[int(off[i]):int(off[i + 1])].copy() for i in range(len(seqs))]
+        return out
+
+    def stats(self):
+        st = UcT5Stats()
+        _check(lib().uc_t5_get_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in UcT5Stats._fields_}
 
 
 class Comm:

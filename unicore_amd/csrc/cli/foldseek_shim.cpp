@@ -7,6 +7,7 @@
 //   rmdb      <out>_cluster -v V                                       cluster.rs:67-73
 //   search    --threads T <queryDB> <targetDB> <out>_aln <tmp> <opts...>   search.rs:44-50
 //   convertalis --threads T <queryDB> <targetDB> <out>_aln <out>.m8        search.rs:57-60
+//   createdb  <fasta> <db> --prostt5-model <dir> [--gpu 1] --threads T     createdb.rs:157-166 (ProstT5 AA -> 3Di on the GPU)
 //   version
 // Exit status is the only error channel (src/util/command.rs:10-14): 0 ok, non-zero + stderr text otherwise.
 #include <cstdio>
@@ -23,7 +24,7 @@ static int die(int rc) {
 }
 
 int main(int argc, char **argv) {
-    if (argc < 2) { fprintf(stderr, "usage: foldseek <cluster|createtsv|search|convertalis|rmdb|version> ...\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: foldseek <cluster|createtsv|search|convertalis|createdb|rmdb|version> ...\n"); return 2; }
     const std::string cmd = argv[1];
     if (cmd == "version") { puts(uc_version()); return 0; }
     // Flags may appear anywhere (the reference puts them after the positionals, cluster.rs:45-49, but
@@ -49,6 +50,29 @@ int main(int argc, char **argv) {
         if (a == "--threads") threads = atoi(val.c_str());
         else if (a == "-v") verbosity = atoi(val.c_str());
         else opts += (opts.empty() ? "" : " ") + a + (has_val ? " " + val : "");
+    }
+    if (cmd == "createdb") {
+        // createdb <fasta> [<fasta> ...] <db> --prostt5-model <dir> [--gpu 0|1] [--threads T] [-v V]        createdb.rs:157-166
+        std::vector<std::string> cpos;
+        std::string model;
+        int cverb = 3;
+        for (int i = 2; i < argc; i++) {
+            const std::string a = argv[i];
+            if ((a == "--prostt5-model" || a == "--gpu" || a == "--threads" || a == "-v") && i + 1 < argc) {
+                const char *v = argv[++i];
+                if (a == "--prostt5-model") model = v;
+                else if (a == "-v") cverb = atoi(v);
+            } else if (a.size() > 1 && a[0] == '-') { fprintf(stderr, "Error: createdb: option %s is not provided by this engine\n", a.c_str()); return 2; }
+            else cpos.push_back(a);
+        }
+        if (cpos.size() < 2 || model.empty()) { fprintf(stderr, "Error: createdb expects <fasta> [...] <db> --prostt5-model <dir> (structure input is not provided by this engine)\n"); return 2; }
+        std::vector<const char *> fp;
+        for (size_t i = 0; i + 1 < cpos.size(); i++) fp.push_back(cpos[i].c_str());
+        uc_opts co;
+        memset(&co, 0, sizeof co);
+        co.struct_size = sizeof co; co.threads = 1; co.verbosity = cverb; co.device = -1; co.num_gpus = 1;
+        int rc = uc_createdb(fp.data(), (int)fp.size(), cpos.back().c_str(), model.c_str(), &co, nullptr);
+        return rc ? die(rc) : 0;
     }
     uc_opts o;
     memset(&o, 0, sizeof o);

@@ -11,6 +11,7 @@
 
 #include "uc_engine.h"
 #include "uc_multi.h"
+#include "uc_t5.h"
 
 using namespace uc;
 
@@ -19,6 +20,9 @@ struct uc_engine {
 };
 struct uc_comm {
     Comm c;
+};
+struct uc_t5 {
+    T5Model m;
 };
 
 namespace {
@@ -634,6 +638,60 @@ int uc_createtsv(const char *db, const char *cluster_db, const char *out_tsv, co
         require(db, "db"); require(cluster_db, "cluster_db"); require(out_tsv, "out_tsv");
         if (o) g_verbosity = o->verbosity;
         create_tsv(db, cluster_db, out_tsv);
+    });
+}
+
+int uc_createdb(const char *const *fasta_paths, int n_fasta, const char *out_db, const char *model, const uc_opts *o, uc_t5_stats *stats_out) {
+    return guard([&] {
+        require(fasta_paths, "fasta_paths"); require(out_db, "out_db"); require(model, "model");
+        if (n_fasta < 1) fail(UC_ERR_ARGS, "createdb: no input files");
+        std::vector<std::string> fp;
+        for (int i = 0; i < n_fasta; i++) { require(fasta_paths[i], "fasta path"); fp.push_back(fasta_paths[i]); }
+        T5Stats st;
+        t5_createdb(fp, out_db, model, o ? o->device : -1, o ? o->verbosity : 3, &st);
+        if (stats_out) { stats_out->n_seqs = st.n_seqs; stats_out->n_tokens = st.n_tokens; stats_out->flops = st.flops; stats_out->gpu_ms = st.total_ms; }
+    });
+}
+
+int uc_t5_load(const char *model, int32_t device, uc_t5 **out) {
+    return guard([&] {
+        require(model, "model"); require(out, "out");
+        *out = nullptr;
+        std::string path = model;
+        struct stat st;
+        if (stat(path.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) path += "/prostt5-f16.gguf";
+        auto h = std::make_unique<uc_t5>();
+        h->m.load(path, device);
+        *out = h.release();
+    });
+}
+
+void uc_t5_free(uc_t5 *m) { delete m; }
+
+int uc_t5_encode(uc_t5 *m, uint32_t n, const uint64_t *off, const char *aa, uint8_t *codes, float *logits) {
+    return guard([&] {
+        require(m, "model");
+        if (!n) return;
+        require(off, "off"); require(aa, "aa"); require(codes, "codes");
+        std::vector<std::string> seqs(n);
+        for (uint32_t i = 0; i < n; i++) {
+            if (off[i + 1] < off[i]) fail(UC_ERR_ARGS, "t5_encode: offsets must be non-decreasing");
+            seqs[i].assign(aa + off[i], aa + off[i + 1]);
+        }
+        std::vector<std::vector<uint8_t>> out;
+        std::vector<std::vector<float>> lg;
+        m->m.encode(seqs, out, logits ? &lg : nullptr);
+        for (uint32_t i = 0; i < n; i++) {
+            if (!out[i].empty()) memcpy(codes + off[i], out[i].data(), out[i].size());
+            if (logits && !lg[i].empty()) memcpy(logits + off[i] * (size_t)m->m.cfg.n_out, lg[i].data(), lg[i].size() * 4);
+        }
+    });
+}
+
+int uc_t5_get_stats(const uc_t5 *m, uc_t5_stats *out) {
+    return guard([&] {
+        require(m, "model"); require(out, "out");
+        out->n_seqs = m->m.stats.n_seqs; out->n_tokens = m->m.stats.n_tokens; out->flops = m->m.stats.flops; out->gpu_ms = m->m.stats.total_ms;
     });
 }
 

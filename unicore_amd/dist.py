@@ -1,4 +1,9 @@
-"""unicore_amd.dist — the multi-GPU layout of the cluster path, one process per GPU.
+"""unicore_amd.dist — Python/torch.distributed TEST DRIVER of the multi-GPU layout, one process per rank.
+
+The product's N-GPU path lives in the library (csrc/uc_multi.cpp: RCCL called from C, T = N target shards by default,
+`uc_cluster` num_gpus / `uc_comm_*` + `uc_engine_cluster_step`); bench.py and the CLIs use that.  This module remains as the
+host-side stand-in the CPU tests run with 2-4 `gloo` ranks (tests/test_dist.py) and keeps the cost-based grid heuristic
+(grid_shape) that picked query groups for small databases; it is not on any product path.
 
     rank r:  index target shard r % T  ->  match query group r // T against it (E1-E4)  ->  per-rank hit lists
              (Q x T = world; grid_shape picks T: 1 while the DB fits one prefilter chunk, see there)
