@@ -1,0 +1,238 @@
+"""The ProstT5 AA -> 3Di encoder (BASELINE configs[4]; reference call site createdb.rs:157-166).
+PARITY UNPINNED: no ProstT5 weights and no Foldseek here, so the checker is the fp32 PyTorch restatement of the published
+architecture (oracle/prostt5_ref.py) on seeded synthetic weights.
+
+Tolerance (f16 operands with fp32 accumulation and an fp32 residual stream against fp32 everywhere): the worst logit error
+must stay below 5e-3 of the largest logit of the sequence, and the predicted 3Di state must agree wherever the reference's
+top-2 margin exceeds twice that error bound (positions with a thinner margin may legitimately flip)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import util
+
+ROOT = util.ROOT
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from oracle import prostt5_ref as R  # noqa: E402
+import make_t5_golden as G  # noqa: E402
+
+REL_TOL = 5e-3
+
+
+def _tiny(tmp_path, **kw):
+    cfg = R.default_config(**dict(G.CFG, **kw))
+    path = str(tmp_path / "t5.gguf")
+    R.write_synthetic_gguf(path, cfg, seed=G.SEED)
+    return cfg, path
+
+
+def test_gguf_writer_and_reader_round_trip(tmp_path):
+    cfg, path = _tiny(tmp_path)
+    kv, w = R.read_gguf(path)
+    assert kv["general.architecture"] == "t5encoder" and kv["t5encoder.block_count"] == 2 and kv["t5encoder.embedding_length"] == 128
+    assert kv["tokenizer.ggml.tokens"][149] == "<AA2fold>" and kv["tokenizer.ggml.tokens"][3] == "▁A"
+    assert w["enc.blk.1.ffn_up.weight"].shape == (512, 128) and w["enc.blk.1.ffn_up.weight"].dtype == np.float16
+    assert w["enc.blk.0.attn_rel_b.weight"].shape == (32, 2) and w["cnn.conv1.weight"].shape == (32, 128, 7)
+    R.write_synthetic_gguf(str(tmp_path / "again.gguf"), cfg, seed=G.SEED)
+    assert open(path, "rb").read() == open(tmp_path / "again.gguf", "rb").read()          # the writer is deterministic
+
+
+def test_relative_position_buckets_known_answers():
+    """T5's bidirectional bucketing, 32 buckets / max distance 128 (Raffel et al. 2020, transformers
+    T5Attention._relative_position_bucket): exact below 8, log-spaced up to 128, keys after the query in the upper half"""
+    import torch
+    rel = torch.tensor([0, -1, 1, -7, 7, -8, 8, -11, -12, -15, -16, -31, -32, -64, -127, -128, -1000, 1000])
+    got = R.relative_position_bucket(rel, 32, 128).tolist()
+    assert got == [0, 1, 17, 7, 23, 8, 24, 8, 9, 9, 10, 11, 12, 14, 15, 15, 15, 31]
+
+
+def test_oracle_reproduces_the_committed_fixture(tmp_path):
+    cfg, path = _tiny(tmp_path)
+    _, w = R.read_gguf(path)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "t5_tiny.npz"))
+    assert list(z["seqs"]) == G.SEQS
+    for i, s in enumerate(G.SEQS):
+        lg, codes = R.forward(w, cfg, s)
+        assert lg.shape == (len(s), 20) and np.allclose(lg, z["logits%d" % i], rtol=1e-4, atol=1e-4)
+        assert np.array_equal(codes, z["codes%d" % i])
+
+
+def _forward_numpy(w, cfg, seq):
+    """second, torch-free restatement (float64 numpy, explicit loops for the bucket rule and the convolutions)"""
+    W = {k: np.asarray(v, np.float64) for k, v in w.items()}
+    tok = R.tokenize(seq, cfg)
+    L, H, dk = len(tok), cfg["n_heads"], cfg["d_kv"]
+    h = W["token_embd.weight"][tok]
+
+    def rms(x, g):
+        return x / np.sqrt((x * x).mean(-1, keepdims=True) + cfg["eps"]) * g
+
+    def bucket(rel):
+        nb = cfg["rel_buckets"] // 2
+        r = nb if rel > 0 else 0
+        n = abs(rel)
+        if n < nb // 2:
+            return r + n
+        v = nb // 2 + int(np.float32(np.log(np.float32(n) / np.float32(nb // 2))) / np.float32(np.log(cfg["rel_max_dist"] / (nb // 2))) * np.float32(nb - nb // 2))
+        return r + min(v, nb - 1)
+    bias = np.zeros((H, L, L))
+    for i in range(L):
+        for j in range(L):
+            bias[:, i, j] = W["enc.blk.0.attn_rel_b.weight"][bucket(j - i)]
+    for l in range(cfg["n_layers"]):
+        b = "enc.blk.%d." % l
+        x = rms(h, W[b + "attn_norm.weight"])
+        q, k, v = [(x @ W[b + n].T).reshape(L, H, dk).transpose(1, 0, 2) for n in ("attn_q.weight", "attn_k.weight", "attn_v.weight")]
+        s_ = np.einsum("hid,hjd->hij", q, k) + bias
+        p = np.exp(s_ - s_.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
+        h = h + np.einsum("hij,hjd->ihd", p, v).reshape(L, H * dk) @ W[b + "attn_o.weight"].T
+        x = rms(h, W[b + "ffn_norm.weight"])
+        h = h + np.maximum(x @ W[b + "ffn_up.weight"].T, 0) @ W[b + "ffn_down.weight"].T
+    x = rms(h, W["enc.output_norm.weight"])[1:]                      # <AA2fold> off before the head
+    KW = cfg["cnn_kernel"]
+
+    def conv(x, w_, b_):                                             # x [n, cin], w_ [cout, cin, k]: cross-correlation, zero padding
+        n = len(x)
+        y = np.tile(b_, (n, 1))
+        for t in range(n):
+            for k in range(KW):
+                u = t + k - KW // 2
+                if 0 <= u < n:
+                    y[t] += w_[:, :, k] @ x[u]
+        return y
+    y = conv(np.maximum(conv(x, W["cnn.conv1.weight"], W["cnn.conv1.bias"]), 0), W["cnn.conv2.weight"], W["cnn.conv2.bias"])
+    return y[:-1]                                                    # </s> off after it
+
+
+def test_oracle_against_a_second_independent_restatement(tmp_path):
+    """the torch restatement (the checker of the GPU tests) agrees with a torch-free float64 numpy one: bucket rule, shared
+    bias of block 0, un-scaled attention, pre-norm residual blocks, and the head's slicing convention (prefix off before
+    the convolutions, </s> after: ProstT5 predict_3Di)"""
+    cfg, path = _tiny(tmp_path)
+    _, w = R.read_gguf(path)
+    for seq in ("M", "MKTAYIAKQRQISFVKSH", "ACDEFGHIKLMNPQRSTVWYXBZ" * 7):
+        lg, codes = R.forward(w, cfg, seq)
+        ref = _forward_numpy(w, cfg, seq)
+        assert ref.shape == lg.shape and np.abs(ref - lg).max() <= 2e-4 * max(np.abs(ref).max(), 1.0), seq
+        assert (ref.argmax(1) == codes).mean() > 0.99
+
+
+def test_encoder_fails_loudly_without_a_gpu(tmp_path):
+    import unicore_amd as U
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    _, path = _tiny(tmp_path)
+    with pytest.raises(U.UcError) as ei:
+        U.T5Encoder(path)
+    assert ei.value.code == U.UC_ERR_DEVICE and "no CPU fallback" in str(ei.value)
+    with pytest.raises(U.UcError) as ei:
+        U.T5Encoder(str(tmp_path / "missing.gguf"))
+    shim = os.path.join(ROOT, "bin", "foldseek")
+    r = subprocess.run([shim, "createdb", "in.fasta", "out_db"], capture_output=True, text=True)
+    assert r.returncode == 2 and "--prostt5-model" in r.stderr
+
+
+# ---------------------------------------------------------------------------------------------- GPU
+def _check(codes, logits, ref_logits, ref_codes, what):
+    err = float(np.abs(logits - ref_logits).max())
+    scale = float(np.abs(ref_logits).max())
+    assert err <= REL_TOL * scale, (what, err, scale)
+    top2 = np.sort(ref_logits, axis=1)[:, -2:]
+    safe = (top2[:, 1] - top2[:, 0]) > 2 * REL_TOL * scale
+    assert np.array_equal(codes[safe], ref_codes[safe]), what
+    assert (codes == ref_codes).mean() >= 0.98, what
+
+
+@pytest.mark.gpu
+def test_hip_encoder_against_the_fixture_and_the_fp32_restatement(tmp_path):
+    import unicore_amd as U
+    cfg, path = _tiny(tmp_path)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "t5_tiny.npz"))
+    enc = U.T5Encoder(path)
+    codes, logits = enc.encode(G.SEQS, logits=True)
+    for i, s in enumerate(G.SEQS):
+        assert logits[i].shape == (len(s), 20)
+        _check(codes[i], logits[i], z["logits%d" % i], z["codes%d" % i], "fixture %d" % i)
+    # batching must not matter: one sequence at a time gives the same bytes as the batch
+    for i in (0, 2, 3):
+        c1, l1 = enc.encode([G.SEQS[i]], logits=True)
+        assert np.array_equal(c1[0], codes[i]) and np.array_equal(l1[0], logits[i])
+    st = enc.stats()
+    assert st["n_tokens"] > 0 and st["flops"] > 0 and st["gpu_ms"] > 0
+    enc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [dict(d_model=256, n_heads=4, d_ff=1024, n_layers=3), dict(d_model=1024, n_heads=32, d_ff=16384, n_layers=2)])
+def test_hip_encoder_wider_models_and_ragged_batches(geom, tmp_path):
+    """ProtT5-XL width (1024 / 32 heads / 16384) with few blocks, lengths around the tile edges (63, 64, 65, 127, 129), a
+    1-residue sequence, non-standard residues, and small token batches (UC_T5_BATCH_TOKENS) against one big batch"""
+    import unicore_amd as U
+    cfg = R.default_config(d_kv=128, **geom)
+    path = str(tmp_path / "m.gguf")
+    R.write_synthetic_gguf(path, cfg, seed=0x5EED0006, with_vocab=geom["n_layers"] == 3)      # with and without a vocabulary in the file
+    _, w = R.read_gguf(path)
+    rng = np.random.default_rng(5)
+    seqs = ["".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWY"), L)) for L in (1, 2, 63, 64, 65, 127, 129, 300)] + ["MKXXBZOUACDEFGHIKLMNPQRSTVWYmkt"]
+    enc = U.T5Encoder(path)
+    codes, logits = enc.encode(seqs, logits=True)
+    for s, c, lg in zip(seqs, codes, logits):
+        rl, rc = R.forward(w, cfg, s)
+        _check(c, lg, rl, rc, (geom, len(s)))
+    os.environ["UC_T5_BATCH_TOKENS"] = "200"
+    try:
+        c2, l2 = enc.encode(seqs, logits=True)
+    finally:
+        del os.environ["UC_T5_BATCH_TOKENS"]
+    for a, b, la, lb in zip(codes, c2, logits, l2):
+        assert np.array_equal(a, b) and np.array_equal(la, lb)
+    enc.close()
+
+
+@pytest.mark.gpu
+def test_createdb_writes_the_database_the_cluster_path_reads(tmp_path):
+    """`foldseek createdb <fasta> <db> --prostt5-model <dir>` (createdb.rs:157-166) through the shim, then `foldseek
+    cluster` + `createtsv` on the result: the whole chain of `unicore createdb` -> `unicore cluster` without Foldseek"""
+    import unicore_amd as U
+    cfg, path = _tiny(tmp_path)
+    mdir = tmp_path / "weights"
+    mdir.mkdir()
+    os.rename(path, mdir / "prostt5-f16.gguf")                    # createdb.rs:148: <model>/prostt5-f16.gguf
+    rng = np.random.default_rng(9)
+    fams = ["".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWY"), int(rng.integers(60, 200)))) for _ in range(6)]
+    recs = []
+    for f, a in enumerate(fams):
+        for m in range(4):
+            s = list(a)
+            for p in rng.choice(len(s), len(s) // 12, replace=False):
+                s[p] = rng.choice(list("ACDEFGHIKLMNPQRSTVWY"))
+            recs.append(("unicore_%010x fam%d member%d" % (f * 16 + m + 1, f, m), "".join(s)))
+    fa = tmp_path / "combined_aa.fasta"
+    fa.write_text("".join(">%s\n%s\n" % (h, "\n".join(s[i:i + 60] for i in range(0, len(s), 60))) for h, s in recs))
+    shim = os.path.join(ROOT, "bin", "foldseek")
+    db = str(tmp_path / "proteome_db")
+    r = subprocess.run([shim, "createdb", str(fa), db, "--prostt5-model", str(mdir), "--threads", "4", "--gpu", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for sfx in ("", "_ss", "_h", ".index", "_ss.index", "_h.index", ".dbtype", "_ss.dbtype", "_h.dbtype", ".lookup"):
+        assert os.path.exists(db + sfx), sfx
+    aa = open(db, "rb").read().split(b"\n\0")[:-1]
+    ss = open(db + "_ss", "rb").read().split(b"\n\0")[:-1]
+    assert [a.decode() for a in aa] == [s for _, s in recs]
+    assert all(len(a) == len(b) and set(b.decode()) <= set("ACDEFGHIKLMNPQRSTVWY") for a, b in zip(aa, ss))
+    # the 3Di track is what the library's own encoder predicts
+    _, w = R.read_gguf(str(mdir / "prostt5-f16.gguf"))
+    enc = U.T5Encoder(str(mdir))
+    codes = enc.encode([s for _, s in recs])
+    assert ["".join("ACDEFGHIKLMNPQRSTVWY"[c] for c in cs) for cs in codes] == [b.decode() for b in ss]
+    enc.close()
+    # ... and the cluster path runs on it (members of one family differ in ~8 % of their residues)
+    out = str(tmp_path / "clust")
+    subprocess.run([shim, "cluster", "--threads", "4", "-v", "1", db, out + "_cluster", str(tmp_path / "tmp"), "-c", "0.8"], check=True)
+    subprocess.run([shim, "createtsv", "--threads", "4", "-v", "1", db, db, out + "_cluster", out + ".tsv"], check=True)
+    names = [h.split()[0] for h, _ in recs]
+    rows = util.tsv_invariants(out + ".tsv", names)
+    assert len(rows) == len(recs)
