@@ -147,120 +147,186 @@ void t5_rmsnorm(const float *x, const float *w, void *y, int T, int D, float eps
 }
 
 // ---------------------------------------------------------------------------------------------- attention
-// One workgroup = one (query tile of 64 rows, head) of one sequence; wave w owns query rows 16w .. 16w+15.  d_kv = 128.
 // qkv: [T, 3 * H * 128] f16 (q | k | v), out: [T, H * 128] f16.  bias: [H][2 * bias_span - 1] fp32, entry (key - query) +
-// bias_span - 1.  T5 applies NO 1/sqrt(d) scaling.
-constexpr int ADK = 128, AKT = 32;                      // head dim, keys per tile
-constexpr int SK_LD = ADK + 8, SV_LD = AKT + 8, SP_LD = AKT + 8;
+// bias_span - 1.  T5 applies NO 1/sqrt(d) scaling.  d_kv = 128.
+//
+// Both contractions are computed TRANSPOSED so that nothing has to be re-laid-out between them and no LDS is needed:
+//   S^T = K . Q^T   (A = K rows: 16 keys x 32 dims, B = Q^T: this lane's query l & 15, 8 contiguous dims)
+//         -> lane holds S[query l & 15][keys (l >> 4) * 4 + r] of each 16-key sub-tile: a query's softmax statistics live in
+//            the 4 lanes {q, q + 16, q + 32, q + 48}: in-lane reduction over 8 values + two xor-shuffles (16, 32);
+//   O^T = V^T . P^T (A = V^T rows: 16 dims x 32 keys, B = P^T: the very registers the softmax left, as f16)
+//         -> lane holds O[query l & 15][dims (l >> 4) * 4 + r]: the same query as its statistics, so the online-softmax
+//            rescale is a plain per-lane multiply and the result leaves as 8-byte stores.
+// The 32 keys of a block enter the second contraction in the order the first one produced them (k = g * 8 + e <-> key
+// g * 4 + e for e < 4, 16 + g * 4 + e - 4 otherwise); V^T is read in the same order, a sum does not care.
+// V^T comes from a per-layer transpose of the V third of qkv into vt[H * 128][Tp] (every sequence padded to a multiple of
+// 64 keys with zeros), so its A fragments are contiguous.
+constexpr int ADK = 128, AQW = 32;            // head dim, keys per block, queries per wave (2 tiles of 16)
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // dword-aligned 16-byte access
 
-__global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__restrict__ qkv, const T5AttnTile *__restrict__ tiles, const float *__restrict__ bias,
-                                                           int bias_span, int H, _Float16 *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) _Float16 sK[AKT * SK_LD];
-    __shared__ __attribute__((aligned(16))) _Float16 sVt[ADK * SV_LD];
-    __shared__ __attribute__((aligned(16))) _Float16 sP[4 * 16 * SP_LD];
-    const T5AttnTile tl = tiles[blockIdx.x];
-    const int h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int L = tl.len, q0 = tl.q0;
+// V third of qkv -> vt[H * 128][Tp]; one workgroup = 32 padded tokens x 64 dims
+__global__ void __launch_bounds__(256) t5_vt_kernel(const _Float16 *__restrict__ qkv, const T5VtTile *__restrict__ tiles, int H, size_t Tp,
+                                                    _Float16 *__restrict__ vt) {
+    __shared__ _Float16 sm[32][72];
+    const T5VtTile tl = tiles[blockIdx.x];
+    const int d0 = blockIdx.y * 64, tid = threadIdx.x;
     const size_t ld = (size_t)3 * H * ADK;
-    const _Float16 *qb = qkv + (size_t)tl.tok0 * ld + (size_t)h * ADK;
-    const _Float16 *kb = qb + (size_t)H * ADK, *vb = qb + (size_t)2 * H * ADK;
-    const float *bh = bias + (size_t)h * (2 * bias_span - 1) + (bias_span - 1);
-    // this lane's A fragments of Q: row 16w + (lane & 15), dims kk * 32 + (lane >> 4) * 8 ..
-    half8 qf[4];
     {
-        const int qi = q0 + 16 * w + (lane & 15);
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            if (qi < L) qf[kk] = *(const half8 *)(qb + (size_t)qi * ld + kk * 32 + (lane >> 4) * 8);
-            else qf[kk] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
+        const int t = tid >> 3, dc = (tid & 7) * 8;
+        uint4 v = {0, 0, 0, 0};
+        if (t < tl.count) v = *(const uint4 *)(qkv + (size_t)(tl.src + t) * ld + (size_t)2 * H * ADK + d0 + dc);
+        *(uint4 *)(&sm[t][dc]) = v;
     }
-    f32x4 o[8];
+    __syncthreads();
+    {
+        const int d = tid >> 2, tc = (tid & 3) * 8;
+        half8 o;
 #pragma unroll
-    for (int d = 0; d < 8; d++) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float mrow[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, lrow[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < L; k0 += AKT) {
-        // K tile row-major, V tile transposed (dims x keys): both become 16-byte B fragments
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int c = tid + 256 * i, key = c >> 4, dc = (c & 15) * 8;
-            uint4 kv = {0, 0, 0, 0};
-            half8 vv = half8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (k0 + key < L) {
-                kv = *(const uint4 *)(kb + (size_t)(k0 + key) * ld + dc);
-                vv = *(const half8 *)(vb + (size_t)(k0 + key) * ld + dc);
-            }
-            *(uint4 *)(sK + key * SK_LD + dc) = kv;
-#pragma unroll
-            for (int e = 0; e < 8; e++) sVt[(dc + e) * SV_LD + key] = vv[e];
-        }
-        __syncthreads();
-        f32x4 sacc[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++) {
-            sacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                const half8 kf = *(const half8 *)(sK + (nt * 16 + (lane & 15)) * SK_LD + kk * 32 + (lane >> 4) * 8);
-                sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[kk], kf, sacc[nt], 0, 0, 0);
-            }
-        }
-        // bias, mask, online softmax: this lane holds rows (lane >> 4) * 4 + r, columns nt * 16 + (lane & 15)
-        float p[2][4], alpha[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int qi = q0 + 16 * w + (lane >> 4) * 4 + r;
-            float mx = -INFINITY;
-#pragma unroll
-            for (int nt = 0; nt < 2; nt++) {
-                const int kj = k0 + nt * 16 + (lane & 15);
-                float sv = -INFINITY;
-                if (kj < L) sv = sacc[nt][r] + bh[kj - min(qi, L - 1)];
-                p[nt][r] = sv;
-                mx = fmaxf(mx, sv);
-            }
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
-            const float mnew = fmaxf(mrow[r], mx);
-            alpha[r] = __expf(mrow[r] - mnew);            // first tile: exp(-inf) = 0
-            float sum = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < 2; nt++) { p[nt][r] = __expf(p[nt][r] - mnew); sum += p[nt][r]; }
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1) sum += __shfl_xor(sum, m, 64);
-            lrow[r] = lrow[r] * alpha[r] + sum;
-            mrow[r] = mnew;
-        }
-        // P: C layout -> A layout through this wave's LDS slice
-        _Float16 *pw = sP + w * 16 * SP_LD;
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) pw[((lane >> 4) * 4 + r) * SP_LD + nt * 16 + (lane & 15)] = (_Float16)p[nt][r];
-        __syncthreads();
-        const half8 pf = *(const half8 *)(pw + (lane & 15) * SP_LD + (lane >> 4) * 8);
-#pragma unroll
-        for (int d = 0; d < 8; d++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) o[d][r] *= alpha[r];
-            const half8 vf = *(const half8 *)(sVt + (d * 16 + (lane & 15)) * SV_LD + (lane >> 4) * 8);
-            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, vf, o[d], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    _Float16 *ob = out + (size_t)tl.tok0 * ((size_t)H * ADK) + (size_t)h * ADK;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int qi = q0 + 16 * w + (lane >> 4) * 4 + r;
-        if (qi >= L) continue;
-        const float inv = 1.f / lrow[r];
-#pragma unroll
-        for (int d = 0; d < 8; d++) ob[(size_t)qi * ((size_t)H * ADK) + d * 16 + (lane & 15)] = (_Float16)(o[d][r] * inv);
+        for (int e = 0; e < 8; e++) o[e] = sm[tc + e][d];
+        *(half8 *)(vt + (size_t)(d0 + d) * Tp + tl.dst + tc) = o;
     }
 }
-void t5_attention(const void *qkv, const T5AttnTile *tiles, int n_tiles, const float *bias, int bias_span, int H, void *out, hipStream_t s) {
+
+// One workgroup = 128 queries of one (sequence, head): 4 waves x 32 queries.  The K block (64 keys x 128 dims) and the V^T
+// block (128 dims x 64 keys) are loaded ONCE per workgroup with coalesced 16-byte loads (the next block travels in registers
+// while this one is multiplied) and shared through LDS: per-wave fragment loads straight from L2 re-read every block once
+// per 32 queries and were bandwidth / address-bound (77 TFLOP/s; profiles/r3_t5).
+constexpr int AKB = 64;                                  // keys per block
+constexpr int SK_LD = ADK + 8, SV_LD = AKB + 8;          // LDS row strides in halves (272 B / 144 B: conflict-free fragment reads)
+
+__global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__restrict__ qkv, const _Float16 *__restrict__ vt, size_t Tp,
+                                                           const T5AttnTile *__restrict__ tiles, const float *__restrict__ bias, int bias_span, int H,
+                                                           _Float16 *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) _Float16 sK[AKB * SK_LD];
+    __shared__ __attribute__((aligned(16))) _Float16 sV[ADK * SV_LD];
+    const T5AttnTile tl = tiles[blockIdx.x];
+    const int h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int L = tl.len, q0 = tl.q0 + w * AQW;
+    const size_t ld = (size_t)3 * H * ADK;
+    const _Float16 *qb = qkv + (size_t)tl.tok0 * ld + (size_t)h * ADK, *kb = qb + (size_t)H * ADK;
+    const _Float16 *vb = vt + (size_t)h * ADK * Tp + tl.poff;
+    const float *bh = bias + (size_t)h * (2 * bias_span - 1) + (bias_span - 1);
+    half8 qf[2][4];                                      // B fragments of Q^T: query q0 + qt * 16 + c, dims kk * 32 + g * 8 ..
+#pragma unroll
+    for (int qt = 0; qt < 2; qt++) {
+        const int qi = q0 + qt * 16 + c;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) qf[qt][kk] = qi < L ? *(const half8 *)(qb + (size_t)qi * ld + kk * 32 + g * 8) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    f32x4 o[2][8];
+#pragma unroll
+    for (int qt = 0; qt < 2; qt++)
+#pragma unroll
+        for (int d = 0; d < 8; d++) o[qt][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrow[2] = {-INFINITY, -INFINITY}, lrow[2] = {0.f, 0.f};
+    // staging: K block = 64 rows x 16 chunks of 16 B, V^T block = 128 rows x 8 chunks: 4 + 4 chunks per thread
+    uint4 rk[4], rv[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int ch = tid + 256 * i;
+            const int key = ch >> 4, dc = (ch & 15) * 8;
+            rk[i] = k0 + key < L ? *(const uint4 *)(kb + (size_t)(k0 + key) * ld + dc) : uint4{0, 0, 0, 0};
+            const int dim = ch >> 3, kc = (ch & 7) * 8;
+            rv[i] = *(const uint4 *)(vb + (size_t)dim * Tp + k0 + kc);       // the sequence is zero-padded to a multiple of 64 keys in vt
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int ch = tid + 256 * i;
+            *(uint4 *)(sK + (ch >> 4) * SK_LD + (ch & 15) * 8) = rk[i];
+            *(uint4 *)(sV + (ch >> 3) * SV_LD + (ch & 7) * 8) = rv[i];
+        }
+    };
+    for (int k0 = 0; k0 < L; k0 += AKB) {
+        gload(k0);           // (keeping the next block in registers across the compute phase spilled them to scratch: 2-3 workgroups
+        sstore();            //  per CU hide this latency instead)
+        __syncthreads();
+        if (q0 < L) {                                    // (waves without queries only help with the staging)
+            f32x4 sacc[2][4];                            // [query tile][16-key sub-tile]
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                sacc[0][st] = f32x4{0.f, 0.f, 0.f, 0.f};
+                sacc[1][st] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const half8 kf = *(const half8 *)(sK + (st * 16 + c) * SK_LD + kk * 32 + g * 8);
+                    sacc[0][st] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][kk], sacc[0][st], 0, 0, 0);
+                    sacc[1][st] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][kk], sacc[1][st], 0, 0, 0);
+                }
+            }
+            half8 pf[2][2];                              // [query tile][32-key half]
+            float alpha[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; qt++) {
+                const int qi = min(q0 + qt * 16 + c, L - 1);
+                float p[16], mx = -INFINITY;
+#pragma unroll
+                for (int st = 0; st < 4; st++) {
+                    // the lane's 4 keys are consecutive: one unconditional 16-byte (dword-aligned) load of their biases — a
+                    // load per key under `kj < L` became 32 branchy, serialized loads per block and cost 10x the MFMA time
+                    const int kb0 = k0 + st * 16 + g * 4;
+                    const f32x4u bv = *(const f32x4u *)(bh + (min(kb0, L - 1) - qi));      // (the table is padded by 4 entries)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float sv = kb0 + r < L ? sacc[qt][st][r] + bv[r] : -INFINITY;
+                        p[st * 4 + r] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mnew = fmaxf(mrow[qt], mx);
+                alpha[qt] = __expf(mrow[qt] - mnew);      // first block: exp(-inf) = 0
+                float sum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; e++) { p[e] = __expf(p[e] - mnew); sum += p[e]; pf[qt][e >> 3][e & 7] = (_Float16)p[e]; }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                lrow[qt] = lrow[qt] * alpha[qt] + sum;
+                mrow[qt] = mnew;
+            }
+#pragma unroll
+            for (int d = 0; d < 8; d++) {
+#pragma unroll
+                for (int qt = 0; qt < 2; qt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[qt][d][r] *= alpha[qt];
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    // A fragment of V^T: dim d * 16 + c, keys in the order of pf: [32 hf + g*4 .. +3 | 32 hf + 16 + g*4 .. +3]
+                    const _Float16 *vr = sV + (d * 16 + c) * SV_LD + 32 * hf + g * 4;
+                    const half4 v0 = *(const half4 *)vr, v1 = *(const half4 *)(vr + 16);
+                    const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    o[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[0][hf], o[0][d], 0, 0, 0);
+                    o[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[1][hf], o[1][d], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (q0 >= L) return;
+    _Float16 *ob = out + (size_t)tl.tok0 * ((size_t)H * ADK) + (size_t)h * ADK;
+#pragma unroll
+    for (int qt = 0; qt < 2; qt++) {
+        const int qi = q0 + qt * 16 + c;
+        if (qi >= L) continue;
+        const float inv = 1.f / lrow[qt];
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            const half4 v = {(_Float16)(o[qt][d][0] * inv), (_Float16)(o[qt][d][1] * inv), (_Float16)(o[qt][d][2] * inv), (_Float16)(o[qt][d][3] * inv)};
+            *(half4 *)(ob + (size_t)qi * ((size_t)H * ADK) + d * 16 + g * 4) = v;
+        }
+    }
+}
+void t5_attention(const void *qkv, void *vt, size_t Tp, const T5VtTile *vt_tiles, int n_vt_tiles, const T5AttnTile *tiles, int n_tiles, const float *bias,
+                  int bias_span, int H, void *out, hipStream_t s) {
     if (n_tiles <= 0) return;
-    hipLaunchKernelGGL(t5_attention_kernel, dim3(n_tiles, H), dim3(256), 0, s, (const _Float16 *)qkv, tiles, bias, bias_span, H, (_Float16 *)out);
+    hipLaunchKernelGGL(t5_vt_kernel, dim3(n_vt_tiles, H * ADK / 64), dim3(256), 0, s, (const _Float16 *)qkv, vt_tiles, H, Tp, (_Float16 *)vt);
+    hipLaunchKernelGGL(t5_attention_kernel, dim3(n_tiles, H), dim3(256), 0, s, (const _Float16 *)qkv, (const _Float16 *)vt, Tp, tiles, bias, bias_span, H,
+                       (_Float16 *)out);
 }
 
 // ---------------------------------------------------------------------------------------------- 3Di CNN head
