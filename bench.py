@@ -12,7 +12,8 @@ also    : `value_disk_to_tsv` — SURVEY.md 8(d)'s definition: wall of uc_cluste
 workload: --config c2 (default) = BASELINE.json configs[1]: 50 synthetic proteomes (~150 k sequences), tools/gen_synth.c
           seed 0x5EED0002, "-c 0.8", the plain all-vs-all step (`--single-step-clustering` semantics);
           --config c3 = configs[2] (500 proteomes, seed 0x5EED0003); --config c4-lite = configs[3]'s options
-          ("-c 0.8 --min-seq-id 0.3 -s 7.5") on 50 proteomes (seed 0x5EED0004).
+          ("-c 0.8 --min-seq-id 0.3 -s 7.5") on 50 proteomes (seed 0x5EED0004); --config c5 = configs[4]: the ProstT5 AA -> 3Di
+          encoder (MFMA) fused ahead of the cluster path on --proteomes 5 (its own metric line, see bench_c5).
 N > 1   : one process per GPU (torch.distributed.run).  The data path is inside the library: the target DB is range-
           partitioned across the ranks (Q x T grid, T = N by default = the north-star layout), the per-shard hit lists are
           all-gathered with RCCL over xGMI from C (uc_comm_*), merged on the device, every rank aligns the pairs it owns,
@@ -138,12 +139,87 @@ def cpu_baseline(prefix, opts, n_seqs, target_seconds=20.0):
     return out
 
 
+def bench_c5(args):
+    """BASELINE configs[4]: createdb's ProstT5 AA -> 3Di encoder (hand-written f16 MFMA kernels) fused ahead of the cluster
+    path, no disk round trip: AA residues -> uc_t5_encode -> 3Di codes -> uc_engine_set_db -> uc_engine_cluster_step.
+    ProtT5-XL geometry (24 blocks, 1024 / 32 x 128 / 16384) with seeded random-init weights (the real prostt5-f16.gguf
+    cannot be shipped; same loader).  One step = the whole chain on `--proteomes` synthetic proteomes (default 5)."""
+    import torch
+    import unicore_amd as U
+    from oracle import prostt5_ref as R
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    proteomes = args.proteomes if args.proteomes is not None else 5
+    seed = 0x5EED0005
+    workdir = os.path.join(args.workdir, "p%d_f6000_s1_%x" % (proteomes, seed))
+    prefix = gen_db(workdir, proteomes, 6000, 1.0, seed)
+    aa = [e.decode() for e in open(prefix, "rb").read().split(b"\n\0")[:-1]]
+    n, residues = len(aa), sum(len(x) for x in aa)
+    gguf = os.path.join(args.workdir, "prostt5_synth_24.gguf")
+    if not os.path.exists(gguf):
+        R.write_synthetic_gguf(gguf + ".tmp", R.default_config(), seed=seed)
+        os.replace(gguf + ".tmp", gguf)
+    enc = U.T5Encoder(gguf)
+    options = args.options if args.options is not None else "-c 0.8"
+    eng = U.Engine(options, threads=os.cpu_count() or 1, verbosity=1)
+    lut = np.full(256, 20, np.uint8)
+    for i, c in enumerate("ACDEFGHIKLMNPQRSTVWY"):
+        lut[ord(c)] = i
+    sa = lut[np.frombuffer("".join(aa).encode(), np.uint8)]
+    off = np.zeros(n + 1, np.uint64)
+    off[1:] = np.cumsum([len(x) for x in aa])
+    t_enc = t_clu = 0.0
+    n_aln = 0
+    assign = None
+
+    def step(timed):
+        nonlocal t_enc, t_clu, n_aln, assign
+        t0 = time.perf_counter()
+        codes = enc.encode(aa)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        eng.set_db(off, np.concatenate(codes), sa)
+        assign, a = eng.cluster_step()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if timed:
+            t_enc += t1 - t0; t_clu += t2 - t1; n_aln += a
+    for _ in range(args.warmup):
+        step(False)
+    s0 = enc.stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    s1 = enc.stats()
+    steps = max(args.steps, 1)
+    fl, ms = s1["flops"] - s0["flops"], s1["gpu_ms"] - s0["gpu_ms"]
+    tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    print(json.dumps({
+        "metric": "3Di alignments/sec (createdb ProstT5 AA->3Di encoder + cluster path, end to end)", "value": n_aln / dt, "unit": "alignments/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f16 (MFMA, fp32 accumulate) + u16 (packed DP)", "data": "synthetic (sequences and random-init weights)",
+        "config": {"workload": "BASELINE configs[4] chain at %d synthetic proteomes: %d sequences, %d residues; ProtT5-XL-geometry encoder (24 blocks, d_model 1024, "
+                               "32 x 128 heads, d_ff 16384, 3Di CNN head) with seeded random-init f16 weights -> 3Di codes -> cluster '%s' (plain all-vs-all step); "
+                               "no disk round trip" % (proteomes, n, residues, options),
+                   "alignments_per_step": n_aln // steps, "clusters": int((assign == np.arange(n)).sum()) if assign is not None else None},
+        "stages_s_per_step": {"prostt5_encode": t_enc / steps, "set_db_and_cluster": t_clu / steps},
+        "encoder_residues_per_s": residues * steps / t_enc if t_enc > 0 else 0.0,
+        "roofline": {"bound": "mfma", "kernel": "t5_gemm_kernel + t5_attention_kernel (f16 v_mfma_f32_16x16x32_f16, fp32 accumulate)", "achieved": tf, "peak": 2500.0,
+                     "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None,
+                     "algorithmic_flops_per_step": fl / steps, "gpu_ms_per_step": ms / steps,
+                     "note": "algorithmic FLOPs = linear layers (2 x tokens x weights) + attention (4 L^2 x 4096 per sequence and block) / HIP-event time of the encoder passes"},
+    }))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS) + ["c5"])
     ap.add_argument("--proteomes", type=int)
     ap.add_argument("--families", type=int)
     ap.add_argument("--len-scale", type=float)
@@ -155,6 +231,8 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the disk-to-TSV and default-workflow legs")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
+    if args.config == "c5":
+        return bench_c5(args)
     proteomes, families, len_scale, seed, options, label = CONFIGS[args.config]
     custom = any(v is not None for v in (args.proteomes, args.families, args.len_scale, args.options))
     proteomes = args.proteomes if args.proteomes is not None else proteomes

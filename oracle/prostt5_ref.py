@@ -122,9 +122,13 @@ def read_gguf(path):
     return kv, out
 
 
-def write_synthetic_gguf(path, cfg, seed=0x5EED0005, f16=True, with_vocab=True):
+def write_synthetic_gguf(path, cfg, seed=0x5EED0005, f16=True, with_vocab=True, resid_scale=0.15):
     """Seeded random-init weights of the given geometry in llama.cpp's t5encoder naming (+ cnn.* for the 3Di head).
-    Scales keep activations O(1) through the stack so that the argmax is not degenerate."""
+    Scales keep activations O(1) through the stack; the two projections that write into the residual stream (attn_o,
+    ffn_down) are scaled by `resid_scale` so that the stream stays dominated by the token embeddings: the predicted 3Di
+    state then depends on the local residue window (diverse strings, homologous proteins get similar ones) instead of
+    collapsing to one or two states, which would turn the downstream cluster stage of the chained benchmark into an
+    everything-hits-everything corner case that says nothing about either stage."""
     rng = np.random.default_rng(seed)
     D, HD, F = cfg["d_model"], cfg["n_heads"] * cfg["d_kv"], cfg["d_ff"]
     wt = np.float16 if f16 else np.float32
@@ -136,9 +140,9 @@ def write_synthetic_gguf(path, cfg, seed=0x5EED0005, f16=True, with_vocab=True):
         b = "enc.blk.%d." % l
         tensors += [(b + "attn_norm.weight", (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32)),
                     (b + "attn_q.weight", mat(HD, D, 0.3 / math.sqrt(D))), (b + "attn_k.weight", mat(HD, D, 1.0 / math.sqrt(D))),
-                    (b + "attn_v.weight", mat(HD, D, 1.0 / math.sqrt(D))), (b + "attn_o.weight", mat(D, HD, 1.0 / math.sqrt(HD))),
+                    (b + "attn_v.weight", mat(HD, D, 1.0 / math.sqrt(D))), (b + "attn_o.weight", mat(D, HD, resid_scale / math.sqrt(HD))),
                     (b + "ffn_norm.weight", (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32)),
-                    (b + "ffn_up.weight", mat(F, D, 1.0 / math.sqrt(D))), (b + "ffn_down.weight", mat(D, F, 1.0 / math.sqrt(F)))]
+                    (b + "ffn_up.weight", mat(F, D, 1.0 / math.sqrt(D))), (b + "ffn_down.weight", mat(D, F, resid_scale / math.sqrt(F)))]
         if l == 0:
             tensors.append((b + "attn_rel_b.weight", (rng.standard_normal((cfg["rel_buckets"], cfg["n_heads"])) * 0.5).astype(np.float32)))
     tensors += [("enc.output_norm.weight", (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32)),

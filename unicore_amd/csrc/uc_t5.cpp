@@ -286,7 +286,7 @@ void T5Model::load(const std::string &gguf_path, int dev) {
     for (int c = 'a'; c <= 'z'; c++) aa_token[c] = aa_token[c - 32];
     const int x = aa_token['X'] >= 0 ? aa_token['X'] : cfg.unk_token;
     for (int c = 0; c < 256; c++) if (aa_token[c] < 0) aa_token[c] = x;
-    logf(3, "ProstT5 encoder: %s: %d layers, d_model %d, %d heads x %d, d_ff %d, vocab %d, CNN %d->%d->%d (k=%d), device %d\n", gguf_path.c_str(), cfg.n_layers,
+    if (g_verbosity >= 3) fprintf(stderr, "ProstT5 encoder: %s: %d layers, d_model %d, %d heads x %d, d_ff %d, vocab %d, CNN %d->%d->%d (k=%d), device %d\n", gguf_path.c_str(), cfg.n_layers,
          cfg.d_model, cfg.n_heads, cfg.d_kv, cfg.d_ff, cfg.vocab, cfg.d_model, cfg.cnn_hidden, cfg.n_out, cfg.cnn_kernel, device);
 }
 
