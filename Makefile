@@ -8,7 +8,7 @@ CXX     ?= g++
 ARCH    ?= gfx950
 OPT     ?= -O3
 
-.PHONY: all oracle tools product clean
+.PHONY: all oracle oracle-asan tools product clean
 all: oracle tools product
 
 # ---------------------------------------------------------------- oracle (plain C, OpenMP)
@@ -16,6 +16,12 @@ oracle: oracle/liboracle.so
 # -march=x86-64-v3 (AVX2), not -march=native: the .so is built in the dev container and runs on the GPU box's host CPU
 oracle/liboracle.so: oracle/uc_oracle.c oracle/uc_simd.c oracle/uc_oracle.h
 	$(CC) -std=c11 $(OPT) -march=x86-64-v3 -fopenmp -fPIC -shared -Wall -Wextra -D_POSIX_C_SOURCE=200809L -o $@ oracle/uc_oracle.c oracle/uc_simd.c -lm
+
+# address + undefined-behaviour sanitizer build of the checker (tests/test_oracle_kat.py runs a pipeline through it once)
+oracle-asan: oracle/_asan/liboracle_asan.so
+oracle/_asan/liboracle_asan.so: oracle/uc_oracle.c oracle/uc_simd.c oracle/uc_oracle.h
+	@mkdir -p oracle/_asan
+	$(CC) -std=c11 -O1 -g -march=x86-64-v3 -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -fPIC -shared -D_POSIX_C_SOURCE=200809L -o $@ oracle/uc_oracle.c oracle/uc_simd.c -lm
 
 # ---------------------------------------------------------------- tools
 tools: bin/gen_synth

@@ -119,7 +119,7 @@ static idx_ent *read_index(const char *path, uint32_t *n) {
         while (*s == '\n' || *s == '\r' || *s == ' ' || *s == '\t') s++;
     }
     free(txt);
-    qsort(e, cnt, sizeof *e, cmp_idx);
+    if (cnt) qsort(e, cnt, sizeof *e, cmp_idx);
     *n = (uint32_t)cnt;
     return e;
 }
@@ -323,7 +323,7 @@ int uco_prefilter_query(const uco_db *db, const uco_index *ix, uint32_t q, const
     }
     free(sim.v);
     if (cnt) cnt->n_kmer_hits += nh;
-    qsort(hk, nh, sizeof(uint64_t), cmp_u64);
+    if (nh) qsort(hk, nh, sizeof(uint64_t), cmp_u64);   /* (qsort(NULL, 0, ..) is undefined: found by the UBSan job) */
     /* per target: diagonal with most hits (tie: smallest diagonal); double-hit rule */
     uco_hit *cand = NULL; size_t nc = 0, ccap = 0;
     size_t a = 0;
@@ -352,9 +352,9 @@ int uco_prefilter_query(const uco_db *db, const uco_index *ix, uint32_t q, const
     if (cnt) cnt->n_candidates += nc;
     size_t kept = 0;
     for (size_t k = 0; k < nc; k++) if (cand[k].score >= p->min_ungapped) cand[kept++] = cand[k];
-    qsort(cand, kept, sizeof *cand, cmp_hit);
+    if (kept) qsort(cand, kept, sizeof *cand, cmp_hit);
     if (kept > (size_t)p->max_seqs) kept = (size_t)p->max_seqs;
-    memcpy(hits, cand, kept * sizeof *cand);
+    if (kept) memcpy(hits, cand, kept * sizeof *cand);
     free(cand);
     if (cnt) cnt->n_prefilter_hits += kept;
     return (int)kept;
@@ -527,7 +527,7 @@ int uco_setcover(uint32_t n, const uint32_t *edges, uint64_t n_edges, uint32_t *
         keys[nk++] = ((uint64_t)a << 32) | b;
         keys[nk++] = ((uint64_t)b << 32) | a;
     }
-    qsort(keys, nk, sizeof(uint64_t), cmp_u64);
+    if (nk) qsort(keys, nk, sizeof(uint64_t), cmp_u64);
     uint64_t u = 0;
     for (uint64_t k = 0; k < nk; k++) if (k == 0 || keys[k] != keys[k - 1]) keys[u++] = keys[k];
     nk = u;
@@ -710,7 +710,7 @@ int uco_write_m8(const char *path, const uco_db *qdb, const uco_db *tdb, const u
         uint32_t m = 0;
         for (uint32_t k = 0; k < hit_cnt[q]; k++)
             if (aln[(size_t)q * M + k].accepted) { ord[m].corrected = aln[(size_t)q * M + k].corrected; ord[m].t = hits[(size_t)q * M + k].t; ord[m].k = k; m++; }
-        qsort(ord, m, sizeof(m8ord), m8cmp);
+        if (m) qsort(ord, m, sizeof(m8ord), m8cmp);
         const double lq = (double)(qdb->off[q + 1] - qdb->off[q]);
         for (uint32_t j = 0; j < m; j++) {
             const uco_aln *a = &aln[(size_t)q * M + ord[j].k];
@@ -770,11 +770,11 @@ int uco_linclust_pairs(const uco_db *db, const uco_params *p, int m, uint32_t **
             if (nc == ccap) { ccap *= 2; cand = (lc_cand *)realloc(cand, ccap * sizeof(lc_cand)); }
             cand[nc].h = lc_hash(v); cand[nc].v = v; cand[nc].pos = (uint32_t)j; nc++;
         }
-        qsort(cand, nc, sizeof(lc_cand), lc_cand_cmp);
+        if (nc) qsort(cand, nc, sizeof(lc_cand), lc_cand_cmp);
         for (size_t k = 0; k < nc && k < (size_t)m; k++) { ent[ne].v = cand[k].v; ent[ne].seq = t; ne++; }
     }
     free(cand);
-    qsort(ent, ne, sizeof(lc_ent), lc_ent_cmp);
+    if (ne) qsort(ent, ne, sizeof(lc_ent), lc_ent_cmp);
     uint32_t *pairs = (uint32_t *)malloc((2 * ne + 2) * sizeof(uint32_t));
     uint64_t np = 0;
     for (size_t b = 0; b < ne;) {
@@ -793,7 +793,7 @@ int uco_linclust_pairs(const uco_db *db, const uco_params *p, int m, uint32_t **
         b = e;
     }
     free(ent);
-    qsort(pairs, np, 2 * sizeof(uint32_t), lc_pair_cmp);
+    if (np) qsort(pairs, np, 2 * sizeof(uint32_t), lc_pair_cmp);
     uint64_t w = 0;
     for (uint64_t k = 0; k < np; k++)
         if (k == 0 || pairs[2 * k] != pairs[2 * k - 2] || pairs[2 * k + 1] != pairs[2 * k - 1]) { pairs[2 * w] = pairs[2 * k]; pairs[2 * w + 1] = pairs[2 * k + 1]; w++; }

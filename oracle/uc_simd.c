@@ -114,7 +114,7 @@ void uco_simd_align_query(const uco_db *db, uint32_t q, const uint32_t *targets,
     res_t rs[L];
     /* pass 1: forward, targets grouped by length */
     for (uint32_t h = 0; h < nh; h++) { ord[h].idx = h; ord[h].key = (int)(db->off[targets[h] + 1] - db->off[targets[h]]); }
-    qsort(ord, nh, sizeof(ord_t), ord_cmp);
+    if (nh) qsort(ord, nh, sizeof(ord_t), ord_cmp);
     for (uint32_t b = 0; b < nh; b += L) {
         const int nl = (int)(nh - b < L ? nh - b : L);
         for (int l = 0; l < nl; l++) {
@@ -132,7 +132,7 @@ void uco_simd_align_query(const uco_db *db, uint32_t q, const uint32_t *targets,
     uint32_t n2 = 0;
     for (uint32_t h = 0; h < nh; h++)
         if (!redo[h] && p->rev_correction && out[h].score >= min_score) { ord[n2].idx = h; ord[n2].key = (int)(db->off[targets[h] + 1] - db->off[targets[h]]); n2++; }
-    qsort(ord, n2, sizeof(ord_t), ord_cmp);
+    if (n2) qsort(ord, n2, sizeof(ord_t), ord_cmp);
     for (uint32_t b = 0; b < n2; b += L) {
         const int nl = (int)(n2 - b < L ? n2 - b : L);
         for (int l = 0; l < nl; l++) {
@@ -150,7 +150,7 @@ void uco_simd_align_query(const uco_db *db, uint32_t q, const uint32_t *targets,
     uint32_t n3 = 0;
     for (uint32_t h = 0; h < nh; h++)
         if (!redo[h] && out[h].pass_evalue) { ord[n3].idx = h; ord[n3].key = out[h].tend + 1; n3++; }
-    qsort(ord, n3, sizeof(ord_t), ord_cmp);
+    if (n3) qsort(ord, n3, sizeof(ord_t), ord_cmp);
     for (uint32_t b = 0; b < n3; b += L) {
         const int nl = (int)(n3 - b < L ? n3 - b : L);
         for (int l = 0; l < nl; l++) {
@@ -207,7 +207,7 @@ uint64_t uco_simd_sample_run(const uco_db *db, const uco_index *ix, const uco_pa
     /* one task = one query with its whole hit list (its targets share the query profile); heavy queries first */
     ord_t *qo = (ord_t *)malloc(((size_t)n_queries + 1) * sizeof(ord_t));
     for (uint32_t k = 0; k < n_queries; k++) { qo[k].idx = k; qo[k].key = (int)((db->off[queries[k] + 1] - db->off[queries[k]]) * (uint64_t)hcnt[k] >> 6); }
-    qsort(qo, n_queries, sizeof(ord_t), ord_cmp);
+    if (n_queries) qsort(qo, n_queries, sizeof(ord_t), ord_cmp);
 #pragma omp parallel
     {
         uco_aln *buf = aln_out ? NULL : (uco_aln *)malloc((size_t)M * sizeof(uco_aln));

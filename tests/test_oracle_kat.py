@@ -4,13 +4,17 @@ The reference holds no golden vector for this path (parity unpinned, oracle/uc_o
 pinned by (a) hand-computable cases, (b) an independent pure-Python restatement of every stage on small
 inputs, (c) the committed fixtures in tests/golden/ (test_golden.py).
 """
+import ctypes as C
 import itertools
+import os
 
 import numpy as np
 import pytest
 
 import util
 from oracle import oracle_py as O
+
+ROOT = util.ROOT
 
 LET = "ACDEFGHIKLMNPQRSTVWY"
 
@@ -329,3 +333,83 @@ def test_simd_cpu_leg_equals_the_scalar_oracle(opts, tmp_path):
                     assert got[f] == ref[f], (opts, int(q), int(hits[k, h]["t"]), f, got, ref)
             checked += 1
     assert checked == n
+
+
+# ------------------------------------------------------------------ published constants / textbook properties
+def test_blosum62_is_the_ncbi_matrix(p):
+    """BLOSUM62 (Henikoff & Henikoff 1992, NCBI half-bit rounding): the diagonal, symmetry, range and a column are fixed
+    published values that do not depend on any Foldseek data"""
+    idx = {c: i for i, c in enumerate(LET)}
+    diag = dict(A=4, R=5, N=6, D=6, C=9, Q=5, E=5, G=6, H=8, I=4, L=4, K=5, M=5, F=6, P=7, S=4, T=5, W=11, Y=7, V=4)
+    m = np.array(p.SA[:]).reshape(21, 21)[:20, :20]
+    assert all(m[idx[c], idx[c]] == v for c, v in diag.items()) and int(np.trace(m)) == 116
+    assert (m == m.T).all() and m.min() == -4 and m.max() == 11
+    w_col = dict(A=-3, R=-3, N=-4, D=-4, C=-2, Q=-2, E=-3, G=-2, H=-2, I=-3, L=-2, K=-3, M=-1, F=1, P=-4, S=-3, T=-2, W=11, Y=2, V=-3)
+    assert all(m[idx[c], idx["W"]] == v for c, v in w_col.items())
+    # expected score of BLOSUM62 under the Robinson & Robinson background is negative (a local-alignment matrix must be)
+    bg = dict(A=.078, R=.051, N=.045, D=.054, C=.019, Q=.043, E=.063, G=.074, H=.022, I=.051, L=.091, K=.057, M=.022, F=.039, P=.052, S=.071, T=.058, W=.013, Y=.032, V=.064)
+    f = np.array([bg[c] for c in LET])
+    assert -1.2 < float(f @ m @ f) < -0.7
+
+
+def test_spaced_seed_is_the_mmseqs2_k6_pattern(p):
+    """MMseqs2's spaced seed for k = 6 (src/commons/Sequence.h: seed_6_spaced = {1,1,0,1,0,1,0,0,1,1}; EXT-UNVERIFIED for
+    Foldseek, which embeds MMseqs2): span 10, offsets 0 1 3 5 8 9 - the default of both the oracle and the engine"""
+    off = (C.c_int * 6)()
+    assert O.lib().uco_pattern_offsets(b"1101010011", off) == 10 and list(off) == [0, 1, 3, 5, 8, 9]
+    assert (p.pattern.decode() if isinstance(p.pattern, bytes) else p.pattern) == "1101010011"
+    import unicore_amd as U
+    assert U.check_options("--spaced-kmer-pattern 1101010011") == 0
+
+
+def test_affine_gap_properties_of_gotoh(p):
+    """Gotoh 1982 affine gaps as the spec fixes them (a gap of k residues costs open + (k - 1) * ext): one long gap beats
+    two short ones exactly when it is cheaper, gaps in query and target are symmetric, and a gap is never opened when the
+    mismatch path scores more"""
+    blk = [enc(x) for x in ("WCHWCHWC", "MFYMFYMF", "HWCKPRHW")]
+    a, b, c = blk
+    junk1, junk3 = enc("G"), enc("GGG")
+    full = lambda s: sum(S3(p, x, x) + SA(p, x, x) for x in s)
+    q = np.concatenate([a, b, c])
+    # two separate 1-residue insertions in the target: 2 * open
+    t2 = np.concatenate([a, junk1, b, junk1, c])
+    assert O.sw(q, q, t2, t2, p)[0] == full(q) - 2 * p.gap_open
+    # one 3-residue insertion: open + 2 ext (cheaper than the two above although it skips more residues)
+    t1 = np.concatenate([a, junk3, b, c])
+    assert O.sw(q, q, t1, t1, p)[0] == full(q) - (p.gap_open + 2 * p.gap_ext)
+    assert O.sw(t1, t1, q, q, p)[0] == O.sw(q, q, t1, t1, p)[0]                 # deletion == insertion
+    # a single substituted residue is aligned as a mismatch, not bridged by two gaps
+    m = q.copy(); m[10] = enc("G")[0]
+    mm = S3(p, q[10], m[10]) + SA(p, q[10], m[10]) - (S3(p, q[10], q[10]) + SA(p, q[10], q[10]))
+    assert mm > -2 * p.gap_open and O.sw(q, q, m, m, p)[0] == full(q) + mm
+
+
+def test_oracle_under_address_and_ub_sanitizers(tmp_path):
+    """the C checker (scalar + SIMD legs) through gcc's address and undefined-behaviour sanitizers on a small family DB:
+    prefilter, gapped passes, traceback, cascade + pre-step, set cover, TSV writer - no report, same result as the normal build"""
+    import subprocess, sys
+    so = os.path.join(ROOT, "oracle", "_asan", "liboracle_asan.so")
+    subprocess.check_call(["make", "-C", ROOT, "oracle-asan"], stdout=subprocess.DEVNULL)
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import util
+from oracle import oracle_py as O
+s3, sa = util.family_db(5, n_fam=6, members=5, extra=(300,))
+odb = O.OracleDb(s3=s3, sa=sa)
+p = util.oracle_params(O, "-c 0.5 --min-seq-id 0.3")
+r = O.cluster(odb, p, threads=2)
+w = O.cluster_workflow(odb, p, O.cascade_thresholds(p, 4.0, 2), linclust_m=5, threads=2)
+ix = O.build_index(odb, p)
+n, _, _, cnt, hits, alns = O.simd_sample_run(odb, ix, p, np.arange(odb.n, dtype=np.uint32), threads=2, records=True)
+O.free_index(ix)
+O.write_tsv(%r, odb, r["assign"])
+print("RESULT", int(r["counts"]["n_alignments"]), int(r["counts"]["n_clusters"]), int(w["counts"]["n_clusters"]), n, int(alns["accepted"].sum()))
+""" % (ROOT, os.path.join(ROOT, "tests"), str(tmp_path / "a.tsv"))
+    outs = []
+    for lib_env in ({"UC_ORACLE_LIB": so, "LD_PRELOAD": subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip(),
+                     "ASAN_OPTIONS": "detect_leaks=0:abort_on_error=1", "UBSAN_OPTIONS": "halt_on_error=1"}, {}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **lib_env), timeout=600)
+        assert r.returncode == 0 and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("RESULT")][0])
+    assert outs[0] == outs[1]
