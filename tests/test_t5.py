@@ -4,7 +4,7 @@ architecture (oracle/prostt5_ref.py) on seeded synthetic weights.
 
 Tolerance (f16 operands with fp32 accumulation and an fp32 residual stream against fp32 everywhere): the worst logit error
 must stay below 5e-3 of the largest logit of the sequence, and the predicted 3Di state must agree wherever the reference's
-top-2 margin exceeds twice that error bound (positions with a thinner margin may legitimately flip)."""
+top-2 margin exceeds twice that error bound (positions with a thinner margin may legitimately flip: at most 2 % of a sequence, or one residue)."""
 import os
 import subprocess
 import sys
@@ -144,7 +144,7 @@ def _check(codes, logits, ref_logits, ref_codes, what):
     top2 = np.sort(ref_logits, axis=1)[:, -2:]
     safe = (top2[:, 1] - top2[:, 0]) > 2 * REL_TOL * scale
     assert np.array_equal(codes[safe], ref_codes[safe]), what
-    assert (codes == ref_codes).mean() >= 0.98, what
+    assert (codes != ref_codes).sum() <= max(1, 0.02 * len(ref_codes)), what       # thin-margin positions may flip: at most 2 % (or one residue)
 
 
 @pytest.mark.gpu

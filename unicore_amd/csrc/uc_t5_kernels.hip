@@ -27,13 +27,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------- GEMM
 // out[M, N] (+)= A[M, K] . W[N, K]^T      A, W f16 row-major (K contiguous: the layout of a torch Linear weight)
 // EPI 0: f16 store, 1: ReLU + f16 store, 2: fp32 accumulate into out (the residual stream)
-constexpr int GBM = 128, GBN = 128, GBK = 64, GLD = 72;   // LDS row stride in halves: 144 B keeps the 16-byte fragment reads of 16 rows on distinct banks
+//
+// 128 x 128 x 64 tiles, 4 waves x (4 x 4 MFMA tiles of 16 x 16 x 32).  Operands go from global memory STRAIGHT into LDS
+// (global_load_lds, 16 bytes per lane: no staging registers, no ds_write), two stages: the loads of K-tile kt + 1 are in
+// flight while tile kt is multiplied, ONE barrier per K-step.  A wave's load instruction fills 1 KB = 8 rows of 128 bytes;
+// the image is linear (the DMA writes lane-linear) but XOR-swizzled through the GLOBAL address each lane picks: slot c of
+// row r holds 16-byte chunk c ^ (r & 7), so the 16 rows of an MFMA fragment read (same chunk, consecutive rows) spread over
+// all banks (2-way instead of 16-way conflicts on the 128-byte row stride).
+constexpr int GBM = 128, GBN = 128, GBK = 64;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
 
 template <int EPI>
 __global__ void __launch_bounds__(256) t5_gemm_kernel(const _Float16 *__restrict__ A, const _Float16 *__restrict__ W, void *__restrict__ out,
                                                       int M, int N, int K) {
-    __shared__ __attribute__((aligned(16))) _Float16 sA[GBM * GLD];
-    __shared__ __attribute__((aligned(16))) _Float16 sB[GBN * GLD];
+    __shared__ __attribute__((aligned(1024))) _Float16 sm[2][2][GBM * GBK];      // [stage][A | B][row * 64 + slot * 8]: 64 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
     f32x4 acc[4][4];
@@ -41,43 +49,47 @@ __global__ void __launch_bounds__(256) t5_gemm_kernel(const _Float16 *__restrict
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    uint4 ra[4], rb[4];
-    auto gload = [&](int kt) {
+    // this lane's source rows / chunks of the 4 + 4 load instructions of a K-tile (instruction i of wave w fills rows
+    // (4 w + i) * 8 .. + 7; lane l -> row + l / 8, slot l % 8, which receives chunk slot ^ (row & 7))
+    const _Float16 *ga[4], *gb[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3), kc = ((lane & 7) ^ (row & 7)) * 8;
+        ga[i] = A + (size_t)min(m0 + row, M - 1) * K + kc;              // rows beyond M are never stored: any valid address will do
+        gb[i] = W + (size_t)min(n0 + row, N - 1) * K + kc;
+    }
+    auto issue = [&](int kt, int st) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
-            ra[i] = (m0 + row < M) ? *(const uint4 *)(A + (size_t)(m0 + row) * K + (size_t)kt * GBK + kc) : uint4{0, 0, 0, 0};
-            rb[i] = (n0 + row < N) ? *(const uint4 *)(W + (size_t)(n0 + row) * K + (size_t)kt * GBK + kc) : uint4{0, 0, 0, 0};
-        }
-    };
-    auto sstore = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
-            *(uint4 *)(sA + row * GLD + kc) = ra[i];
-            *(uint4 *)(sB + row * GLD + kc) = rb[i];
+            __builtin_amdgcn_global_load_lds((gbl_void *)(ga[i] + (size_t)kt * GBK), (lds_void *)(&sm[st][0][(wave * 4 + i) * 8 * GBK]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(gb[i] + (size_t)kt * GBK), (lds_void *)(&sm[st][1][(wave * 4 + i) * 8 * GBK]), 16, 0, 0);
         }
     };
     const int nk = K / GBK;
-    gload(0);
-    sstore();
-    __syncthreads();
+    issue(0, 0);
     for (int kt = 0; kt < nk; kt++) {
-        if (kt + 1 < nk) gload(kt + 1);          // the next tile travels while this one is multiplied
+        const int st = kt & 1;
+        __syncthreads();                             // tile kt has landed for every wave (the compiler drains vmcnt here) and everybody is done with tile kt - 1
+        if (kt + 1 < nk) issue(kt + 1, st ^ 1);
+        const _Float16 *sA = sm[st][0], *sB = sm[st][1];
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
             half8 af[4], bf[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) af[i] = *(const half8 *)(sA + (wm * 64 + i * 16 + (lane & 15)) * GLD + ks * 32 + (lane >> 4) * 8);
+            for (int i = 0; i < 4; i++) {
+                const int r = wm * 64 + i * 16 + (lane & 15);
+                af[i] = *(const half8 *)(sA + r * GBK + (((ks * 4 + (lane >> 4)) ^ (r & 7)) * 8));
+            }
 #pragma unroll
-            for (int j = 0; j < 4; j++) bf[j] = *(const half8 *)(sB + (wn * 64 + j * 16 + (lane & 15)) * GLD + ks * 32 + (lane >> 4) * 8);
+            for (int j = 0; j < 4; j++) {
+                const int r = wn * 64 + j * 16 + (lane & 15);
+                bf[j] = *(const half8 *)(sB + r * GBK + (((ks * 4 + (lane >> 4)) ^ (r & 7)) * 8));
+            }
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
-        if (kt + 1 < nk) { sstore(); __syncthreads(); }
     }
 #pragma unroll
     for (int i = 0; i < 4; i++)
