@@ -44,6 +44,10 @@ product: unicore_amd/libunicore_cluster.so bin/unicore bin/foldseek
 $(CSRC)/%.o: $(CSRC)/%.cpp $(HDRS)
 	$(HIPCC) -x c++ -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include $(CXXFLAGS) -c $< -o $@
 
+# the MFMA kernels keep their accumulators in VGPRs (gfx950's register file is unified): without this flag the compiler parks
+# them in AGPRs and pays a v_accvgpr_read/write for every VALU touch of an accumulator (352 copies per attention block)
+$(CSRC)/uc_t5_kernels.o: HIPFLAGS += -mllvm -amdgpu-mfma-vgpr-form
+
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
