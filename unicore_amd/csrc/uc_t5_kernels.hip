@@ -88,27 +88,30 @@ __global__ void __launch_bounds__(256) t5_gemm_kernel(const _Float16 *__restrict
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
         }
     }
+    // the tiles are computed TRANSPOSED (W fragment as the A operand): a lane holds out[row l & 15][4 consecutive columns
+    // (l >> 4) * 4 ..], so the epilogue moves 8 / 16 bytes per access instead of 2 / 4
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 4; i++) {
+        const int row = m0 + wm * 64 + i * 16 + (lane & 15);
+        if (row >= M) continue;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-            if (row >= M) continue;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int col = n0 + wn * 64 + j * 16 + (lane & 15);
-                if (col >= N) continue;
-                float v = acc[i][j][r];
-                if (EPI == 2) ((float *)out)[(size_t)row * N + col] += v;
-                else {
-                    if (EPI == 1) v = v > 0.f ? v : 0.f;
-                    ((_Float16 *)out)[(size_t)row * N + col] = (_Float16)v;
-                }
+        for (int j = 0; j < 4; j++) {
+            const int col = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            if (col >= N) continue;                                  // (N is a multiple of 4)
+            f32x4 v = acc[i][j];
+            if (EPI == 2) {
+                f32x4 *o = (f32x4 *)((float *)out + (size_t)row * N + col);
+                *o = *o + v;
+            } else {
+                if (EPI == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                *(h4 *)((_Float16 *)out + (size_t)row * N + col) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
             }
         }
+    }
 }
 
 void t5_gemm(int epi, const void *A, const void *W, void *out, int M, int N, int K, hipStream_t s) {
@@ -232,29 +235,29 @@ __global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__res
 #pragma unroll
         for (int d = 0; d < 8; d++) o[qt][d] = f32x4{0.f, 0.f, 0.f, 0.f};
     float mrow[2] = {-INFINITY, -INFINITY}, lrow[2] = {0.f, 0.f};
-    // staging: K block = 64 rows x 16 chunks of 16 B, V^T block = 128 rows x 8 chunks: 4 + 4 chunks per thread
-    uint4 rk[4], rv[4];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int ch = tid + 256 * i;
-            const int key = ch >> 4, dc = (ch & 15) * 8;
-            rk[i] = k0 + key < L ? *(const uint4 *)(kb + (size_t)(k0 + key) * ld + dc) : uint4{0, 0, 0, 0};
-            const int dim = ch >> 3, kc = (ch & 7) * 8;
-            rv[i] = *(const uint4 *)(vb + (size_t)dim * Tp + k0 + kc);       // the sequence is zero-padded to a multiple of 64 keys in vt
-        }
-    };
-    auto sstore = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int ch = tid + 256 * i;
-            *(uint4 *)(sK + (ch >> 4) * SK_LD + (ch & 15) * 8) = rk[i];
-            *(uint4 *)(sV + (ch >> 3) * SV_LD + (ch & 7) * 8) = rv[i];
-        }
-    };
+    // staging: K block = 64 rows x 16 chunks of 16 B, V^T block = 128 rows x 8 chunks: 4 + 4 chunks per thread.  All eight
+    // loads are unconditional (key rows clamped: keys >= L are masked in the softmax anyway; V^T is zero-padded) and issued
+    // back to back - as lambdas over register arrays under `key < L` they were compiled to branchy, serialized loads spilled
+    // through scratch memory
+    const int skey = tid >> 4, sdc = (tid & 15) * 8;                 // K: thread -> (key row, dim chunk); + 16 keys per i
+    const int sdim = tid >> 3, skc = (tid & 7) * 8;                  // V^T: thread -> (dim row, key chunk); + 32 dims per i
     for (int k0 = 0; k0 < L; k0 += AKB) {
-        gload(k0);           // (keeping the next block in registers across the compute phase spilled them to scratch: 2-3 workgroups
-        sstore();            //  per CU hide this latency instead)
+        const uint4 rk0 = *(const uint4 *)(kb + (size_t)min(k0 + skey, L - 1) * ld + sdc);
+        const uint4 rk1 = *(const uint4 *)(kb + (size_t)min(k0 + skey + 16, L - 1) * ld + sdc);
+        const uint4 rk2 = *(const uint4 *)(kb + (size_t)min(k0 + skey + 32, L - 1) * ld + sdc);
+        const uint4 rk3 = *(const uint4 *)(kb + (size_t)min(k0 + skey + 48, L - 1) * ld + sdc);
+        const uint4 rv0 = *(const uint4 *)(vb + (size_t)sdim * Tp + k0 + skc);
+        const uint4 rv1 = *(const uint4 *)(vb + (size_t)(sdim + 32) * Tp + k0 + skc);
+        const uint4 rv2 = *(const uint4 *)(vb + (size_t)(sdim + 64) * Tp + k0 + skc);
+        const uint4 rv3 = *(const uint4 *)(vb + (size_t)(sdim + 96) * Tp + k0 + skc);
+        *(uint4 *)(sK + skey * SK_LD + sdc) = rk0;
+        *(uint4 *)(sK + (skey + 16) * SK_LD + sdc) = rk1;
+        *(uint4 *)(sK + (skey + 32) * SK_LD + sdc) = rk2;
+        *(uint4 *)(sK + (skey + 48) * SK_LD + sdc) = rk3;
+        *(uint4 *)(sV + sdim * SV_LD + skc) = rv0;
+        *(uint4 *)(sV + (sdim + 32) * SV_LD + skc) = rv1;
+        *(uint4 *)(sV + (sdim + 64) * SV_LD + skc) = rv2;
+        *(uint4 *)(sV + (sdim + 96) * SV_LD + skc) = rv3;
         __syncthreads();
         if (q0 < L) {                                    // (waves without queries only help with the staging)
             f32x4 sacc[2][4];                            // [query tile][16-key sub-tile]
