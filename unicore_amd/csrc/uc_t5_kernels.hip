@@ -34,7 +34,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // the image is linear (the DMA writes lane-linear) but XOR-swizzled through the GLOBAL address each lane picks: slot c of
 // row r holds 16-byte chunk c ^ (r & 7), so the 16 rows of an MFMA fragment read (same chunk, consecutive rows) spread over
 // all banks (2-way instead of 16-way conflicts on the 128-byte row stride).
-constexpr int GBM = 128, GBN = 128, GBK = 64;
+constexpr int GBM = 128, GBN = 128, GBK = 64, GXM = 8;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
@@ -43,7 +43,20 @@ __global__ void __launch_bounds__(256) t5_gemm_kernel(const _Float16 *__restrict
                                                       int M, int N, int K) {
     __shared__ __attribute__((aligned(1024))) _Float16 sm[2][2][GBM * GBK];      // [stage][A | B][row * 64 + slot * 8]: 64 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own 4 MB L2: XCD x owns
+    // the row tiles x, x + 8, ... and walks them in groups of GXM rows x all column tiles, rows fastest - the ~70 workgroups
+    // an XCD runs at a time then share GXM A tiles and a handful of W tiles through ITS L2 instead of every XCD streaming
+    // every A row tile (plain row-major order with 8 column tiles put column tile x on XCD x: A was read 8 times over)
+    int m0, n0;
+    {
+        const int nn = (N + GBN - 1) / GBN, nm = (M + GBM - 1) / GBM;
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int g = k / (GXM * nn), r = k % (GXM * nn);
+        const int ml = g * GXM + r % GXM, mt = xcd + 8 * ml;
+        if (mt >= nm) return;
+        m0 = mt * GBM;
+        n0 = (r / GXM) * GBN;
+    }
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -116,7 +129,8 @@ __global__ void __launch_bounds__(256) t5_gemm_kernel(const _Float16 *__restrict
 
 void t5_gemm(int epi, const void *A, const void *W, void *out, int M, int N, int K, hipStream_t s) {
     if (M <= 0) return;
-    const dim3 grid((N + GBN - 1) / GBN, (M + GBM - 1) / GBM);
+    const int nn = (N + GBN - 1) / GBN, nm = (M + GBM - 1) / GBM, per_xcd = ((nm + 7) / 8 + GXM - 1) / GXM * GXM;
+    const dim3 grid((unsigned)(8 * per_xcd * nn));
     if (epi == 0) hipLaunchKernelGGL(t5_gemm_kernel<0>, grid, dim3(256), 0, s, (const _Float16 *)A, (const _Float16 *)W, out, M, N, K);
     else if (epi == 1) hipLaunchKernelGGL(t5_gemm_kernel<1>, grid, dim3(256), 0, s, (const _Float16 *)A, (const _Float16 *)W, out, M, N, K);
     else hipLaunchKernelGGL(t5_gemm_kernel<2>, grid, dim3(256), 0, s, (const _Float16 *)A, (const _Float16 *)W, out, M, N, K);
