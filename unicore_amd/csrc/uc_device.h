@@ -28,6 +28,7 @@ struct PerDeviceOnce {
 struct DeviceDb {
     uint32_t n = 0;
     const uint8_t *s3 = nullptr, *sa = nullptr;
+    const uint16_t *lt = nullptr;    // same offsets: 3Di | AA << 8 per residue, SW_PADPACK in the padding (and at lt[-1])
     const uint32_t *off = nullptr;   // n+1
     const uint32_t *len = nullptr;   // n
     const int8_t *S3 = nullptr, *SA = nullptr;   // 21x21 each

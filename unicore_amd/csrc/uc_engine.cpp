@@ -86,11 +86,15 @@ void Engine::upload_db() {
     }
     h_poff[n] = (uint32_t)tot;
     std::vector<uint8_t> p3(tot + 64, 20), pa(tot + 64, 20);
+    std::vector<uint16_t> plt(tot + 64 + 16, (uint16_t)(21u | (21u << 8)));   // letter-pair stream of the gapped kernels, 16 PAD pairs in front
     {
         auto pad_copy = [&](uint32_t b, uint32_t e) {
             for (uint32_t i = b; i < e; i++) {
                 memcpy(p3.data() + h_poff[i], hdb.s3.data() + hdb.off[i], h_len[i]);
                 memcpy(pa.data() + h_poff[i], hdb.sa.data() + hdb.off[i], h_len[i]);
+                uint16_t *w = plt.data() + 16 + h_poff[i];
+                const uint8_t *x3 = hdb.s3.data() + hdb.off[i], *xa = hdb.sa.data() + hdb.off[i];
+                for (uint32_t j = 0; j < h_len[i]; j++) w[j] = (uint16_t)(x3[j] | (xa[j] << 8));
             }
         };
         const unsigned T = tot < (1u << 22) ? 1u : std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
@@ -101,14 +105,16 @@ void Engine::upload_db() {
     }
     d_s3.reserve(tot + 64);
     d_sa.reserve(tot + 64);
+    d_lt.reserve(tot + 64 + 16);
     d_off.reserve((size_t)n + 1);
     d_len.reserve(std::max<size_t>(n, 1));
     UC_HIP(hipMemcpy(d_s3.p, p3.data(), tot + 64, hipMemcpyHostToDevice));
     UC_HIP(hipMemcpy(d_sa.p, pa.data(), tot + 64, hipMemcpyHostToDevice));
+    UC_HIP(hipMemcpy(d_lt.p, plt.data(), (tot + 64 + 16) * 2, hipMemcpyHostToDevice));
     UC_HIP(hipMemcpy(d_off.p, h_poff.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
     if (n) UC_HIP(hipMemcpy(d_len.p, h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     ddb.n = n;
-    ddb.s3 = d_s3.p; ddb.sa = d_sa.p; ddb.off = d_off.p; ddb.len = d_len.p;
+    ddb.s3 = d_s3.p; ddb.sa = d_sa.p; ddb.lt = d_lt.p + 16; ddb.off = d_off.p; ddb.len = d_len.p;
     ddb.S3 = d_S3.p; ddb.SA = d_SA.p;
     have_db = true;
     hit_cnt.assign(n, 0);

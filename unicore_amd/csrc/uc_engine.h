@@ -95,6 +95,7 @@ struct Engine {
 
     // device DB
     DevBuf<uint8_t> d_s3, d_sa;
+    DevBuf<uint16_t> d_lt;
     DevBuf<uint32_t> d_off, d_len;
     DevBuf<int8_t> d_S3, d_SA;
     DeviceDb ddb;

@@ -48,6 +48,17 @@ __device__ __forceinline__ int shift_from_prev_lane(int v, int boundary, int g) 
     }
 }
 
+// boundary 0: DPP bound_ctrl writes 0 into the lanes without a source, so no register has to be preset
+template <int G>
+__device__ __forceinline__ int shift_from_prev_lane_zero(int v, int g) {
+    if constexpr (G == 16) {
+        return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    } else {
+        const int r = __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true);
+        return (G == 64 || g != 0) ? r : 0;
+    }
+}
+
 // NW = waves per workgroup: all of them stream targets through the one LDS profile of the task's query
 template <int G, int R, int MODE, int NW>
 __global__ void __launch_bounds__(NW * 64) sw_group_kernel(const SwArgs a) {

@@ -118,33 +118,47 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
     bool vB = false, active = false;
     int lst = 0, nst = 0;
     uint32_t c1 = 0, cin = 0;
-    struct RawLetters { uint32_t a3, aa, b3, ba; } r2 = {0, 0, 0, 0};
+    struct RawLetters { uint32_t a3, aa, b3, ba; } r2 = {0, 0, 0, 0};   // G < 64: a3 / b3 hold the whole 16-bit letter pair
     uint32_t nA3[RW], nAa[RW], nB3[RW], nBa[RW];
+    // G < 64: both letters of a residue come from the interleaved stream a.db.lt (3Di | AA << 8, PAD pairs between the
+    // sequences): one 16-bit load per target and step, the index clamped onto the PAD entry behind (REVT: before) the
+    // sequence, so neither a second byte load nor a "past the end" select is needed.  ltA / ltB point at element 0
+    // (REVT: at the PAD entry before it, so that the index stays unsigned).
+    [[maybe_unused]] const uint16_t *ltA = nullptr, *ltB = nullptr;
 
-    // letters of both targets travel as one dword: [c3A | caA << 8 | c3B << 16 | caB << 24].  The byte loads are
+    // letters of both targets travel as one dword: [c3A | caA << 8 | c3B << 16 | caB << 24].  The loads are
     // branch-free (clamped index, every lane of the group reads the same address) and are only combined a full
     // step after they were issued, so no step waits on global-memory latency.
     auto issue_letters = [&](int st) -> RawLetters {
-        const int ia = max(min(st, tlenA - 1), 0), ib = max(min(st, tlenB - 1), 0);
-        const uint32_t pa = toffA + (uint32_t)(REVT ? max(tlenA - 1 - ia, 0) : ia);
-        const uint32_t pb_ = toffB + (uint32_t)(REVT ? max(tlenB - 1 - ib, 0) : ib);
         RawLetters r;
         if constexpr (G == 64) {   // one group per wave: the slot state is wave-uniform, so the letters come through the scalar
                                    // cache (aligned dword + shift on the SALU) and cost no VALU issue slots at all
+            const int ia = max(min(st, tlenA - 1), 0), ib = max(min(st, tlenB - 1), 0);
+            const uint32_t pa = toffA + (uint32_t)(REVT ? max(tlenA - 1 - ia, 0) : ia);
+            const uint32_t pb_ = toffB + (uint32_t)(REVT ? max(tlenB - 1 - ib, 0) : ib);
             auto ld = [&](const uint8_t *base, uint32_t p) -> uint32_t {
                 const sw_cu32p w = (sw_cu32p)(uintptr_t)(base + (p & ~3u));
                 return (*w >> (8u * (p & 3u))) & 0xffu;
             };
             r.a3 = ld(a.db.s3, pa); r.aa = ld(a.db.sa, pa); r.b3 = ld(a.db.s3, pb_); r.ba = ld(a.db.sa, pb_);
         } else {
-            r.a3 = a.db.s3[pa]; r.aa = a.db.sa[pa]; r.b3 = a.db.s3[pb_]; r.ba = a.db.sa[pb_];
+            const uint32_t ia = REVT ? (uint32_t)max(tlenA - st, 0) : (uint32_t)min(st, tlenA);
+            const uint32_t ib = REVT ? (uint32_t)max(tlenB - st, 0) : (uint32_t)min(st, tlenB);
+            r.a3 = ltA[ia]; r.b3 = ltB[ib];
+            r.aa = 0; r.ba = 0;
         }
         return r;
     };
     auto pack_letters = [&](const RawLetters &r, int st) -> uint32_t {
-        const uint32_t ca_ = st < tlenA ? (r.a3 | (r.aa << 8)) : SW_PADPACK;
-        const uint32_t cb_ = st < tlenB ? (r.b3 | (r.ba << 8)) : SW_PADPACK;
-        return ca_ | (cb_ << 16);
+        if constexpr (G == 64) {
+            const uint32_t ca_ = st < tlenA ? (r.a3 | (r.aa << 8)) : SW_PADPACK;
+            const uint32_t cb_ = st < tlenB ? (r.b3 | (r.ba << 8)) : SW_PADPACK;
+            return ca_ | (cb_ << 16);
+        } else if constexpr (TBB) {   // a box ends inside its sequence: the columns past it are PAD by selection
+            return (st < tlenA ? r.a3 : SW_PADPACK) | ((st < tlenB ? r.b3 : SW_PADPACK) << 16);
+        } else {
+            return r.a3 | (r.b3 << 16);
+        }
     };
     uint32_t off3 = (uint32_t)(g * BW) * 4u, offa = (uint32_t)(SW_NLET * RSW + g * BW) * 4u;
     asm volatile("" : "+v"(off3), "+v"(offa));
@@ -205,6 +219,11 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
                 mskA[k] = ma; mskB[k] = mb;
             }
         }
+        if constexpr (G != 64) {
+            ltA = a.db.lt + toffA - (REVT ? 1 : 0);
+            // no second pair: every index lands on a PAD entry (the one before A's first residue)
+            ltB = vB ? a.db.lt + toffB - (REVT ? 1 : 0) : a.db.lt + toffA - 1;
+        }
 #pragma unroll
         for (int r = 0; r < R; r++) { H[r] = 0; E[r] = 0; }
         if constexpr (TRACK && !KNOWN) {
@@ -243,8 +262,8 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
         c1 = pack_letters(r2, st + 2);
         r2 = issue_letters(st + 3);
         fetch_profile();
-        const uint32_t Hup = (uint32_t)shift_from_prev_lane<G>((int)Hlast, 0, g);
-        uint32_t f = (uint32_t)shift_from_prev_lane<G>((int)fout, 0, g);
+        const uint32_t Hup = (uint32_t)shift_from_prev_lane_zero<G>((int)Hlast, g);
+        uint32_t f = (uint32_t)shift_from_prev_lane_zero<G>((int)fout, g);
         uint32_t diag = prevHup;
         uint32_t colmax = 0;
         [[maybe_unused]] uint32_t code[TBB ? R : 1];
