@@ -153,7 +153,9 @@ constexpr int SIM_MAX_BLOCKS = 1280;     // 256 CUs x 5 resident workgroups (29 
 
 __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCfg cfg, uint32_t qbegin, uint32_t qend,
                                                             uint32_t p0, uint32_t p1, const uint32_t *koff, RunList out,
-                                                            unsigned long long *counters) {
+                                                            unsigned long long *counters,
+                                                            const uint32_t *dk /* distinct mode: work item i = k-mer value dk[i] */,
+                                                            uint32_t *nsim_k /* distinct mode: similar k-mers per work item */) {
     __shared__ SimTables tab;
     __shared__ uint32_t s_mul[K];
     __shared__ uint32_t s_n[4];
@@ -224,13 +226,16 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
     const uint64_t nwaves = (uint64_t)gridDim.x * 4, region = (npos + nwaves - 1) / nwaves;
     {
         const uint64_t rg = (uint64_t)blockIdx.x * 4 + wv;
-        const uint64_t rbeg = min(rg * region, npos), rend = min(rbeg + region, npos);
+        // distinct mode: every wave walks the logical range [0, region) of its own stride-nwaves item sequence
+        const uint64_t rbeg = dk ? 0 : min(rg * region, npos), rend = dk ? region : min(rbeg + region, npos);
         uint64_t next = rbeg;                      // wave-uniform cursor into the region
         uint32_t qn = 0;                           // wave-uniform fill of the leaf queue
         uint32_t head = 0, tail = 0;               // wave-uniform: pool of decoded positions (ring of POSQ entries)
         // per-lane DFS state
         bool idle = true, out_of_work = false;
         uint32_t cpack = 0, kpack = 0, pidx = 0, vcur = 0;
+        uint32_t lc = 0;                           // leaves of the work item in hand
+        bool has_item = false;
         int L = 0, scur = 0;
         uint64_t restpack = 0;                     // rest[m] (m = 1..6) in 8-bit fields, biased by 64
         for (;;) {
@@ -238,12 +243,24 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
             //      must not sit in front of every single hand-out) ----
             if (tail - head <= POSQ - 64 && next < rend) {
                 const uint64_t mine = next + lane;
+                // distinct mode: k-mer values come sorted and neighbours cost alike, so a wave takes every nwaves-th item
+                // instead of a contiguous region
+                const uint64_t item = dk ? mine * nwaves + rg : mine;
                 bool ok = false;
                 uint32_t cp = 0;
                 uint64_t rp = 0;
-                if (mine < rend) {
+                if (mine < rend && item < npos) {
                     uint32_t q, i, c[K];
-                    if (query_kmer_at(db, cfg, qbegin, qend, p0 + (uint32_t)mine, &q, &i, c)) {
+                    bool valid;
+                    if (dk) {
+                        uint32_t v = dk[item];
+#pragma unroll
+                        for (int m = 0; m < K; m++) { c[m] = v % (uint32_t)KA; v /= (uint32_t)KA; }
+                        valid = true;
+                    } else {
+                        valid = query_kmer_at(db, cfg, qbegin, qend, p0 + (uint32_t)mine, &q, &i, c);
+                    }
+                    if (valid) {
                         int rest = 0;
 #pragma unroll
                         for (int m = K - 1; m >= 0; m--) {
@@ -257,7 +274,7 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
                 const uint64_t om = __builtin_amdgcn_ballot_w64(ok);
                 if (ok) {
                     const uint32_t slot = (tail + (uint32_t)__popcll(om & ((1ull << lane) - 1ull))) % POSQ;
-                    pc[slot] = cp; pr[slot] = rp; pp[slot] = (uint32_t)mine;
+                    pc[slot] = cp; pr[slot] = rp; pp[slot] = (uint32_t)item;
                 }
                 tail += (uint32_t)__popcll(om);
                 next = min(next + 64, rend);
@@ -270,6 +287,8 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
                 const uint32_t take = head + (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
                 if (idle && !out_of_work) {
                     if (take < tail) {
+                        if (nsim_k && has_item) nsim_k[pidx] = lc;
+                        lc = 0; has_item = true;
                         const uint32_t slot = take % POSQ;
                         cpack = pc[slot]; restpack = pr[slot]; pidx = pp[slot];
                         kpack = 0; L = 0; scur = 0; vcur = 0; idle = false;
@@ -300,6 +319,7 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
                 const bool push = ok && L < K - 1, pop = act && !ok && L > 0;
                 leaf = ok && L == K - 1;
                 leafv = vcur + o1 * mulL;
+                lc += leaf ? 1u : 0u;
                 idle = idle || (act && !ok && L == 0);
                 scur = push ? cand : (pop ? scur - sc2 : scur);
                 vcur = push ? leafv : (pop ? vcur - o2 * mulM : vcur);
@@ -319,6 +339,7 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
         }
         __builtin_amdgcn_wave_barrier();
         drain_leaves(qn);
+        if (nsim_k && has_item) nsim_k[pidx] = lc;
     }
     __builtin_amdgcn_wave_barrier();
     flush_runs();
@@ -326,6 +347,113 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
     if (lane == 0) {
         if (nsim) atomicAdd(counters + 0, nsim);
         if (nhit) atomicAdd(counters + 4, nhit);
+    }
+}
+
+// ---- E2, distinct mode: the similar k-mers of a k-mer do not depend on where it occurs, and a batch of queries holds every
+// k-mer several times (C2: 46.0 M positions, 14.9 M distinct k-mers; the ratio grows with the database).  So the DFS and the
+// offset-table lookups run once per DISTINCT k-mer of the batch, the resulting run lists are sorted by k-mer rank (a third of
+// the runs, 24-bit keys) and a copy kernel lays them out per query position, already in position order - the big sort of
+// all runs by position is gone.
+__global__ void __launch_bounds__(256) query_kmer_kernel(const DeviceDb db, KmerCfg cfg, uint32_t qbegin, uint32_t qend, uint32_t p0, uint32_t p1,
+                                                         uint32_t *qk, uint8_t *flag) {
+    for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < p1 - p0; idx += (uint64_t)gridDim.x * 256) {
+        uint32_t q, i, c[K];
+        uint32_t key = KMER_INVALID;
+        if (query_kmer_at(db, cfg, qbegin, qend, p0 + (uint32_t)idx, &q, &i, c)) {
+            uint32_t v = 0, mul = 1;
+#pragma unroll
+            for (int m = 0; m < K; m++) { v += c[m] * mul; mul *= KA; }
+            key = v;
+            flag[v] = 1;
+        }
+        qk[idx] = key;
+    }
+}
+
+struct FlagToU32 {
+    __host__ __device__ uint32_t operator()(uint8_t x) const { return (uint32_t)x; }
+};
+
+__global__ void __launch_bounds__(256) distinct_kmer_kernel(const uint8_t *flag, const uint32_t *kid, uint32_t *dk) {
+    for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < KSPACE; v += (uint64_t)gridDim.x * 256)
+        if (flag[v]) dk[kid[v]] = (uint32_t)v;
+}
+
+// first run of every k-mer rank in the runs sorted by rank (nd + 1 entries), and the rank's hit total
+__global__ void __launch_bounds__(256) rank_offsets_kernel(const uint32_t *rk, uint32_t n_runs, uint32_t nd, uint32_t *roff) {
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k <= nd; k += (uint64_t)gridDim.x * 256) {
+        uint32_t lo = 0, hi = n_runs;
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (rk[mid] < (uint32_t)k) lo = mid + 1; else hi = mid;
+        }
+        roff[k] = lo;
+    }
+}
+
+struct RankRec { uint32_t roff, nr, hits, nsim; };   // one 16-byte record per distinct k-mer: first run, runs, k-mer hits, similar k-mers
+
+__global__ void __launch_bounds__(256) rank_rec_kernel(const uint32_t *roff, const uint64_t *val, const uint32_t *nsim_k, uint32_t nd, RankRec *rec) {
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < nd; k += (uint64_t)gridDim.x * 256) {
+        uint64_t h = 0;
+        const uint32_t r0 = roff[k], r1 = roff[k + 1];
+        for (uint32_t r = r0; r < r1; r++) h += val[r] >> 32;
+        RankRec x;
+        x.roff = r0; x.nr = r1 - r0; x.nsim = nsim_k[k];
+        x.hits = (uint32_t)min(h, (uint64_t)0xffffffffu);      // <= number of index entries < 2^32
+        rec[k] = x;
+    }
+}
+
+// per query position: runs, first run of its k-mer's list, k-mer hits; similar k-mers summed into counters[0]
+__global__ void __launch_bounds__(256) position_runs_kernel(const uint32_t *qk, uint32_t npos, const uint32_t *kid, const RankRec *rec, uint32_t *nr,
+                                                            uint32_t *src, uint32_t *ph, unsigned long long *counters) {
+    unsigned long long sims = 0;
+    for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < npos; idx += (uint64_t)gridDim.x * 256) {
+        const uint32_t v = qk[idx];
+        RankRec x = {0, 0, 0, 0};
+        if (v != KMER_INVALID) x = rec[kid[v]];
+        nr[idx] = x.nr; src[idx] = x.roff; ph[idx] = x.hits;
+        sims += x.nsim;
+    }
+    for (int o = 32; o > 0; o >>= 1) sims += __shfl_down(sims, o, 64);
+    if ((threadIdx.x & 63) == 0 && sims) atomicAdd(counters + 0, sims);
+}
+
+// per query: k-mer hits and runs (differences of the running sums over positions at the sequence boundaries)
+__global__ void __launch_bounds__(256) query_totals_kernel(const uint32_t *off, uint32_t qbegin, uint32_t nq, uint32_t p0, const uint64_t *cumh,
+                                                           const uint64_t *cumr, uint64_t *qh, uint64_t *qr) {
+    for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (uint64_t)gridDim.x * 256) {
+        const uint32_t a = off[qbegin + q] - p0, b = off[qbegin + q + 1] - p0;
+        qh[q] = cumh[b] - cumh[a];
+        qr[q] = cumr[b] - cumr[a];
+    }
+}
+
+// a wave lays out the run lists of 64 consecutive positions of the batch [b0, b1): position order, runs of one position contiguous
+__global__ void __launch_bounds__(256) position_expand_kernel(uint32_t b0, uint32_t b1, const uint32_t *nr, const uint32_t *src, const uint64_t *cumr,
+                                                              const uint64_t *val, uint32_t *opidx, uint64_t *oval) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4, w0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t rbase = cumr[b0];
+    for (uint64_t base = b0 + w0 * 64; base < b1; base += nwaves * 64) {
+        const uint64_t idx = base + lane;
+        uint32_t n = 0, s = 0, dst = 0;
+        if (idx < b1) {
+            n = nr[idx];
+            if (n) { s = src[idx]; dst = (uint32_t)(cumr[idx] - rbase); }
+        }
+        uint64_t m = __builtin_amdgcn_ballot_w64(n != 0);
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t nj = (uint32_t)__shfl((int)n, j, 64), sj = (uint32_t)__shfl((int)s, j, 64), dj = (uint32_t)__shfl((int)dst, j, 64);
+            for (uint32_t i = lane; i < nj; i += 64) {
+                oval[dj + i] = val[sj + i];
+                opidx[dj + i] = (uint32_t)(base + j - b0);
+            }
+        }
     }
 }
 
@@ -906,6 +1034,11 @@ struct PrefilterScratch {
     DevBuf<uint32_t> d_cnt, d_flag, d_cq, d_ct, d_rpidx, d_rpidx2, d_qsurv;
     DevBuf<uint64_t> d_keys, d_keys2, d_pos, d_skey, d_skey2, d_rval, d_rval2, d_qbase, d_soff, d_qr;
     DevBuf<int32_t> d_cd, d_cd2, d_score;
+    // distinct-k-mer enumeration (E2)
+    DevBuf<uint8_t> d_kflag;
+    DevBuf<uint32_t> d_qk, d_kid, d_dk, d_nsimk, d_drk, d_drk2, d_roff, d_nr, d_src, d_ph;
+    DevBuf<uint64_t> d_drv, d_drv2, d_cumh, d_cumr, d_qh, d_qrn;
+    DevBuf<RankRec> d_rec;
 };
 void free_prefilter_scratch(PrefilterScratch *p) { delete p; }
 
@@ -1098,7 +1231,10 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
     stats.stage_seconds[UC_ST_INDEX] += t_index.seconds();
 
     // ------------------------------------------------------------ E2-E4 over query batches
-    const uint64_t HIT_CAP = 1ull << 31;       // keys per batch (16 GiB)
+    const bool distinct_mode = !getenv("UC_SIM_PER_POSITION");   // the r2 path (DFS per query position + sort of all runs by position), kept for A/B runs
+    // keys per batch: the filter's regions hold < 2^32 keys (2 x 4 B x 3.75 G = 30 GiB in compact mode); the r2 path sizes its
+    // batches by estimate and keeps the smaller cap
+    const uint64_t HIT_CAP = distinct_mode ? (15ull << 28) : (1ull << 31);
     const uint64_t RUN_MAX = 1ull << 29;       // runs per batch (6 GiB + 6 GiB sort double buffer)
     double hits_per_res = 64.0;                // adaptive estimates
     uint64_t run_cap = 1ull << 20;
@@ -1108,12 +1244,123 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
     DevBuf<int32_t> &d_cd = S.d_cd, &d_cd2 = S.d_cd2, &d_score = S.d_score;
     uint64_t n_hits_total = 0, n_cand_total = 0, cand_cap = 0;
     double t_kmer = 0, t_ung = 0, t_sel = 0;
+    const auto sim_grid = [](uint64_t items) {
+        return dim3((uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (items + 4 * SIM_MIN_WAVE_POS - 1) / (4 * SIM_MIN_WAVE_POS)), SIM_MAX_BLOCKS));
+    };
+
+    // ---- distinct mode, once per target chunk: similar k-mers and index ranges of every DISTINCT query k-mer, then per query
+    //      position the length and source of its run list and its k-mer hits; exact per-query totals for the batch plan ----
+    const uint32_t P0 = h_poff[qbegin], NP = h_poff[qend] - P0;
+    std::vector<uint64_t> h_qh, h_qr;          // k-mer hits / runs per query
+    uint64_t plan_sims = 0, plan_hits = 0;
+    if (distinct_mode && qend > qbegin) {
+        Timer t_p;
+        timed_ms_begin();
+        const uint32_t nqa = qend - qbegin;
+        S.d_qk.reserve((size_t)NP + 1); S.d_kflag.reserve((size_t)KSPACE + 1); S.d_kid.reserve((size_t)KSPACE + 1);
+        UC_HIP(hipMemsetAsync(S.d_kflag.p, 0, (size_t)KSPACE + 1, stream));
+        hipLaunchKernelGGL(query_kmer_kernel, grid_for(NP), dim3(256), 0, stream, ddb, cfg, qbegin, qend, P0, P0 + NP, S.d_qk.p, S.d_kflag.p);
+        size_t tb = 0;
+        auto fin = rocprim::make_transform_iterator(S.d_kflag.p, FlagToU32());
+        UC_HIP(rocprim::exclusive_scan(nullptr, tb, fin, S.d_kid.p, 0u, (size_t)KSPACE + 1, rocprim::plus<uint32_t>(), stream));
+        temp_reserve(tb);
+        UC_HIP(rocprim::exclusive_scan(d_temp.p, tb, fin, S.d_kid.p, 0u, (size_t)KSPACE + 1, rocprim::plus<uint32_t>(), stream));
+        uint32_t nd = 0;
+        UC_HIP(hipMemcpyAsync(&nd, S.d_kid.p + KSPACE, 4, hipMemcpyDeviceToHost, stream));
+        UC_HIP(hipStreamSynchronize(stream));
+        S.d_dk.reserve(std::max<uint32_t>(nd, 1)); S.d_nsimk.reserve(std::max<uint32_t>(nd, 1));
+        UC_HIP(hipMemsetAsync(S.d_nsimk.p, 0, (size_t)std::max<uint32_t>(nd, 1) * 4, stream));
+        hipLaunchKernelGGL(distinct_kmer_kernel, grid_for(KSPACE), dim3(256), 0, stream, S.d_kflag.p, S.d_kid.p, S.d_dk.p);
+        uint64_t n_druns = 0, drun_cap = S.d_drk.cap;
+        for (;;) {   // runs of the distinct k-mers, tagged with the k-mer's rank
+            drun_cap = std::min<uint64_t>(1ull << 32, std::max<uint64_t>(drun_cap, std::max<uint64_t>(1u << 20, (uint64_t)nd * 16)));
+            S.d_drk.reserve(drun_cap); S.d_drv.reserve(drun_cap);
+            UC_HIP(hipMemsetAsync(d_counters.p + 3, 0, 32, stream));
+            UC_HIP(hipMemsetAsync(d_counters.p, 0, 8, stream));
+            const RunList rl{S.d_drk.p, S.d_drv.p, drun_cap};
+            hipLaunchKernelGGL(sim_runs_kernel, sim_grid(nd), dim3(256), 0, stream, ddb, cfg, 0u, 0u, 0u, nd, d_koff.p, rl, d_counters.p, S.d_dk.p, S.d_nsimk.p);
+            unsigned long long c5[5];
+            UC_HIP(hipMemcpyAsync(c5, d_counters.p, 40, hipMemcpyDeviceToHost, stream));
+            UC_HIP(hipStreamSynchronize(stream));
+            n_druns = c5[3];
+            if (n_druns > drun_cap) {
+                if (n_druns >= (1ull << 32)) fail(UC_ERR_GENERIC, "%u distinct k-mers produce %llu index ranges", nd, (unsigned long long)n_druns);
+                drun_cap = n_druns;
+                UC_HIP(hipMemsetAsync(S.d_nsimk.p, 0, (size_t)std::max<uint32_t>(nd, 1) * 4, stream));
+                continue;
+            }
+            break;
+        }
+        unsigned dbits = 1;
+        while ((1ull << dbits) < nd) dbits++;
+        S.d_drk2.reserve(drun_cap); S.d_drv2.reserve(drun_cap);
+        if (n_druns) {
+            UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, S.d_drk.p, S.d_drk2.p, S.d_drv.p, S.d_drv2.p, (size_t)n_druns, 0u, dbits, stream));
+            temp_reserve(tb);
+            UC_HIP(rocprim::radix_sort_pairs(d_temp.p, tb, S.d_drk.p, S.d_drk2.p, S.d_drv.p, S.d_drv2.p, (size_t)n_druns, 0u, dbits, stream));
+        }
+        S.d_roff.reserve((size_t)nd + 1); S.d_rec.reserve(std::max<uint32_t>(nd, 1));
+        hipLaunchKernelGGL(rank_offsets_kernel, grid_for((uint64_t)nd + 1), dim3(256), 0, stream, S.d_drk2.p, (uint32_t)n_druns, nd, S.d_roff.p);
+        if (nd) hipLaunchKernelGGL(rank_rec_kernel, grid_for(nd), dim3(256), 0, stream, S.d_roff.p, S.d_drv2.p, S.d_nsimk.p, nd, S.d_rec.p);
+        // per position (one trailing zero element so that the exclusive sums end with the totals)
+        S.d_nr.reserve((size_t)NP + 1); S.d_src.reserve((size_t)NP + 1); S.d_ph.reserve((size_t)NP + 1);
+        S.d_cumh.reserve((size_t)NP + 1); S.d_cumr.reserve((size_t)NP + 1);
+        UC_HIP(hipMemsetAsync(d_counters.p, 0, 8, stream));
+        UC_HIP(hipMemsetAsync(S.d_nr.p + NP, 0, 4, stream));
+        UC_HIP(hipMemsetAsync(S.d_ph.p + NP, 0, 4, stream));
+        hipLaunchKernelGGL(position_runs_kernel, grid_for(NP), dim3(256), 0, stream, S.d_qk.p, NP, S.d_kid.p, S.d_rec.p, S.d_nr.p, S.d_src.p, S.d_ph.p, d_counters.p);
+        auto hin = rocprim::make_transform_iterator(S.d_ph.p, WidenU32());
+        auto rin = rocprim::make_transform_iterator(S.d_nr.p, WidenU32());
+        UC_HIP(rocprim::exclusive_scan(nullptr, tb, hin, S.d_cumh.p, (uint64_t)0, (size_t)NP + 1, rocprim::plus<uint64_t>(), stream));
+        temp_reserve(tb);
+        UC_HIP(rocprim::exclusive_scan(d_temp.p, tb, hin, S.d_cumh.p, (uint64_t)0, (size_t)NP + 1, rocprim::plus<uint64_t>(), stream));
+        UC_HIP(rocprim::exclusive_scan(d_temp.p, tb, rin, S.d_cumr.p, (uint64_t)0, (size_t)NP + 1, rocprim::plus<uint64_t>(), stream));
+        S.d_qh.reserve(nqa); S.d_qrn.reserve(nqa);
+        hipLaunchKernelGGL(query_totals_kernel, grid_for(nqa), dim3(256), 0, stream, ddb.off, qbegin, nqa, P0, S.d_cumh.p, S.d_cumr.p, S.d_qh.p, S.d_qrn.p);
+        h_qh.resize(nqa); h_qr.resize(nqa);
+        unsigned long long c0 = 0;
+        UC_HIP(hipMemcpyAsync(h_qh.data(), S.d_qh.p, (size_t)nqa * 8, hipMemcpyDeviceToHost, stream));
+        UC_HIP(hipMemcpyAsync(h_qr.data(), S.d_qrn.p, (size_t)nqa * 8, hipMemcpyDeviceToHost, stream));
+        UC_HIP(hipMemcpyAsync(&c0, d_counters.p, 8, hipMemcpyDeviceToHost, stream));
+        UC_HIP(hipStreamSynchronize(stream));
+        plan_sims = c0;
+        for (uint32_t i = 0; i < nqa; i++) plan_hits += h_qh[i];
+        gpu_ms += timed_ms_end();
+        t_kmer += t_p.seconds();
+        if (density_out) *density_out = (double)plan_hits / std::max<uint32_t>(1, NP);
+        if (density_limit > 0 && p.min_diag_hits >= 2 && tend - tbegin > 1 && (double)plan_hits / std::max<uint32_t>(1, NP) > density_limit) {
+            stats.n_index_entries -= n_entries;
+            stats.algorithmic_bytes[UC_ST_INDEX] -= 6ull * n_entries + 8ull * KSPACE;
+            stats.prefilter_kernel_ms += gpu_ms;
+            return false;
+        }
+        if (count_sims) stats.n_sim_kmers += plan_sims;
+    }
 
     for (uint32_t qa = qbegin; qa < qend;) {
         Timer t_b;
         timed_ms_begin();
-        // choose batch [qa, qb) by estimated hits
         uint32_t qb = qa;
+        uint64_t total_hits = 0, n_runs = 0, sims_this_batch = 0;
+        uint32_t qp0 = 0, qp1 = 0, nq_res = 0;
+        if (distinct_mode) {
+            // exact plan: as many queries as fit the key and run buffers (a single query may exceed them and takes the wide path)
+            while (qb < qend && qb - qa < (1u << 23) - 1) {
+                const uint64_t h = h_qh[qb - qbegin], r = h_qr[qb - qbegin];
+                if (qb > qa && (total_hits + h > HIT_CAP || n_runs + r > RUN_MAX)) break;
+                total_hits += h; n_runs += r;
+                qb++;
+            }
+            if (n_runs >= (1ull << 32)) fail(UC_ERR_GENERIC, "query %u alone produces %llu index ranges", qa, (unsigned long long)n_runs);
+            qp0 = h_poff[qa]; qp1 = h_poff[qb]; nq_res = qp1 - qp0;
+            run_cap = std::max<uint64_t>(run_cap, n_runs);
+            d_rpidx2.reserve(run_cap); d_rval2.reserve(run_cap);
+            UC_HIP(hipMemsetAsync(d_counters.p + 3, 0, 32, stream));   // run cursor, batch hits, key cursor, candidate cursor
+            if (n_runs)
+                hipLaunchKernelGGL(position_expand_kernel, grid_for(nq_res), dim3(256), 0, stream, qp0 - P0, qp1 - P0, S.d_nr.p, S.d_src.p, S.d_cumr.p, S.d_drv2.p,
+                                   d_rpidx2.p, d_rval2.p);
+        } else {
+        // choose batch [qa, qb) by estimated hits
         {
             const double budget = (double)HIT_CAP * 0.5;
             uint64_t res = 0;
@@ -1123,22 +1370,21 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
                 qb++;
             }
         }
-        uint64_t total_hits = 0, n_runs = 0, sims_this_batch = 0;
-        uint32_t qp0 = 0, qp1 = 0, nq_res = 0;
         for (;;) {   // pass 1: runs + exact hit count; shrink the batch / grow the run list if it does not fit
             qp0 = h_poff[qa]; qp1 = h_poff[qb]; nq_res = qp1 - qp0;
+            const bool single = qb - qa == 1;
             run_cap = std::min<uint64_t>(RUN_MAX, std::max<uint64_t>(run_cap, (uint64_t)nq_res * 16));
             d_rpidx.reserve(run_cap); d_rval.reserve(run_cap);
             UC_HIP(hipMemsetAsync(d_counters.p + 3, 0, 32, stream));   // run cursor, batch hits, key cursor, candidate cursor
             UC_HIP(hipMemsetAsync(d_counters.p, 0, 8, stream));
             const RunList rl{d_rpidx.p, d_rval.p, run_cap};
-            hipLaunchKernelGGL(sim_runs_kernel, dim3((uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (nq_res + 4 * SIM_MIN_WAVE_POS - 1) / (4 * SIM_MIN_WAVE_POS)), SIM_MAX_BLOCKS)), dim3(256), 0, stream, ddb, cfg, qa, qb, qp0, qp1, d_koff.p, rl, d_counters.p);
+            hipLaunchKernelGGL(sim_runs_kernel, sim_grid(nq_res), dim3(256), 0, stream, ddb, cfg, qa, qb, qp0, qp1, d_koff.p, rl, d_counters.p,
+                               (const uint32_t *)nullptr, (uint32_t *)nullptr);
             unsigned long long c5[5];
             UC_HIP(hipMemcpyAsync(c5, d_counters.p, 40, hipMemcpyDeviceToHost, stream));
             UC_HIP(hipStreamSynchronize(stream));
             n_runs = c5[3];
             total_hits = c5[4];
-            const bool single = qb - qa == 1;
             if (total_hits > HIT_CAP && !single) { qb = qa + std::max<uint32_t>(1, (qb - qa) / 2); continue; }
             if (n_runs > run_cap) {
                 if (run_cap < RUN_MAX || single) {
@@ -1154,8 +1400,9 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
             if (count_sims) stats.n_sim_kmers += c5[0];
             break;
         }
-        if (density_out && qa == qbegin) *density_out = (double)total_hits / std::max<uint32_t>(1, nq_res);
-        if (density_limit > 0 && qa == qbegin && p.min_diag_hits >= 2 && tend - tbegin > 1 &&
+        }
+        if (!distinct_mode && density_out && qa == qbegin) *density_out = (double)total_hits / std::max<uint32_t>(1, nq_res);
+        if (!distinct_mode && density_limit > 0 && qa == qbegin && p.min_diag_hits >= 2 && tend - tbegin > 1 &&
             (double)total_hits / std::max<uint32_t>(1, nq_res) > density_limit) {
             // undo what this abandoned attempt counted
             if (count_sims) stats.n_sim_kmers -= std::min<uint64_t>(stats.n_sim_kmers, sims_this_batch);
@@ -1181,9 +1428,11 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
                 unsigned pbits = 1;
                 while ((1ull << pbits) < nq_res) pbits++;
                 d_rpidx2.reserve(run_cap); d_rval2.reserve(run_cap);
-                UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, d_rpidx.p, d_rpidx2.p, d_rval.p, d_rval2.p, (size_t)n_runs, 0u, pbits, stream));
-                temp_reserve(tb);
-                UC_HIP(rocprim::radix_sort_pairs(d_temp.p, tb, d_rpidx.p, d_rpidx2.p, d_rval.p, d_rval2.p, (size_t)n_runs, 0u, pbits, stream));
+                if (!distinct_mode) {   // distinct mode laid the runs out by position already
+                    UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, d_rpidx.p, d_rpidx2.p, d_rval.p, d_rval2.p, (size_t)n_runs, 0u, pbits, stream));
+                    temp_reserve(tb);
+                    UC_HIP(rocprim::radix_sort_pairs(d_temp.p, tb, d_rpidx.p, d_rpidx2.p, d_rval.p, d_rval2.p, (size_t)n_runs, 0u, pbits, stream));
+                }
                 d_qbase.reserve(nq); d_qsurv.reserve(nq); d_soff.reserve((size_t)nq + 1);
                 // the query regions hold (target, diagonal) keys: u32 in compact mode (half of the u64 buffer stays unused),
                 // every region rounded up to KPT keys
@@ -1242,7 +1491,7 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
             } else {
                 d_keys.reserve(total_hits);
                 d_keys2.reserve(total_hits);
-                const RunList rl{d_rpidx.p, d_rval.p, run_cap};
+                const RunList rl{distinct_mode ? d_rpidx2.p : d_rpidx.p, distinct_mode ? d_rval2.p : d_rval.p, run_cap};
                 hipLaunchKernelGGL(expand_kernel, grid_for(n_runs), dim3(256), 0, stream, ddb, qa, qb, qp0, rl, n_runs, ent_p, fmt,
                                    d_counters.p + 5, d_keys.p, total_hits);
                 UC_HIP(rocprim::radix_sort_keys(nullptr, tb, d_keys.p, d_keys2.p, (size_t)total_hits, 0u, kbits, stream));
