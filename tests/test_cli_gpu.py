@@ -145,6 +145,19 @@ def test_uc_cluster_virtual_gpus_shard_by_shard_exchange(synth_db, tmp_path):
     assert got == ref
 
 
+@pytest.mark.parametrize("opts", ["-c 0.8 --single-step-clustering", "-c 0.8 --single-step-clustering -s 7.5"])
+def test_prefilter_execution_variants_give_identical_tsv(synth_db, opts, tmp_path):
+    """E2 runs the similar-k-mer enumeration once per DISTINCT query k-mer and plans its batches from exact per-query totals.
+    Neither the cut into query super-batches (forced here by a tiny run-list budget) nor the older per-position path
+    (UC_SIM_PER_POSITION=1) may change a byte of the result or any of the prefilter counts."""
+    ref, st1 = _tsv(synth_db, tmp_path, "v0", opts, 1)
+    keys = ("n_sim_kmers", "n_kmer_hits", "n_filtered_hits", "n_candidates", "n_prefilter_hits", "n_gapped_alignments", "n_clusters")
+    for tag, env in (("v1", {"UC_DRUN_MAX": "20000"}), ("v2", {"UC_DRUN_MAX": "3000"}), ("v3", {"UC_SIM_PER_POSITION": "1"})):
+        got, st = _tsv(synth_db, tmp_path, tag, opts, 1, env=env)
+        assert got == ref, (tag, opts)
+        assert {k: st[k] for k in keys} == {k: st1[k] for k in keys}, tag
+
+
 def test_more_gpus_than_visible_is_an_error_not_a_silent_fallback(synth_db, tmp_path):
     import unicore_amd as U
     with pytest.raises(U.UcError) as ei:

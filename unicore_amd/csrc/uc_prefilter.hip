@@ -155,7 +155,8 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
                                                             uint32_t p0, uint32_t p1, const uint32_t *koff, RunList out,
                                                             unsigned long long *counters,
                                                             const uint32_t *dk /* distinct mode: work item i = k-mer value dk[i] */,
-                                                            uint32_t *nsim_k /* distinct mode: similar k-mers per work item */) {
+                                                            uint32_t *nsim_k /* distinct mode: similar k-mers per work item */,
+                                                            uint32_t item_stride /* distinct mode: every item_stride-th item only (run-count estimate) */) {
     __shared__ SimTables tab;
     __shared__ uint32_t s_mul[K];
     __shared__ uint32_t s_n[4];
@@ -221,7 +222,7 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
     };
 
     unsigned long long nsim = 0;
-    const uint64_t npos = (uint64_t)p1 - p0;
+    const uint64_t npos = dk ? ((uint64_t)p1 - p0 + item_stride - 1) / item_stride : (uint64_t)p1 - p0;   // distinct mode: p1 - p0 items, sampled
     // one contiguous region per wave: the more positions a lane works through, the less the heaviest single position weighs
     const uint64_t nwaves = (uint64_t)gridDim.x * 4, region = (npos + nwaves - 1) / nwaves;
     {
@@ -245,11 +246,11 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
                 const uint64_t mine = next + lane;
                 // distinct mode: k-mer values come sorted and neighbours cost alike, so a wave takes every nwaves-th item
                 // instead of a contiguous region
-                const uint64_t item = dk ? mine * nwaves + rg : mine;
+                const uint64_t item = dk ? (mine * nwaves + rg) * item_stride : mine;
                 bool ok = false;
                 uint32_t cp = 0;
                 uint64_t rp = 0;
-                if (mine < rend && item < npos) {
+                if (mine < rend && item < (dk ? (uint64_t)p1 - p0 : npos)) {
                     uint32_t q, i, c[K];
                     bool valid;
                     if (dk) {
@@ -1248,12 +1249,20 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
         return dim3((uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (items + 4 * SIM_MIN_WAVE_POS - 1) / (4 * SIM_MIN_WAVE_POS)), SIM_MAX_BLOCKS));
     };
 
-    // ---- distinct mode, once per target chunk: similar k-mers and index ranges of every DISTINCT query k-mer, then per query
-    //      position the length and source of its run list and its k-mer hits; exact per-query totals for the batch plan ----
-    const uint32_t P0 = h_poff[qbegin], NP = h_poff[qend] - P0;
-    std::vector<uint64_t> h_qh, h_qr;          // k-mer hits / runs per query
-    uint64_t plan_sims = 0, plan_hits = 0;
-    if (distinct_mode && qend > qbegin) {
+    // ---- distinct mode, once per target chunk and query "super-batch" [sa, sb) (normally all queries; cut when the run lists
+    //      of its distinct k-mers exceed DRUN_MAX, i.e. at high sensitivity): similar k-mers and index ranges of every
+    //      DISTINCT query k-mer, then per query position the length and source of its run list and its k-mer hits; exact
+    //      per-query totals for the batch plan ----
+    const uint32_t first_query = qbegin;
+    const uint64_t DRUN_MAX = getenv("UC_DRUN_MAX") ? std::max<uint64_t>(1, strtoull(getenv("UC_DRUN_MAX"), nullptr, 10)) : (1ull << 31);   // 24 GiB + 24 GiB sort double buffer (env: tests)
+    uint32_t P0 = 0, NP = 0;
+    std::vector<uint64_t> h_qh, h_qr;          // k-mer hits / runs per query of the super-batch
+    uint64_t over_runs = 0;
+    // 0 = planned, 1 = density limit exceeded (first super-batch only), 2 = too many runs (over_runs says how many)
+    const auto plan_superbatch = [&](uint32_t sa, uint32_t sb) -> int {
+        uint64_t plan_sims = 0, plan_hits = 0;
+        P0 = h_poff[sa]; NP = h_poff[sb] - P0;
+        const uint32_t qbegin = sa, qend = sb;   // this block works on the super-batch only
         Timer t_p;
         timed_ms_begin();
         const uint32_t nqa = qend - qbegin;
@@ -1271,20 +1280,32 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
         S.d_dk.reserve(std::max<uint32_t>(nd, 1)); S.d_nsimk.reserve(std::max<uint32_t>(nd, 1));
         UC_HIP(hipMemsetAsync(S.d_nsimk.p, 0, (size_t)std::max<uint32_t>(nd, 1) * 4, stream));
         hipLaunchKernelGGL(distinct_kmer_kernel, grid_for(KSPACE), dim3(256), 0, stream, S.d_kflag.p, S.d_kid.p, S.d_dk.p);
+        if (nqa > 1 && nd > (1u << 16)) {   // run-count estimate from every 64th distinct k-mer: cut the super-batch BEFORE the full enumeration
+            const uint32_t st = 64;
+            UC_HIP(hipMemsetAsync(d_counters.p + 3, 0, 32, stream));
+            UC_HIP(hipMemsetAsync(d_counters.p, 0, 8, stream));
+            hipLaunchKernelGGL(sim_runs_kernel, sim_grid((nd + st - 1) / st), dim3(256), 0, stream, ddb, cfg, 0u, 0u, 0u, nd, d_koff.p, RunList{nullptr, nullptr, 0},
+                               d_counters.p, S.d_dk.p, (uint32_t *)nullptr, st);
+            unsigned long long c5[5];
+            UC_HIP(hipMemcpyAsync(c5, d_counters.p, 40, hipMemcpyDeviceToHost, stream));
+            UC_HIP(hipStreamSynchronize(stream));
+            if ((double)c5[3] * st > 0.9 * (double)DRUN_MAX) { over_runs = (uint64_t)((double)c5[3] * st / 0.9); gpu_ms += timed_ms_end(); t_kmer += t_p.seconds(); return 2; }
+        }
         uint64_t n_druns = 0, drun_cap = S.d_drk.cap;
         for (;;) {   // runs of the distinct k-mers, tagged with the k-mer's rank
-            drun_cap = std::min<uint64_t>(1ull << 32, std::max<uint64_t>(drun_cap, std::max<uint64_t>(1u << 20, (uint64_t)nd * 16)));
+            drun_cap = std::min<uint64_t>(1ull << 32, std::max<uint64_t>(drun_cap, std::max<uint64_t>(1u << 20, std::min<uint64_t>(DRUN_MAX, (uint64_t)nd * 16))));
             S.d_drk.reserve(drun_cap); S.d_drv.reserve(drun_cap);
             UC_HIP(hipMemsetAsync(d_counters.p + 3, 0, 32, stream));
             UC_HIP(hipMemsetAsync(d_counters.p, 0, 8, stream));
             const RunList rl{S.d_drk.p, S.d_drv.p, drun_cap};
-            hipLaunchKernelGGL(sim_runs_kernel, sim_grid(nd), dim3(256), 0, stream, ddb, cfg, 0u, 0u, 0u, nd, d_koff.p, rl, d_counters.p, S.d_dk.p, S.d_nsimk.p);
+            hipLaunchKernelGGL(sim_runs_kernel, sim_grid(nd), dim3(256), 0, stream, ddb, cfg, 0u, 0u, 0u, nd, d_koff.p, rl, d_counters.p, S.d_dk.p, S.d_nsimk.p, 1u);
             unsigned long long c5[5];
             UC_HIP(hipMemcpyAsync(c5, d_counters.p, 40, hipMemcpyDeviceToHost, stream));
             UC_HIP(hipStreamSynchronize(stream));
             n_druns = c5[3];
+            if (n_druns > DRUN_MAX && nqa > 1) { over_runs = n_druns; gpu_ms += timed_ms_end(); t_kmer += t_p.seconds(); return 2; }
             if (n_druns > drun_cap) {
-                if (n_druns >= (1ull << 32)) fail(UC_ERR_GENERIC, "%u distinct k-mers produce %llu index ranges", nd, (unsigned long long)n_druns);
+                if (n_druns >= (1ull << 32)) fail(UC_ERR_GENERIC, "%u distinct k-mers of query %u produce %llu index ranges", nd, qbegin, (unsigned long long)n_druns);
                 drun_cap = n_druns;
                 UC_HIP(hipMemsetAsync(S.d_nsimk.p, 0, (size_t)std::max<uint32_t>(nd, 1) * 4, stream));
                 continue;
@@ -1327,17 +1348,38 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
         for (uint32_t i = 0; i < nqa; i++) plan_hits += h_qh[i];
         gpu_ms += timed_ms_end();
         t_kmer += t_p.seconds();
-        if (density_out) *density_out = (double)plan_hits / std::max<uint32_t>(1, NP);
-        if (density_limit > 0 && p.min_diag_hits >= 2 && tend - tbegin > 1 && (double)plan_hits / std::max<uint32_t>(1, NP) > density_limit) {
-            stats.n_index_entries -= n_entries;
-            stats.algorithmic_bytes[UC_ST_INDEX] -= 6ull * n_entries + 8ull * KSPACE;
-            stats.prefilter_kernel_ms += gpu_ms;
-            return false;
+        if (sa == first_query) {
+            if (density_out) *density_out = (double)plan_hits / std::max<uint32_t>(1, NP);
+            if (density_limit > 0 && p.min_diag_hits >= 2 && tend - tbegin > 1 && (double)plan_hits / std::max<uint32_t>(1, NP) > density_limit) return 1;
         }
         if (count_sims) stats.n_sim_kmers += plan_sims;
-    }
+        return 0;
+    };
+    uint32_t sb_end = qbegin;                  // end of the planned super-batch
+    double sb_frac = 1.0;                      // share of the remaining queries to try next
 
+    uint32_t sb_begin = qbegin;
     for (uint32_t qa = qbegin; qa < qend;) {
+        if (distinct_mode && qa >= sb_end) {
+            for (;;) {
+                const uint32_t left = qend - qa;
+                const uint32_t sb = sb_frac >= 1.0 ? qend : qa + std::max<uint32_t>(1, std::min<uint32_t>(left, (uint32_t)(left * sb_frac)));
+                const int rc = plan_superbatch(qa, sb);
+                if (rc == 1) {   // undo what this abandoned attempt counted
+                    stats.n_index_entries -= n_entries;
+                    stats.algorithmic_bytes[UC_ST_INDEX] -= 6ull * n_entries + 8ull * KSPACE;
+                    stats.prefilter_kernel_ms += gpu_ms;
+                    return false;
+                }
+                if (rc == 2) {   // distinct k-mers grow sublinearly with the queries: cut a little deeper than proportionally
+                    sb_frac = (double)(sb - qa) / left * 0.8 * (double)DRUN_MAX / (double)over_runs;
+                    continue;
+                }
+                sb_begin = qa; sb_end = sb;
+                if (sb_frac < 1.0) sb_frac = std::min(1.0, (double)(sb - qa) / std::max<uint32_t>(1, qend - sb));   // the same number of queries again
+                break;
+            }
+        }
         Timer t_b;
         timed_ms_begin();
         uint32_t qb = qa;
@@ -1345,8 +1387,8 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
         uint32_t qp0 = 0, qp1 = 0, nq_res = 0;
         if (distinct_mode) {
             // exact plan: as many queries as fit the key and run buffers (a single query may exceed them and takes the wide path)
-            while (qb < qend && qb - qa < (1u << 23) - 1) {
-                const uint64_t h = h_qh[qb - qbegin], r = h_qr[qb - qbegin];
+            while (qb < sb_end && qb - qa < (1u << 23) - 1) {
+                const uint64_t h = h_qh[qb - sb_begin], r = h_qr[qb - sb_begin];
                 if (qb > qa && (total_hits + h > HIT_CAP || n_runs + r > RUN_MAX)) break;
                 total_hits += h; n_runs += r;
                 qb++;
@@ -1379,7 +1421,7 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
             UC_HIP(hipMemsetAsync(d_counters.p, 0, 8, stream));
             const RunList rl{d_rpidx.p, d_rval.p, run_cap};
             hipLaunchKernelGGL(sim_runs_kernel, sim_grid(nq_res), dim3(256), 0, stream, ddb, cfg, qa, qb, qp0, qp1, d_koff.p, rl, d_counters.p,
-                               (const uint32_t *)nullptr, (uint32_t *)nullptr);
+                               (const uint32_t *)nullptr, (uint32_t *)nullptr, 1u);
             unsigned long long c5[5];
             UC_HIP(hipMemcpyAsync(c5, d_counters.p, 40, hipMemcpyDeviceToHost, stream));
             UC_HIP(hipStreamSynchronize(stream));
