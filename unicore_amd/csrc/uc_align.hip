@@ -601,7 +601,17 @@ static void build_plan(Engine &E, SwPlan &P, DevBuf<char> &tmp, uint32_t n, cons
         static bool uploaded[64] = {};
         std::lock_guard<std::mutex> g(mu);
         if (E.device < 0 || E.device >= 64 || !uploaded[E.device]) {
-            UC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), h_tab, sizeof h_tab));
+            ClassTable t[3];
+            memcpy(t, h_tab, sizeof t);
+            if (const char *e = getenv("UC_SW_TCAP")) {   // tuning aid: pairs per task of table 1 for G = 16, G = 32, G = 64 (R <= 24), G = 64 (R > 24)
+                unsigned v[4] = {0, 0, 0, 0};
+                if (sscanf(e, "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]) == 4)
+                    for (int c = 0; c < t[1].n; c++) {
+                        const unsigned x = t[1].G[c] == 16 ? v[0] : t[1].G[c] == 32 ? v[1] : t[1].R[c] <= 24 ? v[2] : v[3];
+                        if (x) t[1].tcap[c] = x;
+                    }
+            }
+            UC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), t, sizeof t));
             if (E.device >= 0 && E.device < 64) uploaded[E.device] = true;
         }
     }

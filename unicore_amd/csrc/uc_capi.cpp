@@ -432,8 +432,16 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
             Engine E(p, devices[(size_t)r]);
             Comm &C = *comms[(size_t)r];
             if (W > 1 && !virtual_gpus) comm_init_rank(C, nccl_id, r, W, devices[(size_t)r]);
+            const bool timing = getenv("UC_TIMING") != nullptr;
+            Timer tph;
+            auto phase = [&](const char *what, int rr) {
+                if (timing && r == 0) fprintf(stderr, "unicore-cluster[timing]: round %d %-14s %.1f ms\n", rr, what, 1e3 * tph.seconds());
+                tph = Timer();
+            };
             for (int rr = 0; rr < p.cluster_steps + pre; rr++) {
                 const int rd = rr - pre;             // cascade round index (-1 = the pre-step)
+                phase("(between)", rr);
+                if (W == 1 && rr == 1) full = std::move(E.hdb);      // a single rank borrows the databases instead of copying them
                 if (r == 0) {
                     if (rr > 0) round_db = sub_db(full, cur);
                     round_kmer_thr = p.kmer_thr;
@@ -441,12 +449,17 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
                         round_kmer_thr = kmer_thr_for(p, 1.0 + (p.sensitivity - 1.0) * rd / (p.cluster_steps - 1));
                 }
                 C.barrier(E);
-                E.hdb = rr == 0 ? full : round_db;
+                phase("sub_db", rr);
+                if (W == 1) E.hdb = std::move(rr == 0 ? full : round_db);
+                else E.hdb = rr == 0 ? full : round_db;
+                phase("hdb copy", rr);
                 E.p.kmer_thr = round_kmer_thr;
                 E.upload_db();
+                phase("upload", rr);
                 const uint32_t m = E.hdb.n;
                 if (rd < 0) {   // E8a: candidate pairs (centre, member) from shared minimum-hash k-mers, the centre is the query
-                    if (r == 0) pre_pairs = linclust_pairs(E.hdb, p, p.threads);
+                    if (r == 0) pre_pairs = E.linclust_pairs();
+                    phase("linclust_pairs", rr);
                     C.barrier(E);
                     // a rank aligns the pairs of the centres it owns (centre mod world): whole queries stay together
                     std::vector<uint32_t> cnt(m, 0);
@@ -471,7 +484,9 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
                         logf(3, "unicore-cluster: step %d: %u sequences, prefilter kept %llu pairs%s (k-score %d, max-seqs %d)\n", rd + 1, m,
                              (unsigned long long)E.n_hits, W > 1 ? " on rank 0" : "", E.p.kmer_thr, p.max_seqs);
                 }
+                phase("hits", rr);
                 E.align(0, m);
+                phase("align", rr);
                 std::vector<uint32_t> all;
                 Timer te;
                 C.gather_edges(E, all);
@@ -491,8 +506,10 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
                     cur.swap(next);
                     E.stats.n_edges = all.size() / 2;
                 }
+                phase("cover+merge", rr);
             }
             C.barrier(E);
+            if (W == 1 && p.cluster_steps + pre == 1) full = std::move(E.hdb);
             if (r == 0) n_clusters = cur.size();
             rank_stats[(size_t)r] = E.stats;
         };

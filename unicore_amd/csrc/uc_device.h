@@ -70,5 +70,9 @@ void launch_sw_long(int mode, const SwArgs &a, uint32_t n_tasks, uint32_t pair_b
 void launch_ungapped(const DeviceDb &db, uint64_t n, const uint32_t *q, const uint32_t *t, const int32_t *diag,
                      int32_t *score, unsigned long long *overlap_sum /* nullable */, hipStream_t s);
 bool sw_class_for(int lq, int *G, int *R);
+// padded device layout of the sequence tracks from the raw (unpadded) ones: s3 / sa[total] with pad letter 20, lt[total + 16]
+// (16 PAD pairs in front) with the PAD pair in all padding; off = padded offsets (n + 1), roff = raw offsets (n + 1)
+void launch_db_pad(uint32_t n, const uint32_t *off, const uint32_t *len, const uint64_t *roff, const uint8_t *r3, const uint8_t *ra,
+                   uint64_t total, uint8_t *s3, uint8_t *sa, uint16_t *lt, hipStream_t s);
 
 }  // namespace uc

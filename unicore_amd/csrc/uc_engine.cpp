@@ -85,34 +85,30 @@ void Engine::upload_db() {
         if (tot >= (1ull << 32) - 64) fail(UC_ERR_ARGS, "database too large for 32-bit device offsets");
     }
     h_poff[n] = (uint32_t)tot;
-    std::vector<uint8_t> p3(tot + 64, 20), pa(tot + 64, 20);
-    std::vector<uint16_t> plt(tot + 64 + 16, (uint16_t)(21u | (21u << 8)));   // letter-pair stream of the gapped kernels, 16 PAD pairs in front
-    {
-        auto pad_copy = [&](uint32_t b, uint32_t e) {
-            for (uint32_t i = b; i < e; i++) {
-                memcpy(p3.data() + h_poff[i], hdb.s3.data() + hdb.off[i], h_len[i]);
-                memcpy(pa.data() + h_poff[i], hdb.sa.data() + hdb.off[i], h_len[i]);
-                uint16_t *w = plt.data() + 16 + h_poff[i];
-                const uint8_t *x3 = hdb.s3.data() + hdb.off[i], *xa = hdb.sa.data() + hdb.off[i];
-                for (uint32_t j = 0; j < h_len[i]; j++) w[j] = (uint16_t)(x3[j] | (xa[j] << 8));
-            }
-        };
-        const unsigned T = tot < (1u << 22) ? 1u : std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < T; t++) th.emplace_back(pad_copy, (uint32_t)((uint64_t)n * t / T), (uint32_t)((uint64_t)n * (t + 1) / T));
-        pad_copy(0, (uint32_t)((uint64_t)n / T));
-        for (auto &x : th) x.join();
-    }
+    // the raw tracks go up as they are (two contiguous copies); the padded layout - 16-byte aligned sequence starts, >= 16 pad
+    // letters behind every sequence, the interleaved letter-pair stream of the gapped kernels - is laid out on the device
+    // (building it on the host cost 55 ms of a 75 ms upload at 47 M residues)
+    const uint64_t raw = hdb.residues();
     d_s3.reserve(tot + 64);
     d_sa.reserve(tot + 64);
     d_lt.reserve(tot + 64 + 16);
     d_off.reserve((size_t)n + 1);
     d_len.reserve(std::max<size_t>(n, 1));
-    UC_HIP(hipMemcpy(d_s3.p, p3.data(), tot + 64, hipMemcpyHostToDevice));
-    UC_HIP(hipMemcpy(d_sa.p, pa.data(), tot + 64, hipMemcpyHostToDevice));
-    UC_HIP(hipMemcpy(d_lt.p, plt.data(), (tot + 64 + 16) * 2, hipMemcpyHostToDevice));
-    UC_HIP(hipMemcpy(d_off.p, h_poff.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
-    if (n) UC_HIP(hipMemcpy(d_len.p, h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    {
+        DevBuf<uint8_t> r3, ra;
+        DevBuf<uint64_t> roff;
+        r3.reserve(std::max<uint64_t>(raw, 1)); ra.reserve(std::max<uint64_t>(raw, 1)); roff.reserve((size_t)n + 1);
+        if (raw) {
+            UC_HIP(hipMemcpyAsync(r3.p, hdb.s3.data(), raw, hipMemcpyHostToDevice, stream));
+            UC_HIP(hipMemcpyAsync(ra.p, hdb.sa.data(), raw, hipMemcpyHostToDevice, stream));
+        }
+        UC_HIP(hipMemcpyAsync(roff.p, hdb.off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, stream));
+        UC_HIP(hipMemcpyAsync(d_off.p, h_poff.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, stream));
+        if (n) UC_HIP(hipMemcpyAsync(d_len.p, h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
+        launch_db_pad(n, d_off.p, d_len.p, roff.p, r3.p, ra.p, tot + 64, d_s3.p, d_sa.p, d_lt.p, stream);
+        UC_HIP(hipStreamSynchronize(stream));
+        UC_HIP(hipGetLastError());
+    }
     ddb.n = n;
     ddb.s3 = d_s3.p; ddb.sa = d_sa.p; ddb.lt = d_lt.p + 16; ddb.off = d_off.p; ddb.len = d_len.p;
     ddb.S3 = d_S3.p; ddb.SA = d_SA.p;

@@ -137,6 +137,8 @@ struct Engine {
     void align(uint32_t qbegin, uint32_t qend);
     // E7: adjacency (sort + unique of both edge directions) on the device, greedy cover on the host
     void set_cover_device(uint32_t n, const uint32_t *h_edges, uint64_t n_edges, uint32_t *assign);
+    // E8a: (centre, member) candidate pairs of the linear-time pre-step for the resident DB, sorted by (centre, member), unique (uc_linclust.hip)
+    std::vector<uint32_t> linclust_pairs();
     // kernel-level
     void ungapped_batch(uint64_t n, const uint32_t *q, const uint32_t *t, const int32_t *diag, int32_t *out);
     void sw_batch(int mode, const std::vector<PairIn> &pairs, int32_t *score, int32_t *qe, int32_t *te);
@@ -147,8 +149,6 @@ struct Engine {
 
 void set_cover(uint32_t n, const uint32_t *edges, uint64_t n_edges, uint32_t *assign);
 void set_cover_csr(uint32_t n, const uint64_t *off, const uint32_t *adj, uint32_t *assign);
-// E8a: (centre, member) candidate pairs of the linear-time pre-step, sorted by (centre, member), unique   (uc_linclust.cpp)
-std::vector<uint32_t> linclust_pairs(const HostDb &db, const Params &p, int threads);
 void merge_hits(uint32_t n, int max_seqs, int n_parts, const uint32_t *const *counts, const uc_hit *const *hits,
                 std::vector<uint32_t> &out_cnt, std::vector<uc_hit> &out_hits);
 const char *last_error_cstr();

@@ -42,6 +42,37 @@ void launch_sw_pk_class(int G, int R, int mode, const SwArgs &a, uint32_t n_task
     else launch_sw_pk_class_m7(G, R, a, n_tasks, s);
 }
 
+// ---- device layout of the database (Engine::upload_db) ----
+__global__ void __launch_bounds__(256) db_pad_kernel(uint32_t n, const uint32_t *off, const uint32_t *len, const uint64_t *roff, const uint8_t *r3,
+                                                     const uint8_t *ra, uint64_t total, uint8_t *s3, uint8_t *sa, uint16_t *lt) {
+    for (uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x; p < total + 16; p += (uint64_t)gridDim.x * 256) {
+        if (p < 16) { lt[p] = (uint16_t)SW_PADPACK; continue; }     // the PAD pairs in front of the stream
+        const uint64_t q = p - 16;
+        uint8_t c3 = 20, ca = 20;
+        uint16_t pair = (uint16_t)SW_PADPACK;
+        if (n) {
+            uint32_t lo = 0, hi = n;                                 // last sequence starting at or before q
+            while (hi - lo > 1) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (off[mid] <= q) lo = mid; else hi = mid;
+            }
+            const uint64_t j = q - off[lo];
+            if (j < len[lo]) {
+                c3 = r3[roff[lo] + j]; ca = ra[roff[lo] + j];
+                pair = (uint16_t)(c3 | (ca << 8));
+            }
+        }
+        s3[q] = c3; sa[q] = ca; lt[p] = pair;
+    }
+}
+
+void launch_db_pad(uint32_t n, const uint32_t *off, const uint32_t *len, const uint64_t *roff, const uint8_t *r3, const uint8_t *ra,
+                   uint64_t total, uint8_t *s3, uint8_t *sa, uint16_t *lt, hipStream_t s) {
+    const uint64_t work = total + 16;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((work + 255) / 256, 1u << 20);
+    hipLaunchKernelGGL(db_pad_kernel, dim3(blocks), dim3(256), 0, s, n, off, len, roff, r3, ra, total, s3, sa, lt);
+}
+
 // ---- stage E3: ungapped diagonal score (MMseqs2 UngappedAlignment on the 3Di track) ----
 // One lane per candidate (q, t, diag): Kadane along the whole diagonal, saturating at 255.  The 21x21
 // 3Di matrix sits in LDS; candidates arrive sorted by (q, t) so neighbouring lanes share the query.
