@@ -62,7 +62,7 @@ if os.path.exists(sb + "/out_kernel_stats.csv"):
         o.write(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sw_class_times.py"), os.path.relpath(sb, ROOT)], cwd=ROOT, capture_output=True, text=True).stdout)
 # prefilter traffic (everything that is not a gapped-SW / set-cover / planner kernel of uc_align.hip)
 PRE = ("kmer_extract", "kmer_offsets", "sim_runs", "filter_kernel", "run_range", "run_order", "compact_kernel", "diag_select", "ungapped_kernel", "select_key", "rank_flag",
-       "hit_scatter", "hit_count", "expand_kernel")
+       "hit_scatter", "hit_count", "expand_kernel", "query_kmer", "distinct_kmer", "rank_offsets", "rank_rec", "position_runs", "query_totals", "position_expand")
 pt = {}
 for sfx, cname in (("_fetch", "FETCH_SIZE"), ("_write", "WRITE_SIZE")):
     f = base + sfx + "/out_counter_collection.csv"
