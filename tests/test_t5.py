@@ -194,6 +194,33 @@ def test_hip_encoder_wider_models_and_ragged_batches(geom, tmp_path):
 
 
 @pytest.mark.gpu
+def test_hip_encoder_large_batches_use_the_256_tile_gemm_with_identical_results(tmp_path):
+    """batches of >= 2048 tokens run the linear layers on the 256 x 256 tile kernel, smaller ones on the 128 x 128 one: the K order
+    per output element is the same, so states AND logits must be bit-identical; a few sequences also go against the fp32
+    restatement"""
+    import unicore_amd as U
+    cfg = R.default_config(d_kv=128, d_model=1024, n_heads=32, d_ff=16384, n_layers=1)
+    path = str(tmp_path / "m.gguf")
+    R.write_synthetic_gguf(path, cfg, seed=0x5EED0008)
+    _, w = R.read_gguf(path)
+    rng = np.random.default_rng(9)
+    seqs = ["".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWY"), L)) for L in (400, 391, 380, 333, 300, 290, 257, 255, 129, 64, 17)]   # 2816 residues
+    enc = U.T5Encoder(path)
+    codes, logits = enc.encode(seqs, logits=True)                     # one batch of 2838 tokens -> 256 tile
+    os.environ["UC_T5_BATCH_TOKENS"] = "900"                          # batches below 2048 tokens -> 128 tile
+    try:
+        c2, l2 = enc.encode(seqs, logits=True)
+    finally:
+        del os.environ["UC_T5_BATCH_TOKENS"]
+    for a, b, la, lb in zip(codes, c2, logits, l2):
+        assert np.array_equal(a, b) and np.array_equal(la, lb)
+    for i in (0, 7, 10):
+        rl, rc = R.forward(w, cfg, seqs[i])
+        _check(codes[i], logits[i], rl, rc, ("256 tile", len(seqs[i])))
+    enc.close()
+
+
+@pytest.mark.gpu
 def test_createdb_writes_the_database_the_cluster_path_reads(tmp_path):
     """`foldseek createdb <fasta> <db> --prostt5-model <dir>` (createdb.rs:157-166) through the shim, then `foldseek
     cluster` + `createtsv` on the result: the whole chain of `unicore createdb` -> `unicore cluster` without Foldseek"""

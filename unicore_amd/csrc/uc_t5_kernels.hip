@@ -127,8 +127,119 @@ __global__ void __launch_bounds__(256) t5_gemm_kernel(const _Float16 *__restrict
     }
 }
 
+// ---- the large-tile variant: 256 x 256 x 64, 8 waves x (128 x 64) -------------------------------------------------------
+// With 64 x 64 per wave the 128^2 kernel reads 16 fragments (16 B per lane) from LDS per 32 MFMAs: at 128 B / cycle / CU that
+// is as many cycles as the MFMAs themselves take, so the two pipes cannot both be full.  A wave tile of 128 x 64 reads 24
+// fragments per 64 MFMAs (0.375 instead of 0.5 per MFMA); the 256 x 256 workgroup tile also halves the global -> LDS traffic
+// per FLOP.  Same staging (global_load_lds into a double-buffered XOR-swizzled tile, one barrier per K-step), 128 KB of LDS,
+// one workgroup of 8 waves per CU, accumulators 128 VGPRs.
+constexpr int HBM_ = 256, HBN_ = 256;
+
+template <int EPI>
+__global__ void __launch_bounds__(512) t5_gemm256_kernel(const _Float16 *__restrict__ A, const _Float16 *__restrict__ W, void *__restrict__ out,
+                                                         int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(1024))) _Float16 smd[];                // [stage][A | B][256 rows * 64]: 128 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+    int m0, n0;
+    {
+        const int nn = (N + HBN_ - 1) / HBN_, nm = (M + HBM_ - 1) / HBM_;
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int g = k / (GXM * nn), r = k % (GXM * nn);
+        const int ml = g * GXM + r % GXM, mt = xcd + 8 * ml;
+        if (mt >= nm) return;
+        m0 = mt * HBM_;
+        n0 = (r / GXM) * HBN_;
+    }
+    auto tile = [&](int st, int op) -> _Float16 * { return smd + (size_t)(st * 2 + op) * (HBM_ * GBK); };
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const _Float16 *ga[4], *gb[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3), kc = ((lane & 7) ^ (row & 7)) * 8;
+        ga[i] = A + (size_t)min(m0 + row, M - 1) * K + kc;
+        gb[i] = W + (size_t)min(n0 + row, N - 1) * K + kc;
+    }
+    auto issue = [&](int kt, int st) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            __builtin_amdgcn_global_load_lds((gbl_void *)(ga[i] + (size_t)kt * GBK), (lds_void *)(tile(st, 0) + (wave * 4 + i) * 8 * GBK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(gb[i] + (size_t)kt * GBK), (lds_void *)(tile(st, 1) + (wave * 4 + i) * 8 * GBK), 16, 0, 0);
+        }
+    };
+    const int nk = K / GBK;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; kt++) {
+        const int st = kt & 1;
+        __syncthreads();
+        if (kt + 1 < nk) issue(kt + 1, st ^ 1);
+        const _Float16 *sA = tile(st, 0), *sB = tile(st, 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            half8 af[8], bf[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int r = wn * 64 + j * 16 + (lane & 15);
+                bf[j] = *(const half8 *)(sB + r * GBK + (((ks * 4 + (lane >> 4)) ^ (r & 7)) * 8));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int r = wm * 128 + i * 16 + (lane & 15);
+                af[i] = *(const half8 *)(sA + r * GBK + (((ks * 4 + (lane >> 4)) ^ (r & 7)) * 8));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int row = m0 + wm * 128 + i * 16 + (lane & 15);
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int col = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            if (col >= N) continue;
+            f32x4 v = acc[i][j];
+            if (EPI == 2) {
+                f32x4 *o = (f32x4 *)((float *)out + (size_t)row * N + col);
+                *o = *o + v;
+            } else {
+                if (EPI == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                *(h4 *)((_Float16 *)out + (size_t)row * N + col) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            }
+        }
+    }
+}
+
+template <int EPI>
+static void t5_gemm256_launch(const void *A, const void *W, void *out, int M, int N, int K, hipStream_t s) {
+    constexpr int LDS = 2 * 2 * HBM_ * GBK * 2;
+    static bool once[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !once[dev]) {
+        (void)hipFuncSetAttribute((const void *)t5_gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        once[dev] = true;
+    }
+    const int nn = (N + HBN_ - 1) / HBN_, nm = (M + HBM_ - 1) / HBM_, per_xcd = ((nm + 7) / 8 + GXM - 1) / GXM * GXM;
+    hipLaunchKernelGGL(t5_gemm256_kernel<EPI>, dim3((unsigned)(8 * per_xcd * nn)), dim3(512), LDS, s, (const _Float16 *)A, (const _Float16 *)W, out, M, N, K);
+}
+
 void t5_gemm(int epi, const void *A, const void *W, void *out, int M, int N, int K, hipStream_t s) {
     if (M <= 0) return;
+    static const int big = getenv("UC_T5_GEMM256") ? atoi(getenv("UC_T5_GEMM256")) : 1;
+    if (big && M >= 2048 && N % HBN_ == 0) {     // large batches: the 256 x 256 tile (small ones would leave most CUs without a tile)
+        if (epi == 0) t5_gemm256_launch<0>(A, W, out, M, N, K, s);
+        else if (epi == 1) t5_gemm256_launch<1>(A, W, out, M, N, K, s);
+        else t5_gemm256_launch<2>(A, W, out, M, N, K, s);
+        return;
+    }
     const int nn = (N + GBN - 1) / GBN, nm = (M + GBM - 1) / GBM, per_xcd = ((nm + 7) / 8 + GXM - 1) / GXM * GXM;
     const dim3 grid((unsigned)(8 * per_xcd * nn));
     if (epi == 0) hipLaunchKernelGGL(t5_gemm_kernel<0>, grid, dim3(256), 0, s, (const _Float16 *)A, (const _Float16 *)W, out, M, N, K);
