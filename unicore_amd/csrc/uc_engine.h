@@ -30,6 +30,12 @@ struct DevBuf {   // plain owning device allocation (hipMalloc), grows geometric
         if (n <= cap) return;
         release();
         size_t want = n + n / 8 + 64;
+        if (want * sizeof(T) >= (1ull << 30) && getenv("UC_ALLOC_LOG")) {
+            size_t fr = 0, tot = 0;
+            (void)hipMemGetInfo(&fr, &tot);
+            fprintf(stderr, "unicore-cluster[alloc]: %.2f GiB (%zu x %zu B), %.1f GiB free before\n", (double)(want * sizeof(T)) / (1ull << 30), want, sizeof(T),
+                    (double)fr / (1ull << 30));
+        }
         UC_HIP(hipMalloc((void **)&p, want * sizeof(T)));
         cap = want;
     }

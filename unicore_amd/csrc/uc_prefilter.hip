@@ -1040,6 +1040,25 @@ struct PrefilterScratch {
     DevBuf<uint32_t> d_qk, d_kid, d_dk, d_nsimk, d_drk, d_drk2, d_roff, d_nr, d_src, d_ph;
     DevBuf<uint64_t> d_drv, d_drv2, d_cumh, d_cumr, d_qh, d_qrn;
     DevBuf<RankRec> d_rec;
+    // every buffer (for the size bookkeeping below)
+    template <class F> void each(F f) {
+        f(d_counters); f(d_prof); f(d_temp); f(d_koff); f(k_in); f(k_out); f(d_ent32); f(v_in32); f(d_okey); f(d_okey2); f(d_oidx); f(d_order);
+        f(d_ent); f(v_in); f(d_cnt); f(d_flag); f(d_cq); f(d_ct); f(d_rpidx); f(d_rpidx2); f(d_qsurv); f(d_keys); f(d_keys2); f(d_pos); f(d_skey);
+        f(d_skey2); f(d_rval); f(d_rval2); f(d_qbase); f(d_soff); f(d_qr); f(d_cd); f(d_cd2); f(d_score); f(d_kflag); f(d_qk); f(d_kid); f(d_dk);
+        f(d_nsimk); f(d_drk); f(d_drk2); f(d_roff); f(d_nr); f(d_src); f(d_ph); f(d_drv); f(d_drv2); f(d_cumh); f(d_cumr); f(d_qh); f(d_qrn); f(d_rec);
+    }
+    size_t bytes() {
+        size_t b = 0;
+        each([&](auto &x) { b += x.cap * sizeof(*x.p); });
+        return b;
+    }
+    // Large databases grow this set to well over 100 GB (per-position arrays, run lists, 30 GiB of key regions); the gapped
+    // stage sizes its own batches by the memory that is FREE, so above `limit` the big buffers go back before it starts
+    // (re-allocating them costs milliseconds per step at a scale where a step takes a minute; small databases keep everything).
+    void trim(size_t limit) {
+        if (bytes() <= limit) return;
+        each([&](auto &x) { if (x.cap * sizeof(*x.p) >= ((size_t)1 << 30)) x.release(); });
+    }
 };
 void free_prefilter_scratch(PrefilterScratch *p) { delete p; }
 
@@ -1105,7 +1124,7 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t
         bool ok = true;
         if (chunks.size() <= 1) {
             ok = prefilter_one(tbegin, tend, qbegin, qend, true, limit, &density);
-            if (ok) { stats.n_prefilter_hits += n_hits; return; }
+            if (ok) { stats.n_prefilter_hits += n_hits; if (pre) pre->trim((size_t)48 << 30); return; }
         } else {
             DevBuf<uint32_t> aq, at, tq, tt;
             DevBuf<int32_t> as, ad, ts, td;
@@ -1136,6 +1155,7 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t
                 // install the accumulated lists (also rebuilds the per-query counts)
                 import_hits_dev(acc_n, aq.p, at.p, as.p, ad.p, 0, 1);
                 stats.n_prefilter_hits += n_hits;
+                if (pre) pre->trim((size_t)48 << 30);
                 return;
             }
         }
