@@ -1677,17 +1677,23 @@ uint64_t Engine::import_hits_dev(uint64_t n_in, const uint32_t *dq, const uint32
     if (!n_in) return 0;
     Timer tm;
     timed_ms_begin();
-    DevBuf<uint64_t> skey, skey2, pos;
-    DevBuf<int32_t> cd2;
-    DevBuf<uint32_t> flag, bad, cnt;
-    DevBuf<char> tmp;
+    // work buffers from the engine's prefilter scratch: a chunked or sharded run merges once per chunk / shard, and allocating
+    // ~50 B per record anew every time was most of the merge time at 10^9 records
+    if (!pre) pre = take_prefilter_scratch(device);
+    DevBuf<uint64_t> &skey = pre->d_skey, &skey2 = pre->d_skey2, &pos = pre->d_pos;
+    DevBuf<int32_t> &cd2 = pre->d_cd2;
+    DevBuf<uint32_t> &flag = pre->d_flag, &cnt = pre->d_cnt;
+    DevBuf<uint32_t> bad;
+    DevBuf<char> &tmp = pre->d_temp;
     skey.reserve(n_in); skey2.reserve(n_in); cd2.reserve(n_in); flag.reserve(n_in); pos.reserve(n_in); bad.reserve(1);
     UC_HIP(hipMemsetAsync(bad.p, 0, 4, stream));
     hipLaunchKernelGGL(merge_key_kernel, grid_for(n_in), dim3(256), 0, stream, n_in, dq, dt, ds, n, skey.p, bad.p);
     size_t tb = 0;
-    UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, skey.p, skey2.p, dd, cd2.p, (size_t)n_in, 0u, 64u, stream));
+    unsigned kb = 33;                              // [query | 255 - score : 8 | target : 24]: the query field ends at bit 32 + log2 n
+    while (kb < 64 && (1ull << (kb - 32)) < n) kb++;
+    UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, skey.p, skey2.p, dd, cd2.p, (size_t)n_in, 0u, kb, stream));
     tmp.reserve(tb + 256);
-    UC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, skey.p, skey2.p, dd, cd2.p, (size_t)n_in, 0u, 64u, stream));
+    UC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, skey.p, skey2.p, dd, cd2.p, (size_t)n_in, 0u, kb, stream));
     hipLaunchKernelGGL(rank_flag_kernel, grid_for(n_in), dim3(256), 0, stream, skey2.p, n_in, (uint32_t)p.max_seqs, flag.p);
     if (world > 1) hipLaunchKernelGGL(owner_flag_kernel, grid_for(n_in), dim3(256), 0, stream, skey2.p, n_in, ddb.len, rank, world, flag.p);
     auto rin = rocprim::make_transform_iterator(flag.p, WidenU32());
