@@ -27,3 +27,34 @@ for seed in range(first, first + n):
     finally:
         for k in env: os.environ.pop(k, None)
 print("property campaign: seeds %d..%d, %d failures %s, %.0f s" % (first, first + n - 1, len(bad), bad, time.time() - t0))
+
+# ---- workflows: random synthetic proteome sets through uc_cluster (pre-step on/off, 1-3 cascade steps, coverage, k-mers per
+#      sequence) against uco_cluster_workflow: clust.tsv bytes, cluster and alignment counts
+import numpy as np, shutil, tempfile
+import unicore_amd as U, util
+nw = int(sys.argv[3]) if len(sys.argv) > 3 else max(1, n // 6)
+badw, t0 = [], time.time()
+for seed in range(first, first + nw):
+    rng = np.random.default_rng(7000 + seed)
+    d = tempfile.mkdtemp(prefix="uc_wf_")
+    try:
+        db = util.gen_synth_db(os.path.join(d, "db"), int(rng.integers(3, 9)), 0x5EED1000 + seed, int(rng.integers(20, 80)), float(rng.choice([0.4, 0.6, 1.0])))
+        steps, lin, m = int(rng.integers(1, 4)), int(rng.integers(0, 2)), int(rng.choice([3, 5, 20, 40]))
+        base = "-c %.1f --cov-mode %d" % (rng.choice([0.5, 0.8, 0.9]), rng.integers(0, 3))
+        if rng.random() < 0.3: base += " --min-seq-id %.1f" % rng.choice([0.3, 0.5])
+        opts = base + " --linclust %d --cluster-steps %d" % (lin, steps) + (" --kmer-per-seq %d" % m if lin else "")
+        if steps == 1 and not lin: opts = base + " --single-step-clustering"
+        st = U.cluster(db, os.path.join(d, "c_cluster"), os.path.join(d, "tmp"), opts, threads=4)
+        U.createtsv(db, os.path.join(d, "c_cluster"), os.path.join(d, "c.tsv"))
+        odb = O.OracleDb(db)
+        p = util.oracle_params(O, base)
+        ref = O.cluster_workflow(odb, p, O.cascade_thresholds(p, 4.0, steps), linclust_m=m if lin else 0, threads=8)
+        O.write_tsv(os.path.join(d, "r.tsv"), odb, ref["assign"])
+        same = open(os.path.join(d, "c.tsv"), "rb").read() == open(os.path.join(d, "r.tsv"), "rb").read()
+        if not (same and st["n_clusters"] == ref["counts"]["n_clusters"] and st["n_gapped_alignments"] == ref["counts"]["n_alignments"]):
+            badw.append(seed); print("workflow seed", seed, "FAILED:", opts, st["n_clusters"], ref["counts"]["n_clusters"], st["n_gapped_alignments"], ref["counts"]["n_alignments"], flush=True)
+    except Exception as e:   # noqa: BLE001
+        badw.append(seed); print("workflow seed", seed, "FAILED:", "".join(traceback.format_exception_only(type(e), e)).strip()[:400], flush=True)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+print("workflow campaign: seeds %d..%d, %d failures %s, %.0f s" % (first, first + nw - 1, len(badw), badw, time.time() - t0))
