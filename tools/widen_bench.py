@@ -3,8 +3,10 @@
 uc_cluster single step vs 3-step cascade, and uc_search (a 5-proteome query DB against the 50-proteome DB) +
 uc_convertalis.  From-disk wall clock (read + encode + upload included), stats from the C ABI."""
 import os, sys, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("UC_ALLOW_SYNTHETIC", "1")
+import torch  # noqa: F401
 import bench, unicore_amd as U
 wd = "/tmp/uc_bench/p50"
 bench.gen_db(wd, 50, 6000, 1.0, 0x5EED0002)
@@ -13,7 +15,8 @@ wq = "/tmp/uc_bench/p5q"
 bench.gen_db(wq, 5, 6000, 1.0, 0x5EED0002)    # same families as the target DB (its first 5 proteomes)
 qdb = os.path.join(wq, "db")
 out = {}
-for name, opts in (("cluster_single", "-c 0.8"), ("cluster_cascade3", "-c 0.8 --cluster-steps 3"), ("cluster_linclust_cascade3", "-c 0.8 --linclust 1 --cluster-steps 3"), ("cluster_seqid", "-c 0.8 --min-seq-id 0.3")):
+for name, opts in (("cluster_single", "-c 0.8 --single-step-clustering"), ("cluster_cascade3", "-c 0.8 --linclust 0 --cluster-steps 3"), ("cluster_default_workflow", "-c 0.8"),
+                   ("cluster_seqid", "-c 0.8 --single-step-clustering --min-seq-id 0.3")):
     U.cluster(db, "/tmp/uc_bench/w_cluster", "/tmp/uc_bench/tmp", opts)          # warm-up (allocations, page cache)
     t = time.perf_counter()
     st = U.cluster(db, "/tmp/uc_bench/w_cluster", "/tmp/uc_bench/tmp", opts)

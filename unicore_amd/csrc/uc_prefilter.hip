@@ -1093,6 +1093,15 @@ PrefilterScratch *take_prefilter_scratch(int device) {
     return new PrefilterScratch;
 }
 
+// the prefilter's work buffers stay allocated between steps (re-allocating the 34 GiB key regions alone costs a second per
+// step at configs[1]) unless they hold more than 40 % of the device memory: then the gapped stage, which sizes its batches by
+// the free memory, gets them back (2.5 M sequences: 170 GB)
+static size_t scratch_trim_limit() {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || tot == 0) return (size_t)96 << 30;
+    return (size_t)((double)tot * 0.4);
+}
+
 // E1-E4 for a target range.  Large ranges are processed as several index chunks whose per-query top-M lists are
 // merged on the device (lossless, same argument as the multi-GPU shards): the double-hit filter keeps one query's
 // (target, diagonal) hashes in 2 x 2^19 LDS bits, which only works while a query has well under ~500 k k-mer hits,
@@ -1124,7 +1133,7 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t
         bool ok = true;
         if (chunks.size() <= 1) {
             ok = prefilter_one(tbegin, tend, qbegin, qend, true, limit, &density);
-            if (ok) { stats.n_prefilter_hits += n_hits; if (pre) pre->trim((size_t)48 << 30); return; }
+            if (ok) { stats.n_prefilter_hits += n_hits; if (pre) pre->trim(scratch_trim_limit()); return; }
         } else {
             DevBuf<uint32_t> aq, at, tq, tt;
             DevBuf<int32_t> as, ad, ts, td;
@@ -1155,7 +1164,7 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t
                 // install the accumulated lists (also rebuilds the per-query counts)
                 import_hits_dev(acc_n, aq.p, at.p, as.p, ad.p, 0, 1);
                 stats.n_prefilter_hits += n_hits;
-                if (pre) pre->trim((size_t)48 << 30);
+                if (pre) pre->trim(scratch_trim_limit());
                 return;
             }
         }
