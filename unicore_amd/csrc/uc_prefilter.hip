@@ -1262,9 +1262,10 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
 
     // ------------------------------------------------------------ E2-E4 over query batches
     const bool distinct_mode = !getenv("UC_SIM_PER_POSITION");   // the r2 path (DFS per query position + sort of all runs by position), kept for A/B runs
-    // keys per batch: the filter's regions hold < 2^32 keys (2 x 4 B x 3.75 G = 30 GiB in compact mode); the r2 path sizes its
-    // batches by estimate and keeps the smaller cap
-    const uint64_t HIT_CAP = distinct_mode ? (15ull << 28) : (1ull << 31);
+    // keys per batch (the filter's regions hold < 2^32 keys).  1.5 G keys = 12 GiB of regions: a one-shot `foldseek cluster` process
+    // pays for every byte it allocates (34 GiB of regions at 3.75 G keys: 5.2 s from process start to clust.tsv at configs[1]
+    // instead of 1.25 s), and a resident engine loses nothing measurable (681 vs 681 ms per step; UC_HIT_CAP overrides)
+    const uint64_t HIT_CAP = getenv("UC_HIT_CAP") ? std::max<uint64_t>(1u << 20, strtoull(getenv("UC_HIT_CAP"), nullptr, 10)) : distinct_mode ? (3ull << 29) : (1ull << 31);
     const uint64_t RUN_MAX = 1ull << 29;       // runs per batch (6 GiB + 6 GiB sort double buffer)
     double hits_per_res = 64.0;                // adaptive estimates
     uint64_t run_cap = 1ull << 20;
