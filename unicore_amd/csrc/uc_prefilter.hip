@@ -1266,6 +1266,10 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
     // pays for every byte it allocates (34 GiB of regions at 3.75 G keys: 5.2 s from process start to clust.tsv at configs[1]
     // instead of 1.25 s), and a resident engine loses nothing measurable (681 vs 681 ms per step; UC_HIT_CAP overrides)
     const uint64_t HIT_CAP = getenv("UC_HIT_CAP") ? std::max<uint64_t>(1u << 20, strtoull(getenv("UC_HIT_CAP"), nullptr, 10)) : distinct_mode ? (3ull << 29) : (1ull << 31);
+    // ... unless the chunk has so many hits that the batches would run into the hundreds (2.5 M sequences: 1.5e12 hits): then the
+    // per-batch costs outweigh the allocation and the regions take 3.75 G keys (30 GiB)
+    const uint64_t HIT_CAP_BIG = getenv("UC_HIT_CAP") ? HIT_CAP : (15ull << 28);
+    uint64_t hit_cap = HIT_CAP;
     const uint64_t RUN_MAX = 1ull << 29;       // runs per batch (6 GiB + 6 GiB sort double buffer)
     double hits_per_res = 64.0;                // adaptive estimates
     uint64_t run_cap = 1ull << 20;
@@ -1376,6 +1380,7 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
         UC_HIP(hipStreamSynchronize(stream));
         plan_sims = c0;
         for (uint32_t i = 0; i < nqa; i++) plan_hits += h_qh[i];
+        hit_cap = distinct_mode && plan_hits > 16 * HIT_CAP ? HIT_CAP_BIG : HIT_CAP;
         gpu_ms += timed_ms_end();
         t_kmer += t_p.seconds();
         if (sa == first_query) {
@@ -1419,7 +1424,7 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
             // exact plan: as many queries as fit the key and run buffers (a single query may exceed them and takes the wide path)
             while (qb < sb_end && qb - qa < (1u << 23) - 1) {
                 const uint64_t h = h_qh[qb - sb_begin], r = h_qr[qb - sb_begin];
-                if (qb > qa && (total_hits + h > HIT_CAP || n_runs + r > RUN_MAX)) break;
+                if (qb > qa && (total_hits + h > hit_cap || n_runs + r > RUN_MAX)) break;
                 total_hits += h; n_runs += r;
                 qb++;
             }
