@@ -1238,9 +1238,15 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                 if (ne) {
                     d_e.reserve(2 * (size_t)ne);
                     hipLaunchKernelGGL(edge_scatter_kernel, grid_for(n2), dim3(256), 0, s, n2, eflag.p, epos.p, q2.p, t2.p, d_e.p);
-                    const size_t old = edges.size();
-                    edges.resize(old + 2 * (size_t)ne);
-                    UC_HIP(hipMemcpyAsync(edges.data() + old, d_e.p, 2 * (size_t)ne * 4, hipMemcpyDeviceToHost, s));
+                    if (edges_on_host && !edges.empty()) {   // a host list from an earlier call that was read back: continue on the device
+                        d_edges.reserve(edges.size());
+                        UC_HIP(hipMemcpyAsync(d_edges.p, edges.data(), edges.size() * 4, hipMemcpyHostToDevice, s));
+                        n_edges_dev = edges.size() / 2;
+                    }
+                    d_edges.grow_preserve(2 * (n_edges_dev + ne), 2 * n_edges_dev);
+                    UC_HIP(hipMemcpyAsync(d_edges.p + 2 * n_edges_dev, d_e.p, 2 * (size_t)ne * 4, hipMemcpyDeviceToDevice, s));
+                    n_edges_dev += ne;
+                    edges_on_host = false;
                 }
             }
             uint32_t bad = 0;
@@ -1254,7 +1260,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
         qa = qb;
     }
     alns_valid = true;
-    stats.n_edges = edges.size() / 2;
+    stats.n_edges = edges_on_host ? edges.size() / 2 : n_edges_dev;
     stats.algorithmic_bytes[UC_ST_GAPPED] = stats.sw_algorithmic_bytes;
     stats.stage_seconds[UC_ST_GAPPED] += tm.seconds();
 }
@@ -1287,8 +1293,30 @@ __global__ void __launch_bounds__(256) edge_off_kernel(uint32_t n, const uint64_
     }
 }
 
+const std::vector<uint32_t> &Engine::host_edges() {
+    if (!edges_on_host) {
+        UC_HIP(hipSetDevice(device));
+        edges.resize(2 * n_edges_dev);
+        if (n_edges_dev) UC_HIP(hipMemcpy(edges.data(), d_edges.p, 2 * n_edges_dev * 4, hipMemcpyDeviceToHost));
+        edges_on_host = true;
+    }
+    return edges;
+}
+
+void Engine::set_cover_own_edges(uint32_t n, uint32_t *assign) {
+    if (edges_on_host) { set_cover_device(n, edges.data(), edges.size() / 2, assign); return; }
+    if (n_edges_dev >= (1ull << 31)) { const std::vector<uint32_t> &h = host_edges(); set_cover(n, h.data(), h.size() / 2, assign); return; }
+    set_cover_graph(n, nullptr, d_edges.p, n_edges_dev, assign);
+}
+
 void Engine::set_cover_device(uint32_t n, const uint32_t *h_edges, uint64_t n_edges, uint32_t *assign) {
     if (n_edges >= (1ull << 31)) { set_cover(n, h_edges, n_edges, assign); return; }   // 32-bit scan positions below
+    set_cover_graph(n, h_edges, nullptr, n_edges, assign);
+}
+
+// the graph (CSR, both directions, duplicates and self loops removed) on the device from a host or a device edge list, the
+// greedy cover on the host
+void Engine::set_cover_graph(uint32_t n, const uint32_t *h_edges, const uint32_t *dev_edges, uint64_t n_edges, uint32_t *assign) {
     UC_HIP(hipSetDevice(device));
     Timer t_graph;
     AlignScratch &A = scratch_of(*this);
@@ -1302,10 +1330,15 @@ void Engine::set_cover_device(uint32_t n, const uint32_t *h_edges, uint64_t n_ed
         DevBuf<uint32_t> &d_e = A.sc_e, &flag = A.sc_flag, &pos = A.sc_pos, &d_adj = A.sc_dadj, &bad = A.sc_bad;
         DevBuf<uint64_t> &key = A.sc_key, &key2 = A.sc_key2, &ukey = A.sc_ukey, &d_off = A.sc_doff;
         DevBuf<char> &tmp = A.sc_tmp;
-        d_e.reserve(m); key.reserve(m); key2.reserve(m); flag.reserve(m); pos.reserve(m); bad.reserve(1); d_off.reserve((size_t)n + 1);
-        UC_HIP(hipMemcpyAsync(d_e.p, h_edges, m * 4, hipMemcpyHostToDevice, stream));
+        key.reserve(m); key2.reserve(m); flag.reserve(m); pos.reserve(m); bad.reserve(1); d_off.reserve((size_t)n + 1);
+        const uint32_t *e_in = dev_edges;
+        if (!e_in) {
+            d_e.reserve(m);
+            UC_HIP(hipMemcpyAsync(d_e.p, h_edges, m * 4, hipMemcpyHostToDevice, stream));
+            e_in = d_e.p;
+        }
         UC_HIP(hipMemsetAsync(bad.p, 0, 4, stream));
-        hipLaunchKernelGGL(edge_key_kernel, grid_for(n_edges), dim3(256), 0, stream, n_edges, d_e.p, n, key.p, bad.p);
+        hipLaunchKernelGGL(edge_key_kernel, grid_for(n_edges), dim3(256), 0, stream, n_edges, e_in, n, key.p, bad.p);
         size_t tb = 0;
         UC_HIP(rocprim::radix_sort_keys(nullptr, tb, key.p, key2.p, (size_t)m, 0u, 64u, stream));
         tmp.reserve(tb + 256);

@@ -251,13 +251,14 @@ int uc_engine_alns_get(const uc_engine *e, uint32_t qbegin, uint32_t qend, uc_al
 }
 
 int uc_engine_edges_size(const uc_engine *e, uint64_t *n_edges) {
-    return guard([&] { require(e, "engine"); require(n_edges, "n_edges"); *n_edges = e->e->edges.size() / 2; });
+    return guard([&] { require(e, "engine"); require(n_edges, "n_edges"); *n_edges = e->e->edges_on_host ? e->e->edges.size() / 2 : e->e->n_edges_dev; });
 }
 
 int uc_engine_edges_get(const uc_engine *e, uint32_t *edges) {
     return guard([&] {
         require(e, "engine");
-        if (!e->e->edges.empty()) { require(edges, "edges"); memcpy(edges, e->e->edges.data(), e->e->edges.size() * 4); }
+        const std::vector<uint32_t> &h = e->e->host_edges();
+        if (!h.empty()) { require(edges, "edges"); memcpy(edges, h.data(), h.size() * 4); }
     });
 }
 
@@ -489,22 +490,24 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
                 phase("align", rr);
                 std::vector<uint32_t> all;
                 Timer te;
-                C.gather_edges(E, all);
-                if (W > 1) E.stats.exchange_seconds += te.seconds();
+                uint64_t n_acc = 0;                  // accepted pairs of the round (all ranks)
+                if (W > 1) { C.gather_edges(E, all); n_acc = all.size() / 2; E.stats.exchange_seconds += te.seconds(); }
+                else n_acc = E.edges_on_host ? E.edges.size() / 2 : E.n_edges_dev;
                 if (r == 0) {
                     Timer tc;
                     std::vector<uint32_t> sa(m);
-                    E.set_cover_device(m, all.data(), all.size() / 2, sa.data());
+                    if (W > 1) E.set_cover_device(m, all.data(), all.size() / 2, sa.data());
+                    else E.set_cover_own_edges(m, sa.data());      // one rank: graph straight from the device-resident edge list
                     // mergeclusters: the representative of a sequence is the representative of its representative
                     for (uint32_t i = 0; i < cur.size(); i++) posmap[cur[i]] = i;
                     for (uint32_t x = 0; x < n; x++) assign[x] = cur[sa[posmap[assign[x]]]];
                     std::vector<uint32_t> next;
                     for (uint32_t i = 0; i < cur.size(); i++) if (sa[i] == i) next.push_back(cur[i]);
-                    E.stats.algorithmic_bytes[UC_ST_SETCOVER] += 8ull * (all.size() / 2) + 4ull * m;
+                    E.stats.algorithmic_bytes[UC_ST_SETCOVER] += 8ull * n_acc + 4ull * m;
                     E.stats.stage_seconds[UC_ST_SETCOVER] += tc.seconds();
-                    logf(3, "unicore-cluster: step %d: %llu accepted pairs, %zu representatives\n", rd + 1, (unsigned long long)(all.size() / 2), next.size());
+                    logf(3, "unicore-cluster: step %d: %llu accepted pairs, %zu representatives\n", rd + 1, (unsigned long long)n_acc, next.size());
                     cur.swap(next);
-                    E.stats.n_edges = all.size() / 2;
+                    E.stats.n_edges = n_acc;
                 }
                 phase("cover+merge", rr);
             }

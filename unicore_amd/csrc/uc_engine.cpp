@@ -117,7 +117,7 @@ void Engine::upload_db() {
     hit_off.assign((size_t)n + 1, 0);
     n_hits = 0;
     alns_valid = false;
-    edges.clear();
+    clear_edges();
     max_len = 1;
     for (uint32_t i = 0; i < n; i++) max_len = std::max(max_len, h_len[i]);
     stats.n_seqs = n;
@@ -170,7 +170,7 @@ void Engine::set_hits(const uint32_t *counts, const uc_hit *h, bool check_max_se
         UC_HIP(hipMemcpy(d_hd.p, hd.data(), n_hits * 4, hipMemcpyHostToDevice));
     }
     alns_valid = false;
-    edges.clear();
+    clear_edges();
 }
 
 void Engine::get_hits(uc_hit *out) const { get_hits_range(0, n_hits, out); }

@@ -118,7 +118,14 @@ struct Engine {
     DevBuf<int32_t> d_hs, d_hd;        // ungapped score / diagonal per hit
     DevBuf<uc_aln> d_alns;             // parallel to the hit arrays
     bool alns_valid = false;
-    std::vector<uint32_t> edges;
+    // accepted edges (E6): appended on the DEVICE by align(); the host copy is made only when somebody asks for it (getters,
+    // multi-rank gather) - a single-rank step builds the set-cover graph straight from the device list
+    DevBuf<uint32_t> d_edges;          // 2 x n_edges_dev
+    uint64_t n_edges_dev = 0;
+    std::vector<uint32_t> edges;       // host copy, valid iff edges_on_host
+    bool edges_on_host = true;
+    void clear_edges() { edges.clear(); n_edges_dev = 0; edges_on_host = true; }
+    const std::vector<uint32_t> &host_edges();   // downloads if needed
 
     uc_stats stats{};
 
@@ -143,6 +150,8 @@ struct Engine {
     void align(uint32_t qbegin, uint32_t qend);
     // E7: adjacency (sort + unique of both edge directions) on the device, greedy cover on the host
     void set_cover_device(uint32_t n, const uint32_t *h_edges, uint64_t n_edges, uint32_t *assign);
+    void set_cover_own_edges(uint32_t n, uint32_t *assign);   // the engine's own (device-resident) edge list
+    void set_cover_graph(uint32_t n, const uint32_t *h_edges, const uint32_t *dev_edges, uint64_t n_edges, uint32_t *assign);
     // E8a: (centre, member) candidate pairs of the linear-time pre-step for the resident DB, sorted by (centre, member), unique (uc_linclust.hip)
     std::vector<uint32_t> linclust_pairs();
     // kernel-level

@@ -135,6 +135,7 @@ void Comm::broadcast_dev(Engine &E, void *buf, size_t bytes, int root) {
 
 void Comm::gather_edges(Engine &E, std::vector<uint32_t> &out) {
     out.clear();
+    E.host_edges();                     // the exchange below works on the host copies
     if (world == 1 && !nccl) { out = E.edges; return; }
     if (grp) {   // threads of one process: rank 0 reads its peers' host vectors ("edges are copied D2H per GPU ... the host runs set cover once")
         grp->ptr[(size_t)rank] = &E.edges;
@@ -298,6 +299,15 @@ uint64_t cluster_step(Engine &E, Comm &C, int target_shards, uint32_t *assign) {
     uint64_t n_aln = E.n_hits;
     if (C.world > 1 || C.nccl) n_aln = exchange_hits(E, C);
     E.align(0, n);
+    if (C.world == 1 && !C.nccl) {   // one rank: the graph is built straight from the device-resident edge list
+        if (!assign && n) fail(UC_ERR_ARGS, "cluster_step: rank 0 needs an assignment buffer");
+        Timer tc;
+        const uint64_t ne = E.edges_on_host ? E.edges.size() / 2 : E.n_edges_dev;
+        E.set_cover_own_edges(n, assign);
+        E.stats.algorithmic_bytes[UC_ST_SETCOVER] += 8ull * ne + 4ull * n;
+        E.stats.stage_seconds[UC_ST_SETCOVER] += tc.seconds();
+        return n_aln;
+    }
     std::vector<uint32_t> all;
     Timer te;
     C.gather_edges(E, all);

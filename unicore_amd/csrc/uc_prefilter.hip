@@ -1191,7 +1191,7 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
     hit_off.assign((size_t)n + 1, 0);
     n_hits = 0;
     alns_valid = false;
-    edges.clear();
+    clear_edges();
 
     if (n > (1u << 24)) fail(UC_ERR_GENERIC, "prefilter: %u sequences exceed the 2^24 limit of the hit keys", n);
     // counters: [0] similar k-mers, [1] kept candidates, [2] ungapped overlap residues, [3] run cursor,
@@ -1688,7 +1688,7 @@ uint64_t Engine::import_hits_dev(uint64_t n_in, const uint32_t *dq, const uint32
     hit_off.assign((size_t)n + 1, 0);
     n_hits = 0;
     alns_valid = false;
-    edges.clear();
+    clear_edges();
     if (!n_in) return 0;
     Timer tm;
     timed_ms_begin();
