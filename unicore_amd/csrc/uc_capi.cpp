@@ -458,7 +458,12 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
                 E.upload_db();
                 phase("upload", rr);
                 const uint32_t m = E.hdb.n;
-                if (rd < 0) {   // E8a: candidate pairs (centre, member) from shared minimum-hash k-mers, the centre is the query
+                if (rd < 0 && W == 1) {   // E8a on one rank: the candidate pairs become the hit lists without leaving the device
+                    const uint64_t np = E.linclust_hits();
+                    phase("linclust_pairs", rr);
+                    E.stats.n_prefilter_hits += np;
+                    logf(3, "unicore-cluster: pre-step: %u sequences, %llu candidate pairs (%d k-mers per sequence)\n", m, (unsigned long long)np, p.kmer_per_seq);
+                } else if (rd < 0) {   // E8a: candidate pairs (centre, member) from shared minimum-hash k-mers, the centre is the query
                     if (r == 0) pre_pairs = E.linclust_pairs();
                     phase("linclust_pairs", rr);
                     C.barrier(E);

@@ -154,6 +154,8 @@ struct Engine {
     void set_cover_graph(uint32_t n, const uint32_t *h_edges, const uint32_t *dev_edges, uint64_t n_edges, uint32_t *assign);
     // E8a: (centre, member) candidate pairs of the linear-time pre-step for the resident DB, sorted by (centre, member), unique (uc_linclust.hip)
     std::vector<uint32_t> linclust_pairs();
+    uint64_t linclust_hits();                                        // ... installed as the hit lists (query = centre); returns the pair count
+    std::vector<uint32_t> linclust_pairs_impl(uint64_t *install);
     // kernel-level
     void ungapped_batch(uint64_t n, const uint32_t *q, const uint32_t *t, const int32_t *diag, int32_t *out);
     void sw_batch(int mode, const std::vector<PairIn> &pairs, int32_t *score, int32_t *qe, int32_t *te);

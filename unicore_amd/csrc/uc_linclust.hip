@@ -105,13 +105,21 @@ __global__ void __launch_bounds__(256) lc_scatter_kernel(const uint64_t *pr, con
         if (flag[i]) { out[2ull * pos[i]] = (uint32_t)(pr[i] >> 32); out[2ull * pos[i] + 1] = (uint32_t)pr[i]; }
 }
 
+__global__ void __launch_bounds__(256) lc_hits_kernel(const uint32_t *pairs, uint64_t np, uint32_t *hq, uint32_t *ht, uint32_t *cnt) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < np; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t c = pairs[2 * i];
+        hq[i] = c; ht[i] = pairs[2 * i + 1];
+        atomicAdd(cnt + c, 1u);
+    }
+}
+
 inline dim3 lc_grid(uint64_t n) { return dim3((uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (n + 255) / 256), 16384)); }
 
 }  // namespace
 
 // (centre, member) candidate pairs of the linear-time pre-step for the database resident on this engine's device, sorted by
 // (centre, member), unique
-std::vector<uint32_t> Engine::linclust_pairs() {
+std::vector<uint32_t> Engine::linclust_pairs_impl(uint64_t *install) {
     if (!have_db) fail(UC_ERR_ARGS, "no database loaded");
     UC_HIP(hipSetDevice(device));
     const uint32_t n = hdb.n;
@@ -158,11 +166,47 @@ std::vector<uint32_t> Engine::linclust_pairs() {
     if (np == 0) return out;
     dout.reserve(2 * np);
     hipLaunchKernelGGL(lc_scatter_kernel, lc_grid(ne), dim3(256), 0, stream, pr2.p, flag.p, pos.p, (uint64_t)ne, dout.p);
+    if (install) {   // the pairs ARE the hit lists of the pre-step: query = centre, target = member, sorted by (centre, member)
+        const size_t cap = (size_t)np;
+        d_hq.reserve(cap); d_ht.reserve(cap); d_hs.reserve(cap); d_hd.reserve(cap);
+        DevBuf<uint32_t> dcnt;
+        dcnt.reserve(n);
+        UC_HIP(hipMemsetAsync(dcnt.p, 0, (size_t)n * 4, stream));
+        UC_HIP(hipMemsetAsync(d_hs.p, 0, cap * 4, stream));
+        UC_HIP(hipMemsetAsync(d_hd.p, 0, cap * 4, stream));
+        hipLaunchKernelGGL(lc_hits_kernel, lc_grid(np), dim3(256), 0, stream, dout.p, np, d_hq.p, d_ht.p, dcnt.p);
+        hit_cnt.assign(n, 0);
+        UC_HIP(hipMemcpyAsync(hit_cnt.data(), dcnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+        UC_HIP(hipStreamSynchronize(stream));
+        UC_HIP(hipGetLastError());
+        hit_off.assign((size_t)n + 1, 0);
+        for (uint32_t q = 0; q < n; q++) hit_off[q + 1] = hit_off[q] + hit_cnt[q];
+        n_hits = hit_off[n];
+        if (n_hits != np) fail(UC_ERR_GENERIC, "linclust: hit list bookkeeping mismatch");
+        alns_valid = false;
+        clear_edges();
+        *install = np;
+        return out;
+    }
     out.resize(2 * np);
     UC_HIP(hipMemcpyAsync(out.data(), dout.p, 2 * np * 4, hipMemcpyDeviceToHost, stream));
     UC_HIP(hipStreamSynchronize(stream));
     UC_HIP(hipGetLastError());
     return out;
+}
+
+std::vector<uint32_t> Engine::linclust_pairs() { return linclust_pairs_impl(nullptr); }
+
+// the same pairs installed as this engine's hit lists (one rank: nothing goes through the host); returns their number
+uint64_t Engine::linclust_hits() {
+    uint64_t np = 0;
+    hit_cnt.assign(hdb.n, 0);
+    hit_off.assign((size_t)hdb.n + 1, 0);
+    n_hits = 0;
+    alns_valid = false;
+    clear_edges();
+    (void)linclust_pairs_impl(&np);
+    return np;
 }
 
 }  // namespace uc
