@@ -443,19 +443,23 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
                 const int rd = rr - pre;             // cascade round index (-1 = the pre-step)
                 phase("(between)", rr);
                 if (W == 1 && rr == 1) full = std::move(E.hdb);      // a single rank borrows the databases instead of copying them
+                const bool dev_sub = W == 1 && rr > 0;                // ... and lays the representatives' sub-database out on the device
                 if (r == 0) {
-                    if (rr > 0) round_db = sub_db(full, cur);
+                    if (rr > 0 && !dev_sub) round_db = sub_db(full, cur);
                     round_kmer_thr = p.kmer_thr;
                     if (rd >= 0 && p.cluster_steps > 1 && !p.kmer_thr_explicit)   // sensitivity rises linearly from 1 to the target (spec UC-1 E8)
                         round_kmer_thr = kmer_thr_for(p, 1.0 + (p.sensitivity - 1.0) * rd / (p.cluster_steps - 1));
                 }
                 C.barrier(E);
                 phase("sub_db", rr);
-                if (W == 1) E.hdb = std::move(rr == 0 ? full : round_db);
-                else E.hdb = rr == 0 ? full : round_db;
+                if (!dev_sub) {
+                    if (W == 1) E.hdb = std::move(rr == 0 ? full : round_db);
+                    else E.hdb = rr == 0 ? full : round_db;
+                }
                 phase("hdb copy", rr);
                 E.p.kmer_thr = round_kmer_thr;
-                E.upload_db();
+                if (dev_sub) E.upload_sub_db(cur, full.off);
+                else E.upload_db(/*keep_raw=*/W == 1 && p.cluster_steps + pre > 1);
                 phase("upload", rr);
                 const uint32_t m = E.hdb.n;
                 if (rd < 0 && W == 1) {   // E8a on one rank: the candidate pairs become the hit lists without leaving the device

@@ -72,7 +72,8 @@ void launch_ungapped(const DeviceDb &db, uint64_t n, const uint32_t *q, const ui
 bool sw_class_for(int lq, int *G, int *R);
 // padded device layout of the sequence tracks from the raw (unpadded) ones: s3 / sa[total] with pad letter 20, lt[total + 16]
 // (16 PAD pairs in front) with the PAD pair in all padding; off = padded offsets (n + 1), roff = raw offsets (n + 1)
-void launch_db_pad(uint32_t n, const uint32_t *off, const uint32_t *len, const uint64_t *roff, const uint8_t *r3, const uint8_t *ra,
+void launch_db_pad(uint32_t n, const uint32_t *off, const uint32_t *len, const uint32_t *cur /* nullable: raw sequence id of sequence i */,
+                   const uint64_t *roff, const uint8_t *r3, const uint8_t *ra,
                    uint64_t total, uint8_t *s3, uint8_t *sa, uint16_t *lt, hipStream_t s);
 
 }  // namespace uc

@@ -71,9 +71,8 @@ double Engine::timed_ms_end() {
     return ms;
 }
 
-void Engine::upload_db() {
-    Timer tm;
-    UC_HIP(hipSetDevice(device));
+// padded device layout for the sequences of `hdb` (h_poff, h_len, buffers reserved); returns the padded size
+uint64_t Engine::plan_db_layout() {
     const uint32_t n = hdb.n;
     h_poff.assign((size_t)n + 1, 0);
     h_len.resize(n);
@@ -85,30 +84,18 @@ void Engine::upload_db() {
         if (tot >= (1ull << 32) - 64) fail(UC_ERR_ARGS, "database too large for 32-bit device offsets");
     }
     h_poff[n] = (uint32_t)tot;
-    // the raw tracks go up as they are (two contiguous copies); the padded layout - 16-byte aligned sequence starts, >= 16 pad
-    // letters behind every sequence, the interleaved letter-pair stream of the gapped kernels - is laid out on the device
-    // (building it on the host cost 55 ms of a 75 ms upload at 47 M residues)
-    const uint64_t raw = hdb.residues();
     d_s3.reserve(tot + 64);
     d_sa.reserve(tot + 64);
     d_lt.reserve(tot + 64 + 16);
     d_off.reserve((size_t)n + 1);
     d_len.reserve(std::max<size_t>(n, 1));
-    {
-        DevBuf<uint8_t> r3, ra;
-        DevBuf<uint64_t> roff;
-        r3.reserve(std::max<uint64_t>(raw, 1)); ra.reserve(std::max<uint64_t>(raw, 1)); roff.reserve((size_t)n + 1);
-        if (raw) {
-            UC_HIP(hipMemcpyAsync(r3.p, hdb.s3.data(), raw, hipMemcpyHostToDevice, stream));
-            UC_HIP(hipMemcpyAsync(ra.p, hdb.sa.data(), raw, hipMemcpyHostToDevice, stream));
-        }
-        UC_HIP(hipMemcpyAsync(roff.p, hdb.off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, stream));
-        UC_HIP(hipMemcpyAsync(d_off.p, h_poff.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, stream));
-        if (n) UC_HIP(hipMemcpyAsync(d_len.p, h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
-        launch_db_pad(n, d_off.p, d_len.p, roff.p, r3.p, ra.p, tot + 64, d_s3.p, d_sa.p, d_lt.p, stream);
-        UC_HIP(hipStreamSynchronize(stream));
-        UC_HIP(hipGetLastError());
-    }
+    UC_HIP(hipMemcpyAsync(d_off.p, h_poff.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, stream));
+    if (n) UC_HIP(hipMemcpyAsync(d_len.p, h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    return tot;
+}
+
+void Engine::finish_db_install(Timer &tm) {
+    const uint32_t n = hdb.n;
     ddb.n = n;
     ddb.s3 = d_s3.p; ddb.sa = d_sa.p; ddb.lt = d_lt.p + 16; ddb.off = d_off.p; ddb.len = d_len.p;
     ddb.S3 = d_S3.p; ddb.SA = d_SA.p;
@@ -124,6 +111,61 @@ void Engine::upload_db() {
     stats.n_residues = hdb.residues();
     stats.algorithmic_bytes[UC_ST_LOAD] += 2 * hdb.residues() + 12ull * n;
     stats.stage_seconds[UC_ST_LOAD] += tm.seconds();
+}
+
+void Engine::upload_db(bool keep_raw) {
+    Timer tm;
+    UC_HIP(hipSetDevice(device));
+    const uint32_t n = hdb.n;
+    const uint64_t tot = plan_db_layout();
+    // the raw tracks go up as they are (two contiguous copies); the padded layout - 16-byte aligned sequence starts, >= 16 pad
+    // letters behind every sequence, the interleaved letter-pair stream of the gapped kernels - is laid out on the device
+    // (building it on the host cost 55 ms of a 75 ms upload at 47 M residues).  keep_raw: the raw copy stays resident, so that
+    // sub-databases (the representatives of a cascade round) can be laid out from it without the host (upload_sub_db)
+    const uint64_t raw = hdb.residues();
+    DevBuf<uint8_t> l3, la;
+    DevBuf<uint64_t> loff;
+    DevBuf<uint8_t> &r3 = keep_raw ? d_raw3 : l3, &ra = keep_raw ? d_rawa : la;
+    DevBuf<uint64_t> &roff = keep_raw ? d_rawoff : loff;
+    r3.reserve(std::max<uint64_t>(raw, 1)); ra.reserve(std::max<uint64_t>(raw, 1)); roff.reserve((size_t)n + 1);
+    if (raw) {
+        UC_HIP(hipMemcpyAsync(r3.p, hdb.s3.data(), raw, hipMemcpyHostToDevice, stream));
+        UC_HIP(hipMemcpyAsync(ra.p, hdb.sa.data(), raw, hipMemcpyHostToDevice, stream));
+    }
+    UC_HIP(hipMemcpyAsync(roff.p, hdb.off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, stream));
+    launch_db_pad(n, d_off.p, d_len.p, (const uint32_t *)nullptr, roff.p, r3.p, ra.p, tot + 64, d_s3.p, d_sa.p, d_lt.p, stream);
+    UC_HIP(hipStreamSynchronize(stream));
+    UC_HIP(hipGetLastError());
+    raw_n = keep_raw ? n : 0;
+    finish_db_install(tm);
+}
+
+// the sequences `cur` (ascending ids of the database uploaded with keep_raw) become the engine's database: offsets on the
+// host (full_off = raw offsets of that database), the sequence data gathered on the device from the resident raw copy
+void Engine::upload_sub_db(const std::vector<uint32_t> &cur, const std::vector<uint64_t> &full_off) {
+    Timer tm;
+    UC_HIP(hipSetDevice(device));
+    if (!raw_n || full_off.size() != (size_t)raw_n + 1) fail(UC_ERR_GENERIC, "upload_sub_db: no resident raw database");
+    HostDb sub;
+    sub.n = (uint32_t)cur.size();
+    sub.off.resize((size_t)sub.n + 1);
+    uint64_t t = 0;
+    for (uint32_t i = 0; i < sub.n; i++) {
+        if (cur[i] >= raw_n) fail(UC_ERR_GENERIC, "upload_sub_db: sequence id out of range");
+        sub.off[i] = t;
+        t += full_off[cur[i] + 1] - full_off[cur[i]];
+    }
+    sub.off[sub.n] = t;
+    hdb = std::move(sub);                      // offsets only: nothing on the host reads the letters of a resident database
+    const uint32_t n = hdb.n;
+    const uint64_t tot = plan_db_layout();
+    DevBuf<uint32_t> dcur;
+    dcur.reserve(std::max<uint32_t>(n, 1));
+    if (n) UC_HIP(hipMemcpyAsync(dcur.p, cur.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    launch_db_pad(n, d_off.p, d_len.p, dcur.p, d_rawoff.p, d_raw3.p, d_rawa.p, tot + 64, d_s3.p, d_sa.p, d_lt.p, stream);
+    UC_HIP(hipStreamSynchronize(stream));
+    UC_HIP(hipGetLastError());
+    finish_db_install(tm);
 }
 
 void Engine::ungapped_batch(uint64_t n, const uint32_t *q, const uint32_t *t, const int32_t *diag, int32_t *out) {

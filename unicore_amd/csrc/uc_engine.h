@@ -102,6 +102,9 @@ struct Engine {
     // device DB
     DevBuf<uint8_t> d_s3, d_sa;
     DevBuf<uint16_t> d_lt;
+    DevBuf<uint8_t> d_raw3, d_rawa;    // unpadded tracks of the database uploaded with keep_raw (sub-databases are gathered from it)
+    DevBuf<uint64_t> d_rawoff;
+    uint32_t raw_n = 0;
     DevBuf<uint32_t> d_off, d_len;
     DevBuf<int8_t> d_S3, d_SA;
     DeviceDb ddb;
@@ -131,7 +134,10 @@ struct Engine {
 
     explicit Engine(const Params &pp, int dev);
     ~Engine();
-    void upload_db();
+    void upload_db(bool keep_raw = false);
+    void upload_sub_db(const std::vector<uint32_t> &cur, const std::vector<uint64_t> &full_off);   // after upload_db(true)
+    uint64_t plan_db_layout();
+    void finish_db_install(struct Timer &tm);
     // E1-E4: index targets [tbegin,tend), match queries [qbegin,qend) (default: all) against it       (uc_prefilter.hip)
     void prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin = 0, uint32_t qend = UINT32_MAX);
     bool prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend, bool count_sims, double density_limit = 0.0,

@@ -43,7 +43,7 @@ void launch_sw_pk_class(int G, int R, int mode, const SwArgs &a, uint32_t n_task
 }
 
 // ---- device layout of the database (Engine::upload_db) ----
-__global__ void __launch_bounds__(256) db_pad_kernel(uint32_t n, const uint32_t *off, const uint32_t *len, const uint64_t *roff, const uint8_t *r3,
+__global__ void __launch_bounds__(256) db_pad_kernel(uint32_t n, const uint32_t *off, const uint32_t *len, const uint32_t *cur, const uint64_t *roff, const uint8_t *r3,
                                                      const uint8_t *ra, uint64_t total, uint8_t *s3, uint8_t *sa, uint16_t *lt) {
     for (uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x; p < total + 16; p += (uint64_t)gridDim.x * 256) {
         if (p < 16) { lt[p] = (uint16_t)SW_PADPACK; continue; }     // the PAD pairs in front of the stream
@@ -58,7 +58,8 @@ __global__ void __launch_bounds__(256) db_pad_kernel(uint32_t n, const uint32_t 
             }
             const uint64_t j = q - off[lo];
             if (j < len[lo]) {
-                c3 = r3[roff[lo] + j]; ca = ra[roff[lo] + j];
+                const uint64_t src = roff[cur ? cur[lo] : lo] + j;
+                c3 = r3[src]; ca = ra[src];
                 pair = (uint16_t)(c3 | (ca << 8));
             }
         }
@@ -66,11 +67,11 @@ __global__ void __launch_bounds__(256) db_pad_kernel(uint32_t n, const uint32_t 
     }
 }
 
-void launch_db_pad(uint32_t n, const uint32_t *off, const uint32_t *len, const uint64_t *roff, const uint8_t *r3, const uint8_t *ra,
+void launch_db_pad(uint32_t n, const uint32_t *off, const uint32_t *len, const uint32_t *cur, const uint64_t *roff, const uint8_t *r3, const uint8_t *ra,
                    uint64_t total, uint8_t *s3, uint8_t *sa, uint16_t *lt, hipStream_t s) {
     const uint64_t work = total + 16;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((work + 255) / 256, 1u << 20);
-    hipLaunchKernelGGL(db_pad_kernel, dim3(blocks), dim3(256), 0, s, n, off, len, roff, r3, ra, total, s3, sa, lt);
+    hipLaunchKernelGGL(db_pad_kernel, dim3(blocks), dim3(256), 0, s, n, off, len, cur, roff, r3, ra, total, s3, sa, lt);
 }
 
 // ---- stage E3: ungapped diagonal score (MMseqs2 UngappedAlignment on the 3Di track) ----
