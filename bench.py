@@ -20,6 +20,13 @@ N > 1   : one process per GPU (torch.distributed.run).  The data path is inside 
           edges go to rank 0 for the host set cover.  torch.distributed (gloo) only carries the 128-byte RCCL id, the
           barriers and the max-over-ranks of the timing.  Total work is fixed -> "strong".
 
+          `python bench.py --gpus N` with WORLD_SIZE unset re-executes itself under torch.distributed.run with N ranks.
+also (N = 1, default config): `configs` — sub-records measured in the same run: c3 (BASELINE configs[2] = north_star's quoted
+          1-GPU target size, 500 proteomes: ONE timed pass with its own roofline block and CPU baseline sample) and c5-mini
+          (the ProstT5 encoder's MFMA fraction on one synthetic proteome); `value_one_shot_processes` — what an unmodified
+          Unicore experiences: the two spawns of cluster.rs:45-64 (`foldseek cluster` + `foldseek createtsv` through the shim),
+          wall from process start to clust.tsv.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -139,6 +146,58 @@ def cpu_baseline(prefix, opts, n_seqs, target_seconds=20.0):
     return out
 
 
+def one_shot_processes(prefix, workdir, options, aln_plain, aln_default):
+    """What an unmodified Unicore experiences (cluster.rs:45-64): a NEW `foldseek cluster` process and a NEW `foldseek createtsv`
+    process per call, through the argv-compatible shim with the reference's token order; wall from the first spawn to clust.tsv
+    on disk (process start, HIP initialisation, code-object load and first allocations included), page cache warm, best of 2."""
+    shim = os.path.join(ROOT, "bin", "foldseek")
+    outp = os.path.join(workdir, "oneshot_clust")
+    tmp = os.path.join(workdir, "tmp")
+    res = {"what": "bin/foldseek cluster + bin/foldseek createtsv as two fresh processes (cluster.rs:45-64 argv), first spawn -> clust.tsv; best of 2", "unit": "alignments/s"}
+    T = str(os.cpu_count() or 1)
+    for tag, extra, aln in (("plain_step", ["--single-step-clustering"], aln_plain), ("default_workflow", [], aln_default)):
+        walls = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            subprocess.check_call([shim, "cluster", "--threads", T, "-v", "1", prefix, outp + "_cluster", tmp] + options.split() + extra, stdout=subprocess.DEVNULL)
+            subprocess.check_call([shim, "createtsv", "--threads", T, "-v", "1", prefix, prefix, outp + "_cluster", outp + ".tsv"], stdout=subprocess.DEVNULL)
+            walls.append(time.perf_counter() - t0)
+        res[tag] = {"wall_s_best": min(walls), "wall_s_all": walls, "alignments": aln, "value": aln / min(walls)}
+    subprocess.call([shim, "rmdb", outp + "_cluster", "-v", "1"], stdout=subprocess.DEVNULL)
+    return res
+
+
+def c5_mini(args):
+    """sub-record of the default line: the ProstT5 AA -> 3Di encoder (BASELINE configs[4]'s MFMA stage) on ONE synthetic proteome —
+    full ProtT5-XL geometry, all 24 blocks, seeded random-init f16 weights — for its fraction of the dense f16 MFMA peak."""
+    import unicore_amd as U
+    from oracle import prostt5_ref as R
+    seed = 0x5EED0005
+    workdir = os.path.join(args.workdir, "p1_f6000_s1_%x" % seed)
+    prefix = gen_db(workdir, 1, 6000, 1.0, seed)
+    aa = [e.decode() for e in open(prefix, "rb").read().split(b"\n\0")[:-1]]
+    gguf = os.path.join(args.workdir, "prostt5_synth_24.gguf")
+    if not os.path.exists(gguf):
+        R.write_synthetic_gguf(gguf + ".tmp", R.default_config(), seed=seed)
+        os.replace(gguf + ".tmp", gguf)
+    enc = U.T5Encoder(gguf)
+    enc.encode(aa[:64])                                   # warm-up: code objects, first allocations
+    s0 = enc.stats()
+    t0 = time.perf_counter()
+    enc.encode(aa)
+    dt = time.perf_counter() - t0
+    s1 = enc.stats()
+    enc.close()
+    fl, ms = s1["flops"] - s0["flops"], s1["gpu_ms"] - s0["gpu_ms"]
+    tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    res = sum(len(x) for x in aa)
+    return {"config": {"workload": "BASELINE configs[4]'s encoder stage on 1 synthetic proteome: %d sequences, %d residues; ProtT5-XL geometry, 24 blocks, seeded random-init f16 weights" % (len(aa), res)},
+            "encoder_residues_per_s": res / dt, "wall_s": dt,
+            "roofline": {"bound": "mfma", "kernel": "t5_gemm256_kernel + t5_attention_kernel (f16 v_mfma_f32_16x16x32_f16, fp32 accumulate)", "achieved": tf, "peak": 2500.0,
+                         "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None, "algorithmic_flops": fl, "gpu_ms": ms,
+                         "note": "algorithmic FLOPs = linear layers (2 x tokens x weights) + attention (4 L^2 x 4096 per sequence and block) / HIP-event time of the encoder passes"}}
+
+
 def bench_c5(args):
     """BASELINE configs[4]: createdb's ProstT5 AA -> 3Di encoder (hand-written f16 MFMA kernels) fused ahead of the cluster
     path, no disk round trip: AA residues -> uc_t5_encode -> 3Di codes -> uc_engine_set_db -> uc_engine_cluster_step.
@@ -230,6 +289,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the disk-to-TSV and default-workflow legs")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-sub-records", action="store_true", help="skip the c3 / c5-mini sub-records and the one-shot-process leg of the default line")
     args = ap.parse_args()
     if args.config == "c5":
         return bench_c5(args)
@@ -246,64 +306,78 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (one process per GPU, rendezvous on 127.0.0.1)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
     comm = None
+    dist = None
+    rccl_ranks = 0
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("gloo")                     # control plane only: RCCL id, barriers, max of the timing
         uid = [U.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         comm = U.Comm(uid[0], rank, world, device=local_rank)   # collective: ncclCommInitRank inside the library
+        rccl_ranks = comm.info()[0]                          # what RCCL itself says (ncclCommCount)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    workdir = os.path.join(args.workdir, "p%d_f%d_s%g_%x" % (proteomes, families, len_scale, seed))
-    if rank == 0:
-        gen_db(workdir, proteomes, families, len_scale, seed)
-    barrier()
-    prefix = os.path.join(workdir, "db")
-    lens = read_lens(prefix)
-    n = len(lens)
-
     threads = max(1, (os.cpu_count() or 1) // world)
-    eng = U.Engine(options, threads=threads, verbosity=1, device=local_rank)
-    eng.load_db(prefix)                      # H2D upload: outside the timed region (inputs resident in HBM)
 
-    def step():
-        return eng.cluster_step(comm, args.target_shards)
-
-    assign = None
-    for _ in range(args.warmup):
-        assign, _ = step()
-    eng.reset_stats()
-    barrier()
-    t0 = time.perf_counter()
-    n_aln = 0
-    for _ in range(args.steps):
-        assign, a = step()
-        n_aln += a
-    barrier()
-    dt = time.perf_counter() - t0
-    st = eng.stats()
-    if world > 1:
-        v = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(v, op=dist.ReduceOp.MAX)
-        dt = float(v.item())
-        c = torch.tensor([n_aln, st["exchange_bytes"]], dtype=torch.int64)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        n_aln, xbytes = int(c[0].item()), int(c[1].item())
-    else:
+    def run_config(proteomes, families, len_scale, seed, options, label, custom, steps, warmup):
+        """K timed passes of one workload; returns (the line as a dict on rank 0 / None elsewhere, DB prefix, n, workdir)"""
+        workdir = os.path.join(args.workdir, "p%d_f%d_s%g_%x" % (proteomes, families, len_scale, seed))
+        if rank == 0:
+            gen_db(workdir, proteomes, families, len_scale, seed)
+        barrier()
+        prefix = os.path.join(workdir, "db")
+        lens = read_lens(prefix)
+        n = len(lens)
+        eng = U.Engine(options, threads=threads, verbosity=1, device=local_rank)
+        eng.load_db(prefix)                      # H2D upload: outside the timed region (inputs resident in HBM)
+        assign = None
+        for _ in range(warmup):
+            assign, _ = eng.cluster_step(comm, args.target_shards)
+        eng.reset_stats()
+        barrier()
+        t0 = time.perf_counter()
+        n_aln = 0
+        for _ in range(steps):
+            assign, a = eng.cluster_step(comm, args.target_shards)
+            n_aln += a
+        barrier()
+        dt = time.perf_counter() - t0
+        st = eng.stats()
+        eng.close()
         xbytes = 0
-
-    if rank == 0:
-        steps = max(args.steps, 1)
+        if world > 1:
+            v = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            dt = float(v.item())
+            c = torch.tensor([n_aln, st["exchange_bytes"]], dtype=torch.int64)
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            n_aln, xbytes = int(c[0].item()), int(c[1].item())
+            ph = torch.tensor(st["phase_seconds"], dtype=torch.float64)
+            dist.all_reduce(ph, op=dist.ReduceOp.MAX)
+            st["phase_seconds"] = ph.tolist()
+        if rank != 0:
+            return None, prefix, n, workdir
+        steps_ = max(steps, 1)
         sw_s = st["sw_kernel_ms"] / 1e3
         pre_s = st["prefilter_kernel_ms"] / 1e3
         achieved = st["sw_algorithmic_bytes"] / sw_s / 1e9 if sw_s > 0 else 0.0
@@ -313,59 +387,71 @@ def main():
         pre_bytes = ab["index"] + ab["kmer"] + ab["ungapped"] + ab["select"]
         all_bytes = pre_bytes + ab["gapped"] + ab["setcover"]
         swt, pft = pmc_json("sw_traffic.json"), pmc_json("prefilter_traffic.json")
+        is_c2 = not custom and label == CONFIGS["c2"][5]                       # the PMC files were collected on configs[1]
         n_streams = int(os.environ.get("UC_STREAMS", "8"))
         Q, T = (world // (args.target_shards or world), args.target_shards or world) if world > 1 else (1, 1)
         out = {
             "metric": "3Di alignments/sec (cluster path)",
-            "value": n_aln / dt, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "value": n_aln / dt, "unit": "alignments/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * dt / steps_, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
             "config": {"workload": "%s: %d synthetic proteomes, %d seqs, %d residues, options '%s', plain all-vs-all step (--single-step-clustering "
                                    "semantics), gen_synth seed %#x, synthetic stand-in 3Di matrix" % (label if not custom else "custom size", proteomes, n, int(lens.sum()), options, seed),
-                       "alignments_per_step": n_aln // steps, "clusters": int((assign == np.arange(n)).sum()) if assign is not None else None,
-                       "parallelism": ("%d query groups x %d target shards, RCCL all-gather of the hit lists from the C library (uc_comm_*), device merge, "
-                                       "pair-ownership partition of the gapped stage, edges to rank 0" % (Q, T)) if world > 1 else "single GPU"},
+                       "alignments_per_step": n_aln // steps_, "clusters": int((assign == np.arange(n)).sum()) if assign is not None else None,
+                       "parallelism": ("%d query groups x %d target shards; exchange 1: shard lists to the query's home rank (ragged all-to-all, grouped ncclSend/ncclRecv "
+                                       "from the C library), merge + top-M of 1/N of the queries per rank; exchange 2: surviving pairs to their owner rank; "
+                                       "edges to rank 0" % (Q, T)) if world > 1 else "single GPU"},
+            "rccl_ranks": rccl_ranks,
             "value_definition": "DB resident in HBM at the start of the timed region; see value_disk_to_tsv for SURVEY.md 8(d)'s disk -> clust.tsv wall",
             # dominant kernel: the gapped SW (all classes and passes)
             "roofline": {"bound": "hbm", "kernel": "sw_pk_kernel + sw_group_kernel (gapped 3Di+AA SW, all classes and passes)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": ((swt["fetch_size_kib"] + swt["write_size_kib"]) * 1024.0 / swt["sw_launches"]) if swt else None,
+                         "traffic": ((swt["fetch_size_kib"] + swt["write_size_kib"]) * 1024.0 / swt["sw_launches"]) if (swt and is_c2) else None,
                          "algorithmic_bytes_per_launch": st["sw_algorithmic_bytes"] / max(st["sw_kernel_launches"], 1),
+                         "algorithmic_bytes_per_step": st["sw_algorithmic_bytes"] / steps_, "kernel_ms_per_step": st["sw_kernel_ms"] / steps_,
                          "avg_launch_ms": st["sw_kernel_ms"] / max(st["sw_kernel_launches"], 1),
                          "launches": st["sw_kernel_launches"], "streams": n_streams,
                          "launch_overlap": ("the length classes of a pass run concurrently on %d HIP streams; avg_launch_ms = HIP-event time of the fork/join regions on the engine "
                                             "stream / launches.  With UC_STREAMS=1 the launches are serialized and the per-kernel durations of a rocprofv3 trace add up to that event "
-                                            "time (profiles/r3*_serial_*)" % n_streams),
-                         "note": "integer-VALU-bound by design (SURVEY.md 8d): the meaningful fraction is valu_frac",
+                                            "time (profiles/*_serial_*)" % n_streams),
+                         "note": "integer-VALU-bound by design (SURVEY.md 8d): the meaningful fraction is valu_frac = cells_run x valu_ops_per_cell / (kernel s x valu_peak_lane_ops)",
+                         "cells_run_per_step": cells_run / steps_, "cells_algorithmic_per_step": cells_alg / steps_,
                          "valu_gcups": cells_run / sw_s / 1e9 if sw_s > 0 else 0.0,
                          "valu_gcups_algorithmic": cells_alg / sw_s / 1e9 if sw_s > 0 else 0.0,
                          "valu_peak_lane_ops": VALU_PEAK_LANE_OPS, "valu_ops_per_cell": VALU_OPS_PER_CELL,
                          "valu_frac": (cells_run * VALU_OPS_PER_CELL / sw_s / VALU_PEAK_LANE_OPS) if sw_s > 0 else 0.0},
             # the HBM-bound stages E1-E4 (index, similar-k-mer match + double-hit filter, ungapped, top-M)
             "roofline_prefilter": {"bound": "hbm", "kernels": "kmer_extract, sim_runs, filter, compact, diag_select, ungapped, select/rank/scatter + rocPRIM sorts",
-                                   "algorithmic_bytes_per_step": pre_bytes / steps, "kernel_ms_per_step": 1e3 * pre_s / steps,
+                                   "algorithmic_bytes_per_step": pre_bytes / steps_, "kernel_ms_per_step": 1e3 * pre_s / steps_,
                                    "achieved": pre_bytes / pre_s / 1e9 if pre_s > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": (pre_bytes / pre_s / 1e9 / HBM_PEAK_GBS) if pre_s > 0 else 0.0,
                                    "frac_of_measured_copy_bw": (pre_bytes / pre_s / 1e9 / HBM_COPY_GBS) if pre_s > 0 else 0.0,
-                                   "traffic_per_step": pft["bytes_per_step"] if pft else None,
-                                   "traffic_source": pft["source"] if pft else None},
-            "roofline_end_to_end": {"bound": "hbm", "algorithmic_bytes_per_step": all_bytes / steps,
+                                   "formula": "8 B x n_sim_kmers + 6 B x n_kmer_hits + 8 B x n_candidates (kmer) + 6 B x n_index_entries + 8 B x 20^6 (index) + ungapped + 16 B x "
+                                              "n_candidates (select), all from counts_rank0_per_step / algorithmic_bytes_per_step of this line, divided by kernel_ms_per_step",
+                                   "traffic_per_step": pft["bytes_per_step"] if (pft and is_c2) else None,
+                                   "traffic_source": pft["source"] if (pft and is_c2) else None},
+            "roofline_end_to_end": {"bound": "hbm", "algorithmic_bytes_per_step": all_bytes / steps_,
                                     "bytes_per_alignment": all_bytes / max(n_aln, 1) if world == 1 else None,
                                     "achieved": all_bytes / dt / 1e9, "peak": HBM_COPY_GBS, "unit": "GB/s", "frac": all_bytes / dt / 1e9 / HBM_COPY_GBS,
                                     "note": "SURVEY.md 8(d): sum of per-stage algorithmic bytes / (wall x 6.29 TB/s); rank 0's bytes when N > 1"},
-            "algorithmic_bytes_per_step": {k: v / steps for k, v in ab.items()},
-            "stages_s_per_step": {k: v / steps for k, v in zip(U.STAGES, st["stage_seconds"])},
-            "prefilter_kernel_ms_per_step": st["prefilter_kernel_ms"] / steps,
-            "sw_kernel_ms_per_step": st["sw_kernel_ms"] / steps,
-            "sw_dp_runs_per_step": st["n_sw_runs"] // steps,
-            "exchange_rank0_s_per_step": st["exchange_seconds"] / steps, "exchange_bytes_per_step_all_ranks": xbytes // steps,
-            "counts_rank0_per_step": {k: st[k] // steps for k in ("n_sim_kmers", "n_kmer_hits", "n_filtered_hits", "n_candidates", "n_prefilter_hits",
-                                                                  "n_gapped_alignments", "n_start_alignments", "n_pk_reruns", "n_edges")},
+            "algorithmic_bytes_per_step": {k: v / steps_ for k, v in ab.items()},
+            "stages_s_per_step": {k: v / steps_ for k, v in zip(U.STAGES, st["stage_seconds"])},
+            "prefilter_kernel_ms_per_step": st["prefilter_kernel_ms"] / steps_,
+            "sw_kernel_ms_per_step": st["sw_kernel_ms"] / steps_,
+            "sw_dp_runs_per_step": st["n_sw_runs"] // steps_,
+            "exchange_rank0_s_per_step": st["exchange_seconds"] / steps_, "exchange_bytes_per_step_all_ranks": xbytes // steps_,
+            "counts_rank0_per_step": {k: st[k] // steps_ for k in ("n_index_entries", "n_sim_kmers", "n_kmer_hits", "n_filtered_hits", "n_candidates", "n_prefilter_hits",
+                                                                   "n_gapped_alignments", "n_start_alignments", "n_pk_reruns", "n_edges")},
         }
+        if world > 1:
+            out["phases_max_over_ranks_s_per_step"] = {k: v / steps_ for k, v in zip(U.PHASES, st["phase_seconds"])}
+        return out, prefix, n, workdir
+
+    out, prefix, n, workdir = run_config(proteomes, families, len_scale, seed, options, label, custom, args.steps, args.warmup)
+
+    if rank == 0:
         if world == 1 and not args.no_extra_legs:
             # uc_cluster + uc_createtsv, DB on disk (page cache warm) -> clust.tsv
-            eng.close()
-            eng = None
             outp = os.path.join(workdir, "bench_clust")
             walls = []
             for _ in range(3):
@@ -388,11 +474,29 @@ def main():
                                        "wall_s_best": min(walls), "alignments": s2["n_gapped_alignments"], "clusters": s2["n_clusters"],
                                        "value": s2["n_gapped_alignments"] / min(walls), "unit": "alignments/s"}
             U.rmdb(outp + "_cluster")
+            if not args.no_sub_records:
+                out["value_one_shot_processes"] = one_shot_processes(prefix, workdir, options, s1["n_gapped_alignments"], s2["n_gapped_alignments"])
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(prefix, options, n, args.cpu_seconds)
             best = max(cb, key=lambda d: d["value"])
             out["cpu_baseline"] = best                       # the faster CPU leg is THE baseline ...
             out["cpu_baselines"] = cb                        # ... both are reported
+    if world == 1 and args.config == "c2" and not custom and not args.no_sub_records:
+        U.lib().uc_release_scratch()
+        subs = {}
+        # north_star's quoted 1-GPU target size (BASELINE configs[2] on one GPU): ONE timed pass, its own roofline and CPU sample
+        p3 = CONFIGS["c3"]
+        o3, prefix3, n3, _ = run_config(p3[0], p3[1], p3[2], p3[3], p3[4], p3[5], False, 1, 0)
+        for k in ("metric", "unit", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "value_definition", "rccl_ranks"):
+            o3.pop(k, None)
+        if not args.no_cpu_baseline:
+            cb3 = cpu_baseline(prefix3, p3[4], n3, min(args.cpu_seconds, 12.0))
+            o3["cpu_baseline"] = max(cb3, key=lambda d: d["value"])
+        subs["c3"] = o3
+        U.lib().uc_release_scratch()
+        subs["c5-mini"] = c5_mini(args)
+        out["configs"] = subs
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -47,6 +47,7 @@ typedef struct uc_opts {
 enum { UC_ST_LOAD = 0, UC_ST_INDEX = 1, UC_ST_KMER = 2, UC_ST_UNGAPPED = 3, UC_ST_SELECT = 4,
        UC_ST_GAPPED = 5, UC_ST_SETCOVER = 6, UC_ST_OUTPUT = 7 };
 
+#define UC_NPHASE 8
 typedef struct uc_stats {
     uint64_t n_seqs, n_residues;
     uint64_t n_index_entries, n_sim_kmers, n_kmer_hits, n_candidates, n_prefilter_hits;
@@ -70,6 +71,12 @@ typedef struct uc_stats {
     double exchange_seconds;
     uint64_t exchange_bytes;
     uint32_t n_gpus, target_shards;                      /* the Q x T grid the run used: Q = n_gpus / target_shards */
+    /* N > 1 only: wall seconds of this rank per phase of the sharded pass (uc_cluster reports the slowest rank per phase):
+     * [0] prefilter of the rank's grid cell, [1] exchange 1 (shard lists to the query's home rank), [2] merge + top-M at home,
+     * [3] partition by owner + exchange 2 (surviving pairs to their owner rank), [4] install of the owned lists, [5] gapped stage,
+     * [6] edge gather to rank 0, [7] rank 0's serial tail (graph + greedy cover) */
+    double phase_seconds[UC_NPHASE];
+    uint32_t nccl_ranks, reserved0;                      /* ncclCommCount of the run's communicator (0 = no RCCL: one GPU or virtual ranks) */
 } uc_stats;
 
 /* ---- the three calls of cluster.rs ------------------------------------------------------------ */
@@ -186,6 +193,9 @@ typedef struct uc_comm uc_comm;
 int uc_comm_unique_id(uint8_t id[UC_COMM_ID_BYTES]);
 int uc_comm_create(const uint8_t id[UC_COMM_ID_BYTES], int32_t rank, int32_t world, int32_t device, uc_comm **out);
 void uc_comm_destroy(uc_comm *c);
+/* what RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): the number of ranks
+ * it was built over, this rank, its HIP device.  bench.py prints the count in its line; the N > 1 tests assert it == N. */
+int uc_comm_info(const uc_comm *c, int32_t *nccl_ranks, int32_t *nccl_rank, int32_t *device);
 /* One pass of the hot path on this rank: E1-E4 on the rank's cell of the Q x T grid (target_shards = T, 0 = one target
  * shard per GPU: the north-star layout) -> hit-list all-gather + merge + ownership -> E5/E6 on the rank's pairs -> edges
  * to rank 0 -> set cover on rank 0.  comm == NULL runs the single-GPU pass.  assign[n_seqs] is written on rank 0 only

@@ -10,6 +10,12 @@ time, createdb.rs:148-155) are absent here, so what is restated is the PUBLISHED
   * ProstT5's 3Di head (Heinzinger et al. 2023, github.com/mheinzinger/ProstT5 `CNN`): Conv(1024 -> 32, k = 7, pad 3),
     ReLU, Conv(32 -> 20, k = 7, pad 3), argmax over the 20 classes = 3Di states in alphabetical letter order;
   * input = "<AA2fold>" + residues + "</s>", the prediction of the residue positions is kept.
+  * head convention (EXT-UNVERIFIED for Foldseek; default = the published predict_3Di script run on ONE sequence): </s> takes
+    part in the encoder's attention, its final hidden state is ZEROED before the CNN, the <AA2fold> position is sliced off
+    before the CNN (zero padding on the left), the CNN runs over residues + the zeroed </s> position (whose conv1 output —
+    ReLU(bias + the taps that reach back into the last residues) — is seen by conv2), and rare residues U/Z/O/B are mapped
+    to X before tokenisation.  `eos_in_head=True` / `uzob_to_x=False` give the r2 convention (</s>'s hidden state feeds the
+    CNN, B/O/U/Z keep their own ids); the product mirrors both switches (UC_T5_EOS_IN_HEAD=1, UC_T5_KEEP_UZOB=1).
 The weights used by the tests and the benchmark are SEEDED SYNTHETIC ones written as GGUF by write_synthetic_gguf();
 a real prostt5-f16.gguf drops into the same loader (tensor names: llama.cpp's t5encoder convention, aliases in
 unicore_amd/csrc/uc_t5.cpp; the CNN head's tensor names inside Foldseek's file are EXT-UNVERIFIED).
@@ -122,6 +128,16 @@ def read_gguf(path):
     return kv, out
 
 
+# Mean logit per 3Di state of the full-size synthetic model (default_config(), seed 0x5EED0005, default head convention) over
+# 8 synthetic proteins (tools/t5_state_hist.py --calibrate).  write_synthetic_gguf() subtracts it from the head's output bias for
+# exactly that model, which makes the 20 predicted states about equally frequent (state entropy 2.5 -> 4.3 bits, a state repeats
+# its predecessor 5 % of the time instead of 29 %): uncalibrated, one state takes 47 % of all residues and the cluster stage of
+# the chained benchmark (BASELINE configs[4]) degenerates into an everything-hits-everything k-mer corner case (5 proteomes:
+# 7.7 s of clustering against 0.03 s for a database of that size with protein-like 3Di strings).
+FULL_MODEL_HEAD_CALIBRATION = (-1.5924, 0.2299, -1.1837, -0.6596, -2.658, 2.8708, 0.4811, 1.4601, 0.1189, -0.1402, -1.0279, -0.5418, 1.2743, 2.0177,
+                               -0.3996, -0.6502, -0.1468, -1.4117, -0.7238, 1.6416)
+
+
 def write_synthetic_gguf(path, cfg, seed=0x5EED0005, f16=True, with_vocab=True, resid_scale=0.15):
     """Seeded random-init weights of the given geometry in llama.cpp's t5encoder naming (+ cnn.* for the 3Di head).
     Scales keep activations O(1) through the stack; the two projections that write into the residual stream (attn_o,
@@ -150,6 +166,9 @@ def write_synthetic_gguf(path, cfg, seed=0x5EED0005, f16=True, with_vocab=True, 
                 ("cnn.conv1.bias", (0.1 * rng.standard_normal(cfg["cnn_hidden"])).astype(np.float32)),
                 ("cnn.conv2.weight", (rng.standard_normal((cfg["n_out"], cfg["cnn_hidden"], cfg["cnn_kernel"])) / math.sqrt(cfg["cnn_hidden"])).astype(np.float32)),
                 ("cnn.conv2.bias", (0.1 * rng.standard_normal(cfg["n_out"])).astype(np.float32))]
+    if seed == 0x5EED0005 and f16 and all(cfg[k] == v for k, v in default_config().items() if k in cfg):
+        name, b2 = tensors[-1]
+        tensors[-1] = (name, (b2 - np.asarray(FULL_MODEL_HEAD_CALIBRATION, np.float32)).astype(np.float32))
     a = "t5encoder"
     kv = {"general.architecture": a, a + ".embedding_length": D, a + ".feed_forward_length": F, a + ".block_count": cfg["n_layers"],
           a + ".attention.head_count": cfg["n_heads"], a + ".attention.key_length": cfg["d_kv"], a + ".attention.relative_buckets_count": cfg["rel_buckets"],
@@ -163,9 +182,12 @@ def write_synthetic_gguf(path, cfg, seed=0x5EED0005, f16=True, with_vocab=True, 
 
 
 # ---------------------------------------------------------------------------------------------- the fp32 restatement
-def tokenize(seq, cfg):
+def tokenize(seq, cfg, uzob_to_x=True):
     ids = {c: 3 + i for i, c in enumerate(AA_ORDER)}
     x = ids["X"]
+    if uzob_to_x:
+        for c in "UZOB":
+            ids[c] = x
     return [cfg["vocab"] - 1 if cfg.get("prefix_token") is None else cfg["prefix_token"]] + [ids.get(c.upper(), x) for c in seq] + [cfg["eos_token"]]
 
 
@@ -182,12 +204,19 @@ def relative_position_bucket(rel, num_buckets, max_distance):
     return ret + torch.where(is_small, n, large)
 
 
-def forward(weights, cfg, seq, dtype=None, run_layers=None, part=3):
+def prepare(weights, dtype=None):
+    """numpy weights -> torch tensors of the compute dtype, once (forward() accepts either; a 24-block model is 4.8 GB in fp32)"""
+    import torch
+    dt = dtype or torch.float32
+    return {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.array(v, dtype=np.float32))).to(dt) for k, v in weights.items()}
+
+
+def forward(weights, cfg, seq, dtype=None, run_layers=None, part=3, eos_in_head=False, uzob_to_x=True):
     """fp32 (or `dtype`) forward of one sequence -> (logits [L, n_out] float32 numpy, codes uint8 [L])"""
     import torch
     dt = dtype or torch.float32
-    W = {k: torch.from_numpy(np.array(v, dtype=np.float32)).to(dt) for k, v in weights.items()}
-    tok = torch.tensor(tokenize(seq, cfg), dtype=torch.long)
+    W = prepare(weights, dt)
+    tok = torch.tensor(tokenize(seq, cfg, uzob_to_x), dtype=torch.long)
     L = len(tok)
     H, dk = cfg["n_heads"], cfg["d_kv"]
     h = W["token_embd.weight"][tok]
@@ -210,6 +239,9 @@ def forward(weights, cfg, seq, dtype=None, run_layers=None, part=3):
         if part & 2:
             h = h + torch.relu(x @ W[b + "ffn_up.weight"].T) @ W[b + "ffn_down.weight"].T
     x = rms(h, W["enc.output_norm.weight"])[1:]               # ProstT5 predict_3Di: the <AA2fold> prefix is sliced off BEFORE the CNN
+    if not eos_in_head:
+        x = x.clone()
+        x[-1] = 0                                              # ... and the </s> embedding is masked to zero (its position stays)
     pad = cfg["cnn_kernel"] // 2
     y = torch.nn.functional.conv1d(x.T[None], W["cnn.conv1.weight"], W["cnn.conv1.bias"], padding=pad)
     y = torch.nn.functional.conv1d(torch.relu(y), W["cnn.conv2.weight"], W["cnn.conv2.bias"], padding=pad)[0].T     # [L - 1, n_out]: residues + </s>

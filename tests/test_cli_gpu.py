@@ -139,7 +139,8 @@ def test_uc_cluster_virtual_gpus_give_identical_tsv(synth_db, workflow, tmp_path
 
 
 def test_uc_cluster_virtual_gpus_shard_by_shard_exchange(synth_db, tmp_path):
-    """unions beyond UC_EXCHANGE_LIMIT records are merged shard by shard (one broadcast per rank): same result"""
+    """a home rank that would receive more than UC_EXCHANGE_LIMIT records at once works its query range off in several rounds
+    (sub-ranges of the home ranges, merged round by round): same result"""
     ref, _ = _tsv(synth_db, tmp_path, "g1", "-c 0.8 --single-step-clustering", 1)
     got, _ = _tsv(synth_db, tmp_path, "g3", "-c 0.8 --single-step-clustering", 3, env={"UC_VIRTUAL_GPUS": "1", "UC_EXCHANGE_LIMIT": "10"})
     assert got == ref
@@ -180,8 +181,9 @@ def test_shim_uses_every_rank_it_is_given(synth_db, tmp_path):
 
 def test_cluster_step_and_one_rank_rccl_communicator(synth_db):
     """uc_engine_cluster_step: (a) comm = NULL equals the staged calls; (b) with a 1-rank RCCL communicator the pass goes
-    through the very RCCL calls of an N-rank run (ncclCommInitRank, ncclAllGather of sizes and of the padded hit tensors,
-    the grouped edge gather) and still reproduces it."""
+    through the RCCL entry points of an N-rank run (ncclCommInitRank, ncclAllGather of the count matrices, the grouped
+    point-to-point exchanges — empty with one rank: its own slices are device copies — and the edge gather) and still
+    reproduces it; RCCL itself reports the communicator's rank count."""
     import unicore_amd as U
     e = U.Engine("-c 0.8", threads=4)
     e.load_db(synth_db)
@@ -195,7 +197,8 @@ def test_cluster_step_and_one_rank_rccl_communicator(synth_db):
     a1, k1 = e.cluster_step(comm, target_shards=0)
     assert np.array_equal(a1, ref) and k1 == n_ref
     st = e.stats()
-    assert st["exchange_bytes"] > 0 and st["exchange_seconds"] > 0
+    assert st["exchange_seconds"] > 0 and st["exchange_bytes"] == 0          # bytes received from PEERS: none with one rank
+    assert comm.info()[:2] == (1, 0)
     comm.close()
     e.close()
     U.lib().uc_release_scratch()

@@ -127,3 +127,84 @@ def test_config_at_size(name, O, tmp_path_factory):
     assert len(rows) == n and len({r[0] for r in rows}) == n_clusters
     e.close()
     U.lib().uc_release_scratch()
+
+
+def test_c5_chain_at_50_proteomes(O, tmp_path_factory):
+    """BASELINE configs[4]'s chain at 50 synthetic proteomes (158 k sequences, 47 M residues): ProstT5 AA -> 3Di encoder
+    (24 blocks, full geometry, seeded synthetic weights) -> uc_engine_set_db (no disk round trip) -> cluster step.
+    (a) the 3Di states of a 20-sequence sample equal the fp32 restatement's (same tolerance as tests/test_t5.py) and do not
+    depend on the batch they were encoded in; (b) hit lists and alignment records of 300 random queries equal the CPU
+    oracle's on the encoder's 3Di track; (c) the cluster TSV satisfies the consumer contract of profile.rs."""
+    import sys
+    import unicore_amd as U
+    sys.path.insert(0, os.path.join(util.ROOT, "tests", "golden"))
+    import make_t5_full_depth as F
+    from oracle import prostt5_ref as R
+    import test_t5 as T
+    d = tmp_path_factory.mktemp("c5")
+    db = util.gen_synth_db(str(d / "db"), 50, 0x5EED0005, 6000, 1.0)
+    aa = [e.decode() for e in open(db, "rb").read().split(b"\n\0")[:-1]]
+    n = len(aa)
+    enc = U.T5Encoder(F.ensure_gguf())
+    codes = enc.encode(aa)
+    assert len(codes) == n and all(len(c) == len(a) for c, a in zip(codes, aa))
+    hist = np.bincount(np.concatenate(codes), minlength=20) / sum(len(c) for c in codes)
+    assert hist.max() < 0.15 and (hist > 0.01).sum() == 20          # the calibrated synthetic head predicts all 20 states
+    # (a)
+    cfg = R.default_config()
+    W = R.prepare(R.read_gguf(F.ensure_gguf())[1])
+    rng = np.random.default_rng(5)
+    sample = [int(i) for i in rng.choice(n, 20, replace=False)]
+    c2, l2 = enc.encode([aa[i] for i in sample], logits=True)
+    for k, i in enumerate(sample):
+        assert np.array_equal(c2[k], codes[i]), i                     # batching does not matter
+        rl, rc = R.forward(W, cfg, aa[i])
+        T._check(c2[k], l2[k], rl, rc, ("c5 chain", i))
+    del W
+    enc.close()
+    # the chain: codes straight into the engine
+    lut = np.full(256, 20, np.uint8)
+    for k, ch in enumerate("ACDEFGHIKLMNPQRSTVWY"):
+        lut[ord(ch)] = k
+    sa = lut[np.frombuffer("".join(aa).encode(), np.uint8)]
+    s3 = np.concatenate(codes)
+    off = np.zeros(n + 1, np.uint64)
+    off[1:] = np.cumsum([len(x) for x in aa])
+    e = U.Engine("-c 0.8", threads=16, verbosity=1)
+    e.set_db(off, s3, sa)
+    e.prefilter()
+    e.align()
+    st = e.stats()
+    assert st["n_gapped_alignments"] == e.hits_size() > 1_000_000
+    assign = e.setcover(e.edges())
+    n_clusters = int((assign == np.arange(n)).sum())
+    assert 0 < n_clusters < n
+    # (b) the oracle on the same two tracks (written as a DB with the encoder's 3Di as the _ss file)
+    names = [l.split("\t")[1] for l in open(db + ".lookup")]
+    db2 = str(d / "db_t5")
+    LET = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWYX", np.uint8)
+    util.write_db(db2, [c for c in codes], [sa[int(off[i]):int(off[i + 1])] for i in range(n)], names=names)
+    odb = O.OracleDb(db2)
+    p = util.oracle_params(O, "-c 0.8")
+    ix = O.build_index(odb, p)
+    qs = np.sort(rng.choice(n, 300, replace=False)).astype(np.uint32)
+    n_pairs, _, _, ocnt, ohits, oalns = O.simd_sample_run(odb, ix, p, qs, threads=0, records=True)
+    O.free_index(ix)
+    assert n_pairs > 3000
+    for k, q in enumerate(qs):
+        q = int(q)
+        cnt, hits = e.hits_range(q, q + 1)
+        al = e.alns_range(q, q + 1)
+        c = int(ocnt[k])
+        assert int(cnt[0]) == c, q
+        assert np.array_equal(hits["target"], ohits[k, :c]["t"]) and np.array_equal(hits["score"], ohits[k, :c]["score"]), q
+        for f in ("score", "score_rev", "corrected", "pass_evalue", "accepted"):
+            assert np.array_equal(al[f], oalns[k, :c][f]), (q, f)
+    # (c)
+    out = str(d / "clust")
+    assert U.lib().uc_write_cluster_db((out + "_cluster").encode(), n, assign.ctypes.data) == 0
+    U.createtsv(db2, out + "_cluster", out + ".tsv")
+    rows = util.tsv_invariants(out + ".tsv", names)
+    assert len(rows) == n and len({r[0] for r in rows}) == n_clusters
+    e.close()
+    U.lib().uc_release_scratch()

@@ -520,12 +520,16 @@ def test_degenerate_databases(O, tmp_path):
         db = str(tmp_path / name)
         util.write_db(db, s3, sa)
         odb = O.OracleDb(db)
-        for opts in ("-c 0.8 --single-step-clustering", "-c 0.8 --cluster-steps 2 --linclust 0"):
+        # the bare string is what Unicore passes (arg_parser.rs:238-239): pre-step + 3-step cascade, sub-databases laid out on the device
+        for opts in ("-c 0.8 --single-step-clustering", "-c 0.8 --cluster-steps 2 --linclust 0", "-c 0.8"):
             out = str(tmp_path / (name + "_c"))
             U.cluster(db, out + "_cluster", str(tmp_path / "tmp"), opts)
             U.createtsv(db, out + "_cluster", out + ".tsv")
             p = util.oracle_params(O, "-c 0.8")
-            ref = O.cluster_cascade(odb, p, O.cascade_thresholds(p, 4.0, 2 if "steps" in opts else 1), threads=2)
+            if opts == "-c 0.8":
+                ref = O.cluster_workflow(odb, p, O.cascade_thresholds(p, 4.0, 3), linclust_m=20, threads=2)
+            else:
+                ref = O.cluster_cascade(odb, p, O.cascade_thresholds(p, 4.0, 2 if "steps" in opts else 1), threads=2)
             O.write_tsv(str(tmp_path / "ref.tsv"), odb, ref["assign"])
             assert open(out + ".tsv", "rb").read() == open(str(tmp_path / "ref.tsv"), "rb").read(), (name, opts)
         U.search(db, db, str(tmp_path / (name + "_aln")), str(tmp_path / "tmp"), "-c 0.8")
@@ -534,6 +538,13 @@ def test_degenerate_databases(O, tmp_path):
         rs = O.search(odb, odb, ps, threads=2)
         O.write_m8(str(tmp_path / "ref.m8"), odb, odb, ps, rs)
         assert open(str(tmp_path / (name + ".m8")), "rb").read() == open(str(tmp_path / "ref.m8"), "rb").read(), name
+    # an empty but well-formed database: every workflow succeeds and writes an empty TSV
+    db = str(tmp_path / "empty")
+    util.write_db(db, [], [])
+    for opts in ("-c 0.8 --single-step-clustering", "-c 0.8 --cluster-steps 2 --linclust 0", "-c 0.8"):
+        st = U.cluster(db, db + "_cluster", str(tmp_path / "tmp"), opts)
+        U.createtsv(db, db + "_cluster", db + ".tsv")
+        assert st["n_clusters"] == 0 and open(db + ".tsv", "rb").read() == b"", opts
 
 
 def test_full_size_execution_variants_identical(tmp_path):
@@ -587,6 +598,40 @@ def test_bench_line_contract(tmp_path):
         for k in ("bound", "achieved", "peak", "unit", "frac"):
             assert k in d[blk], (blk, k)
     assert sum(d["algorithmic_bytes_per_step"].values()) > 0
+    # what an unmodified Unicore experiences (two spawns of cluster.rs:45-64) is in the line for a custom size too
+    assert d["value_one_shot_processes"]["plain_step"]["wall_s_best"] > 0 and d["value_one_shot_processes"]["default_workflow"]["value"] > 0
+    # every fraction can be recomputed from the counts in the same line (r2's line could not: a cumulative counter)
+    c, rp = d["counts_rank0_per_step"], d["roofline_prefilter"]
+    ab = d["algorithmic_bytes_per_step"]
+    assert ab["kmer"] == 8 * c["n_sim_kmers"] + 6 * c["n_kmer_hits"] + 8 * c["n_candidates"]
+    assert ab["index"] == 6 * c["n_index_entries"] + 8 * 20 ** 6 and ab["select"] == 16 * c["n_candidates"]
+    pre = ab["index"] + ab["kmer"] + ab["ungapped"] + ab["select"]
+    assert abs(rp["algorithmic_bytes_per_step"] - pre) < 1 and abs(rp["frac"] - pre / (rp["kernel_ms_per_step"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+    r = d["roofline"]
+    assert abs(r["frac"] - r["algorithmic_bytes_per_step"] / (r["kernel_ms_per_step"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+    assert abs(r["valu_frac"] - r["cells_run_per_step"] * r["valu_ops_per_cell"] / (r["kernel_ms_per_step"] * 1e-3) / r["valu_peak_lane_ops"]) < 1e-9
+
+
+def test_bench_line_does_not_depend_on_the_step_count(tmp_path):
+    """r2's line added 8 B x the CUMULATIVE similar-k-mer counter once per step, so roofline_prefilter.frac grew with --steps
+    (0.06 at one step, 0.15 at twenty).  Per-step algorithmic bytes, counts and everything derived from them alone must be
+    identical for --steps 1 and --steps 4."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for steps in (1, 4):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--proteomes", "3", "--families", "60", "--steps", str(steps), "--warmup", "1",
+                            "--no-cpu-baseline", "--no-extra-legs", "--workdir", str(tmp_path)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+    a, b = res
+    assert a["algorithmic_bytes_per_step"] == b["algorithmic_bytes_per_step"]
+    assert a["counts_rank0_per_step"] == b["counts_rank0_per_step"]
+    for blk, key in (("roofline_prefilter", "algorithmic_bytes_per_step"), ("roofline_end_to_end", "algorithmic_bytes_per_step"), ("roofline_end_to_end", "bytes_per_alignment"),
+                     ("roofline", "algorithmic_bytes_per_step"), ("roofline", "cells_run_per_step"), ("roofline", "cells_algorithmic_per_step")):
+        assert a[blk][key] == b[blk][key], (blk, key)
 
 
 def test_traceback_bytes_in_several_batches(O, small):

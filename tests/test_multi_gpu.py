@@ -1,0 +1,121 @@
+"""N > 1 on DISTINCT devices through real RCCL (the call that must use them: cluster.rs:45-49).  These tests
+enable themselves on a box with >= 2 visible GPUs — the single-GPU test box skips them, the virtual-rank tests of
+test_cli_gpu.py cover the same code minus RCCL there — so that the first time an 8-GPU node runs the suite nothing can fail
+for a trivial reason: uc_cluster --gpus {2,4,8} (T = N, Q2 x T2, the multi-round exchange) against the 1-GPU TSV, RCCL's own
+rank count, a rank that dies mid-run, and `python bench.py --gpus 2` launching itself under torch.distributed.run."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+ROOT = util.ROOT
+
+
+def _ndev():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+needs2 = pytest.mark.skipif(_ndev() < 2, reason="needs >= 2 visible GPUs (real RCCL ranks); virtual ranks are covered in test_cli_gpu.py")
+
+
+@pytest.fixture(scope="module")
+def db(tmp_path_factory):
+    d = tmp_path_factory.mktemp("mgpu")
+    return util.gen_synth_db(str(d / "db"), 8, 0x5EED0007, 60, 0.7)
+
+
+def _run(db, out, opts, num_gpus, env=None):
+    import unicore_amd as U
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        st = U.cluster(db, out + "_cluster", out + "_tmp", opts, threads=4, num_gpus=num_gpus)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    U.createtsv(db, out + "_cluster", out + ".tsv")
+    return open(out + ".tsv", "rb").read(), st
+
+
+@needs2
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("workflow", ["-c 0.8 --single-step-clustering", "-c 0.8"])
+def test_real_rccl_ranks_give_the_one_gpu_tsv(db, workflow, tmp_path):
+    ref, st1 = _run(db, str(tmp_path / "g1"), workflow, 1)
+    nd = _ndev()
+    cases = [(n, "") for n in (2, 4, 8) if n <= nd]
+    if nd >= 4:
+        cases.append((4, " --target-shards 2"))                     # Q2 x T2
+    for n, extra in cases:
+        for env in ({}, {"UC_EXCHANGE_LIMIT": "10"}):                # one-shot and multi-round exchange 1
+            got, st = _run(db, str(tmp_path / ("g%d" % n)), workflow + extra, n, env=env)
+            assert got == ref, (n, extra, env)
+            assert st["n_gpus"] == n and st["nccl_ranks"] == n      # what ncclCommCount reports
+            assert st["n_gapped_alignments"] == st1["n_gapped_alignments"] and st["n_clusters"] == st1["n_clusters"]
+            assert st["exchange_bytes"] > 0 and sum(st["phase_seconds"]) > 0
+
+
+@needs2
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("stage", [0, 1])
+def test_a_rank_that_dies_gives_an_error_not_a_hang_real_rccl(db, stage, tmp_path):
+    import unicore_amd as U
+    with pytest.raises(U.UcError) as ei:
+        _run(db, str(tmp_path / "dead"), "-c 0.8 --single-step-clustering", 2, env={"UC_FAIL_RANK": "1:%d" % stage})
+    assert "GPU rank 1" in str(ei.value) and "injected" in str(ei.value)
+    got, _ = _run(db, str(tmp_path / "again"), "-c 0.8 --single-step-clustering", 2)      # the process is still usable afterwards
+    ref, _ = _run(db, str(tmp_path / "g1"), "-c 0.8 --single-step-clustering", 1)
+    assert got == ref
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("stage", [0, 1])
+def test_a_rank_that_dies_gives_an_error_not_a_hang_virtual_ranks(db, stage, tmp_path):
+    """a rank that throws (engine construction, or between its prefilter and the exchange) must surface as an error
+    code of uc_cluster — the survivors leave their next barrier instead of waiting for it forever"""
+    import unicore_amd as U
+    for n in (2, 3):
+        with pytest.raises(U.UcError) as ei:
+            _run(db, str(tmp_path / "dead"), "-c 0.8 --single-step-clustering", n, env={"UC_VIRTUAL_GPUS": "1", "UC_FAIL_RANK": "1:%d" % stage})
+        assert ei.value.code == U.UC_ERR_DEVICE and "GPU rank 1" in str(ei.value) and "injected" in str(ei.value)
+
+
+def test_phase_times_and_serialized_virtual_ranks(db, tmp_path):
+    """the per-phase clock of the sharded pass (uc_stats.phase_seconds) and the emulation mode behind tools/critical_path.py:
+    with UC_VIRTUAL_SERIAL=1 the compute phases of the virtual ranks take turns on the GPU; results are unchanged"""
+    import unicore_amd as U
+    ref, _ = _run(db, str(tmp_path / "g1"), "-c 0.8 --single-step-clustering", 1)
+    got, st = _run(db, str(tmp_path / "g4"), "-c 0.8 --single-step-clustering", 4, env={"UC_VIRTUAL_GPUS": "1", "UC_VIRTUAL_SERIAL": "1"})
+    assert got == ref and st["nccl_ranks"] == 0
+    ph = dict(zip(U.PHASES, st["phase_seconds"]))
+    assert ph["prefilter"] > 0 and ph["gapped"] > 0 and ph["merge_at_home"] > 0 and ph["install_owned"] > 0
+
+
+@needs2
+@pytest.mark.timeout(900)
+def test_bench_launches_itself_for_n_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE re-executes itself under torch.distributed.run (the driver's BENCH form
+    with N > 1 must not exit with a usage error): same alignments per step as one GPU, RCCL rank count in the line"""
+    env = dict(os.environ, UC_BENCH_DIR=str(tmp_path / "bench"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--proteomes", "8", "--families", "60", "--len-scale", "0.7",
+            "--no-cpu-baseline", "--no-extra-legs", "--no-sub-records"]
+    lines = {}
+    for n in (1, 2):
+        r = subprocess.run(base + ["--gpus", str(n)], env=env, capture_output=True, text=True, timeout=800)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines[n] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert lines[2]["n_gpus"] == 2 and lines[2]["rccl_ranks"] == 2
+    assert lines[2]["config"]["alignments_per_step"] == lines[1]["config"]["alignments_per_step"]
+    assert lines[2]["config"]["clusters"] == lines[1]["config"]["clusters"]

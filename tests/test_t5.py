@@ -92,6 +92,7 @@ def _forward_numpy(w, cfg, seq):
         x = rms(h, W[b + "ffn_norm.weight"])
         h = h + np.maximum(x @ W[b + "ffn_up.weight"].T, 0) @ W[b + "ffn_down.weight"].T
     x = rms(h, W["enc.output_norm.weight"])[1:]                      # <AA2fold> off before the head
+    x[-1] = 0                                                        # </s> masked to zero, its position stays
     KW = cfg["cnn_kernel"]
 
     def conv(x, w_, b_):                                             # x [n, cin], w_ [cout, cin, k]: cross-correlation, zero padding
@@ -110,7 +111,7 @@ def _forward_numpy(w, cfg, seq):
 def test_oracle_against_a_second_independent_restatement(tmp_path):
     """the torch restatement (the checker of the GPU tests) agrees with a torch-free float64 numpy one: bucket rule, shared
     bias of block 0, un-scaled attention, pre-norm residual blocks, and the head's slicing convention (prefix off before
-    the convolutions, </s> after: ProstT5 predict_3Di)"""
+    the convolutions, </s> zeroed before and dropped after: ProstT5 predict_3Di; U/Z/O/B -> X)"""
     cfg, path = _tiny(tmp_path)
     _, w = R.read_gguf(path)
     for seq in ("M", "MKTAYIAKQRQISFVKSH", "ACDEFGHIKLMNPQRSTVWYXBZ" * 7):
@@ -218,6 +219,98 @@ def test_hip_encoder_large_batches_use_the_256_tile_gemm_with_identical_results(
         rl, rc = R.forward(w, cfg, seqs[i])
         _check(codes[i], logits[i], rl, rc, ("256 tile", len(seqs[i])))
     enc.close()
+
+
+@pytest.fixture(scope="module")
+def full_model():
+    """the full-size synthetic model file (ProtT5-XL geometry, 24 blocks; shared with bench.py --config c5 through /tmp/uc_bench)"""
+    import make_t5_full_depth as F
+    return F, F.ensure_gguf()
+
+
+@pytest.mark.gpu
+def test_hip_encoder_full_depth_24_blocks(full_model):
+    """BASELINE configs[4]'s model as bench.py times it — ProtT5-XL geometry AND all 24 blocks — against (a) the committed fp32
+    fixture tests/golden/t5_full_depth.npz (generated in the build container, no torch needed for it) and (b) the fp32 PyTorch
+    restatement run on this host for lengths 1 ... 1000 (tile edges 63 / 64 / 65 / 129, one batch, ragged).  Same tolerance as the
+    shallow tests: worst logit error <= 5e-3 of the sequence's largest logit, states equal wherever the margin allows."""
+    import unicore_amd as U
+    F, path = full_model
+    z = np.load(os.path.join(ROOT, "tests", "golden", "t5_full_depth.npz"))
+    assert list(z["seqs"]) == F.SEQS
+    enc = U.T5Encoder(path)
+    codes, logits = enc.encode(F.SEQS, logits=True)
+    for i, s in enumerate(F.SEQS):
+        assert logits[i].shape == (len(s), 20)
+        _check(codes[i], logits[i], z["logits%d" % i], z["codes%d" % i], "full-depth fixture %d" % i)
+    cfg = R.default_config()
+    _, w = R.read_gguf(path)
+    W = R.prepare(w)
+    rng = np.random.default_rng(24)
+    seqs = ["".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWY"), L)) for L in (1, 2, 63, 64, 65, 129, 257, 400, 700, 1000)]
+    codes, logits = enc.encode(seqs, logits=True)
+    worst = 0.0
+    for s, c, lg in zip(seqs, codes, logits):
+        rl, rc = R.forward(W, cfg, s)
+        _check(c, lg, rl, rc, ("24 blocks", len(s)))
+        worst = max(worst, float(np.abs(lg - rl).max() / np.abs(rl).max()))
+    print("full depth: worst relative logit error %.2e" % worst)
+    # the head-convention switches reach the product the same way they reach the oracle (EXT-UNVERIFIED table, INTEGRATION.md)
+    enc.close()
+    os.environ["UC_T5_EOS_IN_HEAD"] = "1"
+    os.environ["UC_T5_KEEP_UZOB"] = "1"
+    try:
+        enc2 = U.T5Encoder(path)
+        s = "MKTAYIAKQRUZOBQISFVKSH"
+        c2, l2 = enc2.encode([s], logits=True)
+        rl, rc = R.forward(W, cfg, s, eos_in_head=True, uzob_to_x=False)
+        _check(c2[0], l2[0], rl, rc, "r2 head convention")
+        rl1, _ = R.forward(W, cfg, s)
+        assert np.abs(rl - rl1).max() > 1e-3                     # the two conventions do differ (last residues, U/Z/O/B)
+        enc2.close()
+    finally:
+        del os.environ["UC_T5_EOS_IN_HEAD"], os.environ["UC_T5_KEEP_UZOB"]
+
+
+@pytest.mark.gpu
+def test_gguf_loader_rejects_malformed_files(tmp_path):
+    """a truncated or foreign prostt5-f16.gguf must fail with UC_ERR_IO, not crash or read out of bounds"""
+    import struct
+    import unicore_amd as U
+    cfg, path = _tiny(tmp_path)
+    good = open(path, "rb").read()
+    kv, w = R.read_gguf(path)
+
+    def expect_io(data, what):
+        bad = str(tmp_path / "bad.gguf")
+        open(bad, "wb").write(data)
+        with pytest.raises(U.UcError) as ei:
+            U.T5Encoder(bad)
+        assert ei.value.code == U.UC_ERR_IO, (what, str(ei.value))
+    expect_io(good[: len(good) // 2], "truncated")
+    expect_io(b"GGML" + good[4:], "foreign magic")
+    # alignment 0 / not a power of two
+    for al in (0, 48):
+        p2 = str(tmp_path / "al.gguf")
+        tens = [(k, np.array(v)) for k, v in w.items()]
+        R.write_gguf(p2, dict(kv, **{"general.alignment": al}), tens)
+        expect_io(open(p2, "rb").read(), "alignment %d" % al)
+    # a norm vector of the wrong length, a 1-d token embedding
+    for name, arr, what in (("enc.blk.0.attn_norm.weight", np.ones(7, np.float32), "short norm"),
+                            ("token_embd.weight", np.ones(150 * 128, np.float16), "1-d embedding"),
+                            ("cnn.conv1.bias", np.zeros(0, np.float32), "empty bias")):
+        p2 = str(tmp_path / "shape.gguf")
+        tens = [(k, arr if k == name else np.array(v)) for k, v in w.items()]
+        if arr.size == 0:
+            continue                                               # the writer cannot express a zero dim; covered by the header patch below
+        R.write_gguf(p2, kv, tens)
+        expect_io(open(p2, "rb").read(), what)
+    # a zero dimension patched into the first tensor's header
+    name = b"token_embd.weight"
+    i = good.index(name) + len(name)
+    nd = struct.unpack_from("<I", good, i)[0]
+    assert nd == 2
+    expect_io(good[: i + 4] + struct.pack("<Q", 0) + good[i + 12:], "zero dim")
 
 
 @pytest.mark.gpu

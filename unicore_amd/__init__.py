@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libunicore_cluster.so")
 
 UC_OK, UC_ERR_GENERIC, UC_ERR_ARGS, UC_ERR_IO, UC_ERR_DEVICE = 0, 1, 2, 3, 4
 NSTAGE = 8
+PHASES = ("prefilter", "exchange_lists_to_home", "merge_at_home", "exchange_pairs_to_owner", "install_owned", "gapped", "edge_gather", "rank0_serial_cover")
 STAGES = ("load", "index", "kmer", "ungapped", "select", "gapped", "setcover", "output")
 
 
@@ -31,7 +32,8 @@ class UcStats(C.Structure):
         ("sw_kernel_ms", C.c_double), ("sw_kernel_launches", C.c_uint64), ("sw_algorithmic_bytes", C.c_uint64),
         ("prefilter_kernel_ms", C.c_double), ("n_filtered_hits", C.c_uint64), ("n_sw_runs", C.c_uint64),
         ("cells_run", C.c_uint64), ("exchange_seconds", C.c_double), ("exchange_bytes", C.c_uint64),
-        ("n_gpus", C.c_uint32), ("target_shards", C.c_uint32)]
+        ("n_gpus", C.c_uint32), ("target_shards", C.c_uint32), ("phase_seconds", C.c_double * 8),
+        ("nccl_ranks", C.c_uint32), ("reserved0", C.c_uint32)]
 
     def as_dict(self):
         d = {}
@@ -52,7 +54,7 @@ ALN_DTYPE = np.dtype([(n, "<i4") for n in ("score", "score_rev", "corrected", "q
 # every symbol include/unicore_cluster.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "uc_cluster", "uc_createtsv", "uc_rmdb", "uc_search", "uc_convertalis", "uc_last_error", "uc_version", "uc_check_options",
-    "uc_option_arity", "uc_release_scratch", "uc_createdb", "uc_t5_load", "uc_t5_free", "uc_t5_encode", "uc_t5_get_stats", "uc_comm_unique_id", "uc_comm_create", "uc_comm_destroy", "uc_engine_cluster_step",
+    "uc_option_arity", "uc_release_scratch", "uc_createdb", "uc_t5_load", "uc_t5_free", "uc_t5_encode", "uc_t5_get_stats", "uc_comm_unique_id", "uc_comm_create", "uc_comm_destroy", "uc_comm_info", "uc_engine_cluster_step",
     "uc_engine_create", "uc_engine_destroy", "uc_engine_load_db", "uc_engine_set_db", "uc_engine_num_seqs",
     "uc_engine_prefilter", "uc_engine_prefilter_range", "uc_engine_hits_size", "uc_engine_hits_get", "uc_engine_hits_get_range", "uc_engine_hits_set", "uc_engine_hits_merge",
     "uc_engine_hits_export_dev", "uc_engine_hits_import_dev", "uc_engine_setcover",
@@ -93,6 +95,7 @@ def lib():
     L.uc_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     L.uc_comm_destroy.argtypes = [vp]
     L.uc_comm_destroy.restype = None
+    L.uc_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.uc_engine_cluster_step.argtypes = [vp, vp, i32, vp, C.POINTER(u64)]
     L.uc_cluster.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(UcOpts), C.POINTER(UcStats)]
     L.uc_createtsv.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(UcOpts)]
@@ -262,6 +265,12 @@ class Comm:
         self.rank, self.world = rank, world
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         _check(lib().uc_comm_create(buf, rank, world, device, C.byref(self._h)))
+
+    def info(self):
+        """(ranks, rank, device) as RCCL itself reports them (ncclCommCount / ncclCommUserRank / ncclCommCuDevice)"""
+        n, r, d = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(lib().uc_comm_info(self._h, C.byref(n), C.byref(r), C.byref(d)))
+        return n.value, r.value, d.value
 
     def close(self):
         if self._h:

@@ -1243,7 +1243,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                         UC_HIP(hipMemcpyAsync(d_edges.p, edges.data(), edges.size() * 4, hipMemcpyHostToDevice, s));
                         n_edges_dev = edges.size() / 2;
                     }
-                    d_edges.grow_preserve(2 * (n_edges_dev + ne), 2 * n_edges_dev);
+                    d_edges.grow_preserve(2 * (n_edges_dev + ne), 2 * n_edges_dev, s);
                     UC_HIP(hipMemcpyAsync(d_edges.p + 2 * n_edges_dev, d_e.p, 2 * (size_t)ne * 4, hipMemcpyDeviceToDevice, s));
                     n_edges_dev += ne;
                     edges_on_host = false;

@@ -344,6 +344,7 @@ void merge_stats(uc_stats &d, const uc_stats &s) {
     d.sw_kernel_ms = std::max(d.sw_kernel_ms, s.sw_kernel_ms);
     d.prefilter_kernel_ms = std::max(d.prefilter_kernel_ms, s.prefilter_kernel_ms);
     d.exchange_seconds = std::max(d.exchange_seconds, s.exchange_seconds);
+    for (int k = 0; k < UC_NPHASE; k++) d.phase_seconds[k] = std::max(d.phase_seconds[k], s.phase_seconds[k]);
 }
 
 // the sub-database of the current representatives (createsubdb)
@@ -407,6 +408,12 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
         read_seq_db(db, full, false);
         const double t_load = tl.seconds();
         const uint32_t n = full.n;
+        if (n == 0) {   // an empty, well-formed database: an empty cluster DB, whatever the workflow
+            write_cluster_db(out_cluster_db, full.keys, nullptr, 0);
+            logf(3, "unicore-cluster: empty database -> %s\n", out_cluster_db);
+            if (stats_out) { *stats_out = uc_stats(); stats_out->n_gpus = (uint32_t)W; stats_out->target_shards = (uint32_t)gT; stats_out->stage_seconds[UC_ST_LOAD] = t_load; }
+            return;
+        }
         const int pre = p.linclust ? 1 : 0;     // E8a: one linear-time pre-clustering round in front of the cascade rounds
         logf(3, "unicore-cluster: %u sequences, %llu residues, %d GPU(s)%s [%d query group(s) x %d target shard(s)], %s%d clustering step(s)\n", n,
              (unsigned long long)full.residues(), W, virtual_gpus ? " (virtual: several ranks per device)" : "", gQ, gT,
@@ -419,20 +426,40 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
         std::vector<uint32_t> pre_pairs;       // candidate pairs of the pre-step
         int round_kmer_thr = p.kmer_thr;
         LocalGroup grp(W);
+        if (virtual_gpus && getenv("UC_VIRTUAL_SERIAL")) grp.serialize = true;   // emulation: one rank's compute phase at a time on the shared GPU
         std::vector<std::unique_ptr<Comm>> comms;
         for (int r = 0; r < W; r++) {
             comms.emplace_back(new Comm);
             comms.back()->rank = r; comms.back()->world = W; comms.back()->grp = W > 1 ? &grp : nullptr;
         }
-        uint8_t nccl_id[UC_COMM_ID_BYTES] = {0};
-        if (W > 1 && !virtual_gpus) comm_unique_id(nccl_id);
         std::vector<uc_stats> rank_stats((size_t)W);
         uint64_t n_clusters = 0;
+        uint32_t nccl_ranks = 0;
 
         auto rank_main = [&](int r) {
             Engine E(p, devices[(size_t)r]);
             Comm &C = *comms[(size_t)r];
-            if (W > 1 && !virtual_gpus) comm_init_rank(C, nccl_id, r, W, devices[(size_t)r]);
+            // test hook: UC_FAIL_RANK="<rank>:<stage>" makes that rank throw (stage 0 = right after its engine exists, 1 = between
+            // its prefilter and the exchange) — the failure paths below must turn that into an error code, never into a hang
+            int fail_rank = -1, fail_stage = -1;
+            if (const char *fr = getenv("UC_FAIL_RANK")) sscanf(fr, "%d:%d", &fail_rank, &fail_stage);
+            if (fail_rank == r && fail_stage == 0) fail(UC_ERR_DEVICE, "injected failure of rank %d (UC_FAIL_RANK)", r);
+            if (W > 1) {
+                // every engine exists (a constructor that threw has failed the group: this barrier then throws on the others)
+                // BEFORE any rank enters RCCL; rank 0 then creates all communicators in one call — a collective init per rank
+                // would leave the survivors of a failed peer blocked inside ncclCommInitRank for good
+                grp.barrier();
+                if (r == 0 && !virtual_gpus) {
+                    std::vector<Comm *> cs;
+                    for (auto &c : comms) cs.push_back(c.get());
+                    comm_init_all(cs, devices);
+                    int cnt = 0, rk = 0, dv = 0;
+                    comm_info(C, &cnt, &rk, &dv);
+                    nccl_ranks = (uint32_t)cnt;
+                    logf(3, "unicore-cluster: RCCL communicator over %d ranks (ncclCommCount)\n", cnt);
+                }
+                grp.barrier();
+            }
             const bool timing = getenv("UC_TIMING") != nullptr;
             Timer tph;
             auto phase = [&](const char *what, int rr) {
@@ -488,19 +515,30 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
                         logf(3, "unicore-cluster: pre-step: %u sequences, %zu candidate pairs (%d k-mers per sequence)\n", m, pre_pairs.size() / 2, p.kmer_per_seq);
                 } else {
                     const GridCell g = grid_cell(E.h_len, W, p.target_shards, r);
-                    E.prefilter(g.tb, g.te, g.qb, g.qe);
+                    {
+                        Turn turn(C);
+                        Timer tp;
+                        E.prefilter(g.tb, g.te, g.qb, g.qe);
+                        E.stats.phase_seconds[0] += tp.seconds();
+                    }
+                    if (fail_rank == r && fail_stage == 1) fail(UC_ERR_DEVICE, "injected failure of rank %d (UC_FAIL_RANK)", r);
                     if (W > 1) exchange_hits(E, C);
                     if (r == 0)
                         logf(3, "unicore-cluster: step %d: %u sequences, prefilter kept %llu pairs%s (k-score %d, max-seqs %d)\n", rd + 1, m,
                              (unsigned long long)E.n_hits, W > 1 ? " on rank 0" : "", E.p.kmer_thr, p.max_seqs);
                 }
                 phase("hits", rr);
-                E.align(0, m);
+                {
+                    Turn turn(C);
+                    Timer ta;
+                    E.align(0, m);
+                    E.stats.phase_seconds[5] += ta.seconds();
+                }
                 phase("align", rr);
                 std::vector<uint32_t> all;
                 Timer te;
                 uint64_t n_acc = 0;                  // accepted pairs of the round (all ranks)
-                if (W > 1) { C.gather_edges(E, all); n_acc = all.size() / 2; E.stats.exchange_seconds += te.seconds(); }
+                if (W > 1) { C.gather_edges(E, all); n_acc = all.size() / 2; E.stats.exchange_seconds += te.seconds(); E.stats.phase_seconds[6] += te.seconds(); }
                 else n_acc = E.edges_on_host ? E.edges.size() / 2 : E.n_edges_dev;
                 if (r == 0) {
                     Timer tc;
@@ -514,6 +552,7 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
                     for (uint32_t i = 0; i < cur.size(); i++) if (sa[i] == i) next.push_back(cur[i]);
                     E.stats.algorithmic_bytes[UC_ST_SETCOVER] += 8ull * n_acc + 4ull * m;
                     E.stats.stage_seconds[UC_ST_SETCOVER] += tc.seconds();
+                    if (W > 1) E.stats.phase_seconds[7] += tc.seconds();
                     logf(3, "unicore-cluster: step %d: %llu accepted pairs, %zu representatives\n", rd + 1, (unsigned long long)n_acc, next.size());
                     cur.swap(next);
                     E.stats.n_edges = n_acc;
@@ -531,11 +570,14 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
             std::vector<std::string> err((size_t)W);
             std::vector<int> code((size_t)W, 0);
             std::vector<std::thread> th;
+            // a rank on its way out fails the group (peers leave their next barrier with an error) and aborts every RCCL
+            // communicator (peers blocked INSIDE a collective return from it)
+            auto bail = [&] { grp.fail_all(); for (auto &c : comms) c->abort(); };
             for (int r = 0; r < W; r++)
                 th.emplace_back([&, r] {
                     try { rank_main(r); }
-                    catch (const Error &e) { code[(size_t)r] = e.code; err[(size_t)r] = e.what(); grp.fail_all(); }
-                    catch (const std::exception &e) { code[(size_t)r] = UC_ERR_GENERIC; err[(size_t)r] = e.what(); grp.fail_all(); }
+                    catch (const Error &e) { code[(size_t)r] = e.code; err[(size_t)r] = e.what(); bail(); }
+                    catch (const std::exception &e) { code[(size_t)r] = UC_ERR_GENERIC; err[(size_t)r] = e.what(); bail(); }
                 });
             for (auto &t : th) t.join();
             // report the rank that failed first-hand, not the ones that were released from a barrier because of it
@@ -553,6 +595,7 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
         st.n_residues = full.residues();
         st.n_gpus = (uint32_t)W;
         st.target_shards = (uint32_t)gT;
+        st.nccl_ranks = nccl_ranks;
         Timer to;
         write_cluster_db(out_cluster_db, full.keys, assign.data(), n);
         st.stage_seconds[UC_ST_OUTPUT] += to.seconds();
@@ -578,6 +621,17 @@ int uc_comm_create(const uint8_t id[UC_COMM_ID_BYTES], int32_t rank, int32_t wor
 }
 
 void uc_comm_destroy(uc_comm *c) { delete c; }
+
+int uc_comm_info(const uc_comm *c, int32_t *nccl_ranks, int32_t *nccl_rank, int32_t *device) {
+    return guard([&] {
+        require(c, "comm");
+        int n = 0, r = 0, d = 0;
+        comm_info(c->c, &n, &r, &d);
+        if (nccl_ranks) *nccl_ranks = n;
+        if (nccl_rank) *nccl_rank = r;
+        if (device) *device = d;
+    });
+}
 
 int uc_engine_cluster_step(uc_engine *e, uc_comm *comm, int32_t target_shards, uint32_t *assign, uint64_t *n_alignments) {
     return guard([&] {

@@ -137,6 +137,7 @@ void Engine::upload_db(bool keep_raw) {
     UC_HIP(hipStreamSynchronize(stream));
     UC_HIP(hipGetLastError());
     raw_n = keep_raw ? n : 0;
+    raw_resident = keep_raw;
     finish_db_install(tm);
 }
 
@@ -145,7 +146,7 @@ void Engine::upload_db(bool keep_raw) {
 void Engine::upload_sub_db(const std::vector<uint32_t> &cur, const std::vector<uint64_t> &full_off) {
     Timer tm;
     UC_HIP(hipSetDevice(device));
-    if (!raw_n || full_off.size() != (size_t)raw_n + 1) fail(UC_ERR_GENERIC, "upload_sub_db: no resident raw database");
+    if (!raw_resident || full_off.size() != (size_t)raw_n + 1) fail(UC_ERR_GENERIC, "upload_sub_db: no resident raw database");
     HostDb sub;
     sub.n = (uint32_t)cur.size();
     sub.off.resize((size_t)sub.n + 1);

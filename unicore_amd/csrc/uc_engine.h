@@ -39,12 +39,15 @@ struct DevBuf {   // plain owning device allocation (hipMalloc), grows geometric
         UC_HIP(hipMalloc((void **)&p, want * sizeof(T)));
         cap = want;
     }
-    void grow_preserve(size_t n, size_t used) {   // keeps the first `used` elements
+    // keeps the first `used` elements.  The copy runs ON `s`, behind whatever that stream still has in flight for the old
+    // buffer (a null-stream hipMemcpy does not order itself against a hipStreamNonBlocking stream), and is complete on return.
+    void grow_preserve(size_t n, size_t used, hipStream_t s) {
         if (n <= cap) return;
         size_t want = n + n / 2 + 64;
         T *np = nullptr;
         UC_HIP(hipMalloc((void **)&np, want * sizeof(T)));
-        if (used && p) UC_HIP(hipMemcpy(np, p, used * sizeof(T), hipMemcpyDeviceToDevice));
+        if (used && p) UC_HIP(hipMemcpyAsync(np, p, used * sizeof(T), hipMemcpyDeviceToDevice, s));
+        UC_HIP(hipStreamSynchronize(s));
         if (p) (void)hipFree(p);
         p = np;
         cap = want;
@@ -105,6 +108,7 @@ struct Engine {
     DevBuf<uint8_t> d_raw3, d_rawa;    // unpadded tracks of the database uploaded with keep_raw (sub-databases are gathered from it)
     DevBuf<uint64_t> d_rawoff;
     uint32_t raw_n = 0;
+    bool raw_resident = false;   // an EMPTY database can be resident too (raw_n == 0): the cascade of a bare "-c 0.8" on it must not fail
     DevBuf<uint32_t> d_off, d_len;
     DevBuf<int8_t> d_S3, d_SA;
     DeviceDb ddb;
@@ -151,6 +155,8 @@ struct Engine {
     void export_hits_dev(uint32_t *dq, uint32_t *dt, int32_t *ds, int32_t *dd) const;
     uint64_t import_hits_dev(uint64_t n, const uint32_t *dq, const uint32_t *dt, const int32_t *ds, const int32_t *dd,
                              uint32_t rank, uint32_t world);
+    // the installed lists regrouped by owner rank of each pair (stable; counts[world] on the host) into caller-owned device arrays
+    void partition_hits_by_owner(uint32_t world, uint32_t *dq, uint32_t *dt, int32_t *ds, int32_t *dd, uint64_t *counts);
     void get_alns(uint64_t begin, uint64_t n, uc_aln *out) const;
     void finish_hit_lists();                                  // counts/offsets from the device arrays
     void align(uint32_t qbegin, uint32_t qend);

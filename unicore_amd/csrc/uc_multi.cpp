@@ -51,6 +51,23 @@ Comm::~Comm() {
     if (nccl) (void)ncclCommDestroy(nccl);
 }
 
+void Comm::abort() {
+    std::lock_guard<std::mutex> lk(nccl_mu);
+    aborted = true;
+    if (nccl) { (void)ncclCommAbort(nccl); nccl = nullptr; }
+}
+
+namespace {
+// RCCL enqueue under the communicator's lock: abort() cannot free the handle between the check and the call; the blocking
+// part of a collective is the stream synchronisation AFTER the enqueue, which runs unlocked (that is what abort() interrupts)
+template <class F>
+void nccl_enqueue(Comm &C, F &&f) {
+    std::lock_guard<std::mutex> lk(C.nccl_mu);
+    if (C.aborted || !C.nccl) fail(UC_ERR_DEVICE, "RCCL communicator of rank %d was aborted (another GPU rank of this run failed)", C.rank);
+    f(C.nccl);
+}
+}  // namespace
+
 void comm_unique_id(uint8_t id[128]) {
     static_assert(NCCL_UNIQUE_ID_BYTES == 128, "uc_comm id size");
     ncclUniqueId u;
@@ -65,6 +82,20 @@ void comm_init_rank(Comm &C, const uint8_t id[128], int rank, int world, int dev
     C.rank = rank;
     C.world = world;
     UC_NCCL(ncclCommInitRank(&C.nccl, world, u, rank));
+}
+
+void comm_info(const Comm &C, int *count, int *rank, int *device) {
+    if (!C.nccl) fail(UC_ERR_ARGS, "communicator has no RCCL handle");
+    UC_NCCL(ncclCommCount(C.nccl, count));
+    UC_NCCL(ncclCommUserRank(C.nccl, rank));
+    UC_NCCL(ncclCommCuDevice(C.nccl, device));
+}
+
+void comm_init_all(const std::vector<Comm *> &comms, const std::vector<int> &devices) {
+    const int W = (int)comms.size();
+    std::vector<ncclComm_t> h((size_t)W, nullptr);
+    UC_NCCL(ncclCommInitAll(h.data(), W, devices.data()));
+    for (int r = 0; r < W; r++) { comms[(size_t)r]->rank = r; comms[(size_t)r]->world = W; comms[(size_t)r]->nccl = h[(size_t)r]; }
 }
 
 // A communicator that owns an RCCL handle always goes through RCCL, even with one rank: a 1-rank communicator on the
@@ -89,7 +120,7 @@ void Comm::all_gather_u64(Engine &E, uint64_t v, uint64_t *out) {
     S.sz_send.reserve(1);
     S.sz_recv.reserve((size_t)world);
     UC_HIP(hipMemcpyAsync(S.sz_send.p, &v, 8, hipMemcpyHostToDevice, E.stream));
-    UC_NCCL(ncclAllGather(S.sz_send.p, S.sz_recv.p, 1, ncclUint64, nccl, E.stream));
+    nccl_enqueue(*this, [&](ncclComm *h) { UC_NCCL(ncclAllGather(S.sz_send.p, S.sz_recv.p, 1, ncclUint64, h, E.stream)); });
     UC_HIP(hipMemcpyAsync(out, S.sz_recv.p, (size_t)world * 8, hipMemcpyDeviceToHost, E.stream));
     UC_HIP(hipStreamSynchronize(E.stream));
 }
@@ -100,10 +131,11 @@ void Comm::all_gather_dev(Engine &E, const void *send, void *recv, size_t bytes)
         UC_HIP(hipStreamSynchronize(E.stream));
         return;
     }
-    if (nccl) {
+    if (nccl || aborted) {
         if (grp) grp->barrier();   // a rank that failed earlier must not leave its peers inside the collective
-        UC_NCCL(ncclAllGather(send, recv, bytes, ncclUint8, nccl, E.stream));
+        nccl_enqueue(*this, [&](ncclComm *h) { UC_NCCL(ncclAllGather(send, recv, bytes, ncclUint8, h, E.stream)); });
         UC_HIP(hipStreamSynchronize(E.stream));
+        if (grp) grp->barrier();   // ... and one that failed DURING it (its handler aborts every communicator) is reported as such
         return;
     }
     // in-process ranks without RCCL (several engines on ONE device — RCCL refuses two ranks per GPU): every rank
@@ -119,10 +151,11 @@ void Comm::all_gather_dev(Engine &E, const void *send, void *recv, size_t bytes)
 
 void Comm::broadcast_dev(Engine &E, void *buf, size_t bytes, int root) {
     if (world == 1 && !nccl) return;
-    if (nccl) {
+    if (nccl || aborted) {
         if (grp) grp->barrier();
-        UC_NCCL(ncclBroadcast(buf, buf, bytes, ncclUint8, root, nccl, E.stream));
+        nccl_enqueue(*this, [&](ncclComm *h) { UC_NCCL(ncclBroadcast(buf, buf, bytes, ncclUint8, root, h, E.stream)); });
         UC_HIP(hipStreamSynchronize(E.stream));
+        if (grp) grp->barrier();
         return;
     }
     UC_HIP(hipStreamSynchronize(E.stream));
@@ -162,17 +195,19 @@ void Comm::gather_edges(Engine &E, std::vector<uint32_t> &out) {
     size_t tot = 0;
     for (uint64_t s : sz) tot += s;
     if (rank == 0) S.e_recv.reserve(std::max<size_t>(tot, 1));
-    UC_NCCL(ncclGroupStart());
-    if (rank == 0) {
-        size_t o = sz[0];
-        for (int r = 1; r < world; r++) {
-            if (sz[(size_t)r]) UC_NCCL(ncclRecv(S.e_recv.p + o, sz[(size_t)r], ncclUint32, r, nccl, E.stream));
-            o += sz[(size_t)r];
+    nccl_enqueue(*this, [&](ncclComm *h) {
+        UC_NCCL(ncclGroupStart());
+        if (rank == 0) {
+            size_t o = sz[0];
+            for (int r = 1; r < world; r++) {
+                if (sz[(size_t)r]) UC_NCCL(ncclRecv(S.e_recv.p + o, sz[(size_t)r], ncclUint32, r, h, E.stream));
+                o += sz[(size_t)r];
+            }
+        } else if (mine) {
+            UC_NCCL(ncclSend(S.e_send.p, mine, ncclUint32, 0, h, E.stream));
         }
-    } else if (mine) {
-        UC_NCCL(ncclSend(S.e_send.p, mine, ncclUint32, 0, nccl, E.stream));
-    }
-    UC_NCCL(ncclGroupEnd());
+        UC_NCCL(ncclGroupEnd());
+    });
     if (rank == 0) {
         out.resize(tot);
         if (mine) memcpy(out.data(), E.edges.data(), mine * 4);
@@ -218,74 +253,194 @@ GridCell grid_cell(const std::vector<uint32_t> &len, int world, int target_shard
 
 // ---------------------------------------------------------------------------------------------- the exchange
 namespace {
-uint64_t one_shot_limit() {   // records in the union above which the lists are merged shard by shard (peak = two lists, not world)
-    if (const char *e = getenv("UC_EXCHANGE_LIMIT")) return strtoull(e, nullptr, 10);
-    return 256ull << 20;
+uint64_t round_limit() {   // records a rank receives per round of exchange 1 (beyond it the home range is worked off in several rounds)
+    if (const char *e = getenv("UC_EXCHANGE_LIMIT")) return std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+    return 1ull << 30;
 }
+
 }  // namespace
 
+void Comm::all_gather_u64s(Engine &E, const uint64_t *v, int k, uint64_t *out) {
+    if (world == 1 && !nccl) { memcpy(out, v, (size_t)k * 8); return; }
+    if (grp) {
+        grp->ptr[(size_t)rank] = v;
+        grp->barrier();
+        for (int r = 0; r < world; r++) memcpy(out + (size_t)r * k, grp->ptr[(size_t)r], (size_t)k * 8);
+        grp->barrier();   // nobody lets go of its vector before everybody has read it
+        return;
+    }
+    CommScratch &S = *scratch;
+    S.sz_send.reserve((size_t)k);
+    S.sz_recv.reserve((size_t)world * k);
+    UC_HIP(hipMemcpyAsync(S.sz_send.p, v, (size_t)k * 8, hipMemcpyHostToDevice, E.stream));
+    nccl_enqueue(*this, [&](ncclComm *h) { UC_NCCL(ncclAllGather(S.sz_send.p, S.sz_recv.p, (size_t)k, ncclUint64, h, E.stream)); });
+    UC_HIP(hipMemcpyAsync(out, S.sz_recv.p, (size_t)world * k * 8, hipMemcpyDeviceToHost, E.stream));
+    UC_HIP(hipStreamSynchronize(E.stream));
+}
+
+// Ragged all-to-all of `na` parallel 4-byte arrays: rank r sends elements [send_off[p], send_off[p] + send_cnt[p]) of every
+// send array to rank p and receives recv_cnt[p] elements from p at recv_off[p] of every recv array.  RCCL: ONE group of
+// point-to-point sends / receives (over xGMI every pair of GPUs has its own link: the transfers of a rank run side by side);
+// virtual ranks: device copies from the peers' published buffers.
+void Comm::all_to_all_dev(Engine &E, int na, const void *const *send, const uint64_t *send_off, const uint64_t *send_cnt,
+                          void *const *recv, const uint64_t *recv_off, const uint64_t *recv_cnt) {
+    const int me = rank;
+    if (send_cnt[me] != recv_cnt[me]) fail(UC_ERR_GENERIC, "all_to_all_dev: inconsistent self segment");
+    if (world == 1 && !nccl) {
+        for (int k = 0; k < na && send_cnt[0]; k++)
+            UC_HIP(hipMemcpyAsync((char *)recv[k] + 4 * recv_off[0], (const char *)send[k] + 4 * send_off[0], 4 * send_cnt[0], hipMemcpyDeviceToDevice, E.stream));
+        UC_HIP(hipStreamSynchronize(E.stream));
+        return;
+    }
+    if (nccl || aborted) {
+        if (grp) grp->barrier();   // a rank that failed earlier must not leave its peers inside the exchange
+        nccl_enqueue(*this, [&](ncclComm *h) {
+            UC_NCCL(ncclGroupStart());
+            for (int p = 0; p < world; p++) {
+                if (p == me) continue;
+                for (int k = 0; k < na; k++) {
+                    if (send_cnt[p]) UC_NCCL(ncclSend((const char *)send[k] + 4 * send_off[p], send_cnt[p], ncclUint32, p, h, E.stream));
+                    if (recv_cnt[p]) UC_NCCL(ncclRecv((char *)recv[k] + 4 * recv_off[p], recv_cnt[p], ncclUint32, p, h, E.stream));
+                }
+            }
+            UC_NCCL(ncclGroupEnd());
+        });
+        for (int k = 0; k < na && send_cnt[me]; k++)
+            UC_HIP(hipMemcpyAsync((char *)recv[k] + 4 * recv_off[me], (const char *)send[k] + 4 * send_off[me], 4 * send_cnt[me], hipMemcpyDeviceToDevice, E.stream));
+        UC_HIP(hipStreamSynchronize(E.stream));
+        if (grp) grp->barrier();   // ... and one that failed DURING it (its handler aborts every communicator) is reported as such
+        return;
+    }
+    // in-process ranks without RCCL (several engines on ONE device): publish the send side, copy from the peers
+    struct Pub { const void *const *send; const uint64_t *off; } pub{send, send_off};
+    UC_HIP(hipStreamSynchronize(E.stream));   // the send buffers are complete
+    grp->ptr[(size_t)me] = &pub;
+    grp->barrier();
+    for (int p = 0; p < world; p++) {
+        if (!recv_cnt[p]) continue;
+        const Pub &pp = *(const Pub *)grp->ptr[(size_t)p];
+        for (int k = 0; k < na; k++)
+            UC_HIP(hipMemcpyAsync((char *)recv[k] + 4 * recv_off[p], (const char *)pp.send[k] + 4 * pp.off[(size_t)me], 4 * recv_cnt[p], hipMemcpyDefault, E.stream));
+    }
+    UC_HIP(hipStreamSynchronize(E.stream));
+    grp->barrier();   // peers may reuse their send buffers only now
+}
+
+// The exchange of the sharded pass, two phases (r4; it replaced "all-gather the union, sort it on every rank, keep 1/N"):
+//   1. every query has a HOME rank (contiguous query ranges of equal residue counts).  A rank's lists are grouped by query, so
+//      the records of one home are one contiguous slice: ragged all-to-all, then the home rank merges the slices of its queries
+//      under (score desc, target asc) and truncates to max_seqs — 1/N of the union per rank instead of all of it on every rank
+//      (lossless: global top-M is a subset of the union of the shard top-Ms);
+//   2. the surviving pairs go to the rank that OWNS them (hash of the unordered pair's representative query: mutual hits meet on
+//      one rank and share their DPs there, a rank owns whole queries): stable partition by owner on the device, second ragged
+//      all-to-all, install.  Every merged pair is aligned exactly once over all ranks; the result does not depend on N or the grid.
 uint64_t exchange_hits(Engine &E, Comm &C) {
     Timer tm;
     UC_HIP(hipSetDevice(E.device));
-    const int W = C.world;
+    const int W = C.world, me = C.rank;
     CommScratch &S = *C.scratch;
-    const uint64_t nloc = E.n_hits;
-    std::vector<uint64_t> sizes((size_t)W);
-    C.all_gather_u64(E, nloc, sizes.data());
-    uint64_t total = 0, m = 1;
-    for (uint64_t s : sizes) { total += s; m = std::max(m, s); }
-    uint64_t kept = 0;
-    if (total > one_shot_limit()) {
-        // BASELINE configs[2] scale: one broadcast per rank, top-M truncation after every merge
-        S.own.reserve(4 * std::max<uint64_t>(nloc, 1));
-        int32_t *own = S.own.p;
-        if (nloc) E.export_hits_dev((uint32_t *)own, (uint32_t *)own + nloc, own + 2 * nloc, own + 3 * nloc);
-        uint64_t nacc = 0;
-        for (int r = 0; r < W; r++) {
-            const uint64_t nr = sizes[(size_t)r];
-            if (!nr) continue;
-            S.part.reserve(4 * nr);
-            if (r == C.rank) UC_HIP(hipMemcpyAsync(S.part.p, own, 16 * nr, hipMemcpyDeviceToDevice, E.stream));
-            C.broadcast_dev(E, S.part.p, 16 * nr, r);
-            E.stats.exchange_bytes += 16 * nr;
-            if (!nacc) {
-                S.acc.reserve(4 * nr);
-                UC_HIP(hipMemcpyAsync(S.acc.p, S.part.p, 16 * nr, hipMemcpyDeviceToDevice, E.stream));
+    const auto homes = shard_ranges(E.h_len, W);
+    std::vector<uint64_t> soff((size_t)W), scnt((size_t)W), mat((size_t)W * W), roff((size_t)W), rcnt((size_t)W);
+
+    // ---- phase 1 (in rounds if a rank would receive more than round_limit() records at once)
+    Timer t1;
+    for (int h = 0; h < W; h++) { soff[(size_t)h] = E.hit_off[homes[(size_t)h].first]; scnt[(size_t)h] = E.hit_off[homes[(size_t)h].second] - soff[(size_t)h]; }
+    C.all_gather_u64s(E, scnt.data(), W, mat.data());
+    uint64_t worst = 0;
+    for (int h = 0; h < W; h++) { uint64_t c = 0; for (int r = 0; r < W; r++) c += mat[(size_t)r * W + h]; worst = std::max(worst, c); }
+    const uint64_t rounds = std::max<uint64_t>(1, (worst + round_limit() - 1) / round_limit());
+    double t_x1 = 0, t_merge = 0;
+    uint64_t nacc = 0;     // merged records of the rounds so far (rounds > 1 only), parked in S.acc as [4][cap]
+    uint64_t acc_cap = 0;
+    for (uint64_t rd = 0; rd < rounds; rd++) {
+        Timer tx;
+        if (rounds > 1) {   // sub-range rd of every home range (by query count); counts are exchanged per round
+            for (int h = 0; h < W; h++) {
+                const uint64_t qb = homes[(size_t)h].first, qn = homes[(size_t)h].second - qb;
+                const uint32_t a = (uint32_t)(qb + qn * rd / rounds), b = (uint32_t)(qb + qn * (rd + 1) / rounds);
+                soff[(size_t)h] = E.hit_off[a]; scnt[(size_t)h] = E.hit_off[b] - E.hit_off[a];
+            }
+            C.all_gather_u64s(E, scnt.data(), W, mat.data());
+        }
+        uint64_t R = 0;
+        for (int r = 0; r < W; r++) { rcnt[(size_t)r] = mat[(size_t)r * W + me]; roff[(size_t)r] = R; R += rcnt[(size_t)r]; }
+        S.all.reserve(4 * std::max<uint64_t>(R, 1));
+        const void *snd[4] = {E.d_hq.p, E.d_ht.p, E.d_hs.p, E.d_hd.p};
+        void *rcv[4] = {S.all.p, S.all.p + R, S.all.p + 2 * R, S.all.p + 3 * R};
+        C.all_to_all_dev(E, 4, snd, soff.data(), scnt.data(), rcv, roff.data(), rcnt.data());
+        E.stats.exchange_bytes += 16 * (R - rcnt[(size_t)me]);
+        t_x1 += tx.seconds();
+        Timer tg;
+        if (rounds == 1) {
+            Turn turn(C);
+            E.import_hits_dev(R, (uint32_t *)S.all.p, (uint32_t *)S.all.p + R, S.all.p + 2 * R, S.all.p + 3 * R, 0, 1);
+        } else {
+            // the engine's own lists are still the send side of the later rounds: merge into a side engine state is not available, so
+            // the round's slice is merged in place of a scratch copy — park own lists, merge, append, restore
+            Turn turn(C);
+            const uint64_t nloc = E.n_hits;
+            S.own.reserve(4 * std::max<uint64_t>(nloc, 1));
+            if (nloc) E.export_hits_dev((uint32_t *)S.own.p, (uint32_t *)S.own.p + nloc, S.own.p + 2 * nloc, S.own.p + 3 * nloc);
+            const std::vector<uint32_t> cnt_keep = E.hit_cnt;
+            const std::vector<uint64_t> off_keep = E.hit_off;
+            const uint64_t k = E.import_hits_dev(R, (uint32_t *)S.all.p, (uint32_t *)S.all.p + R, S.all.p + 2 * R, S.all.p + 3 * R, 0, 1);
+            if (nacc + k > acc_cap) {   // grow the [4][cap] accumulator, keeping its rows
+                const uint64_t ncap = (nacc + k) * 3 / 2 + 64;
+                S.cat.reserve(4 * ncap);
+                for (int a = 0; a < 4 && nacc; a++)
+                    UC_HIP(hipMemcpyAsync(S.cat.p + a * ncap, S.acc.p + a * acc_cap, 4 * nacc, hipMemcpyDeviceToDevice, E.stream));
                 UC_HIP(hipStreamSynchronize(E.stream));
-                nacc = nr;
-                continue;
+                S.cat.swap(S.acc);
+                acc_cap = ncap;
             }
-            const uint64_t tot = nacc + nr;
-            S.cat.reserve(4 * tot);
-            for (int k = 0; k < 4; k++) {
-                UC_HIP(hipMemcpyAsync(S.cat.p + k * tot, S.acc.p + k * nacc, 4 * nacc, hipMemcpyDeviceToDevice, E.stream));
-                UC_HIP(hipMemcpyAsync(S.cat.p + k * tot + nacc, S.part.p + k * nr, 4 * nr, hipMemcpyDeviceToDevice, E.stream));
+            if (k) E.export_hits_dev((uint32_t *)S.acc.p + nacc, (uint32_t *)S.acc.p + acc_cap + nacc, S.acc.p + 2 * acc_cap + nacc, S.acc.p + 3 * acc_cap + nacc);
+            nacc += k;
+            // restore the send side (order is already the list order: the install below only rebuilds counts and offsets)
+            if (rd + 1 < rounds) {
+                E.d_hq.reserve(nloc); E.d_ht.reserve(nloc); E.d_hs.reserve(nloc); E.d_hd.reserve(nloc);
+                UC_HIP(hipMemcpyAsync(E.d_hq.p, S.own.p, 4 * nloc, hipMemcpyDeviceToDevice, E.stream));
+                UC_HIP(hipMemcpyAsync(E.d_ht.p, S.own.p + nloc, 4 * nloc, hipMemcpyDeviceToDevice, E.stream));
+                UC_HIP(hipMemcpyAsync(E.d_hs.p, S.own.p + 2 * nloc, 4 * nloc, hipMemcpyDeviceToDevice, E.stream));
+                UC_HIP(hipMemcpyAsync(E.d_hd.p, S.own.p + 3 * nloc, 4 * nloc, hipMemcpyDeviceToDevice, E.stream));
+                UC_HIP(hipStreamSynchronize(E.stream));
+                E.n_hits = nloc; E.hit_cnt = cnt_keep; E.hit_off = off_keep;
+            } else {
+                E.import_hits_dev(nacc, (uint32_t *)S.acc.p, (uint32_t *)S.acc.p + acc_cap, S.acc.p + 2 * acc_cap, S.acc.p + 3 * acc_cap, 0, 1);
             }
-            UC_HIP(hipStreamSynchronize(E.stream));
-            nacc = E.import_hits_dev(tot, (uint32_t *)S.cat.p, (uint32_t *)S.cat.p + tot, S.cat.p + 2 * tot, S.cat.p + 3 * tot, 0, 1);   // merge + top-M, no ownership yet
-            S.acc.reserve(4 * std::max<uint64_t>(nacc, 1));
-            if (nacc) E.export_hits_dev((uint32_t *)S.acc.p, (uint32_t *)S.acc.p + nacc, S.acc.p + 2 * nacc, S.acc.p + 3 * nacc);
         }
-        kept = E.import_hits_dev(nacc, (uint32_t *)S.acc.p, (uint32_t *)S.acc.p + nacc, S.acc.p + 2 * nacc, S.acc.p + 3 * nacc, (uint32_t)C.rank, (uint32_t)W);
-    } else {
-        // one padded all-gather: [4][m] int32 per rank -> [W][4][m]
-        S.pad.reserve(4 * m);
-        S.all.reserve(4 * m * (uint64_t)W);
-        UC_HIP(hipMemsetAsync(S.pad.p, 0, 16 * m, E.stream));
-        if (nloc) E.export_hits_dev((uint32_t *)S.pad.p, (uint32_t *)S.pad.p + m, S.pad.p + 2 * m, S.pad.p + 3 * m);
-        C.all_gather_dev(E, S.pad.p, S.all.p, 16 * m);
-        E.stats.exchange_bytes += 16 * m * (uint64_t)W;
-        S.cat.reserve(4 * std::max<uint64_t>(total, 1));
-        uint64_t o = 0;
-        for (int r = 0; r < W; r++) {
-            const uint64_t nr = sizes[(size_t)r];
-            for (int k = 0; k < 4 && nr; k++)
-                UC_HIP(hipMemcpyAsync(S.cat.p + k * total + o, S.all.p + ((uint64_t)r * 4 + k) * m, 4 * nr, hipMemcpyDeviceToDevice, E.stream));
-            o += nr;
-        }
-        UC_HIP(hipStreamSynchronize(E.stream));
-        kept = E.import_hits_dev(total, (uint32_t *)S.cat.p, (uint32_t *)S.cat.p + total, S.cat.p + 2 * total, S.cat.p + 3 * total, (uint32_t)C.rank, (uint32_t)W);
+        t_merge += tg.seconds();
     }
+    E.stats.phase_seconds[1] += t_x1;
+    E.stats.phase_seconds[2] += t_merge;
+
+    // ---- phase 2: pairs to their owners
+    Timer t3;
+    const uint64_t K = E.n_hits;
+    S.pad.reserve(4 * std::max<uint64_t>(K, 1));
+    {
+        Turn turn(C);
+        E.partition_hits_by_owner((uint32_t)W, (uint32_t *)S.pad.p, (uint32_t *)S.pad.p + K, S.pad.p + 2 * K, S.pad.p + 3 * K, scnt.data());
+    }
+    uint64_t o = 0;
+    for (int p = 0; p < W; p++) { soff[(size_t)p] = o; o += scnt[(size_t)p]; }
+    C.all_gather_u64s(E, scnt.data(), W, mat.data());
+    uint64_t R2 = 0;
+    for (int r = 0; r < W; r++) { rcnt[(size_t)r] = mat[(size_t)r * W + me]; roff[(size_t)r] = R2; R2 += rcnt[(size_t)r]; }
+    S.all.reserve(4 * std::max<uint64_t>(R2, 1));
+    {
+        const void *snd[4] = {S.pad.p, S.pad.p + K, S.pad.p + 2 * K, S.pad.p + 3 * K};
+        void *rcv[4] = {S.all.p, S.all.p + R2, S.all.p + 2 * R2, S.all.p + 3 * R2};
+        C.all_to_all_dev(E, 4, snd, soff.data(), scnt.data(), rcv, roff.data(), rcnt.data());
+    }
+    E.stats.exchange_bytes += 16 * (R2 - rcnt[(size_t)me]);
+    E.stats.phase_seconds[3] += t3.seconds();
+    Timer t4;
+    uint64_t kept;
+    {
+        Turn turn(C);
+        kept = E.import_hits_dev(R2, (uint32_t *)S.all.p, (uint32_t *)S.all.p + R2, S.all.p + 2 * R2, S.all.p + 3 * R2, 0, 1);
+    }
+    E.stats.phase_seconds[4] += t4.seconds();
     E.stats.exchange_seconds += tm.seconds();
     return kept;
 }
@@ -295,10 +450,20 @@ uint64_t cluster_step(Engine &E, Comm &C, int target_shards, uint32_t *assign) {
     UC_HIP(hipSetDevice(E.device));
     const uint32_t n = E.hdb.n;
     const GridCell g = grid_cell(E.h_len, C.world, target_shards, C.rank);
-    E.prefilter(g.tb, g.te, g.qb, g.qe);
+    {
+        Turn turn(C);
+        Timer tp;
+        E.prefilter(g.tb, g.te, g.qb, g.qe);
+        E.stats.phase_seconds[0] += tp.seconds();
+    }
     uint64_t n_aln = E.n_hits;
     if (C.world > 1 || C.nccl) n_aln = exchange_hits(E, C);
-    E.align(0, n);
+    {
+        Turn turn(C);
+        Timer ta;
+        E.align(0, n);
+        E.stats.phase_seconds[5] += ta.seconds();
+    }
     if (C.world == 1 && !C.nccl) {   // one rank: the graph is built straight from the device-resident edge list
         if (!assign && n) fail(UC_ERR_ARGS, "cluster_step: rank 0 needs an assignment buffer");
         Timer tc;
@@ -312,12 +477,14 @@ uint64_t cluster_step(Engine &E, Comm &C, int target_shards, uint32_t *assign) {
     Timer te;
     C.gather_edges(E, all);
     E.stats.exchange_seconds += C.world > 1 ? te.seconds() : 0.0;
+    E.stats.phase_seconds[6] += te.seconds();
     if (C.rank == 0) {
         if (!assign && n) fail(UC_ERR_ARGS, "cluster_step: rank 0 needs an assignment buffer");
         Timer tc;
         E.set_cover_device(n, all.data(), all.size() / 2, assign);
         E.stats.algorithmic_bytes[UC_ST_SETCOVER] += 8ull * (all.size() / 2) + 4ull * n;
         E.stats.stage_seconds[UC_ST_SETCOVER] += tc.seconds();
+        E.stats.phase_seconds[7] += tc.seconds();
     }
     return n_aln;
 }

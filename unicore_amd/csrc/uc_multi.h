@@ -3,9 +3,10 @@
 // torch.distributed.run), the per-shard hit lists all-gathered device to device with RCCL over xGMI.
 //
 //   rank r : index target shard r % T -> match query group r / T against it (E1-E4)       [Q x T = world]
-//   exchange: ncclAllGather of the padded [4][m] int32 hit tensors (the ONE collective of the path)
-//   every rank: device merge per query under (score desc, target asc), top max_seqs, keep the pairs it owns
-//               (hash of the unordered pair's representative query) -> E5/E6 on its share
+//   exchange 1: the shard lists go to the query's HOME rank (ragged all-to-all: grouped ncclSend / ncclRecv over xGMI), which
+//               merges its 1/N of the queries under (score desc, target asc) and keeps the top max_seqs
+//   exchange 2: the surviving pairs go to the rank that OWNS them (hash of the unordered pair's representative query, so mutual
+//               hits share their DP on one rank) -> E5/E6 on its share
 //   rank 0 : accepted edges of all ranks -> host set cover (E7)
 #pragma once
 #include <condition_variable>
@@ -33,6 +34,10 @@ struct LocalGroup {
     bool failed = false;
     std::vector<const void *> ptr;   // per-rank published pointer (device buffer or host vector)
     std::vector<uint64_t> val;       // per-rank published value
+    // emulation aid for virtual ranks (several engines on ONE device): with `serialize` the compute phases of the ranks take
+    // turns on the GPU, so every rank's phase times are those of a rank with a GPU of its own (UC_VIRTUAL_SERIAL=1)
+    bool serialize = false;
+    std::mutex turn;
     void barrier();                  // throws Error(UC_ERR_GENERIC) if the group failed
     void fail_all();                 // called by a rank on its way out with an exception
 };
@@ -44,18 +49,37 @@ struct Comm {
     LocalGroup *grp = nullptr;       // set when all ranks are threads of this process
     ncclComm *nccl = nullptr;        // set when the ranks sit on distinct devices (RCCL); null = in-process copies (virtual GPUs of the tests)
     std::unique_ptr<CommScratch> scratch;
+    std::mutex nccl_mu;              // serializes RCCL enqueues of this communicator against abort()
+    bool aborted = false;
     Comm();
     ~Comm();
     Comm(const Comm &) = delete;
     Comm &operator=(const Comm &) = delete;
 
+    // failure path: ncclCommAbort, so that a peer blocked inside a collective of this communicator returns (its next barrier
+    // then throws); the handle is gone afterwards.  Safe to call from any thread, once or more.
+    void abort();
     void barrier(Engine &E);
     void all_gather_u64(Engine &E, uint64_t v, uint64_t *out /* world */);
+    void all_gather_u64s(Engine &E, const uint64_t *v, int k, uint64_t *out /* world x k */);
+    // ragged all-to-all of `na` parallel arrays of 4-byte elements (offsets and counts in elements, per peer)
+    void all_to_all_dev(Engine &E, int na, const void *const *send, const uint64_t *send_off, const uint64_t *send_cnt,
+                        void *const *recv, const uint64_t *recv_off, const uint64_t *recv_cnt);
     // recv holds world x bytes; send/recv are device buffers of E's device
     void all_gather_dev(Engine &E, const void *send, void *recv, size_t bytes);
     void broadcast_dev(Engine &E, void *buf, size_t bytes, int root);
     // accepted edges of every rank, concatenated in rank order, on rank 0 (empty elsewhere)
     void gather_edges(Engine &E, std::vector<uint32_t> &out);
+};
+
+// emulation aid (UC_VIRTUAL_SERIAL=1, virtual ranks only): the compute phases of the ranks take turns on the one physical GPU,
+// so that a rank's phase_seconds are what it would measure with a GPU of its own (tools/critical_path.py)
+struct Turn {
+    LocalGroup *g;
+    explicit Turn(Comm &C) : g(C.grp && C.grp->serialize ? C.grp : nullptr) { if (g) g->turn.lock(); }
+    ~Turn() { if (g) g->turn.unlock(); }
+    Turn(const Turn &) = delete;
+    Turn &operator=(const Turn &) = delete;
 };
 
 // Q x T grid: rank r indexes target shard r % T and matches query group r / T.  target_shards = 0 means T = world — the
@@ -73,6 +97,10 @@ uint64_t cluster_step(Engine &E, Comm &C, int target_shards, uint32_t *assign);
 
 // RCCL plumbing for the C ABI
 void comm_unique_id(uint8_t id[128]);
+void comm_info(const Comm &C, int *count, int *rank, int *device);   // asks RCCL
 void comm_init_rank(Comm &C, const uint8_t id[128], int rank, int world, int device);
+// all communicators of an in-process group from ONE thread (ncclCommInitAll): either every rank gets its handle or the call
+// fails as a whole — no rank can be left waiting inside a collective init for a peer that died while building its engine
+void comm_init_all(const std::vector<Comm *> &comms, const std::vector<int> &devices);
 
 }  // namespace uc

@@ -1016,6 +1016,28 @@ __global__ void __launch_bounds__(256) owner_flag_kernel(const uint64_t *skey, u
         if (flag[i] && pair_owner((uint32_t)(skey[i] >> 32), (uint32_t)(skey[i] & 0xFFFFFFu), len, world) != rank) flag[i] = 0;
 }
 
+// owner rank per installed hit + identity index (input of the stable partition by owner)
+__global__ void __launch_bounds__(256) owner_key_kernel(uint64_t n, const uint32_t *hq, const uint32_t *ht, const uint32_t *len, uint32_t world,
+                                                        uint32_t *okey, uint32_t *idx, unsigned long long *count /* world */) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t o = pair_owner(hq[i], ht[i], len, world);
+        okey[i] = o;
+        idx[i] = (uint32_t)i;
+        // one atomic per wave and owner: the lanes of a wave that share an owner elect a leader
+        for (uint32_t w = 0; w < world; w++) {
+            const unsigned long long m = __ballot(o == w);
+            if (m && (threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1) atomicAdd(count + w, (unsigned long long)__popcll(m));
+        }
+    }
+}
+__global__ void __launch_bounds__(256) owner_gather_kernel(uint64_t n, const uint32_t *idx, const uint32_t *hq, const uint32_t *ht, const int32_t *hs,
+                                                           const int32_t *hd, uint32_t *oq, uint32_t *ot, int32_t *os, int32_t *od) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t j = idx[i];
+        oq[i] = hq[j]; ot[i] = ht[j]; os[i] = hs[j]; od[i] = hd[j];
+    }
+}
+
 static inline dim3 grid_for(uint64_t n, uint32_t cap = 16384) {
     const uint64_t b = (n + 255) / 256;
     return dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(b, cap)));
@@ -1192,6 +1214,7 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
     n_hits = 0;
     alns_valid = false;
     clear_edges();
+    const uint64_t sims_before = stats.n_sim_kmers;   // stats accumulate over calls: the byte count below needs THIS call's share
 
     if (n > (1u << 24)) fail(UC_ERR_GENERIC, "prefilter: %u sequences exceed the 2^24 limit of the hit keys", n);
     // counters: [0] similar k-mers, [1] kept candidates, [2] ungapped overlap residues, [3] run cursor,
@@ -1632,8 +1655,8 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
                 UC_HIP(hipMemcpyAsync(&lf, d_flag.p + (kept - 1), 4, hipMemcpyDeviceToHost, stream));
                 UC_HIP(hipStreamSynchronize(stream));
                 const uint64_t add = lp + lf;
-                d_hq.grow_preserve(n_hits + add, n_hits); d_ht.grow_preserve(n_hits + add, n_hits);
-                d_hs.grow_preserve(n_hits + add, n_hits); d_hd.grow_preserve(n_hits + add, n_hits);
+                d_hq.grow_preserve(n_hits + add, n_hits, stream); d_ht.grow_preserve(n_hits + add, n_hits, stream);
+                d_hs.grow_preserve(n_hits + add, n_hits, stream); d_hd.grow_preserve(n_hits + add, n_hits, stream);
                 hipLaunchKernelGGL(hit_scatter_kernel, grid_for(kept), dim3(256), 0, stream, d_skey2.p, d_cd2.p, (uint64_t)kept, d_flag.p, d_pos.p,
                                    d_hq.p + n_hits, d_ht.p + n_hits, d_hs.p + n_hits, d_hd.p + n_hits);
                 n_hits += add;
@@ -1658,7 +1681,7 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
     const uint64_t ungapped_bytes = ovl + 16ull * n_cand_total;   // (overlap + 16) B per candidate, SURVEY.md 8(d)
     stats.n_kmer_hits += n_hits_total;
     stats.n_candidates += n_cand_total;
-    stats.algorithmic_bytes[UC_ST_KMER] += 8ull * stats.n_sim_kmers + 6ull * n_hits_total + 8ull * n_cand_total;
+    stats.algorithmic_bytes[UC_ST_KMER] += 8ull * (stats.n_sim_kmers - sims_before) + 6ull * n_hits_total + 8ull * n_cand_total;
     stats.algorithmic_bytes[UC_ST_UNGAPPED] += ungapped_bytes;
     stats.algorithmic_bytes[UC_ST_SELECT] += 16ull * n_cand_total;
     stats.stage_seconds[UC_ST_KMER] += t_kmer;
@@ -1676,6 +1699,35 @@ void Engine::export_hits_dev(uint32_t *dq, uint32_t *dt, int32_t *ds, int32_t *d
     UC_HIP(hipMemcpyAsync(ds, d_hs.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
     UC_HIP(hipMemcpyAsync(dd, d_hd.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
     UC_HIP(hipStreamSynchronize(stream));
+}
+
+// Multi-GPU phase 2: the engine's (merged, truncated) lists regrouped by the rank that owns each pair.  The partition is a
+// STABLE radix sort on ceil(log2 world) bits, so every owner's segment keeps the list order (query, score desc, target asc).
+// dq..dd: caller-owned device arrays of n_hits elements; counts[world] on the host.
+void Engine::partition_hits_by_owner(uint32_t world, uint32_t *dq, uint32_t *dt, int32_t *ds, int32_t *dd, uint64_t *counts) {
+    for (uint32_t w = 0; w < world; w++) counts[w] = 0;
+    if (!n_hits) return;
+    if (n_hits >= (1ull << 32)) fail(UC_ERR_GENERIC, "partition_hits_by_owner: %llu records exceed the 32-bit index", (unsigned long long)n_hits);
+    UC_HIP(hipSetDevice(device));
+    if (!pre) pre = take_prefilter_scratch(device);
+    DevBuf<uint32_t> &okey = pre->d_cq, &okey2 = pre->d_ct, &idx = pre->d_flag, &idx2 = pre->d_cnt;
+    DevBuf<unsigned long long> cnt;
+    DevBuf<char> &tmp = pre->d_temp;
+    okey.reserve(n_hits); okey2.reserve(n_hits); idx.reserve(n_hits); idx2.reserve(n_hits); cnt.reserve(world);
+    UC_HIP(hipMemsetAsync(cnt.p, 0, (size_t)world * 8, stream));
+    hipLaunchKernelGGL(owner_key_kernel, grid_for(n_hits), dim3(256), 0, stream, n_hits, d_hq.p, d_ht.p, ddb.len, world, okey.p, idx.p, cnt.p);
+    unsigned bits = 1;
+    while ((1u << bits) < world) bits++;
+    size_t tb = 0;
+    UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, okey.p, okey2.p, idx.p, idx2.p, (size_t)n_hits, 0u, bits, stream));
+    tmp.reserve(tb + 256);
+    UC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, okey.p, okey2.p, idx.p, idx2.p, (size_t)n_hits, 0u, bits, stream));
+    hipLaunchKernelGGL(owner_gather_kernel, grid_for(n_hits), dim3(256), 0, stream, n_hits, idx2.p, d_hq.p, d_ht.p, d_hs.p, d_hd.p, dq, dt, ds, dd);
+    std::vector<unsigned long long> hc(world);
+    UC_HIP(hipMemcpyAsync(hc.data(), cnt.p, (size_t)world * 8, hipMemcpyDeviceToHost, stream));
+    UC_HIP(hipStreamSynchronize(stream));
+    UC_HIP(hipGetLastError());
+    for (uint32_t w = 0; w < world; w++) counts[w] = hc[w];
 }
 
 uint64_t Engine::import_hits_dev(uint64_t n_in, const uint32_t *dq, const uint32_t *dt, const int32_t *ds, const int32_t *dd,

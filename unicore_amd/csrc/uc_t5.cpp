@@ -83,13 +83,25 @@ void gguf_read_header(const std::string &path, GgufFile &g) {
             else for (uint64_t k = 0; k < cnt; k++) (void)read_scalar(r, et);
         } else g.kv_num[key] = read_scalar(r, type);
     }
-    if (g.kv_num.count("general.alignment")) alignment = (uint64_t)g.kv_num["general.alignment"];
+    if (g.kv_num.count("general.alignment")) {
+        const double a = g.kv_num["general.alignment"];
+        if (!(a >= 1 && a <= 65536) || ((uint64_t)a & ((uint64_t)a - 1))) fail(UC_ERR_IO, "%s: general.alignment %g is not a power of two in [1, 65536]", path.c_str(), a);
+        alignment = (uint64_t)a;
+    }
+    if (n_tensors > (1u << 20)) fail(UC_ERR_IO, "%s: %llu tensors?", path.c_str(), (unsigned long long)n_tensors);
     for (uint64_t i = 0; i < n_tensors; i++) {
         GgufTensor t;
         t.name = r.str();
         const uint32_t nd = r.get<uint32_t>();
         if (nd > 4) fail(UC_ERR_IO, "GGUF: tensor %s has %u dimensions", t.name.c_str(), nd);
-        for (uint32_t d = 0; d < nd; d++) t.ne.push_back(r.get<uint64_t>());
+        uint64_t elems = 1;
+        for (uint32_t d = 0; d < nd; d++) {
+            const uint64_t e = r.get<uint64_t>();
+            // zero dims and products beyond 2^40 elements are not weights of this model: reject before any size arithmetic can wrap
+            if (e == 0 || e > (1ull << 40) || elems > (1ull << 40) / e) fail(UC_ERR_IO, "GGUF: tensor %s has an empty or absurd shape", t.name.c_str());
+            elems *= e;
+            t.ne.push_back(e);
+        }
         t.type = r.get<uint32_t>();
         t.offset = r.get<uint64_t>();
         g.tensors.push_back(t);
@@ -98,8 +110,8 @@ void gguf_read_header(const std::string &path, GgufFile &g) {
     g.data_offset = (pos + alignment - 1) / alignment * alignment;
     for (const GgufTensor &t : g.tensors) {
         if (t.type > 1) fail(UC_ERR_IO, "GGUF: tensor %s has ggml type %u; this loader reads F32 and F16 (prostt5-f16.gguf)", t.name.c_str(), t.type);
-        const uint64_t bytes = t.n_elems() * (t.type == 0 ? 4 : 2);
-        if (g.data_offset + t.offset + bytes > m.n) fail(UC_ERR_IO, "GGUF: tensor %s reaches beyond the end of the file", t.name.c_str());
+        const uint64_t bytes = t.n_elems() * (t.type == 0 ? 4 : 2);     // <= 2^42: cannot wrap
+        if (g.data_offset > m.n || t.offset > m.n - g.data_offset || bytes > m.n - g.data_offset - t.offset) fail(UC_ERR_IO, "GGUF: tensor %s reaches beyond the end of the file", t.name.c_str());
     }
 }
 
@@ -164,6 +176,7 @@ void T5Model::load(const std::string &gguf_path, int dev) {
     const std::string arch = g.kv_str.count("general.architecture") ? g.kv_str["general.architecture"] : "t5encoder";
     auto num = [&](const std::string &k, double dflt) { auto it = g.kv_num.find(arch + "." + k); return it == g.kv_num.end() ? dflt : it->second; };
     const GgufTensor *te = find_any(g, {"token_embd.weight", "shared.weight"});
+    if (te->ne.size() != 2 || te->ne[0] > 65536 || te->ne[1] > (1u << 24)) fail(UC_ERR_IO, "%s: token embedding is not a [vocab, d_model] matrix", gguf_path.c_str());
     cfg.d_model = (int)te->ne[0];
     cfg.vocab = (int)te->ne[1];
     cfg.n_layers = (int)num("block_count", 24);
@@ -173,6 +186,10 @@ void T5Model::load(const std::string &gguf_path, int dev) {
     cfg.rel_buckets = (int)num("attention.relative_buckets_count", 32);
     cfg.rel_max_dist = (int)num("attention.relative_max_distance", 128);
     cfg.eps = (float)num("attention.layer_norm_epsilon", num("attention.layer_norm_rms_epsilon", 1e-6));
+    if (cfg.n_layers < 1 || cfg.n_layers > 1024 || cfg.n_heads < 1 || cfg.rel_buckets < 2 || cfg.rel_buckets % 2 || cfg.rel_max_dist < 2 || cfg.d_ff < 64)
+        fail(UC_ERR_IO, "%s: implausible encoder geometry (%d layers, %d heads, %d buckets, d_ff %d)", gguf_path.c_str(), cfg.n_layers, cfg.n_heads, cfg.rel_buckets, cfg.d_ff);
+    if (const char *e = getenv("UC_T5_EOS_IN_HEAD")) cfg.eos_in_head = atoi(e) != 0;
+    if (const char *e = getenv("UC_T5_KEEP_UZOB")) cfg.uzob_to_x = atoi(e) == 0;
     if (cfg.d_kv != 128) fail(UC_ERR_ARGS, "ProstT5 encoder: head size %d not supported (the attention kernel is built for d_kv = 128)", cfg.d_kv);
     if (cfg.d_model % 64 || cfg.d_ff % 64 || (cfg.n_heads * cfg.d_kv) % 64) fail(UC_ERR_ARGS, "ProstT5 encoder: model dimensions must be multiples of 64");
 
@@ -183,6 +200,10 @@ void T5Model::load(const std::string &gguf_path, int dev) {
         if (t->type == 0) memcpy(v.data(), src, v.size() * 4);
         else for (size_t i = 0; i < v.size(); i++) { uint16_t h; memcpy(&h, src + 2 * i, 2); v[i] = half_to_float(h); }
         return v;
+    };
+    auto want_vec = [&](const GgufTensor *t, uint64_t n) {
+        if (t->n_elems() != n) fail(UC_ERR_IO, "%s: tensor %s has %llu elements, expected %llu", gguf_path.c_str(), t->name.c_str(), (unsigned long long)t->n_elems(), (unsigned long long)n);
+        return t;
     };
     auto up_f32 = [&](const std::vector<float> &v) { float *p = (float *)dev_alloc(v.size() * 4); UC_HIP(hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice)); return p; };
     // matrix [rows, cols] (ggml ne = [cols, rows]) -> f16 on the device at dst (row-major, cols contiguous)
@@ -223,10 +244,10 @@ void T5Model::load(const std::string &gguf_path, int dev) {
         L.wo = dev_alloc((size_t)D * HD * 2); up_f16_into(o, L.wo);
         L.wi = dev_alloc((size_t)F * D * 2); up_f16_into(wi, L.wi);
         L.wo2 = dev_alloc((size_t)D * F * 2); up_f16_into(wo, L.wo2);
-        L.attn_norm = up_f32(host_f32(an));
-        L.ffn_norm = up_f32(host_f32(fn));
+        L.attn_norm = up_f32(host_f32(want_vec(an, (uint64_t)D)));
+        L.ffn_norm = up_f32(host_f32(want_vec(fn, (uint64_t)D)));
     }
-    final_norm = up_f32(host_f32(find_any(g, {"enc.output_norm.weight", "encoder.final_layer_norm.weight"})));
+    final_norm = up_f32(host_f32(want_vec(find_any(g, {"enc.output_norm.weight", "encoder.final_layer_norm.weight"}), (uint64_t)D)));
     {   // relative attention bias of block 0 (T5 shares it across blocks): stored [bucket][head] (an Embedding) -> [head][bucket]
         const GgufTensor *rb = find_any(g, {"enc.blk.0.attn_rel_b.weight", "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"});
         const std::vector<float> v = host_f32(rb);
@@ -240,11 +261,13 @@ void T5Model::load(const std::string &gguf_path, int dev) {
     {   // 3Di CNN head: conv1 [hidden, d_model, k], conv2 [n_out, hidden, k] (torch Conv1d / Conv2d (k,1) weight order)
         const GgufTensor *c1 = find_any(g, {"cnn.conv1.weight", "cnn.classifier.0.weight", "classifier.0.weight"}), *b1 = find_any(g, {"cnn.conv1.bias", "cnn.classifier.0.bias", "classifier.0.bias"}),
                          *c2 = find_any(g, {"cnn.conv2.weight", "cnn.classifier.3.weight", "classifier.3.weight"}), *b2 = find_any(g, {"cnn.conv2.bias", "cnn.classifier.3.bias", "classifier.3.bias"});
+        if (b1->n_elems() < 1 || b1->n_elems() > 4096 || b2->n_elems() < 1 || b2->n_elems() > 21 || c1->n_elems() < b1->n_elems() * (uint64_t)D)
+            fail(UC_ERR_IO, "%s: unexpected CNN head shapes", gguf_path.c_str());
         const std::vector<float> w1 = host_f32(c1), w2 = host_f32(c2);
         cfg.cnn_hidden = (int)b1->n_elems();
         cfg.n_out = (int)b2->n_elems();
         cfg.cnn_kernel = (int)(c1->n_elems() / ((uint64_t)cfg.cnn_hidden * D));
-        if ((uint64_t)cfg.cnn_hidden * D * cfg.cnn_kernel != c1->n_elems() || (uint64_t)cfg.n_out * cfg.cnn_hidden * cfg.cnn_kernel != c2->n_elems() || cfg.n_out > 21)
+        if (cfg.cnn_kernel < 1 || cfg.cnn_kernel > 31 || !(cfg.cnn_kernel & 1) || (uint64_t)cfg.cnn_hidden * D * cfg.cnn_kernel != c1->n_elems() || (uint64_t)cfg.n_out * cfg.cnn_hidden * cfg.cnn_kernel != c2->n_elems() || cfg.n_out > 21)
             fail(UC_ERR_IO, "%s: unexpected CNN head shapes", gguf_path.c_str());
         const int C1 = cfg.cnn_hidden, KW = cfg.cnn_kernel;
         ldc1 = (KW * C1 + 127) / 128 * 128;
@@ -283,8 +306,9 @@ void T5Model::load(const std::string &gguf_path, int dev) {
         for (int i = 0; order[i]; i++) aa_token[(int)order[i]] = 3 + i;
         cfg.prefix_token = (int)(g.kv_num.count("prostt5.prefix_token_id") ? g.kv_num["prostt5.prefix_token_id"] : std::min(149, cfg.vocab - 1));
     }
-    for (int c = 'a'; c <= 'z'; c++) aa_token[c] = aa_token[c - 32];
     const int x = aa_token['X'] >= 0 ? aa_token['X'] : cfg.unk_token;
+    if (cfg.uzob_to_x) for (char c : {'U', 'Z', 'O', 'B'}) aa_token[(int)c] = x;     // predict_3Di: rare residues are read as X
+    for (int c = 'a'; c <= 'z'; c++) aa_token[c] = aa_token[c - 32];
     for (int c = 0; c < 256; c++) if (aa_token[c] < 0) aa_token[c] = x;
     if (g_verbosity >= 3) fprintf(stderr, "ProstT5 encoder: %s: %d layers, d_model %d, %d heads x %d, d_ff %d, vocab %d, CNN %d->%d->%d (k=%d), device %d\n", gguf_path.c_str(), cfg.n_layers,
          cfg.d_model, cfg.n_heads, cfg.d_kv, cfg.d_ff, cfg.vocab, cfg.d_model, cfg.cnn_hidden, cfg.n_out, cfg.cnn_kernel, device);
@@ -367,7 +391,7 @@ void T5Model::encode_batch(const std::vector<const std::string *> &seqs, std::ve
     }
     t5_rmsnorm(hidden, final_norm, xn, T, D, cfg.eps, stream);
     t5_gemm(0, xn, w_conv1, ycnn, T, ldc1, D, stream);
-    t5_cnn_head(ycnn, ldc1, d_seq_of, d_seq_off, b_conv1, w_conv2, b_conv2, h1, d_codes, out_logits ? logits : nullptr, T, cfg.cnn_hidden, cfg.cnn_kernel, cfg.n_out, stream);
+    t5_cnn_head(ycnn, ldc1, d_seq_of, d_seq_off, b_conv1, w_conv2, b_conv2, h1, d_codes, out_logits ? logits : nullptr, T, cfg.cnn_hidden, cfg.cnn_kernel, cfg.n_out, cfg.eos_in_head, stream);
     UC_HIP(hipEventRecord(ev[1], stream));
     std::vector<uint8_t> codes((size_t)T);
     std::vector<float> lg;

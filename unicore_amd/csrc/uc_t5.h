@@ -17,6 +17,10 @@ struct T5Config {
     float eps = 1e-6f;
     int cnn_hidden = 32, cnn_kernel = 7, n_out = 20;
     int prefix_token = 149, eos_token = 1, unk_token = 2;      // "<AA2fold>", "</s>", "<unk>"
+    // head convention (EXT-UNVERIFIED for Foldseek; default = ProstT5's published predict_3Di script on one sequence): </s> is attended
+    // by the encoder but its final hidden state is masked to zero before the CNN, and U/Z/O/B are read as X.
+    // UC_T5_EOS_IN_HEAD=1 / UC_T5_KEEP_UZOB=1 select the other reading (the r2 behaviour of this library).
+    int eos_in_head = 0, uzob_to_x = 1;
 };
 
 struct T5AttnTile { int32_t tok0, len, q0; int64_t poff; };    // sequence start token, its length, first query row of the workgroup (128 rows), start of the sequence in vt
@@ -48,7 +52,7 @@ void t5_rmsnorm(const float *x, const float *w, void *y, int T, int D, float eps
 void t5_attention(const void *qkv, void *vt, size_t Tp, const T5VtTile *vt_tiles, int n_vt_tiles, const T5AttnTile *tiles, int n_tiles, const float *bias,
                   int bias_span, int H, void *out, hipStream_t s);
 void t5_cnn_head(const void *y, int ldy, const int32_t *seq_of, const int32_t *seq_off, const float *b1, const float *w2, const float *b2, float *h1,
-                 uint8_t *codes, float *logits, int T, int C1, int KW, int NO, hipStream_t s);
+                 uint8_t *codes, float *logits, int T, int C1, int KW, int NO, int eos_in_head, hipStream_t s);
 void t5_f32_to_f16(const float *x, void *y, size_t n, hipStream_t s);
 
 // ---- the model on one GPU ------------------------------------------------------------------------------------------------------

@@ -499,9 +499,11 @@ void t5_attention(const void *qkv, void *vt, size_t Tp, const T5VtTile *vt_tiles
 // token's own sequence with zero padding at both ends: ProstT5 slices the <AA2fold> prefix off BEFORE the CNN
 // (predict_3Di: residue_embedding[:, 1:]), so the first residue sees zeros on its left, the last one sees </s>.
 __global__ void __launch_bounds__(256) t5_conv_h1_kernel(const _Float16 *__restrict__ y, int ldy, const int32_t *__restrict__ seq_of, const int32_t *__restrict__ seq_off,
-                                                         const float *__restrict__ b1, float *__restrict__ h1, int T, int C1, int KW) {
+                                                         const float *__restrict__ b1, float *__restrict__ h1, int T, int C1, int KW, int eos_in_head) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)T * C1; i += (size_t)gridDim.x * 256) {
-        const int t = (int)(i / C1), c = (int)(i % C1), s = seq_of[t], lo = seq_off[s] + 1, hi = seq_off[s + 1];
+        // taps reach the residues only; </s> (the last token of the sequence) contributes its hidden state only in the r2 convention —
+        // by default it is masked to zero before the head (its OWN position still gets a conv1 output that conv2 sees)
+        const int t = (int)(i / C1), c = (int)(i % C1), s = seq_of[t], lo = seq_off[s] + 1, hi = seq_off[s + 1] - (eos_in_head ? 0 : 1);
         float a = b1[c];
         for (int k = 0; k < KW; k++) {
             const int u = t + k - KW / 2;
@@ -533,9 +535,9 @@ __global__ void __launch_bounds__(256) t5_conv2_argmax_kernel(const float *__res
     }
 }
 void t5_cnn_head(const void *y, int ldy, const int32_t *seq_of, const int32_t *seq_off, const float *b1, const float *w2, const float *b2, float *h1,
-                 uint8_t *codes, float *logits, int T, int C1, int KW, int NO, hipStream_t s) {
+                 uint8_t *codes, float *logits, int T, int C1, int KW, int NO, int eos_in_head, hipStream_t s) {
     if (T <= 0) return;
-    hipLaunchKernelGGL(t5_conv_h1_kernel, dim3((unsigned)std::min<size_t>(((size_t)T * C1 + 255) / 256, 65535)), dim3(256), 0, s, (const _Float16 *)y, ldy, seq_of, seq_off, b1, h1, T, C1, KW);
+    hipLaunchKernelGGL(t5_conv_h1_kernel, dim3((unsigned)std::min<size_t>(((size_t)T * C1 + 255) / 256, 65535)), dim3(256), 0, s, (const _Float16 *)y, ldy, seq_of, seq_off, b1, h1, T, C1, KW, eos_in_head);
     hipLaunchKernelGGL(t5_conv2_argmax_kernel, dim3((T + 255) / 256), dim3(256), 0, s, h1, seq_of, seq_off, w2, b2, codes, logits, T, C1, KW, NO);
 }
 
