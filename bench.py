@@ -99,6 +99,20 @@ def real_foldseek():
     return None, None
 
 
+def usable_cores():
+    """threads worth starting: the affinity mask, capped by the cgroup CPU quota if there is one (a container that sees 256 CPUs
+    may be allowed a fraction of them)"""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(per) + 0.5))
+    except Exception:
+        pass
+    return (min(cores, quota) if quota else cores), cores, quota
+
+
 def cpu_baseline(prefix, opts, n_seqs, target_seconds=20.0):
     """CPU legs timed on this host's cores, on a bounded random query sample of the same workload (E2-E6 of the sampled
     queries against the FULL k-mer index; index build charged pro rata):
@@ -106,11 +120,13 @@ def cpu_baseline(prefix, opts, n_seqs, target_seconds=20.0):
                    target) pairs;
       kind "simd": the same pipeline with the gapped stage as inter-sequence SIMD (16 targets of one query per AVX2
                    register, int16, query profile) — what a competent CPU implementation does (oracle/uc_simd.c).
-    Both process the identical pair list, so alignments/s compare one to one with the GPU figure."""
+    Both process the identical pair list, so alignments/s compare one to one with the GPU figure.  The SIMD leg also reports
+    its gapped stage in GCUPS: one thread alone (the per-core figure a CPU person would quote) and all threads together —
+    their ratio is the number of cores the box really gives this process (hyperthreads, quotas and neighbours included)."""
     from oracle import oracle_py as O
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import util
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores, affinity, quota = usable_cores()
     p = util.oracle_params(O, opts)
     odb = O.OracleDb(prefix)
     t0 = time.time()
@@ -123,6 +139,13 @@ def cpu_baseline(prefix, opts, n_seqs, target_seconds=20.0):
         if kind == "simd" and not hasattr(O, "simd_sample_run"):
             continue
         run = O.sample_run if kind == "port" else O.simd_sample_run
+        extra = {}
+        if kind == "simd":   # one thread alone: GCUPS per core of the gapped stage
+            O.simd_cells()
+            n0 = min(n_seqs, 48)
+            _, _, ta0 = run(odb, ix, p, order[n_seqs - n0:], threads=1)
+            c0 = O.simd_cells()
+            extra["gapped_gcups_one_thread"] = c0[0] / ta0 / 1e9 if ta0 > 0 else 0.0
         n1 = min(n_seqs, max(64, 2 * cores))                               # calibration sample
         a1, tp1, ta1 = run(odb, ix, p, order[:n1], threads=cores)
         rate = (tp1 + ta1) / max(n1, 1)
@@ -131,17 +154,27 @@ def cpu_baseline(prefix, opts, n_seqs, target_seconds=20.0):
         n2 = max(n2, 20 * cores - n1)
         n2 = max(0, min(n2, n_seqs - n1))
         a2, tp2, ta2 = (0, 0.0, 0.0)
+        if kind == "simd":
+            O.simd_cells()
         if n2 > 0:
             a2, tp2, ta2 = run(odb, ix, p, order[n1:n1 + n2], threads=cores)
         # rate from the large sample alone (the calibration run also pays thread start-up and cold caches)
         nq, aln, tp, ta = (n2, a2, tp2, ta2) if n2 > 0 else (n1, a1, tp1, ta1)
+        if kind == "simd" and n2 > 0:
+            cu, cs = O.simd_cells()
+            extra["gapped_gcups_all_threads"] = cu / ta / 1e9 if ta > 0 else 0.0
+            extra["gapped_cells"] = cu
+            extra["lane_fill"] = cu / cs if cs else 0.0
+            g1 = extra.get("gapped_gcups_one_thread", 0.0)
+            extra["effective_cores"] = extra["gapped_gcups_all_threads"] / g1 if g1 > 0 else None
         t = tp + ta + t_index * nq / n_seqs
-        out.append({"value": aln / t if t > 0 else 0.0, "unit": "alignments/s", "cores": cores, "kind": kind,
+        out.append(dict({"value": aln / t if t > 0 else 0.0, "unit": "alignments/s", "cores": cores, "kind": kind,
+                    "threads_started": cores, "cpus_in_affinity_mask": affinity, "cgroup_cpu_quota": quota,
                     "implementation": ("oracle/uc_oracle.c (scalar C restatement of the spec, gcc -O3 -march=x86-64-v3, OpenMP dynamic)" if kind == "port" else
                                        "oracle/uc_simd.c (AVX2 inter-sequence int16 Smith-Waterman, 16 targets per register, + the oracle's prefilter; OpenMP dynamic)"),
                     "foldseek": ("%s (%s)" % (fs_path, fs_version)) if fs_path else "not available — the CPU baseline is this repository's own code, not Foldseek",
                     "sample": "%d of %d queries (random, seed 12345, %.1f per thread): %d gapped alignments; prefilter %.2fs + gapped %.2fs "
-                              "+ pro-rata index build %.3fs of %.2fs" % (nq, n_seqs, nq / cores, aln, tp, ta, t_index * nq / n_seqs, t_index)})
+                              "+ pro-rata index build %.3fs of %.2fs" % (nq, n_seqs, nq / cores, aln, tp, ta, t_index * nq / n_seqs, t_index)}, **extra))
     O.free_index(ix)
     return out
 
@@ -441,7 +474,8 @@ def main():
             "sw_dp_runs_per_step": st["n_sw_runs"] // steps_,
             "exchange_rank0_s_per_step": st["exchange_seconds"] / steps_, "exchange_bytes_per_step_all_ranks": xbytes // steps_,
             "counts_rank0_per_step": {k: st[k] // steps_ for k in ("n_index_entries", "n_sim_kmers", "n_kmer_hits", "n_filtered_hits", "n_candidates", "n_prefilter_hits",
-                                                                   "n_gapped_alignments", "n_start_alignments", "n_pk_reruns", "n_edges")},
+                                                                   "n_gapped_alignments", "n_start_alignments", "n_pk_reruns")},
+            "edges_last_step": st["n_edges"],
         }
         if world > 1:
             out["phases_max_over_ranks_s_per_step"] = {k: v / steps_ for k, v in zip(U.PHASES, st["phase_seconds"])}
@@ -481,7 +515,7 @@ def main():
             best = max(cb, key=lambda d: d["value"])
             out["cpu_baseline"] = best                       # the faster CPU leg is THE baseline ...
             out["cpu_baselines"] = cb                        # ... both are reported
-    if world == 1 and args.config == "c2" and not custom and not args.no_sub_records:
+    if world == 1 and args.config == "c2" and not custom and not args.no_sub_records and not args.no_extra_legs:
         U.lib().uc_release_scratch()
         subs = {}
         # north_star's quoted 1-GPU target size (BASELINE configs[2] on one GPU): ONE timed pass, its own roofline and CPU sample

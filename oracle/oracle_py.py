@@ -335,6 +335,13 @@ def simd_sample_run(odb, ix, p, queries, threads=0, records=False):
     return int(n), sec[0], sec[1], cnt, hits, alns
 
 
+def simd_cells():
+    """(useful, swept) DP cells of the SIMD gapped stage since the last call (resets the counters)"""
+    out = (C.c_uint64 * 2)()
+    lib().uco_simd_cells(out)
+    return int(out[0]), int(out[1])
+
+
 def align_pair(odb, p, q, t, min_score):
     """the scalar oracle's E5/E6 record for one pair"""
     out = np.zeros(1, ALN_DTYPE)

@@ -36,6 +36,14 @@ typedef struct {
 
 typedef struct { int32_t score, qend, tend; } res_t;
 
+/* DP cells of the alignments handed to sw_batch16 (rows x columns of every lane's own problem: what a GCUPS figure divides),
+ * and cells the 16-lane batches actually swept (padding to the longest lane included); bench.py reads and resets them */
+static uint64_t g_cells_useful, g_cells_swept;
+void uco_simd_cells(uint64_t out[2]) {
+    out[0] = __atomic_exchange_n(&g_cells_useful, 0, __ATOMIC_RELAXED);
+    out[1] = __atomic_exchange_n(&g_cells_swept, 0, __ATOMIC_RELAXED);
+}
+
 /* one batch: query (q3,qa,lq; rev_q reads it backwards) against up to 16 lanes.  out[l] = (score, qend, tend) with qend
  * counted from the lane's first unmasked row. */
 static void sw_batch16(const uint8_t *q3, const uint8_t *qa, int lq, int rev_q, const lane_t *ln, int nl, const uco_params *p,
@@ -43,6 +51,12 @@ static void sw_batch16(const uint8_t *q3, const uint8_t *qa, int lq, int rev_q, 
     int maxlt = 0, r0 = lq;
     for (int l = 0; l < nl; l++) { if (ln[l].lt > maxlt) maxlt = ln[l].lt; if (ln[l].skip < r0) r0 = ln[l].skip; }
     if (nl == 0 || maxlt == 0) { for (int l = 0; l < nl; l++) { out[l].score = 0; out[l].qend = -1; out[l].tend = -1; } return; }
+    {
+        uint64_t useful = 0;
+        for (int l = 0; l < nl; l++) useful += (uint64_t)(lq - ln[l].skip) * (uint64_t)ln[l].lt;
+        __atomic_fetch_add(&g_cells_useful, useful, __ATOMIC_RELAXED);
+        __atomic_fetch_add(&g_cells_swept, (uint64_t)(lq - r0) * (uint64_t)maxlt * L, __ATOMIC_RELAXED);
+    }
     const __m256i vopen = _mm256_set1_epi16((short)p->gap_open), vext = _mm256_set1_epi16((short)p->gap_ext);
     const __m256i vzero = _mm256_setzero_si256(), vneg = _mm256_set1_epi16(-16000);
     int16_t skipv[L];
