@@ -516,7 +516,7 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
                 } else {
                     const GridCell g = grid_cell(E.h_len, W, p.target_shards, r);
                     {
-                        Turn turn(C);
+                        Turn turn(C, &E);
                         Timer tp;
                         E.prefilter(g.tb, g.te, g.qb, g.qe);
                         E.stats.phase_seconds[0] += tp.seconds();
@@ -529,7 +529,7 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
                 }
                 phase("hits", rr);
                 {
-                    Turn turn(C);
+                    Turn turn(C, &E);
                     Timer ta;
                     E.align(0, m);
                     E.stats.phase_seconds[5] += ta.seconds();
@@ -538,7 +538,7 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
                 std::vector<uint32_t> all;
                 Timer te;
                 uint64_t n_acc = 0;                  // accepted pairs of the round (all ranks)
-                if (W > 1) { C.gather_edges(E, all); n_acc = all.size() / 2; E.stats.exchange_seconds += te.seconds(); E.stats.phase_seconds[6] += te.seconds(); }
+                if (W > 1) { C.gather_edges(E, all); n_acc = all.size() / 2; E.stats.exchange_seconds += te.seconds(); }
                 else n_acc = E.edges_on_host ? E.edges.size() / 2 : E.n_edges_dev;
                 if (r == 0) {
                     Timer tc;

@@ -169,6 +169,15 @@ void Engine::upload_sub_db(const std::vector<uint32_t> &cur, const std::vector<u
     finish_db_install(tm);
 }
 
+void Engine::drop_scratch() {
+    UC_HIP(hipSetDevice(device));
+    UC_HIP(hipStreamSynchronize(stream));
+    // parked, not freed: the next virtual rank on this device takes the same buffers (one set per device), so no rank pays for
+    // tens of GB of hipMalloc inside its timed phase
+    if (pre) { park_prefilter_scratch(pre, device); pre = nullptr; }
+    if (aln) { park_align_scratch(aln, device); aln = nullptr; }
+}
+
 void Engine::ungapped_batch(uint64_t n, const uint32_t *q, const uint32_t *t, const int32_t *diag, int32_t *out) {
     if (!have_db) fail(UC_ERR_ARGS, "no database loaded");
     if (n == 0) return;

@@ -148,6 +148,7 @@ struct Engine {
                        double *density_out = nullptr);   // one target chunk
     PrefilterScratch *pre = nullptr;                       // work buffers kept between prefilter calls
     AlignScratch *aln = nullptr;                           // ... and between align calls
+    void drop_scratch();                                   // frees both (results stay): virtual-rank emulation, memory pressure
     uint64_t prefilter_chunk_residues = 96ull << 20;   // target residues per index chunk (keeps hits/query inside the LDS filter)
     void set_hits(const uint32_t *counts, const uc_hit *h, bool check_max_seqs = true);
     void get_hits(uc_hit *out) const;                        // D2H of the device hit arrays

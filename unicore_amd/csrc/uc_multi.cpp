@@ -173,6 +173,7 @@ void Comm::gather_edges(Engine &E, std::vector<uint32_t> &out) {
     if (grp) {   // threads of one process: rank 0 reads its peers' host vectors ("edges are copied D2H per GPU ... the host runs set cover once")
         grp->ptr[(size_t)rank] = &E.edges;
         grp->barrier();
+        Timer tg;   // phase 6 = the gather itself; the wait for the slowest rank's gapped stage above belongs to that rank's phase 5
         if (rank == 0) {
             size_t tot = 0;
             for (int r = 0; r < world; r++) tot += ((const std::vector<uint32_t> *)grp->ptr[(size_t)r])->size();
@@ -183,9 +184,11 @@ void Comm::gather_edges(Engine &E, std::vector<uint32_t> &out) {
             }
         }
         grp->barrier();
+        E.stats.phase_seconds[6] += tg.seconds();
         return;
     }
     // one process per GPU: sizes, then every rank sends its list to rank 0 (grouped point-to-point over xGMI)
+    Timer tg;
     std::vector<uint64_t> sz((size_t)world);
     all_gather_u64(E, E.edges.size(), sz.data());
     CommScratch &S = *scratch;
@@ -214,6 +217,7 @@ void Comm::gather_edges(Engine &E, std::vector<uint32_t> &out) {
         if (tot > mine) UC_HIP(hipMemcpyAsync(out.data() + mine, S.e_recv.p + mine, (tot - mine) * 4, hipMemcpyDeviceToHost, E.stream));
     }
     UC_HIP(hipStreamSynchronize(E.stream));
+    E.stats.phase_seconds[6] += tg.seconds();
 }
 
 // ---------------------------------------------------------------------------------------------- grid plan
@@ -370,14 +374,16 @@ uint64_t exchange_hits(Engine &E, Comm &C) {
         C.all_to_all_dev(E, 4, snd, soff.data(), scnt.data(), rcv, roff.data(), rcnt.data());
         E.stats.exchange_bytes += 16 * (R - rcnt[(size_t)me]);
         t_x1 += tx.seconds();
-        Timer tg;
         if (rounds == 1) {
-            Turn turn(C);
+            Turn turn(C, &E);
+            Timer tg;      // (started inside the turn: waiting for the other virtual ranks' turns is not this rank's time)
             E.import_hits_dev(R, (uint32_t *)S.all.p, (uint32_t *)S.all.p + R, S.all.p + 2 * R, S.all.p + 3 * R, 0, 1);
+            t_merge += tg.seconds();
         } else {
             // the engine's own lists are still the send side of the later rounds: merge into a side engine state is not available, so
             // the round's slice is merged in place of a scratch copy — park own lists, merge, append, restore
-            Turn turn(C);
+            Turn turn(C, &E);
+            Timer tg;
             const uint64_t nloc = E.n_hits;
             S.own.reserve(4 * std::max<uint64_t>(nloc, 1));
             if (nloc) E.export_hits_dev((uint32_t *)S.own.p, (uint32_t *)S.own.p + nloc, S.own.p + 2 * nloc, S.own.p + 3 * nloc);
@@ -407,20 +413,23 @@ uint64_t exchange_hits(Engine &E, Comm &C) {
             } else {
                 E.import_hits_dev(nacc, (uint32_t *)S.acc.p, (uint32_t *)S.acc.p + acc_cap, S.acc.p + 2 * acc_cap, S.acc.p + 3 * acc_cap, 0, 1);
             }
+            t_merge += tg.seconds();
         }
-        t_merge += tg.seconds();
     }
     E.stats.phase_seconds[1] += t_x1;
     E.stats.phase_seconds[2] += t_merge;
 
     // ---- phase 2: pairs to their owners
-    Timer t3;
     const uint64_t K = E.n_hits;
     S.pad.reserve(4 * std::max<uint64_t>(K, 1));
+    double t_part = 0;
     {
-        Turn turn(C);
+        Turn turn(C, &E);
+        Timer tp;
         E.partition_hits_by_owner((uint32_t)W, (uint32_t *)S.pad.p, (uint32_t *)S.pad.p + K, S.pad.p + 2 * K, S.pad.p + 3 * K, scnt.data());
+        t_part = tp.seconds();
     }
+    Timer t3;
     uint64_t o = 0;
     for (int p = 0; p < W; p++) { soff[(size_t)p] = o; o += scnt[(size_t)p]; }
     C.all_gather_u64s(E, scnt.data(), W, mat.data());
@@ -433,14 +442,14 @@ uint64_t exchange_hits(Engine &E, Comm &C) {
         C.all_to_all_dev(E, 4, snd, soff.data(), scnt.data(), rcv, roff.data(), rcnt.data());
     }
     E.stats.exchange_bytes += 16 * (R2 - rcnt[(size_t)me]);
-    E.stats.phase_seconds[3] += t3.seconds();
-    Timer t4;
+    E.stats.phase_seconds[3] += t3.seconds() + t_part;
     uint64_t kept;
     {
-        Turn turn(C);
+        Turn turn(C, &E);
+        Timer t4;
         kept = E.import_hits_dev(R2, (uint32_t *)S.all.p, (uint32_t *)S.all.p + R2, S.all.p + 2 * R2, S.all.p + 3 * R2, 0, 1);
+        E.stats.phase_seconds[4] += t4.seconds();
     }
-    E.stats.phase_seconds[4] += t4.seconds();
     E.stats.exchange_seconds += tm.seconds();
     return kept;
 }
@@ -451,7 +460,7 @@ uint64_t cluster_step(Engine &E, Comm &C, int target_shards, uint32_t *assign) {
     const uint32_t n = E.hdb.n;
     const GridCell g = grid_cell(E.h_len, C.world, target_shards, C.rank);
     {
-        Turn turn(C);
+        Turn turn(C, &E);
         Timer tp;
         E.prefilter(g.tb, g.te, g.qb, g.qe);
         E.stats.phase_seconds[0] += tp.seconds();
@@ -459,7 +468,7 @@ uint64_t cluster_step(Engine &E, Comm &C, int target_shards, uint32_t *assign) {
     uint64_t n_aln = E.n_hits;
     if (C.world > 1 || C.nccl) n_aln = exchange_hits(E, C);
     {
-        Turn turn(C);
+        Turn turn(C, &E);
         Timer ta;
         E.align(0, n);
         E.stats.phase_seconds[5] += ta.seconds();
@@ -477,7 +486,6 @@ uint64_t cluster_step(Engine &E, Comm &C, int target_shards, uint32_t *assign) {
     Timer te;
     C.gather_edges(E, all);
     E.stats.exchange_seconds += C.world > 1 ? te.seconds() : 0.0;
-    E.stats.phase_seconds[6] += te.seconds();
     if (C.rank == 0) {
         if (!assign && n) fail(UC_ERR_ARGS, "cluster_step: rank 0 needs an assignment buffer");
         Timer tc;

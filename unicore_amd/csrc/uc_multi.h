@@ -76,8 +76,10 @@ struct Comm {
 // so that a rank's phase_seconds are what it would measure with a GPU of its own (tools/critical_path.py)
 struct Turn {
     LocalGroup *g;
-    explicit Turn(Comm &C) : g(C.grp && C.grp->serialize ? C.grp : nullptr) { if (g) g->turn.lock(); }
-    ~Turn() { if (g) g->turn.unlock(); }
+    Engine *e = nullptr;
+    explicit Turn(Comm &C, Engine *E = nullptr) : g(C.grp && C.grp->serialize ? C.grp : nullptr), e(E) { if (g) g->turn.lock(); }
+    // eight engines' work buffers do not fit one GPU at BASELINE configs[2] size: a rank gives its scratch back at the end of its turn
+    ~Turn() { if (g) { if (e) e->drop_scratch(); g->turn.unlock(); } }
     Turn(const Turn &) = delete;
     Turn &operator=(const Turn &) = delete;
 };

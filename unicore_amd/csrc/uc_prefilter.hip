@@ -557,9 +557,11 @@ __global__ void __launch_bounds__(256) expand_kernel(const DeviceDb db, uint32_t
 // Every key of a real multi-hit diagonal survives, plus a few collisions which the exact diagonal count after the sort
 // discards again.  The region is sized by the query's exact hit total (from sim_runs), so nothing can overflow.
 constexpr int FB_LOG2 = 19;            // bits per bitmap: 2 x 64 KiB of the CU's 160 KiB LDS
-constexpr int FT = 1024;               // threads per workgroup = runs per tile
+constexpr int FT = 1024;               // threads per workgroup
 constexpr int KPT = 4;                 // consecutive keys per thread and binary search
-constexpr size_t FILTER_LDS = 2 * ((size_t)1 << FB_LOG2) / 8 + (FT + 1) * 4 + FT * 4 + FT * 4 + 16 * 4 + 64;
+// runs per tile = RPT x FT.  RPT = 2 (r4): half as many tile hand-overs (three workgroup barriers and the drain of 16 waves each) per
+// query; the prefix search takes 11 probes instead of 10
+constexpr size_t filter_lds(int rpt) { return 2 * ((size_t)1 << FB_LOG2) / 8 + ((size_t)rpt * FT + 1) * 4 + (size_t)rpt * FT * 8 + 16 * 4 + 64; }
 
 // first run of every query of the batch (runs are sorted by query position): qr[i] = lower_bound(rpidx, off[qbegin + i] - p0),
 // i = 0..nq.  One thread per query here instead of two serial ~25-step searches at the head of every filter workgroup
@@ -587,7 +589,9 @@ __global__ void __launch_bounds__(256) run_order_key_kernel(uint32_t nq, const u
 template <bool C> struct TdType { using type = uint64_t; };
 template <> struct TdType<true> { using type = uint32_t; };
 
-template <bool C>
+// BB (r4): blocked Bloom filter — both hash positions of a key lie in ONE 64-bit word, so marking a key is one ds_or_rtn_b64 (plus a
+// second one for the few positions that were already set) instead of two dependent 32-bit atomic pairs in two unrelated banks
+template <bool C, int RPT, bool BB>
 __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t qbegin, uint32_t p0, const uint32_t *rpidx,
                                                     const uint64_t *rval, const uint64_t *qr, const uint32_t *order, const void *ent, KeyFmt fmt,
                                                     unsigned long long *region_cursor, void *region_v, uint64_t region_cap,
@@ -601,11 +605,12 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
     TD *region = (TD *)region_v;
     extern __shared__ __attribute__((aligned(16))) uint32_t f_lds[];
     constexpr int BW = 1 << (FB_LOG2 - 5);          // words per bitmap
+    constexpr int TR = RPT * FT;                    // runs per tile
     uint32_t *B1 = f_lds, *B2 = f_lds + BW;
-    uint32_t *s_pref = f_lds + 2 * BW;                          // FT + 1 (hits of one query < 2^32: checked by the host)
-    uint32_t *s_e0 = s_pref + FT + 1;                           // FT
-    int32_t *s_i = (int32_t *)(s_e0 + FT);                      // FT
-    uint32_t *s_wsum = (uint32_t *)(s_i + FT);                  // 16
+    unsigned long long *B1w = (unsigned long long *)B1, *B2w = (unsigned long long *)B2;     // blocked variant: 8192 words per bitmap
+    uint2 *s_run = (uint2 *)(f_lds + 2 * BW);                   // TR: {first index entry - prefix, query position + bias}: ONE 8-byte read per key
+    uint32_t *s_pref = (uint32_t *)(s_run + TR);                // TR + 1 (hits of one query < 2^32: checked by the host)
+    uint32_t *s_wsum = s_pref + TR + 1;                         // 16
     uint64_t *s_misc = (uint64_t *)(((uintptr_t)(s_wsum + 16) + 7) & ~(uintptr_t)7);   // [0] r0, [1] r1, [2] region base, [3] cursors (2 x u32)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t qi = order[blockIdx.x];                      // query of this workgroup (index inside the batch)
@@ -622,21 +627,24 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
     // loads one tile of runs, leaves the exclusive prefix of their lengths in s_pref[0..FT] (s_pref[FT] = total)
     // the run of the NEXT tile is fetched while the current one is expanded (the loads' latency would otherwise sit between
     // two barriers with nothing else to run: one workgroup per CU)
-    uint64_t pf_rv = 0;
-    uint32_t pf_pi = 0;
-    auto prefetch_tile = [&](uint64_t tile) {
-        const uint64_t r = tile + tid;
-        if (r < r1) { pf_rv = rval[r]; pf_pi = rpidx[r]; }
+    uint64_t pf_rv[RPT] = {};
+    uint32_t pf_pi[RPT] = {};
+    auto prefetch_tile = [&](uint64_t tile) {      // thread tid owns runs tile + RPT * tid .. + RPT - 1 (consecutive: the prefix stays a plain scan)
+#pragma unroll
+        for (int j = 0; j < RPT; j++) {
+            const uint64_t r = tile + (uint64_t)RPT * tid + j;
+            if (r < r1) { pf_rv[j] = rval[r]; pf_pi[j] = rpidx[r]; }
+        }
     };
     auto load_tile = [&](uint64_t tile) {
-        const uint64_t r = tile + tid;
-        uint32_t c = 0;
-        if (r < r1) {
-            c = (uint32_t)(pf_rv >> 32);
-            s_e0[tid] = (uint32_t)pf_rv;
-            s_i[tid] = (int32_t)(pf_pi - plo) + fmt.dbias;
+        uint32_t c[RPT], csum = 0;
+#pragma unroll
+        for (int j = 0; j < RPT; j++) {
+            const uint64_t r = tile + (uint64_t)RPT * tid + j;
+            c[j] = r < r1 ? (uint32_t)(pf_rv[j] >> 32) : 0u;
+            csum += c[j];
         }
-        uint32_t inc = c;
+        uint32_t inc = csum;
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t up = (uint32_t)__shfl_up((int)inc, o, 64);
             if (lane >= o) inc += up;
@@ -645,8 +653,14 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
         __syncthreads();
         uint32_t woff = 0;
         for (int w = 0; w < wv; w++) woff += s_wsum[w];
-        s_pref[tid] = woff + inc - c;
-        if (tid == FT - 1) s_pref[FT] = woff + inc;
+        uint32_t pre = woff + inc - csum;
+#pragma unroll
+        for (int j = 0; j < RPT; j++) {
+            s_pref[RPT * tid + j] = pre;
+            s_run[RPT * tid + j] = make_uint2((uint32_t)pf_rv[j] - pre, (uint32_t)((int32_t)(pf_pi[j] - plo) + fmt.dbias));
+            pre += c[j];
+        }
+        if (tid == FT - 1) s_pref[TR] = pre;
         __syncthreads();
     };
     // keys k4 .. k4+KPT-1 of the current tile: one binary search finds the run of the first key; every run holds at least
@@ -656,14 +670,15 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
     auto locate = [&](uint32_t k4, uint32_t T, uint32_t (&idx)[KPT], int32_t (&si)[KPT]) -> int {
         int lo = 0;
 #pragma unroll
-        for (int step = FT / 2; step >= 1; step >>= 1)            // FT = 2^10: ten probes
+        for (int step = TR / 2; step >= 1; step >>= 1)            // TR = 2^10 / 2^11: ten / eleven probes
             if (s_pref[lo + step] <= k4) lo += step;
         const int n = k4 >= T ? 0 : (T - k4 < (uint32_t)KPT ? (int)(T - k4) : KPT);
 #pragma unroll
         for (int i = 0; i < KPT; i++) {
             if (i > 0 && i < n) lo += (s_pref[lo + 1] <= k4 + i) ? 1 : 0;
-            idx[i] = s_e0[lo] + (k4 + i - s_pref[lo]);
-            si[i] = s_i[lo];
+            const uint2 rr = s_run[lo];
+            idx[i] = rr.x + (k4 + i);
+            si[i] = (int32_t)rr.y;
         }
 #pragma unroll
         for (int i = 1; i < KPT; i++) if (i >= n) { idx[i] = idx[0]; si[i] = si[0]; }
@@ -691,6 +706,38 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
         h2 = ((x ^ (x >> 15)) * 0x846CA68Bu) >> (32 - FB_LOG2);
         return (x * 0x2C1B3C6Du) >> (32 - FB_LOG2);
     };
+    // blocked variant: word (13 bits) and two bit positions inside it from one multiplicative hash
+    auto word_of = [&](uint64_t td, unsigned long long &mask) -> uint32_t {
+        const uint32_t x = (uint32_t)td * 0x9E3779B1u ^ (uint32_t)(td >> 32) * 0x85EBCA6Bu;
+        const uint32_t y = (x ^ (x >> 15)) * 0x846CA68Bu;
+        mask = (1ull << (y >> 26)) | (1ull << ((y >> 20) & 63u));
+        return (x * 0x2C1B3C6Du) >> (32 - (FB_LOG2 - 6));
+    };
+    auto mark1 = [&](uint64_t td) {
+        if (BB) {
+            unsigned long long mk;
+            const uint32_t w = word_of(td, mk);
+            const unsigned long long again = atomicOr(&B1w[w], mk) & mk;
+            if (again) atomicOr(&B2w[w], again);
+        } else {
+            uint32_t g;
+            const uint32_t h = slot_of(td, g), bit = 1u << (h & 31), gbit = 1u << (g & 31);
+            const uint32_t old = atomicOr(&B1[h >> 5], bit);
+            if (old & bit) atomicOr(&B2[h >> 5], bit);
+            const uint32_t gold = atomicOr(&B1[g >> 5], gbit);
+            if (gold & gbit) atomicOr(&B2[g >> 5], gbit);
+        }
+    };
+    auto twice1 = [&](uint64_t td) -> uint32_t {
+        if (BB) {
+            unsigned long long mk;
+            const uint32_t w = word_of(td, mk);
+            return (B2w[w] & mk) == mk ? 1u : 0u;
+        }
+        uint32_t g;
+        const uint32_t h = slot_of(td, g);
+        return ((B2[h >> 5] >> (h & 31)) & (B2[g >> 5] >> (g & 31))) & 1u;
+    };
 
     // the query's region: its exact hit total is the sum of its run lengths; reserve it first (rounded up to KPT keys)
     {
@@ -714,22 +761,17 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
     uint32_t total = 0;
     lap(0);                                  // clear + region reservation
     prefetch_tile(r0);
-    for (uint64_t tile = r0; tile < r1; tile += FT) {
+    for (uint64_t tile = r0; tile < r1; tile += TR) {
         load_tile(tile);
         lap(1);                              // tile loads + scan
-        prefetch_tile(tile + FT);
-        const uint32_t T = s_pref[FT];
+        prefetch_tile(tile + TR);
+        const uint32_t T = s_pref[TR];
         using ET = typename std::conditional<C, uint32_t, uint64_t>::type;
         auto mark_store = [&](TD4 &td, int n, uint32_t k4) {
 #pragma unroll
             for (int i = 0; i < KPT; i++) {
                 if (i >= n) { td.v[i] = td.v[0]; continue; }
-                uint32_t g;
-                const uint32_t h = slot_of(td.v[i], g), bit = 1u << (h & 31), gbit = 1u << (g & 31);
-                const uint32_t old = atomicOr(&B1[h >> 5], bit);
-                if (old & bit) atomicOr(&B2[h >> 5], bit);
-                const uint32_t gold = atomicOr(&B1[g >> 5], gbit);
-                if (gold & gbit) atomicOr(&B2[g >> 5], gbit);
+                mark1(td.v[i]);
             }
             const uint64_t w = base + total + k4;
             if (n && w + KPT <= region_cap) {
@@ -784,11 +826,8 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
 #pragma unroll
         for (int g2 = 0; g2 < 2; g2++)
 #pragma unroll
-            for (int i = 0; i < KPT; i++) {
-                uint32_t g;
-                const uint32_t h = slot_of(td[g2].v[i], g);
-                if (i < nn[g2]) keep |= (((B2[h >> 5] >> (h & 31)) & (B2[g >> 5] >> (g & 31))) & 1u) << (KPT * g2 + i);
-            }
+            for (int i = 0; i < KPT; i++)
+                if (i < nn[g2]) keep |= twice1(td[g2].v[i]) << (KPT * g2 + i);
         // wave-level compaction by ballots (the order of the survivors is irrelevant: they get sorted): rank of key j of
         // this lane = survivors of keys < j over the whole wave + survivors of key j in the lanes below
         uint32_t rank[2 * KPT];
@@ -826,7 +865,20 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
         h2 = ((x ^ (x >> 13)) * 0x165667B1u) >> (32 - FB_LOG2);
         return (x * 0x9E3779B1u) >> (32 - FB_LOG2);
     };
+    auto word2_of = [&](uint64_t key, unsigned long long &mask) -> uint32_t {
+        const uint32_t x = (uint32_t)key * 0xC2B2AE35u ^ (uint32_t)(key >> 32) * 0x27D4EB2Fu;
+        const uint32_t y = (x ^ (x >> 13)) * 0x165667B1u;
+        mask = (1ull << (y >> 26)) | (1ull << ((y >> 20) & 63u));
+        return (x * 0x9E3779B1u) >> (32 - (FB_LOG2 - 6));
+    };
     for (uint32_t k = tid; k < n1; k += FT) {
+        if (BB) {
+            unsigned long long mk;
+            const uint32_t w = word2_of(surv[base + k], mk);
+            const unsigned long long again = atomicOr(&B1w[w], mk) & mk;
+            if (again) atomicOr(&B2w[w], again);
+            continue;
+        }
         uint32_t g;
         const uint32_t h = slot2_of(surv[base + k], g), bit = 1u << (h & 31), gbit = 1u << (g & 31);
         const uint32_t old = atomicOr(&B1[h >> 5], bit);
@@ -841,9 +893,15 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
         bool keep = false;
         if (k < n1) {
             key = surv[base + k];
-            uint32_t g;
-            const uint32_t h = slot2_of(key, g);
-            keep = ((B2[h >> 5] >> (h & 31)) & (B2[g >> 5] >> (g & 31))) & 1u;
+            if (BB) {
+                unsigned long long mk;
+                const uint32_t w = word2_of(key, mk);
+                keep = (B2w[w] & mk) == mk;
+            } else {
+                uint32_t g;
+                const uint32_t h = slot2_of(key, g);
+                keep = ((B2[h >> 5] >> (h & 31)) & (B2[g >> 5] >> (g & 31))) & 1u;
+            }
         }
         const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
         if (m) {
@@ -1547,16 +1605,32 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
                 UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, S.d_okey.p, S.d_okey2.p, S.d_oidx.p, S.d_order.p, (size_t)nq, 0u, 32u, stream));
                 temp_reserve(tb);
                 UC_HIP(rocprim::radix_sort_pairs(d_temp.p, tb, S.d_okey.p, S.d_okey2.p, S.d_oidx.p, S.d_order.p, (size_t)nq, 0u, 32u, stream));
-                if (fmt.compact) {
-                    static PerDeviceOnce once;
-                    once([&] { UC_HIP(hipFuncSetAttribute((const void *)filter_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FILTER_LDS)); });
-                    hipLaunchKernelGGL(filter_kernel<true>, dim3(nq), dim3(FT), FILTER_LDS, stream, ddb, qa, qp0, d_rpidx2.p, d_rval2.p, S.d_qr.p, S.d_order.p, ent_p, fmt,
-                                       d_counters.p + 5, (void *)d_keys.p, region_cap, d_qbase.p, d_qsurv.p, prof_p);
-                } else {
-                    static PerDeviceOnce once;
-                    once([&] { UC_HIP(hipFuncSetAttribute((const void *)filter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FILTER_LDS)); });
-                    hipLaunchKernelGGL(filter_kernel<false>, dim3(nq), dim3(FT), FILTER_LDS, stream, ddb, qa, qp0, d_rpidx2.p, d_rval2.p, S.d_qr.p, S.d_order.p, ent_p, fmt,
-                                       d_counters.p + 5, (void *)d_keys.p, region_cap, d_qbase.p, d_qsurv.p, prof_p);
+                {
+                    // variants for A/B runs: UC_FILTER_VARIANT = 0 (r3: 1024-run tiles, two independent hash positions), 1 (2048-run tiles),
+                    // 2 (blocked Bloom), 3 (both, default)
+                    static const int variant = getenv("UC_FILTER_VARIANT") ? atoi(getenv("UC_FILTER_VARIANT")) : 3;
+                    auto launch = [&](auto kern, int rpt) {
+                        static PerDeviceOnce once[8];
+                        const int slot = (fmt.compact ? 4 : 0) + (variant & 3);
+                        once[slot]([&] { UC_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter_lds(rpt))); });
+                        hipLaunchKernelGGL(kern, dim3(nq), dim3(FT), filter_lds(rpt), stream, ddb, qa, qp0, d_rpidx2.p, d_rval2.p, S.d_qr.p, S.d_order.p, ent_p, fmt,
+                                           d_counters.p + 5, (void *)d_keys.p, region_cap, d_qbase.p, d_qsurv.p, prof_p);
+                    };
+                    if (fmt.compact) {
+                        switch (variant & 3) {
+                            case 0: launch(filter_kernel<true, 1, false>, 1); break;
+                            case 1: launch(filter_kernel<true, 2, false>, 2); break;
+                            case 2: launch(filter_kernel<true, 1, true>, 1); break;
+                            default: launch(filter_kernel<true, 2, true>, 2); break;
+                        }
+                    } else {
+                        switch (variant & 3) {
+                            case 0: launch(filter_kernel<false, 1, false>, 1); break;
+                            case 1: launch(filter_kernel<false, 2, false>, 2); break;
+                            case 2: launch(filter_kernel<false, 1, true>, 1); break;
+                            default: launch(filter_kernel<false, 2, true>, 2); break;
+                        }
+                    }
                 }
                 if (prof_p) {
                     unsigned long long hp[8];

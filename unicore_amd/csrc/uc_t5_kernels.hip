@@ -257,7 +257,13 @@ static void t5_gemm256_launch(const void *A, const void *W, void *out, int M, in
 
 void t5_gemm(int epi, const void *A, const void *W, void *out, int M, int N, int K, hipStream_t s) {
     if (M <= 0) return;
-    static const int big = getenv("UC_T5_GEMM256") ? atoi(getenv("UC_T5_GEMM256")) : 1;
+    // UC_T5_GEMM256: 0 = 128 x 128 tile only, 1 = 256 x 256 tile with 8 waves of 128 x 64 (r3), 2 (default) = 256 x 256 tile with 4 waves of
+    // 128 x 128 and the accumulators in AGPRs (uc_t5_gemm4w.hip).  All three sum K in the same order: bit-identical results.
+    static const int big = getenv("UC_T5_GEMM256") ? atoi(getenv("UC_T5_GEMM256")) : 2;
+    if (big >= 2 && M >= 2048 && N % HBN_ == 0 && (size_t)M * K * 2 < (1ull << 32) && (size_t)N * K * 2 < (1ull << 32)) {
+        t5_gemm4w(epi, A, W, out, M, N, K, s);
+        return;
+    }
     if (big && M >= 2048 && N % HBN_ == 0) {     // large batches: the 256 x 256 tile (small ones would leave most CUs without a tile)
         if (epi == 0) t5_gemm256_launch<0>(A, W, out, M, N, K, s);
         else if (epi == 1) t5_gemm256_launch<1>(A, W, out, M, N, K, s);
