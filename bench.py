@@ -47,7 +47,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # the engine's 8 streams nee
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0            # ... and the measured copy bandwidth of the same guide
 VALU_PEAK_LANE_OPS = 39.3e12     # int32/packed VALU: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz — measured: every VALU instruction of the
-                                 # SW kernel occupies its SIMD for 4 cycles (profiles/r1b_pmc_sw.txt, tools/ubench/valu_rate.hip)
+                                 # SW kernel occupies its SIMD for 4 cycles (profiles/round1/r1b_pmc_sw.txt, tools/ubench/valu_rate.hip)
 VALU_OPS_PER_CELL = 5.9          # static ISA count of the packed kernel's step loop at C2's class mix
 
 CONFIGS = {
@@ -446,7 +446,7 @@ def main():
                          "launches": st["sw_kernel_launches"], "streams": n_streams,
                          "launch_overlap": ("the length classes of a pass run concurrently on %d HIP streams; avg_launch_ms = HIP-event time of the fork/join regions on the engine "
                                             "stream / launches.  With UC_STREAMS=1 the launches are serialized and the per-kernel durations of a rocprofv3 trace add up to that event "
-                                            "time (profiles/*_serial_*)" % n_streams),
+                                            "time (profiles/round2/r3d_serial_summary.txt)" % n_streams),
                          "note": "integer-VALU-bound by design (SURVEY.md 8d): the meaningful fraction is valu_frac = cells_run x valu_ops_per_cell / (kernel s x valu_peak_lane_ops)",
                          "cells_run_per_step": cells_run / steps_, "cells_algorithmic_per_step": cells_alg / steps_,
                          "valu_gcups": cells_run / sw_s / 1e9 if sw_s > 0 else 0.0,

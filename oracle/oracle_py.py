@@ -118,6 +118,15 @@ def default_params(**over):
     lib().uco_params_default(C.byref(p))
     assert lib().uco_load_matrix(data_path("mat3di_synthetic.out").encode(), p.S3) == 0
     assert lib().uco_load_matrix(data_path("blosum62.out").encode(), p.SA) == 0
+    bf3, bfa = over.pop("bit_factor_3di", 0.0), over.pop("bit_factor_aa", 0.0)
+    L = lib()
+    L.uco_rescale_matrix.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    L.uco_matrix_header_lambda.argtypes = [C.c_char_p]
+    L.uco_matrix_header_lambda.restype = C.c_double
+    if bf3 > 0:
+        assert L.uco_rescale_matrix(C.addressof(p.S3), bf3, L.uco_matrix_header_lambda(data_path("mat3di_synthetic.out").encode())) == 0
+    if bfa > 0:
+        assert L.uco_rescale_matrix(C.addressof(p.SA), bfa, L.uco_matrix_header_lambda(data_path("blosum62.out").encode())) == 0
     for k, v in over.items():
         if k == "pattern":
             v = v.encode() if isinstance(v, str) else v

@@ -80,6 +80,40 @@ int uco_load_matrix(const char *path, int8_t out[UCO_A * UCO_A]) {
     return seen_rows >= 20 ? 0 : -3;
 }
 
+/* Optional rule UC-1/M (default off): the integer matrix at `bit_factor` units per bit, from a log-odds matrix whose unit is
+ * 1 / lambda nats: score' = round(bit_factor * lambda * score / ln 2) (what MMseqs2's SubstitutionMatrix does with the bit factors
+ * Foldseek passes for its two tracks: believed 2.1 for 3Di, 1.4 for AA — EXT-UNVERIFIED).  lambda <= 0 means half-bit units. */
+int uco_rescale_matrix(int8_t m[UCO_A * UCO_A], double bit_factor, double lambda) {
+    if (!(bit_factor > 0)) return 0;
+    if (!(lambda > 0)) lambda = log(2.0) / 2.0;
+    for (int i = 0; i < UCO_A * UCO_A; i++) {
+        const long v = lround(bit_factor * lambda * (double)m[i] / log(2.0));
+        if (v < -127 || v > 127) return -1;
+        m[i] = (int8_t)v;
+    }
+    return 0;
+}
+
+/* the "# Lambda ..." header of an MMseqs2 / Foldseek matrix file (value on the same line after ':' or on the next comment line); 0 if none */
+double uco_matrix_header_lambda(const char *path) {
+    FILE *f = fopen(path, "r");
+    if (!f) return 0.0;
+    char line[4096];
+    int next = 0;
+    double out = 0.0;
+    while (fgets(line, sizeof line, f)) {
+        if (line[0] != '#') { if (line[0] != '\n' && line[0] != 0) break; continue; }
+        if (next) { const double v = strtod(line + 1, NULL); if (v > 0 && v < 10) out = v; break; }
+        if (strstr(line, "Lambda")) {
+            const char *c = strchr(line, ':');
+            if (c) { const double v = strtod(c + 1, NULL); if (v > 0 && v < 10) { out = v; break; } }
+            next = 1;
+        }
+    }
+    fclose(f);
+    return out;
+}
+
 /* ------------------------------------------------------------------ DB reader
  * Format witness: /root/reference/src/seq/create_gene_specific_fasta.rs:9-36 (entries "TEXT\n\0",
  * three index-aligned files <db>, <db>_ss, <db>_h); index "key\toffset\tlength" (SURVEY.md App. B). */

@@ -125,6 +125,9 @@ typedef struct uco_counts {
 int  uco_letter_code(char c);
 void uco_params_default(uco_params *p);
 int  uco_load_matrix(const char *path, int8_t out[UCO_A * UCO_A]);
+/* optional rule UC-1/M: score' = round(bit_factor * lambda * score / ln 2); lambda from the file header (0 = half-bit units) */
+int  uco_rescale_matrix(int8_t m[UCO_A * UCO_A], double bit_factor, double lambda);
+double uco_matrix_header_lambda(const char *path);
 
 int  uco_db_read(const char *prefix, uco_db *db);     /* <prefix>, <prefix>_ss, <prefix>_h (+.index) */
 void uco_db_free(uco_db *db);

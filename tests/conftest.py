@@ -12,7 +12,7 @@ if ROOT not in sys.path:
 
 
 # torch bundles its own HIP runtime: load it BEFORE libunicore_cluster.so so the process has one runtime (a second
-# one initialised later reports "No HIP GPUs are available"); bench.py and unicore_amd.dist import torch first too
+# one initialised later reports "No HIP GPUs are available"); bench.py imports torch first too
 try:
     import torch  # noqa: F401
 except Exception:   # pragma: no cover

@@ -1,6 +1,7 @@
-"""The N>1 path on CPU: shard plan, ragged all-gather over torch.distributed (gloo, world_size 2), host merge.
-Per-shard hit lists come from the oracle here (no GPU in this container); the exchange + merge + partition
-code is exactly what bench.py runs with backend "nccl" (= RCCL) on the GPUs."""
+"""The N > 1 path on CPU (no GPU in the build container): the shard plan, the two-phase exchange — shard lists to the query's home
+rank, surviving pairs to their owner rank — and the edge gather run as 2 and 4 `gloo` ranks of tests/dist_model.py, a host-side model
+of unicore_amd/csrc/uc_multi.cpp with the oracle standing in for the HIP kernels.  The same data movement through the real library
+(device buffers, RCCL or device copies) is covered on the GPU box: tests/test_cli_gpu.py (virtual ranks), tests/test_multi_gpu.py."""
 import os
 import socket
 
@@ -9,11 +10,11 @@ import pytest
 
 import util
 import unicore_amd as U
-from unicore_amd import dist as ucdist
+import dist_model as ucdist
 from oracle import oracle_py as O
 
 
-def test_shard_and_query_ranges_are_partitions():
+def test_shard_ranges_are_partitions_and_the_grid_covers_every_cell_once():
     rng = np.random.default_rng(0)
     lens = rng.integers(1, 2000, 1000)
     for w in (1, 2, 3, 4, 8):
@@ -21,32 +22,26 @@ def test_shard_and_query_ranges_are_partitions():
         assert r[0][0] == 0 and r[-1][1] == len(lens) and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
         res = [lens[b:e].sum() for b, e in r]
         assert max(res) - min(res) <= 2 * lens.max()        # ~equal residues per shard
-    cnt = rng.integers(0, 20, 1000).astype(np.uint32)
-    hits = np.zeros(int(cnt.sum()), U.HIT_DTYPE)
-    hits["target"] = rng.integers(0, 1000, len(hits))
-    for w in (1, 2, 4, 8):
-        r = ucdist.query_ranges(lens, cnt, hits, w)
-        assert r[0][0] == 0 and r[-1][1] == len(lens) and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
-
-
-def test_grid_shape_and_ranges():
-    """query groups x target shards: T = 1 while the DB fits one prefilter chunk, target shards where they save whole chunks"""
-    small = np.full(1000, 300)                                   # 300 k residues: one chunk
-    for w in (1, 2, 4, 8):
-        assert ucdist.grid_shape(small, w) == (w, 1)
-        g = ucdist.grid_ranges(small, w)
-        assert len(g) == w and all(x[:2] == (0, 1000) for x in g)
-        assert g[0][2] == 0 and g[-1][3] == 1000 and all(g[i][3] == g[i + 1][2] for i in range(w - 1))
-    big = np.full(1_000_000, 192)                                # 192 M residues: two chunks unsharded, one per half
-    assert ucdist.grid_shape(big, 8) == (4, 2)                   # cost 2 for T = 1 and T = 2: the larger T wins the tie
-    assert ucdist.grid_shape(big, 8, target_shards=8) == (1, 8)
-    g = ucdist.grid_ranges(big, 8)
-    cover = np.zeros((8, 8), int)                                # every (query octile, target octile) cell exactly once
-    for tb, te, qb, qe in g:
-        cover[qb // 125000: -(-qe // 125000), tb // 125000: -(-te // 125000)] += 1
-    assert (cover == 1).all()
+    assert ucdist.grid_shape(8) == (1, 8) and ucdist.grid_shape(8, 2) == (4, 2) and ucdist.grid_shape(8, 1) == (8, 1)     # default: T = N, the north-star layout
     with pytest.raises(ValueError):
-        ucdist.grid_shape(small, 8, target_shards=3)
+        ucdist.grid_shape(8, 3)
+    big = np.full(80_000, 192)
+    for t in (8, 2, 1):
+        cover = np.zeros((8, 8), int)                            # every (query octile, target octile) cell exactly once
+        for tb, te, qb, qe in ucdist.grid_ranges(big, 8, t):
+            cover[qb // 10000: -(-qe // 10000), tb // 10000: -(-te // 10000)] += 1
+        assert (cover == 1).all()
+
+
+def test_pair_owner_puts_mutual_hits_on_one_rank_and_spreads_queries():
+    rng = np.random.default_rng(3)
+    lens = rng.integers(30, 900, 5000)
+    a, b = rng.integers(0, 5000, 20000), rng.integers(0, 5000, 20000)
+    for w in (2, 3, 8):
+        o1, o2 = ucdist.pair_owner(a, b, lens, w), ucdist.pair_owner(b, a, lens, w)
+        assert np.array_equal(o1, o2) and o1.min() >= 0 and o1.max() < w
+        share = np.bincount(o1, minlength=w) / len(a)
+        assert share.max() < 1.3 / w and share.min() > 0.7 / w
 
 
 def test_virtual_shards_merge_equals_unsharded_oracle():
@@ -79,29 +74,32 @@ def _rank_main(rank, world, port, tmpdir, target_shards):
         c, h = O.prefilter_shard(odb, p, tb, te)                      # this rank's shard (stands in for the HIP prefilter)
         c[:qb0] = 0; c[qe0:] = 0                                      # ... restricted to its query group
         flat = np.concatenate([h[q, : c[q]] for q in range(odb.n)]).astype(U.HIT_DTYPE)
-        parts = ucdist.exchange_hits(c, flat, device="cpu")           # the collective
-        mc, mh = ucdist.merged_hits(parts, odb.n, p.max_seqs)
-        qb, qe = ucdist.query_ranges(lens, mc, mh, world)[rank]
-        # accepted edges of this rank's query range (oracle alignment as the stand-in for E5/E6)
+        oc, oh, rx = ucdist.exchange_two_phase(c, flat, lens, p.max_seqs)       # the two exchanges
+        # accepted edges of the pairs this rank owns (oracle alignment as the stand-in for E5/E6)
         import ctypes
-        off = np.concatenate([[0], np.cumsum(mc.astype(np.int64))])
+        off = np.concatenate([[0], np.cumsum(oc.astype(np.int64))])
         edges = []
-        for q in range(qb, qe):
+        for q in range(odb.n):
             ms = O.lib().uco_min_score(p, int(lens[q]), int(lens.sum()))
             for k in range(off[q], off[q + 1]):
                 a = O.Aln()
-                O.lib().uco_align_pair(ctypes.byref(odb.db), q, int(mh["target"][k]), ctypes.byref(p), ms, ctypes.byref(a))
+                O.lib().uco_align_pair(ctypes.byref(odb.db), q, int(oh["target"][k]), ctypes.byref(p), ms, ctypes.byref(a))
                 if a.accepted:
-                    edges.append((q, int(mh["target"][k])))
-        alle = ucdist.gather_edges(np.array(edges, np.uint32).reshape(-1, 2), device="cpu")
-        np.save(os.path.join(tmpdir, "rank%d.npy" % rank), U.setcover(odb.n, alle) if rank == 0 else mc)
-        np.save(os.path.join(tmpdir, "hits%d.npy" % rank), mh)
+                    edges.append((q, int(oh["target"][k])))
+        alle = ucdist.gather_edges(np.array(edges, np.uint32).reshape(-1, 2))
+        if rank == 0:
+            np.save(os.path.join(tmpdir, "assign.npy"), U.setcover(odb.n, alle))
+        np.save(os.path.join(tmpdir, "cnt%d.npy" % rank), oc)
+        np.save(os.path.join(tmpdir, "hits%d.npy" % rank), oh)
+        np.save(os.path.join(tmpdir, "rx%d.npy" % rank), np.array([rx]))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,target_shards", [(2, 2), (2, 1), (4, 2)])      # two target shards / two query groups / a Q2 x T2 grid
-def test_gloo_exchange_matches_single_rank(tmp_path, world, target_shards):
+@pytest.mark.parametrize("world,target_shards", [(2, 0), (2, 1), (4, 2), (4, 0)])      # T = N / two query groups / a Q2 x T2 grid / T = N = 4
+def test_gloo_two_phase_exchange_matches_single_rank(tmp_path, world, target_shards):
+    """over all ranks every pair of the unsharded lists is owned exactly once, with its score and diagonal; mutual hits sit on one
+    rank; the clusters equal the single-rank result"""
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_rank_main, args=(world, port, str(tmp_path), target_shards), nprocs=world, join=True)
@@ -109,13 +107,26 @@ def test_gloo_exchange_matches_single_rank(tmp_path, world, target_shards):
     odb = O.OracleDb(s3=s3, sa=sa)
     p = util.oracle_params(O, "-c 0.8 --max-seqs 5")
     ref = O.cluster(odb, p, threads=2)
-    h0 = np.load(tmp_path / "hits0.npy")
-    for r in range(1, world):
-        assert np.array_equal(h0, np.load(tmp_path / ("hits%d.npy" % r)))                 # every rank holds the same merged lists
-    flat = np.concatenate([ref["hits"][q, : ref["hit_cnt"][q]] for q in range(odb.n)])
-    assert np.array_equal(h0["target"], flat["t"]) and np.array_equal(h0["score"], flat["score"])
-    assert np.array_equal(np.load(tmp_path / "rank1.npy"), ref["hit_cnt"])
-    assert np.array_equal(np.load(tmp_path / "rank0.npy"), ref["assign"])                  # same clusters as 1 rank
+    want = {}
+    for q in range(odb.n):
+        for k in range(int(ref["hit_cnt"][q])):
+            h = ref["hits"][q, k]
+            want[(q, int(h["t"]))] = (int(h["score"]), int(h["diag"]))
+    got, owner_of = {}, {}
+    for r in range(world):
+        oc, oh = np.load(tmp_path / ("cnt%d.npy" % r)), np.load(tmp_path / ("hits%d.npy" % r))
+        qs = np.repeat(np.arange(odb.n), oc)
+        for q, h in zip(qs.tolist(), oh):
+            key = (q, int(h["target"]))
+            assert key not in got, key                                   # owned exactly once
+            got[key] = (int(h["score"]), int(h["diag"]))
+            owner_of[key] = r
+        assert int(np.load(tmp_path / ("rx%d.npy" % r))[0]) > 0 or world == 1
+    assert got == want
+    for (q, t), r in owner_of.items():
+        if (t, q) in owner_of:
+            assert owner_of[(t, q)] == r                                  # mutual hits meet on one rank
+    assert np.array_equal(np.load(tmp_path / "assign.npy"), ref["assign"])     # same clusters as 1 rank
 
 
 def _gather_main(rank, world, port, tmpdir, limit):
@@ -124,7 +135,7 @@ def _gather_main(rank, world, port, tmpdir, limit):
     try:
         ucdist.GATHER_ALL_LIMIT = limit
         mine = (np.arange(2 * (3 + 5 * rank), dtype=np.uint32) + 1000 * rank).reshape(-1, 2)
-        got = ucdist.gather_edges(mine, device="cpu")
+        got = ucdist.gather_edges(mine)
         np.save(os.path.join(tmpdir, "g%d.npy" % rank), got)
     finally:
         dist.destroy_process_group()

@@ -112,7 +112,9 @@ def test_sw_long_query_fallback(O):
 @pytest.mark.parametrize("opts", ["-c 0.8", "-c 0.5 -s 6 --max-seqs 5", "-c 0.8 --cov-mode 1 -e 1e-6 --rev-correction 0",
                                   "-c 0.5 --min-seq-id 0.3", "-c 0.8 --cov-mode 2 --min-seq-id 0.55",
                                   "-c 0.8 --min-diag-hits 1 --k-score 40", "-c 0.7 --min-diag-hits 3 -s 5",
-                                  "-c 0.8 --sym-dedup 0", "-c 0.5 -e 1e-6 --sym-dedup 0 --rev-correction 0"])
+                                  "-c 0.8 --sym-dedup 0", "-c 0.5 -e 1e-6 --sym-dedup 0 --rev-correction 0",
+                                  # optional rule UC-1/M (default off): matrices rescaled by MMseqs2-style bit factors, both sides
+                                  "-c 0.8 --mat-bit-factor-3di 2.1 --mat-bit-factor-aa 1.4", "-c 0.5 --mat-bit-factor-3di 2.1 --min-seq-id 0.3 -s 6"])
 def test_pipeline_stage_parity(O, small, opts):
     """prefilter hit lists, per-pair alignment records, edges and the set cover all equal the oracle's"""
     import unicore_amd as U
@@ -306,7 +308,7 @@ def test_device_exchange_virtual_ranks(O, target_shards):
     the union of the ranks' accepted edges equals the single-GPU edge set."""
     import torch
     import unicore_amd as U
-    from unicore_amd import dist as ucdist
+    import dist_model as ucdist
     s3, sa = util.family_db(29, n_fam=12, members=6, lmin=60, lmax=260)
     off, c3, ca = util.flat(s3, sa)
     lens = np.array([len(x) for x in s3])
@@ -320,7 +322,7 @@ def test_device_exchange_virtual_ranks(O, target_shards):
     assert len(edges_ref) > 50
     W = 3 if target_shards != 2 else 4
     bufs = []
-    assert ucdist.grid_shape(lens, W, target_shards) == (W // target_shards, target_shards)
+    assert ucdist.grid_shape(W, target_shards) == (W // target_shards, target_shards)
     for tb, te, qb, qe in ucdist.grid_ranges(lens, W, target_shards):
         e.prefilter(tb, te, qb, qe)
         n = e.hits_size()

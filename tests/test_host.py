@@ -219,6 +219,22 @@ def test_shim_accepts_flags_anywhere(tmp_path):
         assert r.returncode == 2, (argv, r.returncode, r.stderr)
 
 
+def test_shim_answers_the_weight_download_call(tmp_path):
+    """`foldseek databases ProstT5 <model> <model>/tmp --threads T` (createdb.rs:149-155) is what an unmodified Unicore spawns when
+    <model>/prostt5-f16.gguf is missing: the shim cannot download, so it says where the file has to go and exits non-zero (Unicore then
+    stops with its usual 'Command exited with code' message); with the file in place the call succeeds"""
+    shim = os.path.join(ROOT, "bin", "foldseek")
+    model = tmp_path / "weights"
+    (model / "tmp").mkdir(parents=True)
+    r = subprocess.run([shim, "databases", "ProstT5", str(model), str(model / "tmp"), "--threads", "4"], capture_output=True, text=True)
+    assert r.returncode == 1 and "prostt5-f16.gguf" in r.stderr and "does not download" in r.stderr
+    (model / "prostt5-f16.gguf").write_bytes(b"GGUF")
+    r = subprocess.run([shim, "databases", "ProstT5", str(model), str(model / "tmp"), "--threads", "4"], capture_output=True, text=True)
+    assert r.returncode == 0
+    r = subprocess.run([shim, "databases", "PDB", str(model), str(model / "tmp")], capture_output=True, text=True)
+    assert r.returncode == 2
+
+
 def test_synthetic_matrix_needs_an_explicit_opt_in(tmp_path):
     """the shipped 3Di matrix is a seeded stand-in: without UC_ALLOW_SYNTHETIC=1 (or a real mat3di.out /
     --mat3di) the engine refuses to run instead of clustering with a meaningless matrix"""

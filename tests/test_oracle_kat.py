@@ -413,3 +413,40 @@ print("RESULT", int(r["counts"]["n_alignments"]), int(r["counts"]["n_clusters"])
         assert r.returncode == 0 and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
         outs.append([l for l in r.stdout.splitlines() if l.startswith("RESULT")][0])
     assert outs[0] == outs[1]
+
+
+def test_foldseek_diff_tool_self_test():
+    """tools/foldseek_diff.py — the per-stage differ for the day a real `foldseek` binary is on PATH — parses MMseqs-style
+    result databases and names the first diverging stage: its self-test writes the oracle's dumps as such databases, finds no difference,
+    then finds one planted difference per stage (prefilter, alignment, set cover)"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "foldseek_diff.py"), "--self-test"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "self-test ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "foldseek_diff.py"), "/nonexistent/db", "--foldseek", os.path.join(ROOT, "bin", "foldseek")],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "no real foldseek" in (r.stdout + r.stderr)      # this repository's shim is never mistaken for Foldseek
+
+
+def test_matrix_bit_factor_rule_is_the_same_on_both_sides():
+    """optional rule UC-1/M (default off): matrices rescaled to `bit factor` units per bit from the file's lambda (half-bit units without a
+    header): the oracle's C restatement and the engine's loader give the same integers, and the engine rejects what the oracle would"""
+    import unicore_amd as U
+    p0 = util.oracle_params(O, "-c 0.8")
+    p1 = util.oracle_params(O, "-c 0.8 --mat-bit-factor-3di 2.1 --mat-bit-factor-aa 1.4")
+    s0, s1 = np.array(p0.S3[:], np.int64), np.array(p1.S3[:], np.int64)
+    a0, a1 = np.array(p0.SA[:], np.int64), np.array(p1.SA[:], np.int64)
+    assert np.array_equal(s1, np.sign(s0) * np.floor(np.abs(s0) * 1.05 + 0.5).astype(np.int64))      # lround: half away from zero
+    assert np.array_equal(a1, np.sign(a0) * np.floor(np.abs(a0) * 0.7 + 0.5).astype(np.int64))
+    assert U.check_options("-c 0.8 --mat-bit-factor-3di 2.1 --mat-bit-factor-aa 1.4") == 0
+    assert U.check_options("-c 0.8 --mat-bit-factor-3di 40") != 0
+    L = O.lib()
+    import ctypes as C
+    L.uco_matrix_header_lambda.argtypes = [C.c_char_p]
+    L.uco_matrix_header_lambda.restype = C.c_double
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".out", delete=False) as f:
+        f.write("# 3Di bit/2\n# Background (precision=3):\n# 0.05 0.05\n# Lambda     (precision=3):\n# 0.351568\n   A   C\nA   6  -3\nC  -3   9\n")
+    assert abs(L.uco_matrix_header_lambda(f.name.encode()) - 0.351568) < 1e-9
+    assert L.uco_matrix_header_lambda(O.data_path("blosum62.out").encode()) == 0.0
+    os.unlink(f.name)

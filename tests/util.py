@@ -109,6 +109,8 @@ def oracle_params(O, opts=""):
         elif f == "--rev-correction": kw["rev_correction"] = int(v)
         elif f == "--gap-open": kw["gap_open"] = int(v)
         elif f == "--gap-extend": kw["gap_ext"] = int(v)
+        elif f == "--mat-bit-factor-3di": kw["bit_factor_3di"] = float(v)
+        elif f == "--mat-bit-factor-aa": kw["bit_factor_aa"] = float(v)
         elif f in ("--sw-kernel", "--sym-dedup"): pass      # engine-side execution choices, no effect on results
         else: raise ValueError(f)
         i += 2

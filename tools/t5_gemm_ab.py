@@ -32,7 +32,7 @@ if len(sys.argv) > 3:
 nl = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 ns = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 res = []
-for v in ("2", "1", "0"):
+for v in ("2", "1", "0"):      # "2" only exists in a build that links tools/experiments/uc_t5_gemm4w.hip (otherwise it runs the 8-wave kernel again)
     o = "/tmp/t5_ab_%s.npz" % v
     subprocess.check_call([sys.executable, os.path.abspath(__file__), o, str(nl), str(ns)], env=dict(os.environ, UC_T5_GEMM256=v))
     res.append(np.load(o))

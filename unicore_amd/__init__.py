@@ -1,7 +1,7 @@
 """unicore_amd — ctypes binding of libunicore_cluster.so (the MI355X-native `unicore cluster` engine).
 
 The library is the product; this module only mirrors its C ABI (include/unicore_cluster.h) for Python
-callers (tests, bench.py, the multi-GPU driver in unicore_amd.dist).  There is no Python or CPU
+callers (tests, bench.py).  There is no Python or CPU
 fallback: if the HIP library cannot be loaded, importing `lib()` raises, and on a machine without a
 GPU every compute call returns UC_ERR_DEVICE.
 """

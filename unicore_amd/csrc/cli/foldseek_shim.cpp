@@ -13,10 +13,20 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <string>
 #include <vector>
 
 #include "unicore_cluster.h"
+
+// A one-shot process owes nobody a tidy teardown: every output file is closed by the time a command returns, and unwinding the HIP
+// runtime with tens of GB of parked work buffers costs ~0.1 s of the ~1.2 s an unmodified Unicore waits per `foldseek cluster` spawn
+// (tools/cold_stamps.sh).  Successful commands therefore leave through _exit after flushing the standard streams.
+[[noreturn]] static void leave(int rc) {
+    fflush(stdout);
+    fflush(stderr);
+    _exit(rc);
+}
 
 static int die(int rc) {
     fprintf(stderr, "Error: %s\n", uc_last_error());
@@ -24,7 +34,7 @@ static int die(int rc) {
 }
 
 int main(int argc, char **argv) {
-    if (argc < 2) { fprintf(stderr, "usage: foldseek <cluster|createtsv|search|convertalis|createdb|rmdb|version> ...\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: foldseek <cluster|createtsv|search|convertalis|createdb|databases|rmdb|version> ...\n"); return 2; }
     const std::string cmd = argv[1];
     if (cmd == "version") { puts(uc_version()); return 0; }
     // Flags may appear anywhere (the reference puts them after the positionals, cluster.rs:45-49, but
@@ -72,7 +82,8 @@ int main(int argc, char **argv) {
         memset(&co, 0, sizeof co);
         co.struct_size = sizeof co; co.threads = 1; co.verbosity = cverb; co.device = -1; co.num_gpus = 1;
         int rc = uc_createdb(fp.data(), (int)fp.size(), cpos.back().c_str(), model.c_str(), &co, nullptr);
-        return rc ? die(rc) : 0;
+        if (rc) return die(rc);
+        leave(0);
     }
     uc_opts o;
     memset(&o, 0, sizeof o);
@@ -85,28 +96,44 @@ int main(int argc, char **argv) {
     if (cmd == "cluster") {
         if (pos.size() != 3) { fprintf(stderr, "Error: cluster expects <db> <out_cluster_db> <tmp>\n"); return 2; }
         int rc = uc_cluster(pos[0].c_str(), pos[1].c_str(), pos[2].c_str(), &o, nullptr);
-        return rc ? die(rc) : 0;
+        if (rc) return die(rc);
+        leave(0);
     }
     if (cmd == "createtsv") {
         if (pos.size() != 4) { fprintf(stderr, "Error: createtsv expects <db> <db> <cluster_db> <out.tsv>\n"); return 2; }
         int rc = uc_createtsv(pos[0].c_str(), pos[2].c_str(), pos[3].c_str(), &o);
-        return rc ? die(rc) : 0;
+        if (rc) return die(rc);
+        leave(0);
     }
     if (cmd == "search") {
         if (pos.size() != 4) { fprintf(stderr, "Error: search expects <queryDB> <targetDB> <alnDB> <tmp>\n"); return 2; }
         int rc = uc_search(pos[0].c_str(), pos[1].c_str(), pos[2].c_str(), pos[3].c_str(), &o, nullptr);
-        return rc ? die(rc) : 0;
+        if (rc) return die(rc);
+        leave(0);
     }
     if (cmd == "convertalis") {
         if (pos.size() != 4) { fprintf(stderr, "Error: convertalis expects <queryDB> <targetDB> <alnDB> <out.m8>\n"); return 2; }
         int rc = uc_convertalis(pos[0].c_str(), pos[1].c_str(), pos[2].c_str(), pos[3].c_str(), &o);
-        return rc ? die(rc) : 0;
+        if (rc) return die(rc);
+        leave(0);
+    }
+    if (cmd == "databases") {
+        // `foldseek databases ProstT5 <model> <tmp> --threads T` (createdb.rs:149-155): Unicore calls it when <model>/prostt5-f16.gguf is
+        // missing, to DOWNLOAD the weights.  This engine has no network code: it answers the call with where the file must go.
+        if (pos.size() < 2) { fprintf(stderr, "Error: databases expects <name> <outDir> <tmp>\n"); return 2; }
+        if (pos[0] != "ProstT5") { fprintf(stderr, "Error: database '%s' is not known to this engine (only ProstT5 is ever requested by unicore, createdb.rs:152)\n", pos[0].c_str()); return 2; }
+        const std::string f = pos[1] + "/prostt5-f16.gguf";
+        if (FILE *fp = fopen(f.c_str(), "rb")) { fclose(fp); printf("ProstT5 weights already in place: %s\n", f.c_str()); return 0; }
+        fprintf(stderr, "Error: this engine does not download model weights.  Place the ProstT5 encoder + 3Di head as\n  %s\n"
+                        "(GGUF, F16 / F32 tensors: what `foldseek databases ProstT5 <dir> <tmp>` of a stock Foldseek >= 10 fetches) and run `unicore createdb` again.\n", f.c_str());
+        return 1;
     }
     if (cmd == "rmdb") {
         if (pos.size() != 1) { fprintf(stderr, "Error: rmdb expects <db>\n"); return 2; }
         int rc = uc_rmdb(pos[0].c_str());
-        return rc ? die(rc) : 0;
+        if (rc) return die(rc);
+        leave(0);
     }
-    fprintf(stderr, "Error: sub-command '%s' is not provided by this engine (cluster, createtsv, search, convertalis, rmdb, version)\n", cmd.c_str());
+    fprintf(stderr, "Error: sub-command '%s' is not provided by this engine (cluster, createtsv, search, convertalis, createdb, databases, rmdb, version)\n", cmd.c_str());
     return 2;
 }

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <fstream>
 #include <string>
 #include <thread>
@@ -200,6 +201,9 @@ int main(int argc, char **argv) {
         threads = cpus;
     }
     if (threads <= 0) threads = cpus;
-    if (is_search) return search_run(pos[0], pos[1], pos[2], pos[3], keep, copts, threads);
-    return cluster_run(pos[0], pos[1], pos[2], keep, copts, threads);
+    const int rc = is_search ? search_run(pos[0], pos[1], pos[2], pos[3], keep, copts, threads) : cluster_run(pos[0], pos[1], pos[2], keep, copts, threads);
+    // outputs and the checkpoint are on disk: skip the teardown of the HIP runtime and its parked work buffers (~0.1 s per call)
+    fflush(stdout);
+    fflush(stderr);
+    _exit(rc);
 }

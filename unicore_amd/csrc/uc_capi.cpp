@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <memory>
 #include <thread>
 
@@ -373,15 +374,34 @@ extern "C" {
 int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, const uc_opts *o, uc_stats *stats_out) {
     return guard([&] {
         require(db, "db"); require(out_cluster_db, "out_cluster_db");
+        const bool stamp = getenv("UC_TIMING") != nullptr;
+        auto mark = [&](const char *what) { if (stamp) fprintf(stderr, "unicore-cluster[timing]: t+%7.1f ms  %s\n", 1e3 * g_library_loaded.seconds(), what); };
+        mark("uc_cluster entered");
         Params p = params_from(o);
+        mark("options + matrices");
         if (tmp && *tmp) mkdir_p(tmp);   // callee owns <tmp>; nothing is spilled there yet
         if (p.mat3di_synthetic)
             logf(1, "Warning: clustering with the SYNTHETIC 3Di matrix %s (UC_ALLOW_SYNTHETIC=1): results are not Foldseek's\n", p.mat3di_path.c_str());
 
+        // The HIP runtime and the device context take 0.15-0.3 s to come up in a fresh process (tools/cold_stamps.sh): they are initialised on
+        // a helper thread WHILE this thread reads and encodes the database (a one-shot `foldseek cluster` process pays for both every time).
+        const int want_dev = o && o->device >= 0 ? o->device : 0;
+        std::future<int> warm = std::async(std::launch::async, [want_dev]() -> int {
+            int nd = 0;
+            if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) return 0;
+            if (hipSetDevice(want_dev < nd ? want_dev : 0) == hipSuccess) (void)hipFree(nullptr);      // forces the primary context into existence
+            return nd;
+        });
+        Timer tl;
+        logf(3, "unicore-cluster: reading %s\n", db);
+        HostDb full;
+        read_seq_db(db, full, false);
+        const double t_load = tl.seconds();
+        mark("database read + encoded");
         // ---- devices (one engine + one host thread per GPU, hit lists all-gathered with RCCL)
-        int ndev = 0;
-        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-            fail(UC_ERR_DEVICE, "no HIP device available; this engine has no CPU fallback");
+        const int ndev = warm.get();
+        if (ndev <= 0) fail(UC_ERR_DEVICE, "no HIP device available; this engine has no CPU fallback");
+        mark("HIP runtime + device context ready (initialised beside the database read)");
         int W = p.num_gpus == 0 ? ndev : p.num_gpus;
         std::vector<int> devices;
         bool virtual_gpus = false;
@@ -402,11 +422,7 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
         int gQ = 1, gT = 1;
         grid_shape(W, p.target_shards, &gQ, &gT);
 
-        Timer tl;
-        logf(3, "unicore-cluster: reading %s\n", db);
-        HostDb full;
-        read_seq_db(db, full, false);
-        const double t_load = tl.seconds();
+
         const uint32_t n = full.n;
         if (n == 0) {   // an empty, well-formed database: an empty cluster DB, whatever the workflow
             write_cluster_db(out_cluster_db, full.keys, nullptr, 0);
@@ -438,6 +454,7 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
 
         auto rank_main = [&](int r) {
             Engine E(p, devices[(size_t)r]);
+            if (r == 0) mark("engine constructed (streams, events, matrices on the device)");
             Comm &C = *comms[(size_t)r];
             // test hook: UC_FAIL_RANK="<rank>:<stage>" makes that rank throw (stage 0 = right after its engine exists, 1 = between
             // its prefilter and the exchange) — the failure paths below must turn that into an error code, never into a hang
@@ -463,7 +480,7 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
             const bool timing = getenv("UC_TIMING") != nullptr;
             Timer tph;
             auto phase = [&](const char *what, int rr) {
-                if (timing && r == 0) fprintf(stderr, "unicore-cluster[timing]: round %d %-14s %.1f ms\n", rr, what, 1e3 * tph.seconds());
+                if (timing && r == 0) fprintf(stderr, "unicore-cluster[timing]: t+%7.1f ms  round %d %-14s %.1f ms\n", 1e3 * g_library_loaded.seconds(), rr, what, 1e3 * tph.seconds());
                 tph = Timer();
             };
             for (int rr = 0; rr < p.cluster_steps + pre; rr++) {
@@ -599,6 +616,7 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
         Timer to;
         write_cluster_db(out_cluster_db, full.keys, assign.data(), n);
         st.stage_seconds[UC_ST_OUTPUT] += to.seconds();
+        mark("cluster DB written");
         logf(3, "unicore-cluster: %llu clusters -> %s\n", (unsigned long long)n_clusters, out_cluster_db);
         if (stats_out) *stats_out = st;
     });

@@ -44,6 +44,7 @@ struct Timer {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     double seconds() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
+inline const Timer g_library_loaded;      // started when the shared library's initialisers run: UC_TIMING stamps are relative to it
 
 }  // namespace uc
 

@@ -33,6 +33,39 @@ static bool is_matrix_letter(const std::string &tok) {
     return tok.size() == 1 && (letter_code(tok[0]) < 20 || tok[0] == 'X' || tok[0] == 'x');
 }
 
+// MMseqs2 / Foldseek matrix files carry their scale in comment lines: "# Lambda     (precision=N):" followed by "# <value>" (and the
+// same for "# Background").  Returns the lambda of the file, 0 if it states none.
+double matrix_header_lambda(const std::string &path) {
+    std::ifstream f(path);
+    std::string line;
+    bool next = false;
+    while (std::getline(f, line)) {
+        if (line.empty() || line[0] != '#') { if (!line.empty()) break; continue; }
+        if (next) {
+            const double v = std::strtod(line.c_str() + 1, nullptr);
+            return v > 0 && v < 10 ? v : 0.0;
+        }
+        if (line.find("Lambda") != std::string::npos) {
+            const size_t c = line.find(':');      // value on the same line ("# Lambda: 0.3466") or on the next comment line
+            if (c != std::string::npos) { const double v = std::strtod(line.c_str() + c + 1, nullptr); if (v > 0 && v < 10) return v; }
+            next = true;
+        }
+    }
+    return 0.0;
+}
+
+// score' = round(bit_factor x lambda x score / ln 2): the integer a log-odds matrix in units of 1 / lambda nats becomes at
+// bit_factor units per bit.  Values must stay inside the DP kernels' biased-byte range.
+void rescale_matrix(int8_t m[A * A], double bit_factor, double lambda, const std::string &what) {
+    if (!(bit_factor > 0)) return;
+    if (!(lambda > 0)) lambda = std::log(2.0) / 2.0;
+    for (int i = 0; i < A * A; i++) {
+        const long v = std::lround(bit_factor * lambda * (double)m[i] / std::log(2.0));
+        if (v < -48 || v > 48) fail(UC_ERR_ARGS, "%s: rescaled value %ld outside [-48,48] (bit factor %g)", what.c_str(), v, bit_factor);
+        m[i] = (int8_t)v;
+    }
+}
+
 void load_matrix(const std::string &path, int8_t out[A * A]) {
     std::ifstream f(path);
     if (!f) fail(UC_ERR_IO, "cannot open substitution matrix %s", path.c_str());
@@ -85,7 +118,7 @@ int option_arity(const std::string &f) {
         "--gap-open", "--gap-extend", "--spaced-kmer-pattern", "--rev-correction", "--linclust", "--kmer-per-seq", "--sym-dedup",
         "--sw-kernel", "--evalue-lambda", "--evalue-k", "--mat3di", "--mat-aa", "--cluster-mode", "--cluster-steps",
         "--alignment-type", "--alignment-mode", "--threads", "-v", "--remove-tmp-files", "--db-load-mode", "--compressed",
-        "--gpus", "--target-shards"};
+        "--gpus", "--target-shards", "--mat-bit-factor-3di", "--mat-bit-factor-aa"};
     for (const char *v : valued) if (f == v) return 1;
     if (f == "--single-step-clustering") return 2;
     return -1;
@@ -126,6 +159,8 @@ void parse_cluster_options(const std::string &opts, Params &p) {
         else if (f == "--evalue-k") { p.Kconst = to_double(f, value()); }
         else if (f == "--mat3di") { p.mat3di_path = value(); }
         else if (f == "--mat-aa") { p.mataa_path = value(); }
+        else if (f == "--mat-bit-factor-3di") { p.bit_factor_3di = to_double(f, value()); if (p.bit_factor_3di < 0 || p.bit_factor_3di > 16) fail(UC_ERR_ARGS, "--mat-bit-factor-3di must be in [0,16]"); }
+        else if (f == "--mat-bit-factor-aa") { p.bit_factor_aa = to_double(f, value()); if (p.bit_factor_aa < 0 || p.bit_factor_aa > 16) fail(UC_ERR_ARGS, "--mat-bit-factor-aa must be in [0,16]"); }
         else if (f == "--cluster-mode") { p.cluster_mode = to_int(f, value()); if (p.cluster_mode != 0) fail(UC_ERR_ARGS, "--cluster-mode %d unsupported (only 0 = greedy set cover)", p.cluster_mode); }
         else if (f == "--single-step-clustering") { p.single_step = opt_bool(); p.single_step_given = true; }
         else if (f == "--cluster-steps") { p.cluster_steps = to_int(f, value()); p.cluster_steps_given = true; }
@@ -171,6 +206,8 @@ void finalize_params(Params &p, const std::string &data_dir_in) {
     if (p.mataa_path.empty()) p.mataa_path = dd + "/blosum62.out";
     load_matrix(p.mat3di_path, p.S3);
     load_matrix(p.mataa_path, p.SA);
+    rescale_matrix(p.S3, p.bit_factor_3di, matrix_header_lambda(p.mat3di_path), p.mat3di_path);
+    rescale_matrix(p.SA, p.bit_factor_aa, matrix_header_lambda(p.mataa_path), p.mataa_path);
     p.mat_symmetric = true;
     for (int a = 0; a < A; a++)
         for (int b = 0; b < a; b++)

@@ -19,6 +19,10 @@ struct Params {
     int8_t S3[A * A];
     int8_t SA[A * A];
     std::string mat3di_path, mataa_path;
+    // Optional rule (default off = matrices used verbatim): rescale a loaded matrix the way MMseqs2's SubstitutionMatrix does,
+    // score' = round(bit_factor x log2 odds) = round(bit_factor x lambda x score / ln 2), lambda from the file's "# Lambda" header line
+    // (ln 2 / 2 = half-bit units if the file has none).  Foldseek is believed to use 2.1 for 3Di and 1.4 for AA (EXT-UNVERIFIED).
+    double bit_factor_3di = 0.0, bit_factor_aa = 0.0;
     // prefilter
     std::string pattern = "1101010011";
     int koff[K] = {0, 1, 3, 5, 8, 9};

@@ -1,6 +1,6 @@
 // uc_sw_pk_impl.hpp — packed 16-bit variant of the gapped DP kernel (stage E5; see uc_sw_impl.hpp for the
 // systolic-group design it shares).  The int32 kernel is integer-VALU-bound (every int32 VALU instruction
-// occupies its SIMD for 4 cycles, profiles/r1b_pmc_sw.txt), so the only lever left is instructions per cell:
+// occupies its SIMD for 4 cycles, profiles/round1/r1b_pmc_sw.txt), so the only lever left is instructions per cell:
 // here every DP register holds TWO alignments of the same query (target A in the low, target B in the high
 // 16 bits) and the recurrence runs on v_pk_{add,sub,max}_u16, i.e. ~6.3 VALU ops per cell instead of ~9.7.
 //
@@ -18,7 +18,7 @@
 //  * slot streaming: a "slot" is two consecutive pairs of the task (A, B).  Every lane group pulls its next
 //    slot from an LDS counter as soon as it has finished the previous one, so the groups of a wave do NOT
 //    run in lockstep over the longest of their targets (hit lists mix family members with unrelated hits of
-//    very different lengths; lockstep cost ~40 % of the issued instructions, profiles/r1e).
+//    very different lengths; lockstep cost ~40 % of the issued instructions, profiles/round1/r1e).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -51,7 +51,6 @@ void t5_embed(const int32_t *tok, const void *emb, float *hidden, int T, int D, 
 void t5_rmsnorm(const float *x, const float *w, void *y, int T, int D, float eps, hipStream_t s);
 void t5_attention(const void *qkv, void *vt, size_t Tp, const T5VtTile *vt_tiles, int n_vt_tiles, const T5AttnTile *tiles, int n_tiles, const float *bias,
                   int bias_span, int H, void *out, hipStream_t s);
-void t5_gemm4w(int epi, const void *A, const void *W, void *out, int M, int N, int K, hipStream_t s);   // uc_t5_gemm4w.hip: 256 x 256 tile, 4 waves x (128 x 128), AGPR accumulators
 void t5_cnn_head(const void *y, int ldy, const int32_t *seq_of, const int32_t *seq_off, const float *b1, const float *w2, const float *b2, float *h1,
                  uint8_t *codes, float *logits, int T, int C1, int KW, int NO, int eos_in_head, hipStream_t s);
 void t5_f32_to_f16(const float *x, void *y, size_t n, hipStream_t s);

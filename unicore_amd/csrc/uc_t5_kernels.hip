@@ -257,13 +257,12 @@ static void t5_gemm256_launch(const void *A, const void *W, void *out, int M, in
 
 void t5_gemm(int epi, const void *A, const void *W, void *out, int M, int N, int K, hipStream_t s) {
     if (M <= 0) return;
-    // UC_T5_GEMM256: 0 = 128 x 128 tile only, 1 = 256 x 256 tile with 8 waves of 128 x 64 (r3), 2 (default) = 256 x 256 tile with 4 waves of
-    // 128 x 128 and the accumulators in AGPRs (uc_t5_gemm4w.hip).  All three sum K in the same order: bit-identical results.
-    static const int big = getenv("UC_T5_GEMM256") ? atoi(getenv("UC_T5_GEMM256")) : 2;
-    if (big >= 2 && M >= 2048 && N % HBN_ == 0 && (size_t)M * K * 2 < (1ull << 32) && (size_t)N * K * 2 < (1ull << 32)) {
-        t5_gemm4w(epi, A, W, out, M, N, K, s);
-        return;
-    }
+    // UC_T5_GEMM256: 0 = 128 x 128 tile only, 1 (default) = 256 x 256 tile with 8 waves of 128 x 64 for large batches.  Both sum K in the same
+    // order: bit-identical results.  (r4, measured and NOT kept in the library: a 256 x 256 tile with FOUR waves of 128 x 128 — accumulators in
+    // the 256 AGPRs, 25 % less LDS fragment traffic per FLOP, K loop software-pipelined by hand around one barrier — is bit-identical too but
+    // slower: 693 TFLOP/s for the 24-block encoder against 818 with this kernel and 739 with the 128 x 128 one; one wave per SIMD leaves
+    // nobody to cover that wave's barrier and wait stalls.  Source: tools/experiments/uc_t5_gemm4w.hip, numbers: profiles/r03_t5_gemm_ab.json.)
+    static const int big = getenv("UC_T5_GEMM256") ? atoi(getenv("UC_T5_GEMM256")) : 1;
     if (big && M >= 2048 && N % HBN_ == 0) {     // large batches: the 256 x 256 tile (small ones would leave most CUs without a tile)
         if (epi == 0) t5_gemm256_launch<0>(A, W, out, M, N, K, s);
         else if (epi == 1) t5_gemm256_launch<1>(A, W, out, M, N, K, s);
@@ -361,7 +360,7 @@ __global__ void __launch_bounds__(256) t5_vt_kernel(const _Float16 *__restrict__
 // One workgroup = 128 queries of one (sequence, head): 4 waves x 32 queries.  The K block (64 keys x 128 dims) and the V^T
 // block (128 dims x 64 keys) are loaded ONCE per workgroup with coalesced 16-byte loads (the next block travels in registers
 // while this one is multiplied) and shared through LDS: per-wave fragment loads straight from L2 re-read every block once
-// per 32 queries and were bandwidth / address-bound (77 TFLOP/s; profiles/r3_t5).
+// per 32 queries and were bandwidth / address-bound (77 TFLOP/s; profiles/round2/r3_t5).
 constexpr int AKB = 64;                                  // keys per block
 constexpr int SK_LD = ADK + 8, SV_LD = AKB + 8;          // LDS row strides in halves (272 B / 144 B: conflict-free fragment reads)
 
