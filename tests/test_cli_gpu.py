@@ -158,7 +158,8 @@ def test_prefilter_execution_variants_give_identical_tsv(synth_db, opts, tmp_pat
     small = {"UC_PREFILTER_CHUNK_RES": "20000"}
     for tag, env in (("v1", {"UC_DRUN_MAX": "20000"}), ("v2", {"UC_DRUN_MAX": "3000"}), ("v3", {"UC_SIM_PER_POSITION": "1"}),
                      ("v4", small), ("v5", dict(small, UC_LEAF_CACHE="0")), ("v6", dict(small, UC_LEAF_CACHE_MB="0")),
-                     ("v7", dict(small, UC_DRUN_MAX="20000")), ("v8", {"UC_FILTER_VARIANT": "0"}), ("v9", {"UC_FILTER_VARIANT": "1"}),
+                     ("v7", dict(small, UC_DRUN_MAX="20000")),
+                     ("v11", dict(small, UC_LEAF_CACHE_MB="1")),          # a cache that only fits a part of the queries: the queries are cut into parts ("v8", {"UC_FILTER_VARIANT": "0"}), ("v9", {"UC_FILTER_VARIANT": "1"}),
                      ("v10", {"UC_FILTER_VARIANT": "2"})):
         got, st = _tsv(synth_db, tmp_path, tag, opts, 1, env=env)
         assert got == ref, (tag, opts)

@@ -32,12 +32,12 @@ if len(sys.argv) > 3:
 nl = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 ns = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 res = []
-for v in ("2", "1", "0"):      # "2" only exists in a build that links tools/experiments/uc_t5_gemm4w.hip (otherwise it runs the 8-wave kernel again)
+for v in ("3", "1", "0"):      # "3" = the phased 256 x 256 kernel (t5_gemm256p_kernel), "1" = the single-phase one, "0" = 128 x 128
     o = "/tmp/t5_ab_%s.npz" % v
     subprocess.check_call([sys.executable, os.path.abspath(__file__), o, str(nl), str(ns)], env=dict(os.environ, UC_T5_GEMM256=v))
     res.append(np.load(o))
 q, a, b = res
 print(json.dumps({"codes_equal": bool((a["codes"] == b["codes"]).all() and (q["codes"] == b["codes"]).all()),
                   "logits_max_abs_diff": float(max(np.abs(a["logits"] - b["logits"]).max(), np.abs(q["logits"] - b["logits"]).max())),
-                  "tflops_4wave_256": float(q["tflops"]), "tflops_8wave_256": float(a["tflops"]), "tflops_128": float(b["tflops"]),
-                  "gpu_ms_4wave_256": float(q["gpu_ms"]), "gpu_ms_8wave_256": float(a["gpu_ms"]), "gpu_ms_128": float(b["gpu_ms"])}))
+                  "tflops_phased_256": float(q["tflops"]), "tflops_8wave_256": float(a["tflops"]), "tflops_128": float(b["tflops"]),
+                  "gpu_ms_phased_256": float(q["gpu_ms"]), "gpu_ms_8wave_256": float(a["gpu_ms"]), "gpu_ms_128": float(b["gpu_ms"])}))

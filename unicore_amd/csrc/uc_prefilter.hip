@@ -1209,7 +1209,8 @@ struct PrefilterScratch {
     // leaf cache of the distinct-k-mer enumeration (valid for ONE Engine::prefilter call: all its target chunks share the queries)
     DevBuf<uint64_t> d_leaf_off;
     DevBuf<uint32_t> d_leaf_v;
-    bool leaf_enable = false, leaf_valid = false, leaf_refused = false;
+    bool leaf_enable = false, leaf_valid = false, leaf_refused = false, leaf_allow_split = false;
+    uint64_t leaf_split = 0;          // set with a refusal: query parts the caller should cut (0 = none asked)
     uint32_t leaf_sa = 0, leaf_sb = 0, leaf_nd = 0;
     int leaf_thr = 0;
     uint64_t leaf_total = 0;
@@ -1299,65 +1300,121 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t
         ~LeafScope() { s->leaf_reset(false); }
     } leaf_scope{pre};
     const bool leaf_cache_on = !getenv("UC_LEAF_CACHE") || atoi(getenv("UC_LEAF_CACHE")) != 0;
-    for (int attempt = 0;; attempt++) {
-        std::vector<std::pair<uint32_t, uint32_t>> chunks;
-        for (uint32_t b = tbegin; b < tend;) {
-            uint32_t e = b;
-            uint64_t res = 0;
-            while (e < tend && (e == b || res + h_len[e] <= chunk_res)) res += h_len[e++];
-            chunks.emplace_back(b, e);
-            b = e;
-        }
-        double density = 0;
-        const double limit = attempt < 6 ? DENSITY_LIMIT : 0.0;      // after 6 re-cuts: run with what we have
-        bool ok = true;
-        // >= 3 chunks: two extra enumeration passes (count + write) once, one saved per chunk after the first.  Leaves cached by an
-        // earlier attempt stay valid (a re-cut changes the target chunks, not the queries).
-        pre->leaf_enable = leaf_cache_on && chunks.size() >= 3;
-        pre->leaf_refused = false;
-        if (chunks.size() <= 1) {
-            ok = prefilter_one(tbegin, tend, qbegin, qend, true, limit, &density);
-            if (ok) { stats.n_prefilter_hits += n_hits; if (pre) pre->trim(scratch_trim_limit()); return; }
-        } else {
-            DevBuf<uint32_t> aq, at, tq, tt;
-            DevBuf<int32_t> as, ad, ts, td;
-            uint64_t acc_n = 0;
-            for (size_t c = 0; c < chunks.size() && ok; c++) {
-                ok = prefilter_one(chunks[c].first, chunks[c].second, qbegin, qend, c == 0, c == 0 ? limit : 0.0, &density);
-                if (!ok) break;
-                if (c == 0 || acc_n == 0) {
-                    aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd);
-                    acc_n = n_hits;
-                } else if (n_hits) {
-                    const uint64_t tot = acc_n + n_hits;
-                    tq.reserve(tot); tt.reserve(tot); ts.reserve(tot); td.reserve(tot);
-                    UC_HIP(hipMemcpyAsync(tq.p, aq.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
-                    UC_HIP(hipMemcpyAsync(tt.p, at.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
-                    UC_HIP(hipMemcpyAsync(ts.p, as.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
-                    UC_HIP(hipMemcpyAsync(td.p, ad.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
-                    UC_HIP(hipMemcpyAsync(tq.p + acc_n, d_hq.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-                    UC_HIP(hipMemcpyAsync(tt.p + acc_n, d_ht.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-                    UC_HIP(hipMemcpyAsync(ts.p + acc_n, d_hs.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-                    UC_HIP(hipMemcpyAsync(td.p + acc_n, d_hd.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-                    UC_HIP(hipStreamSynchronize(stream));
-                    acc_n = import_hits_dev(tot, tq.p, tt.p, ts.p, td.p, 0, 1);      // merge + truncate to max_seqs
-                    aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd);
+    // E1-E4 of the queries [pb, pe) against all target chunks; 0 = lists installed, 3 = nothing installed: the similar k-mers of
+    // these queries do not fit the leaf-cache budget and the caller should cut the QUERIES (pre->leaf_split says into how many parts)
+    auto run_part = [&](uint32_t pb, uint32_t pe, bool allow_split) -> int {
+        for (int attempt = 0;; attempt++) {
+            std::vector<std::pair<uint32_t, uint32_t>> chunks;
+            for (uint32_t b = tbegin; b < tend;) {
+                uint32_t e = b;
+                uint64_t res = 0;
+                while (e < tend && (e == b || res + h_len[e] <= chunk_res)) res += h_len[e++];
+                chunks.emplace_back(b, e);
+                b = e;
+            }
+            double density = 0;
+            const double limit = attempt < 6 ? DENSITY_LIMIT : 0.0;      // after 6 re-cuts: run with what we have
+            bool ok = true;
+            // >= 3 chunks: two extra enumeration passes (count + write) once, one saved per chunk after the first.  Leaves cached by an
+            // earlier attempt stay valid (a re-cut changes the target chunks, not the queries).
+            pre->leaf_enable = leaf_cache_on && chunks.size() >= 3;
+            pre->leaf_refused = false;
+            pre->leaf_allow_split = allow_split && pre->leaf_enable && pe - pb >= 64;
+            pre->leaf_split = 0;
+            if (chunks.size() <= 1) {
+                ok = prefilter_one(tbegin, tend, pb, pe, true, limit, &density);
+                if (ok) return 0;
+            } else {
+                DevBuf<uint32_t> aq, at, tq, tt;
+                DevBuf<int32_t> as, ad, ts, td;
+                uint64_t acc_n = 0;
+                for (size_t c = 0; c < chunks.size() && ok; c++) {
+                    ok = prefilter_one(chunks[c].first, chunks[c].second, pb, pe, c == 0, c == 0 ? limit : 0.0, &density);
+                    if (!ok) break;
+                    if (c == 0 || acc_n == 0) {
+                        aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd);
+                        acc_n = n_hits;
+                    } else if (n_hits) {
+                        const uint64_t tot = acc_n + n_hits;
+                        tq.reserve(tot); tt.reserve(tot); ts.reserve(tot); td.reserve(tot);
+                        UC_HIP(hipMemcpyAsync(tq.p, aq.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                        UC_HIP(hipMemcpyAsync(tt.p, at.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                        UC_HIP(hipMemcpyAsync(ts.p, as.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                        UC_HIP(hipMemcpyAsync(td.p, ad.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                        UC_HIP(hipMemcpyAsync(tq.p + acc_n, d_hq.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+                        UC_HIP(hipMemcpyAsync(tt.p + acc_n, d_ht.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+                        UC_HIP(hipMemcpyAsync(ts.p + acc_n, d_hs.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+                        UC_HIP(hipMemcpyAsync(td.p + acc_n, d_hd.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+                        UC_HIP(hipStreamSynchronize(stream));
+                        acc_n = import_hits_dev(tot, tq.p, tt.p, ts.p, td.p, 0, 1);      // merge + truncate to max_seqs
+                        aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd);
+                    }
+                }
+                if (ok) {
+                    // install the accumulated lists (also rebuilds the per-query counts)
+                    import_hits_dev(acc_n, aq.p, at.p, as.p, ad.p, 0, 1);
+                    return 0;
                 }
             }
-            if (ok) {
-                // install the accumulated lists (also rebuilds the per-query counts)
-                import_hits_dev(acc_n, aq.p, at.p, as.p, ad.p, 0, 1);
-                stats.n_prefilter_hits += n_hits;
-                if (pre) pre->trim(scratch_trim_limit());
-                return;
-            }
+            if (pre->leaf_split >= 2) return 3;       // not a density abort: the queries want cutting
+            // too dense: smaller chunks, proportionally (and a little more)
+            const uint64_t cur = std::min<uint64_t>(chunk_res, std::max<uint64_t>(1, (uint64_t)h_poff[chunks[0].second] - h_poff[chunks[0].first]));
+            chunk_res = std::max<uint64_t>(1u << 16, (uint64_t)((double)cur * DENSITY_LIMIT / density * 0.75));
+            logf(3, "unicore-cluster: prefilter: %.0f k-mer hits per query residue in a chunk of %llu residues; re-cutting the targets into chunks of %llu\n",
+                 density, (unsigned long long)cur, (unsigned long long)chunk_res);
         }
-        // too dense: smaller chunks, proportionally (and a little more)
-        const uint64_t cur = std::min<uint64_t>(chunk_res, std::max<uint64_t>(1, (uint64_t)h_poff[chunks[0].second] - h_poff[chunks[0].first]));
-        chunk_res = std::max<uint64_t>(1u << 16, (uint64_t)((double)cur * DENSITY_LIMIT / density * 0.75));
-        logf(3, "unicore-cluster: prefilter: %.0f k-mer hits per query residue in a chunk of %llu residues; re-cutting the targets into chunks of %llu\n",
-             density, (unsigned long long)cur, (unsigned long long)chunk_res);
+    };
+    // Query parts.  Normally one: all queries.  At high sensitivity and size the similar k-mers of all queries' distinct k-mers do not
+    // fit the leaf-cache budget (100 proteomes at -s 7.5: > 100 GB); the queries are then cut into parts whose caches fit, every
+    // part runs against all target chunks (the chunk indexes are rebuilt per part: milliseconds) and the lists of the parts —
+    // disjoint queries — are concatenated.  The chunk size found by the first part (density re-cuts) is kept for the others.
+    std::vector<std::pair<uint32_t, uint32_t>> parts{{qbegin, qend}};
+    std::vector<int> depth{0};
+    DevBuf<uint32_t> Pq, Pt;
+    DevBuf<int32_t> Ps, Pd;
+    uint64_t P_n = 0;
+    for (size_t pi = 0; pi < parts.size(); pi++) {
+        const uint32_t pb = parts[pi].first, pe = parts[pi].second;
+        pre->leaf_reset(false);
+        const int rc = run_part(pb, pe, depth[pi] < 3);
+        if (rc == 3) {
+            // cut [pb, pe) into leaf_split parts of ~equal residue counts (distinct k-mers grow sublinearly: a part may ask again)
+            const int S = (int)std::min<uint64_t>(pre->leaf_split, (pe - pb) / 32 + 1);
+            std::vector<std::pair<uint32_t, uint32_t>> sub;
+            const uint64_t r0 = h_poff[pb], rt = (uint64_t)h_poff[pe] - r0;
+            uint32_t b = pb;
+            for (int k = 1; k <= S; k++) {
+                uint32_t e = b;
+                if (k == S) e = pe;
+                else while (e < pe && (uint64_t)h_poff[e] - r0 < rt * k / S) e++;
+                if (e > b) sub.emplace_back(b, e);
+                b = e;
+            }
+            logf(3, "unicore-cluster: prefilter: the similar k-mers of queries [%u, %u) do not fit the leaf cache: %zu query parts\n", pb, pe, sub.size());
+            const int d = depth[pi] + 1;
+            parts.erase(parts.begin() + pi); depth.erase(depth.begin() + pi);
+            parts.insert(parts.begin() + pi, sub.begin(), sub.end());
+            depth.insert(depth.begin() + pi, sub.size(), d);
+            pi--;
+            continue;
+        }
+        if (parts.size() > 1 && n_hits) {     // park this part's lists (queries of different parts are disjoint)
+            Pq.grow_preserve(P_n + n_hits, P_n, stream); Pt.grow_preserve(P_n + n_hits, P_n, stream);
+            Ps.grow_preserve(P_n + n_hits, P_n, stream); Pd.grow_preserve(P_n + n_hits, P_n, stream);
+            UC_HIP(hipMemcpyAsync(Pq.p + P_n, d_hq.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+            UC_HIP(hipMemcpyAsync(Pt.p + P_n, d_ht.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+            UC_HIP(hipMemcpyAsync(Ps.p + P_n, d_hs.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+            UC_HIP(hipMemcpyAsync(Pd.p + P_n, d_hd.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+            UC_HIP(hipStreamSynchronize(stream));
+            P_n += n_hits;
+        }
     }
+    if (parts.size() > 1) {
+        pre->leaf_reset(false);
+        import_hits_dev(P_n, Pq.p, Pt.p, Ps.p, Pd.p, 0, 1);
+    }
+    stats.n_prefilter_hits += n_hits;
+    if (pre) pre->trim(scratch_trim_limit());
 }
 
 // returns false (nothing installed) if density_limit > 0 and the first query batch exceeds it; *density_out = k-mer hits
@@ -1524,7 +1581,12 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
         uint64_t budget = getenv("UC_LEAF_CACHE_MB") ? strtoull(getenv("UC_LEAF_CACHE_MB"), nullptr, 10) << 20
                                                      : std::min<uint64_t>(96ull << 30, (uint64_t)((double)tot_mem * 0.35));
         budget = std::min<uint64_t>(budget, fr > (16ull << 30) ? fr - (16ull << 30) : 0);      // and never the last 16 GiB that are free right now
-        if (est_leaves * 4 > budget + budget / 8) S.leaf_refused = true;       // the sample says it cannot fit: do not even count
+        auto refuse = [&](uint64_t leaves) {      // does not fit: ask the caller to cut the queries, or let every chunk enumerate for itself
+            S.leaf_refused = true;
+            if (S.leaf_allow_split && budget >= (1ull << 20)) S.leaf_split = std::max<uint64_t>(2, (leaves * 4 + budget * 3 / 4 - 1) / (budget * 3 / 4));
+        };
+        if (S.leaf_enable && !cached && !S.leaf_refused && est_leaves * 4 > budget + budget / 8) refuse(est_leaves);      // the sample says it cannot fit: do not even count
+        if (S.leaf_split >= 2 && sa == first_query) { gpu_ms += timed_ms_end(); t_kmer += t_p.seconds(); return 1; }
         // several target chunks ahead (Engine::prefilter said so): enumerate once, keep the leaves — if they fit the budget
         if (S.leaf_enable && !cached && !S.leaf_refused && nd) {
             hipLaunchKernelGGL(sim_runs_kernel<1>, sim_grid(nd), dim3(256), 0, stream, ddb, cfg, 0u, 0u, 0u, nd, (const uint32_t *)nullptr, RunList{nullptr, nullptr, 0},
@@ -1549,7 +1611,8 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
                 logf(3, "unicore-cluster: prefilter: %llu similar k-mers of %u distinct query k-mers cached (%.1f GiB) for the remaining target chunks\n",
                      (unsigned long long)total, nd, (double)total * 4 / (double)(1ull << 30));
             } else {
-                S.leaf_refused = true;    // does not fit: every chunk enumerates for itself (the r3 path)
+                refuse(total);
+                if (S.leaf_split >= 2 && sa == first_query) { gpu_ms += timed_ms_end(); t_kmer += t_p.seconds(); return 1; }
             }
         }
         const bool use_cache = S.leaf_valid && S.leaf_sa == sa && S.leaf_sb == sb && S.leaf_thr == cfg.thr;

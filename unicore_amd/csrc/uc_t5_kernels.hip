@@ -241,6 +241,199 @@ __global__ void __launch_bounds__(512) t5_gemm256_kernel(const _Float16 *__restr
     }
 }
 
+// ---- the phased variant of the 256 x 256 tile (r4) ---------------------------------------------------------------------------
+// Same tile, same 8 waves of 128 x 64 and the same bytes through LDS as t5_gemm256_kernel, but the K-step is no longer "wait for the whole
+// tile, barrier, read, multiply".  A K-tile is staged as FOUR half-tiles of 16 KB, chosen so that each is dead as early as possible:
+//   A-half h = the rows of sub-block h (64 rows) of BOTH row-waves, B-half h = the columns of sub-block h (32 columns) of all four column-waves;
+//   the wave tile is worked off in four C-quadrants (64 x 32, 16 MFMAs each) in the order (0,0) (0,1) (1,1) (1,0):
+//   phase 1 reads A-half 0 + B-half 0 into registers, phase 2 B-half 1, phase 3 A-half 1, phase 4 B-half 0 again.
+// A-half 0 of a buffer is therefore free after phase 1, B-half 1 after phase 2, A-half 1 after phase 3, B-half 0 after phase 4, and every
+// phase re-stages exactly one half-tile: phases 2 / 3 / 4 of tile t load A-half 0 / B-half 1 / A-half 1 of tile t + 2 into the buffer tile t
+// is still being read from, phase 1 of tile t + 1 its B-half 0.  Loads stay in flight ACROSS barriers: the only wait is a counted
+// s_waitcnt vmcnt(6) in phase 4 (three half-tiles = 6 instructions may still be under way; everything tile t + 1 needs has landed), raw
+// s_barrier instead of __syncthreads (whose fence would drain the DMA queue).  A phase is {LDS reads + one stage; lgkmcnt(0); barrier;
+// 16 MFMAs at raised priority; barrier}, and the two row-waves of a SIMD run ONE BARRIER APART (the second row-wave executes one extra
+// barrier up front, the first one extra at the end), so on every SIMD one wave multiplies while the other reads and stages: the matrix
+// pipe and the LDS port work side by side instead of taking turns.  Hazards: a half-tile is re-staged in the phase after its last read,
+// and every read is retired (lgkmcnt(0)) before the barrier that ends its interval — both wave groups included (the later group reads one
+// interval later and stages one interval later); data waited for in phase 4 is read from phase 1 of the next tile on, a barrier after both
+// groups' waits.  The K order per output element is unchanged: bit-identical to the other GEMM kernels.
+template <int EPI>
+__global__ void __launch_bounds__(512) t5_gemm256p_kernel(const _Float16 *__restrict__ A, const _Float16 *__restrict__ W, void *__restrict__ out,
+                                                          int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(1024))) _Float16 smp[];                // [buffer][A0 | A1 | B0 | B1][128 rows * 64]: 128 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3;
+    int m0, n0;
+    {
+        const int nn = (N + HBN_ - 1) / HBN_, nm = (M + HBM_ - 1) / HBM_;
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int g = k / (GXM * nn), r = k % (GXM * nn);
+        const int ml = g * GXM + r % GXM, mt = xcd + 8 * ml;
+        if (mt >= nm) return;
+        m0 = mt * HBM_;
+        n0 = (r / GXM) * HBN_;
+    }
+    constexpr int HT = 128 * GBK;                                                   // elements of a half-tile
+    auto half = [&](int buf, int which) -> _Float16 * { return smp + (size_t)(buf * 4 + which) * HT; };   // which: 0 A0, 1 A1, 2 B0, 3 B1
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // staging: a half-tile = 16 wave-instructions of 8 rows; wave w issues instructions 2 w and 2 w + 1.  Half-tile row r of A-half h is
+    // tile row (r >> 6) * 128 + h * 64 + (r & 63); of B-half h it is tile column (r >> 5) * 64 + h * 32 + (r & 31).  32-bit byte offsets
+    // against the (wave-uniform) operand bases.
+    uint32_t oa[2][2], ob[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int r = (wave * 2 + i) * 8 + (lane >> 3), kc = ((lane & 7) ^ (r & 7)) * 8;
+            const int arow = (r >> 6) * 128 + h * 64 + (r & 63), bcol = (r >> 5) * 64 + h * 32 + (r & 31);
+            oa[h][i] = (uint32_t)(((size_t)min(m0 + arow, M - 1) * K + kc) * 2);
+            ob[h][i] = (uint32_t)(((size_t)min(n0 + bcol, N - 1) * K + kc) * 2);
+        }
+    auto stage = [&](int kt, int buf, int which) {   // which as in half(); compile-time after unrolling
+        const char *base = (which < 2 ? (const char *)A : (const char *)W) + (size_t)kt * (GBK * 2);
+        _Float16 *dst = half(buf, which);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t o = which < 2 ? oa[which][i] : ob[which - 2][i];
+            __builtin_amdgcn_global_load_lds((gbl_void *)(base + o), (lds_void *)(dst + (wave * 2 + i) * 8 * GBK), 16, 0, 0);
+        }
+    };
+    // fragment (16 rows x 32 k) of a half-tile: rows r0 .. r0 + 15, k-slice ks
+    auto frag = [&](const _Float16 *s, int r0, int ks) -> half8 {
+        const int r = r0 + (lane & 15);
+        return *(const half8 *)(s + r * GBK + (((ks * 4 + (lane >> 4)) ^ (r & 7)) * 8));
+    };
+    const int nk = K / GBK;                                                         // even and >= 2 (the launcher checks)
+    // prologue: all of tile 0, and of tile 1 what the steady state would have staged by now (its B-half 0 follows in phase 1 of tile 0)
+    stage(0, 0, 0); stage(0, 0, 3); stage(0, 0, 1); stage(0, 0, 2);
+    stage(1, 1, 0); stage(1, 1, 3); stage(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();                                      // the second row-wave of every SIMD runs one barrier behind
+
+    half8 fa[4][2], fb0[2][2], fb1[2][2];
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        const _Float16 *sA0 = half(buf, 0) + wr * 64 * GBK, *sA1 = half(buf, 1) + wr * 64 * GBK;
+        const _Float16 *sB0 = half(buf, 2) + wc * 32 * GBK, *sB1 = half(buf, 3) + wc * 32 * GBK;
+        // ---- phase 1: A-half 0 + B-half 0 -> registers; stage B-half 0 of tile kt + 1; quadrant (0, 0)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) fb0[j][ks] = frag(sB0, j * 16, ks);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) fa[i][ks] = frag(sA0, i * 16, ks);
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1, 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb0[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2: B-half 1 -> registers; stage A-half 0 of tile kt + 2 (this buffer); quadrant (0, 1)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) fb1[j][ks] = frag(sB1, j * 16, ks);
+        if (kt + 2 < nk) stage(kt + 2, buf, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb1[j][ks], fa[i][ks], acc[i][2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 3: A-half 1 -> registers; stage B-half 1 of tile kt + 2; quadrant (1, 1)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) fa[i][ks] = frag(sA1, i * 16, ks);
+        if (kt + 2 < nk) stage(kt + 2, buf, 3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb1[j][ks], fa[i][ks], acc[4 + i][2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 4: B-half 0 -> registers again; stage A-half 1 of tile kt + 2; counted wait: tile kt + 1 is complete; quadrant (1, 0)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) fb0[j][ks] = frag(sB0, j * 16, ks);
+        if (kt + 2 < nk) {
+            stage(kt + 2, buf, 1);
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb0[j][ks], fa[i][ks], acc[4 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();                                      // barrier counts of the two groups match again
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int row = m0 + wr * 128 + i * 16 + (lane & 15);
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int col = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+            if (col >= N) continue;
+            f32x4 v = acc[i][j];
+            if (EPI == 2) {
+                f32x4 *o = (f32x4 *)((float *)out + (size_t)row * N + col);
+                *o = *o + v;
+            } else {
+                if (EPI == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                *(h4 *)((_Float16 *)out + (size_t)row * N + col) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            }
+        }
+    }
+}
+
+template <int EPI>
+static void t5_gemm256p_launch(const void *A, const void *W, void *out, int M, int N, int K, hipStream_t s) {
+    constexpr int LDS = 2 * 4 * 128 * GBK * 2;
+    static bool once[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !once[dev]) {
+        (void)hipFuncSetAttribute((const void *)t5_gemm256p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        once[dev] = true;
+    }
+    const int nn = (N + HBN_ - 1) / HBN_, nm = (M + HBM_ - 1) / HBM_, per_xcd = ((nm + 7) / 8 + GXM - 1) / GXM * GXM;
+    hipLaunchKernelGGL(t5_gemm256p_kernel<EPI>, dim3((unsigned)(8 * per_xcd * nn)), dim3(512), LDS, s, (const _Float16 *)A, (const _Float16 *)W, out, M, N, K);
+}
+
 template <int EPI>
 static void t5_gemm256_launch(const void *A, const void *W, void *out, int M, int N, int K, hipStream_t s) {
     constexpr int LDS = 2 * 2 * HBM_ * GBK * 2;
@@ -263,6 +456,12 @@ void t5_gemm(int epi, const void *A, const void *W, void *out, int M, int N, int
     // slower: 693 TFLOP/s for the 24-block encoder against 818 with this kernel and 739 with the 128 x 128 one; one wave per SIMD leaves
     // nobody to cover that wave's barrier and wait stalls.  Source: tools/experiments/uc_t5_gemm4w.hip, numbers: profiles/r03_t5_gemm_ab.json.)
     static const int big = getenv("UC_T5_GEMM256") ? atoi(getenv("UC_T5_GEMM256")) : 1;
+    if (big >= 3 && M >= 2048 && N % HBN_ == 0 && (K / GBK) % 2 == 0 && K >= 2 * GBK && (size_t)M * K * 2 < (1ull << 32) && (size_t)N * K * 2 < (1ull << 32)) {
+        if (epi == 0) t5_gemm256p_launch<0>(A, W, out, M, N, K, s);
+        else if (epi == 1) t5_gemm256p_launch<1>(A, W, out, M, N, K, s);
+        else t5_gemm256p_launch<2>(A, W, out, M, N, K, s);
+        return;
+    }
     if (big && M >= 2048 && N % HBN_ == 0) {     // large batches: the 256 x 256 tile (small ones would leave most CUs without a tile)
         if (epi == 0) t5_gemm256_launch<0>(A, W, out, M, N, K, s);
         else if (epi == 1) t5_gemm256_launch<1>(A, W, out, M, N, K, s);
