@@ -85,6 +85,24 @@ __global__ void __launch_bounds__(256) kmer_offsets_kernel(const uint32_t *keys,
     }
 }
 
+// presence bitmap of the chunk's k-mers (bit v = the index holds k-mer v): 8 MB for the 20^6 k-mers — resident in every XCD's L2, where the
+// 256 MB offset table is not.  At high sensitivity the target chunks are small (density cuts: ~5 M residues at 100 proteomes, < 10 % of the
+// k-mer space occupied) and nine of ten similar k-mers miss; the bitmap answers those without touching the offset table (r4: prefilter
+// kernels 7.67 -> 6.93 s at 50 proteomes, 26.0 -> 23.5 s at 100 proteomes with configs[3]'s options; nothing at -s 4, where most k-mers occur).
+__global__ void __launch_bounds__(256) kmer_bits_kernel(const uint32_t *koff, uint32_t *bits) {
+    for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < (KSPACE + 31) / 32; w += (uint64_t)gridDim.x * 256) {
+        uint32_t m = 0;
+        const uint64_t v0 = w * 32;
+        uint32_t prev = koff[v0];
+        for (int b = 0; b < 32 && v0 + b < KSPACE; b++) {
+            const uint32_t nxt = koff[v0 + b + 1];
+            m |= (nxt != prev ? 1u : 0u) << b;
+            prev = nxt;
+        }
+        bits[w] = m;
+    }
+}
+
 // ---------------------------------------------------------------- E2: similar k-mers
 struct SimTables {           // LDS: per query letter a, target letters sorted by score descending
     int8_t sc[KA][KA];
@@ -151,20 +169,13 @@ constexpr int POSQ = 128;           // decoded positions per wave (ring)
 constexpr int SIM_MIN_WAVE_POS = 256;   // fewer positions per wave than this: fewer workgroups
 constexpr int SIM_MAX_BLOCKS = 1280;     // 256 CUs x 5 resident workgroups (29 KB of LDS each)
 
-// MODE 0: enumeration fused with the offset-table lookups (runs out).  The similar k-mers of a k-mer do not depend on the target
-// chunk that is being searched, only the lookups do; when a target range is worked off in several index chunks (high sensitivity:
-// dozens of density-cut chunks) the enumeration is therefore done ONCE and its leaves are kept in HBM (distinct mode only):
-// MODE 1 counts the leaves per work item (nsim_k), MODE 2 writes them to leaf_v[leaf_off[item] ..] (CSR by item); every chunk then
-// only runs leaf_lookup_kernel over them.  At -s 7.5 the enumeration was a third of the prefilter time (r3: 3.3 of 9.9 s at 50
-// proteomes in 9 chunks, 8.5 of 26 s at 100 proteomes in 40).
-template <int MODE>
 __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCfg cfg, uint32_t qbegin, uint32_t qend,
                                                             uint32_t p0, uint32_t p1, const uint32_t *koff, RunList out,
                                                             unsigned long long *counters,
                                                             const uint32_t *dk /* distinct mode: work item i = k-mer value dk[i] */,
                                                             uint32_t *nsim_k /* distinct mode: similar k-mers per work item */,
                                                             uint32_t item_stride /* distinct mode: every item_stride-th item only (run-count estimate) */,
-                                                            const uint64_t *leaf_off = nullptr, uint32_t *leaf_v = nullptr /* MODE 2 */) {
+                                                            const uint32_t *kbits = nullptr /* presence bitmap of the chunk's k-mers (nullable) */) {
     __shared__ SimTables tab;
     __shared__ uint32_t s_mul[K];
     __shared__ uint32_t s_n[4];
@@ -213,8 +224,10 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
             if (i < qn) {
                 const uint32_t v = qv[i];
                 pi = qp[i];
-                e0 = koff[v];
-                n = koff[v + 1] - e0;
+                if (!kbits || ((kbits[v >> 5] >> (v & 31)) & 1u)) {
+                    e0 = koff[v];
+                    n = koff[v + 1] - e0;
+                }
             }
             nhit += n;
             const uint64_t m = __builtin_amdgcn_ballot_w64(n != 0);
@@ -244,7 +257,6 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
         bool idle = true, out_of_work = false;
         uint32_t cpack = 0, kpack = 0, pidx = 0, vcur = 0;
         uint32_t lc = 0;                           // leaves of the work item in hand
-        uint64_t lbase = 0;                        // MODE 2: where the leaves of the item in hand go
         bool has_item = false;
         int L = 0, scur = 0;
         uint64_t restpack = 0;                     // rest[m] (m = 1..6) in 8-bit fields, biased by 64
@@ -301,7 +313,6 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
                         lc = 0; has_item = true;
                         const uint32_t slot = take % POSQ;
                         cpack = pc[slot]; restpack = pr[slot]; pidx = pp[slot];
-                        if (MODE == 2) lbase = leaf_off[pidx];
                         kpack = 0; L = 0; scur = 0; vcur = 0; idle = false;
                     } else if (next >= rend) out_of_work = true;       // pool empty and nothing left to decode
                 }
@@ -330,7 +341,6 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
                 const bool push = ok && L < K - 1, pop = act && !ok && L > 0;
                 leaf = ok && L == K - 1;
                 leafv = vcur + o1 * mulL;
-                if (MODE == 2 && leaf) leaf_v[lbase + lc] = leafv;
                 lc += leaf ? 1u : 0u;
                 idle = idle || (act && !ok && L == 0);
                 scur = push ? cand : (pop ? scur - sc2 : scur);
@@ -343,98 +353,23 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
             }
             const uint64_t lm = __builtin_amdgcn_ballot_w64(leaf);
             if (lm) {
+                if (leaf) { const uint32_t slot = qn + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull)); qv[slot] = leafv; qp[slot] = pidx; }
+                qn += (uint32_t)__popcll(lm);
                 nsim += (lane == 0) ? (unsigned long long)__popcll(lm) : 0ull;
-                if (MODE == 0) {
-                    if (leaf) { const uint32_t slot = qn + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull)); qv[slot] = leafv; qp[slot] = pidx; }
-                    qn += (uint32_t)__popcll(lm);
-                    if (qn > LEAFQ - 64) { __builtin_amdgcn_wave_barrier(); drain_leaves(qn); qn = 0; }
-                }
+                if (qn > LEAFQ - 64) { __builtin_amdgcn_wave_barrier(); drain_leaves(qn); qn = 0; }
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (MODE == 0) drain_leaves(qn);
+        drain_leaves(qn);
         if (nsim_k && has_item) nsim_k[pidx] = lc;
     }
     __builtin_amdgcn_wave_barrier();
-    if (MODE == 0) flush_runs();
+    flush_runs();
     for (int o = 32; o > 0; o >>= 1) { nsim += __shfl_down(nsim, o, 64); nhit += __shfl_down(nhit, o, 64); }
     if (lane == 0) {
         if (nsim) atomicAdd(counters + 0, nsim);
         if (nhit) atomicAdd(counters + 4, nhit);
     }
-}
-
-// The per-chunk half of the cached enumeration: offset-table lookups of the stored leaves.  A wave takes 64 work items (distinct
-// query k-mers) at a time and walks their leaf lists one after the other, 64 leaves per step: coalesced reads of the leaves, one
-// gather pair into the chunk's offset table per leaf, the non-empty index ranges staged per wave and appended behind one global
-// atomic per RUN_STAGE runs — the same run records sim_runs_kernel<0> emits (run order is irrelevant: they get sorted by rank).
-__global__ void __launch_bounds__(256) leaf_lookup_kernel(const uint64_t *leaf_off, const uint32_t *leaf_v, uint32_t nd, const uint32_t *koff, RunList out,
-                                                          unsigned long long *counters) {
-    __shared__ uint32_t s_n[4];
-    __shared__ uint64_t s_val[4][RUN_STAGE];
-    __shared__ uint32_t s_pi[4][RUN_STAGE];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) s_n[wv] = 0;
-    __builtin_amdgcn_wave_barrier();
-    volatile uint32_t *vn = &s_n[wv];
-    volatile uint64_t *vval = s_val[wv];
-    volatile uint32_t *vpi = s_pi[wv];
-    auto flush_runs = [&]() {   // whole wave
-        const uint32_t n = *vn;
-        uint32_t blo = 0, bhi = 0;
-        if (lane == 0) {
-            const unsigned long long b = atomicAdd(counters + 3, (unsigned long long)n);
-            blo = (uint32_t)b; bhi = (uint32_t)(b >> 32);
-        }
-        blo = (uint32_t)__shfl((int)blo, 0, 64);
-        bhi = (uint32_t)__shfl((int)bhi, 0, 64);
-        const uint64_t base = ((uint64_t)bhi << 32) | blo;
-        for (uint32_t k = lane; k < n; k += 64) {
-            const uint64_t w = base + k;
-            if (w < out.cap) { out.pidx[w] = vpi[k]; out.val[w] = vval[k]; }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) *vn = 0;
-        __builtin_amdgcn_wave_barrier();
-    };
-    unsigned long long nhit = 0;
-    const uint64_t nwaves = (uint64_t)gridDim.x * 4, w0 = (uint64_t)blockIdx.x * 4 + wv;
-    for (uint64_t base = w0 * 64; base < nd; base += nwaves * 64) {
-        const uint64_t item = base + lane;
-        uint64_t lo = 0;
-        uint32_t n = 0;
-        if (item < nd) { lo = leaf_off[item]; n = (uint32_t)(leaf_off[item + 1] - lo); }
-        uint64_t m = __builtin_amdgcn_ballot_w64(n != 0);
-        while (m) {
-            const int j = __builtin_ctzll(m);
-            m &= m - 1;
-            const uint32_t nj = (uint32_t)__shfl((int)n, j, 64);
-            const uint64_t loj = ((uint64_t)(uint32_t)__shfl((int)(lo >> 32), j, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)lo, j, 64);
-            for (uint32_t i0 = 0; i0 < nj; i0 += 64) {
-                const uint32_t i = i0 + lane;
-                uint32_t e0 = 0, c = 0;
-                if (i < nj) {
-                    const uint32_t v = leaf_v[loj + i];
-                    e0 = koff[v];
-                    c = koff[v + 1] - e0;
-                }
-                nhit += c;
-                const uint64_t rm = __builtin_amdgcn_ballot_w64(c != 0);
-                if (rm) {
-                    if (*vn + 64 > RUN_STAGE) flush_runs();
-                    const uint32_t slot = *vn + (uint32_t)__popcll(rm & ((1ull << lane) - 1ull));
-                    if (c) { vval[slot] = ((uint64_t)c << 32) | e0; vpi[slot] = (uint32_t)(base + j); }
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == 0) *vn = *vn + (uint32_t)__popcll(rm);
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    flush_runs();
-    for (int o = 32; o > 0; o >>= 1) nhit += __shfl_down(nhit, o, 64);
-    if (lane == 0 && nhit) atomicAdd(counters + 4, nhit);
 }
 
 // ---- E2, distinct mode: the similar k-mers of a k-mer do not depend on where it occurs, and a batch of queries holds every
@@ -637,7 +572,7 @@ __global__ void __launch_bounds__(256) expand_kernel(const DeviceDb db, uint32_t
 //           (seen once / seen twice, two hash positions per key) and STREAMS the (target, diagonal) keys it computed
 //           into the query's region of the key buffer (coalesced 16-byte stores);
 //   sweep 2 reads that stream back — a coalesced scan instead of a second round of binary searches and index gathers
-//           (the gathers were the kernel's critical path: 69 % of its cycles waited on them, profiles/round1/r2b) — keeps the
+//           (the gathers were the kernel's critical path: 69 % of its cycles waited on them, profiles/r2b) — keeps the
 //           keys whose two hash positions were both seen twice, and compacts them in place;
 //   level 2 repeats the once/twice test over the survivors alone with independent hash functions (below).
 // Every key of a real multi-hit diagonal survives, plus a few collisions which the exact diagonal count after the sort
@@ -1024,7 +959,7 @@ __global__ void __launch_bounds__(256) compact_kernel(const void *region_v, cons
 // one pass over the sorted hit keys: the first key of every (query,target) group walks its group, run-length-
 // counts the diagonals and keeps the best (count desc, diagonal asc).  Candidates are staged per wave in LDS and
 // appended in blocks of >= 64 behind one global atomic (one atomic per wave ballot serialised on a single
-// address: +90 ms per step, profiles/round1/r1g); their order is irrelevant (E4 sorts on a unique key).
+// address: +90 ms per step, profiles/r1g); their order is irrelevant (E4 sorts on a unique key).
 __global__ void __launch_bounds__(256) diag_select_kernel(const uint64_t *keys, uint64_t n, int min_hits, KeyFmt fmt, uint32_t qbegin,
                                                           unsigned long long *n_cand, uint64_t cap,
                                                           uint32_t *cq, uint32_t *ct, int32_t *cd) {
@@ -1206,21 +1141,13 @@ struct PrefilterScratch {
     DevBuf<uint32_t> d_qk, d_kid, d_dk, d_nsimk, d_drk, d_drk2, d_roff, d_nr, d_src, d_ph;
     DevBuf<uint64_t> d_drv, d_drv2, d_cumh, d_cumr, d_qh, d_qrn;
     DevBuf<RankRec> d_rec;
-    // leaf cache of the distinct-k-mer enumeration (valid for ONE Engine::prefilter call: all its target chunks share the queries)
-    DevBuf<uint64_t> d_leaf_off;
-    DevBuf<uint32_t> d_leaf_v;
-    bool leaf_enable = false, leaf_valid = false, leaf_refused = false, leaf_allow_split = false;
-    uint64_t leaf_split = 0;          // set with a refusal: query parts the caller should cut (0 = none asked)
-    uint32_t leaf_sa = 0, leaf_sb = 0, leaf_nd = 0;
-    int leaf_thr = 0;
-    uint64_t leaf_total = 0;
-    void leaf_reset(bool enable) { leaf_enable = enable; leaf_valid = false; leaf_refused = false; d_leaf_v.release(); }
+    DevBuf<uint32_t> d_kbits;       // presence bitmap of the chunk's k-mers
     // every buffer (for the size bookkeeping below)
     template <class F> void each(F f) {
         f(d_counters); f(d_prof); f(d_temp); f(d_koff); f(k_in); f(k_out); f(d_ent32); f(v_in32); f(d_okey); f(d_okey2); f(d_oidx); f(d_order);
         f(d_ent); f(v_in); f(d_cnt); f(d_flag); f(d_cq); f(d_ct); f(d_rpidx); f(d_rpidx2); f(d_qsurv); f(d_keys); f(d_keys2); f(d_pos); f(d_skey);
         f(d_skey2); f(d_rval); f(d_rval2); f(d_qbase); f(d_soff); f(d_qr); f(d_cd); f(d_cd2); f(d_score); f(d_kflag); f(d_qk); f(d_kid); f(d_dk);
-        f(d_nsimk); f(d_drk); f(d_drk2); f(d_roff); f(d_nr); f(d_src); f(d_ph); f(d_drv); f(d_drv2); f(d_cumh); f(d_cumr); f(d_qh); f(d_qrn); f(d_rec); f(d_leaf_off); f(d_leaf_v);
+        f(d_nsimk); f(d_drk); f(d_drk2); f(d_roff); f(d_nr); f(d_src); f(d_ph); f(d_drv); f(d_drv2); f(d_cumh); f(d_cumr); f(d_qh); f(d_qrn); f(d_rec); f(d_kbits);
     }
     size_t bytes() {
         size_t b = 0;
@@ -1294,127 +1221,61 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t
     // (k-mer hits per query residue) of its first batch and gives up before expanding anything if the chunk is too dense;
     // the range is then re-cut into proportionally smaller chunks (one wasted enumeration pass).
     const double DENSITY_LIMIT = getenv("UC_DENSITY_LIMIT") ? atof(getenv("UC_DENSITY_LIMIT")) : 400.0;   // hits per query residue and chunk (C2 whole DB at -s 4: 124)
-    if (!pre) pre = take_prefilter_scratch(device);
-    struct LeafScope {   // the leaf cache lives for this call only: its chunks share the queries; the memory goes back before the gapped stage
-        PrefilterScratch *s;
-        ~LeafScope() { s->leaf_reset(false); }
-    } leaf_scope{pre};
-    const bool leaf_cache_on = !getenv("UC_LEAF_CACHE") || atoi(getenv("UC_LEAF_CACHE")) != 0;
-    // E1-E4 of the queries [pb, pe) against all target chunks; 0 = lists installed, 3 = nothing installed: the similar k-mers of
-    // these queries do not fit the leaf-cache budget and the caller should cut the QUERIES (pre->leaf_split says into how many parts)
-    auto run_part = [&](uint32_t pb, uint32_t pe, bool allow_split) -> int {
-        for (int attempt = 0;; attempt++) {
-            std::vector<std::pair<uint32_t, uint32_t>> chunks;
-            for (uint32_t b = tbegin; b < tend;) {
-                uint32_t e = b;
-                uint64_t res = 0;
-                while (e < tend && (e == b || res + h_len[e] <= chunk_res)) res += h_len[e++];
-                chunks.emplace_back(b, e);
-                b = e;
-            }
-            double density = 0;
-            const double limit = attempt < 6 ? DENSITY_LIMIT : 0.0;      // after 6 re-cuts: run with what we have
-            bool ok = true;
-            // >= 3 chunks: two extra enumeration passes (count + write) once, one saved per chunk after the first.  Leaves cached by an
-            // earlier attempt stay valid (a re-cut changes the target chunks, not the queries).
-            pre->leaf_enable = leaf_cache_on && chunks.size() >= 3;
-            pre->leaf_refused = false;
-            pre->leaf_allow_split = allow_split && pre->leaf_enable && pe - pb >= 64;
-            pre->leaf_split = 0;
-            if (chunks.size() <= 1) {
-                ok = prefilter_one(tbegin, tend, pb, pe, true, limit, &density);
-                if (ok) return 0;
-            } else {
-                DevBuf<uint32_t> aq, at, tq, tt;
-                DevBuf<int32_t> as, ad, ts, td;
-                uint64_t acc_n = 0;
-                for (size_t c = 0; c < chunks.size() && ok; c++) {
-                    ok = prefilter_one(chunks[c].first, chunks[c].second, pb, pe, c == 0, c == 0 ? limit : 0.0, &density);
-                    if (!ok) break;
-                    if (c == 0 || acc_n == 0) {
-                        aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd);
-                        acc_n = n_hits;
-                    } else if (n_hits) {
-                        const uint64_t tot = acc_n + n_hits;
-                        tq.reserve(tot); tt.reserve(tot); ts.reserve(tot); td.reserve(tot);
-                        UC_HIP(hipMemcpyAsync(tq.p, aq.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
-                        UC_HIP(hipMemcpyAsync(tt.p, at.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
-                        UC_HIP(hipMemcpyAsync(ts.p, as.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
-                        UC_HIP(hipMemcpyAsync(td.p, ad.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
-                        UC_HIP(hipMemcpyAsync(tq.p + acc_n, d_hq.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-                        UC_HIP(hipMemcpyAsync(tt.p + acc_n, d_ht.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-                        UC_HIP(hipMemcpyAsync(ts.p + acc_n, d_hs.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-                        UC_HIP(hipMemcpyAsync(td.p + acc_n, d_hd.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-                        UC_HIP(hipStreamSynchronize(stream));
-                        acc_n = import_hits_dev(tot, tq.p, tt.p, ts.p, td.p, 0, 1);      // merge + truncate to max_seqs
-                        aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd);
-                    }
-                }
-                if (ok) {
-                    // install the accumulated lists (also rebuilds the per-query counts)
-                    import_hits_dev(acc_n, aq.p, at.p, as.p, ad.p, 0, 1);
-                    return 0;
+    for (int attempt = 0;; attempt++) {
+        std::vector<std::pair<uint32_t, uint32_t>> chunks;
+        for (uint32_t b = tbegin; b < tend;) {
+            uint32_t e = b;
+            uint64_t res = 0;
+            while (e < tend && (e == b || res + h_len[e] <= chunk_res)) res += h_len[e++];
+            chunks.emplace_back(b, e);
+            b = e;
+        }
+        double density = 0;
+        const double limit = attempt < 6 ? DENSITY_LIMIT : 0.0;      // after 6 re-cuts: run with what we have
+        bool ok = true;
+        if (chunks.size() <= 1) {
+            ok = prefilter_one(tbegin, tend, qbegin, qend, true, limit, &density);
+            if (ok) { stats.n_prefilter_hits += n_hits; if (pre) pre->trim(scratch_trim_limit()); return; }
+        } else {
+            DevBuf<uint32_t> aq, at, tq, tt;
+            DevBuf<int32_t> as, ad, ts, td;
+            uint64_t acc_n = 0;
+            for (size_t c = 0; c < chunks.size() && ok; c++) {
+                ok = prefilter_one(chunks[c].first, chunks[c].second, qbegin, qend, c == 0, c == 0 ? limit : 0.0, &density);
+                if (!ok) break;
+                if (c == 0 || acc_n == 0) {
+                    aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd);
+                    acc_n = n_hits;
+                } else if (n_hits) {
+                    const uint64_t tot = acc_n + n_hits;
+                    tq.reserve(tot); tt.reserve(tot); ts.reserve(tot); td.reserve(tot);
+                    UC_HIP(hipMemcpyAsync(tq.p, aq.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipMemcpyAsync(tt.p, at.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipMemcpyAsync(ts.p, as.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipMemcpyAsync(td.p, ad.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipMemcpyAsync(tq.p + acc_n, d_hq.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipMemcpyAsync(tt.p + acc_n, d_ht.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipMemcpyAsync(ts.p + acc_n, d_hs.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipMemcpyAsync(td.p + acc_n, d_hd.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipStreamSynchronize(stream));
+                    acc_n = import_hits_dev(tot, tq.p, tt.p, ts.p, td.p, 0, 1);      // merge + truncate to max_seqs
+                    aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd);
                 }
             }
-            if (pre->leaf_split >= 2) return 3;       // not a density abort: the queries want cutting
-            // too dense: smaller chunks, proportionally (and a little more)
-            const uint64_t cur = std::min<uint64_t>(chunk_res, std::max<uint64_t>(1, (uint64_t)h_poff[chunks[0].second] - h_poff[chunks[0].first]));
-            chunk_res = std::max<uint64_t>(1u << 16, (uint64_t)((double)cur * DENSITY_LIMIT / density * 0.75));
-            logf(3, "unicore-cluster: prefilter: %.0f k-mer hits per query residue in a chunk of %llu residues; re-cutting the targets into chunks of %llu\n",
-                 density, (unsigned long long)cur, (unsigned long long)chunk_res);
-        }
-    };
-    // Query parts.  Normally one: all queries.  At high sensitivity and size the similar k-mers of all queries' distinct k-mers do not
-    // fit the leaf-cache budget (100 proteomes at -s 7.5: > 100 GB); the queries are then cut into parts whose caches fit, every
-    // part runs against all target chunks (the chunk indexes are rebuilt per part: milliseconds) and the lists of the parts —
-    // disjoint queries — are concatenated.  The chunk size found by the first part (density re-cuts) is kept for the others.
-    std::vector<std::pair<uint32_t, uint32_t>> parts{{qbegin, qend}};
-    std::vector<int> depth{0};
-    DevBuf<uint32_t> Pq, Pt;
-    DevBuf<int32_t> Ps, Pd;
-    uint64_t P_n = 0;
-    for (size_t pi = 0; pi < parts.size(); pi++) {
-        const uint32_t pb = parts[pi].first, pe = parts[pi].second;
-        pre->leaf_reset(false);
-        const int rc = run_part(pb, pe, depth[pi] < 3);
-        if (rc == 3) {
-            // cut [pb, pe) into leaf_split parts of ~equal residue counts (distinct k-mers grow sublinearly: a part may ask again)
-            const int S = (int)std::min<uint64_t>(pre->leaf_split, (pe - pb) / 32 + 1);
-            std::vector<std::pair<uint32_t, uint32_t>> sub;
-            const uint64_t r0 = h_poff[pb], rt = (uint64_t)h_poff[pe] - r0;
-            uint32_t b = pb;
-            for (int k = 1; k <= S; k++) {
-                uint32_t e = b;
-                if (k == S) e = pe;
-                else while (e < pe && (uint64_t)h_poff[e] - r0 < rt * k / S) e++;
-                if (e > b) sub.emplace_back(b, e);
-                b = e;
+            if (ok) {
+                // install the accumulated lists (also rebuilds the per-query counts)
+                import_hits_dev(acc_n, aq.p, at.p, as.p, ad.p, 0, 1);
+                stats.n_prefilter_hits += n_hits;
+                if (pre) pre->trim(scratch_trim_limit());
+                return;
             }
-            logf(3, "unicore-cluster: prefilter: the similar k-mers of queries [%u, %u) do not fit the leaf cache: %zu query parts\n", pb, pe, sub.size());
-            const int d = depth[pi] + 1;
-            parts.erase(parts.begin() + pi); depth.erase(depth.begin() + pi);
-            parts.insert(parts.begin() + pi, sub.begin(), sub.end());
-            depth.insert(depth.begin() + pi, sub.size(), d);
-            pi--;
-            continue;
         }
-        if (parts.size() > 1 && n_hits) {     // park this part's lists (queries of different parts are disjoint)
-            Pq.grow_preserve(P_n + n_hits, P_n, stream); Pt.grow_preserve(P_n + n_hits, P_n, stream);
-            Ps.grow_preserve(P_n + n_hits, P_n, stream); Pd.grow_preserve(P_n + n_hits, P_n, stream);
-            UC_HIP(hipMemcpyAsync(Pq.p + P_n, d_hq.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-            UC_HIP(hipMemcpyAsync(Pt.p + P_n, d_ht.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-            UC_HIP(hipMemcpyAsync(Ps.p + P_n, d_hs.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-            UC_HIP(hipMemcpyAsync(Pd.p + P_n, d_hd.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-            UC_HIP(hipStreamSynchronize(stream));
-            P_n += n_hits;
-        }
+        // too dense: smaller chunks, proportionally (and a little more)
+        const uint64_t cur = std::min<uint64_t>(chunk_res, std::max<uint64_t>(1, (uint64_t)h_poff[chunks[0].second] - h_poff[chunks[0].first]));
+        chunk_res = std::max<uint64_t>(1u << 16, (uint64_t)((double)cur * DENSITY_LIMIT / density * 0.75));
+        logf(3, "unicore-cluster: prefilter: %.0f k-mer hits per query residue in a chunk of %llu residues; re-cutting the targets into chunks of %llu\n",
+             density, (unsigned long long)cur, (unsigned long long)chunk_res);
     }
-    if (parts.size() > 1) {
-        pre->leaf_reset(false);
-        import_hits_dev(P_n, Pq.p, Pt.p, Ps.p, Pd.p, 0, 1);
-    }
-    stats.n_prefilter_hits += n_hits;
-    if (pre) pre->trim(scratch_trim_limit());
 }
 
 // returns false (nothing installed) if density_limit > 0 and the first query batch exceeds it; *density_out = k-mer hits
@@ -1493,6 +1354,8 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
         }
         // number of valid entries = first index with key >= KSPACE: the offsets kernel's last slot
         hipLaunchKernelGGL(kmer_offsets_kernel, grid_for((uint64_t)KSPACE + 1), dim3(256), 0, stream, k_out.p, nres, d_koff.p);
+        S.d_kbits.reserve((KSPACE + 31) / 32);
+        hipLaunchKernelGGL(kmer_bits_kernel, grid_for((KSPACE + 31) / 32), dim3(256), 0, stream, (const uint32_t *)d_koff.p, S.d_kbits.p);
         UC_HIP(hipMemcpyAsync(&n_entries, d_koff.p + KSPACE, 4, hipMemcpyDeviceToHost, stream));
         UC_HIP(hipStreamSynchronize(stream));
     }
@@ -1542,80 +1405,31 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
         Timer t_p;
         timed_ms_begin();
         const uint32_t nqa = qend - qbegin;
+        S.d_qk.reserve((size_t)NP + 1); S.d_kflag.reserve((size_t)KSPACE + 1); S.d_kid.reserve((size_t)KSPACE + 1);
+        UC_HIP(hipMemsetAsync(S.d_kflag.p, 0, (size_t)KSPACE + 1, stream));
+        hipLaunchKernelGGL(query_kmer_kernel, grid_for(NP), dim3(256), 0, stream, ddb, cfg, qbegin, qend, P0, P0 + NP, S.d_qk.p, S.d_kflag.p);
         size_t tb = 0;
+        auto fin = rocprim::make_transform_iterator(S.d_kflag.p, FlagToU32());
+        UC_HIP(rocprim::exclusive_scan(nullptr, tb, fin, S.d_kid.p, 0u, (size_t)KSPACE + 1, rocprim::plus<uint32_t>(), stream));
+        temp_reserve(tb);
+        UC_HIP(rocprim::exclusive_scan(d_temp.p, tb, fin, S.d_kid.p, 0u, (size_t)KSPACE + 1, rocprim::plus<uint32_t>(), stream));
         uint32_t nd = 0;
-        uint64_t est_leaves = 0;      // similar k-mers of the distinct query k-mers, estimated from every 64th (0 = no estimate)
-        // the leaf cache of an earlier target chunk of this prefilter() call serves the same queries at the same threshold
-        const bool cached = S.leaf_valid && S.leaf_sa == sa && S.leaf_sb == sb && S.leaf_thr == cfg.thr;
-        if (cached) {
-            nd = S.leaf_nd;      // d_qk, d_kid, d_dk, d_nsimk, d_leaf_off, d_leaf_v are still those of this super-batch
-        } else {
-            S.leaf_valid = false;
-            S.d_qk.reserve((size_t)NP + 1); S.d_kflag.reserve((size_t)KSPACE + 1); S.d_kid.reserve((size_t)KSPACE + 1);
-            UC_HIP(hipMemsetAsync(S.d_kflag.p, 0, (size_t)KSPACE + 1, stream));
-            hipLaunchKernelGGL(query_kmer_kernel, grid_for(NP), dim3(256), 0, stream, ddb, cfg, qbegin, qend, P0, P0 + NP, S.d_qk.p, S.d_kflag.p);
-            auto fin = rocprim::make_transform_iterator(S.d_kflag.p, FlagToU32());
-            UC_HIP(rocprim::exclusive_scan(nullptr, tb, fin, S.d_kid.p, 0u, (size_t)KSPACE + 1, rocprim::plus<uint32_t>(), stream));
-            temp_reserve(tb);
-            UC_HIP(rocprim::exclusive_scan(d_temp.p, tb, fin, S.d_kid.p, 0u, (size_t)KSPACE + 1, rocprim::plus<uint32_t>(), stream));
-            UC_HIP(hipMemcpyAsync(&nd, S.d_kid.p + KSPACE, 4, hipMemcpyDeviceToHost, stream));
-            UC_HIP(hipStreamSynchronize(stream));
-            S.d_dk.reserve(std::max<uint32_t>(nd, 1)); S.d_nsimk.reserve(std::max<uint32_t>(nd, 1));
-            UC_HIP(hipMemsetAsync(S.d_nsimk.p, 0, (size_t)std::max<uint32_t>(nd, 1) * 4, stream));
-            hipLaunchKernelGGL(distinct_kmer_kernel, grid_for(KSPACE), dim3(256), 0, stream, S.d_kflag.p, S.d_kid.p, S.d_dk.p);
-        }
+        UC_HIP(hipMemcpyAsync(&nd, S.d_kid.p + KSPACE, 4, hipMemcpyDeviceToHost, stream));
+        UC_HIP(hipStreamSynchronize(stream));
+        S.d_dk.reserve(std::max<uint32_t>(nd, 1)); S.d_nsimk.reserve(std::max<uint32_t>(nd, 1));
+        UC_HIP(hipMemsetAsync(S.d_nsimk.p, 0, (size_t)std::max<uint32_t>(nd, 1) * 4, stream));
+        hipLaunchKernelGGL(distinct_kmer_kernel, grid_for(KSPACE), dim3(256), 0, stream, S.d_kflag.p, S.d_kid.p, S.d_dk.p);
         if (nqa > 1 && nd > (1u << 16)) {   // run-count estimate from every 64th distinct k-mer: cut the super-batch BEFORE the full enumeration
             const uint32_t st = 64;
             UC_HIP(hipMemsetAsync(d_counters.p + 3, 0, 32, stream));
             UC_HIP(hipMemsetAsync(d_counters.p, 0, 8, stream));
-            hipLaunchKernelGGL(sim_runs_kernel<0>, sim_grid((nd + st - 1) / st), dim3(256), 0, stream, ddb, cfg, 0u, 0u, 0u, nd, d_koff.p, RunList{nullptr, nullptr, 0},
-                               d_counters.p, S.d_dk.p, (uint32_t *)nullptr, st, (const uint64_t *)nullptr, (uint32_t *)nullptr);
+            hipLaunchKernelGGL(sim_runs_kernel, sim_grid((nd + st - 1) / st), dim3(256), 0, stream, ddb, cfg, 0u, 0u, 0u, nd, d_koff.p, RunList{nullptr, nullptr, 0},
+                               d_counters.p, S.d_dk.p, (uint32_t *)nullptr, st, (const uint32_t *)S.d_kbits.p);
             unsigned long long c5[5];
             UC_HIP(hipMemcpyAsync(c5, d_counters.p, 40, hipMemcpyDeviceToHost, stream));
             UC_HIP(hipStreamSynchronize(stream));
             if ((double)c5[3] * st > 0.9 * (double)DRUN_MAX) { over_runs = (uint64_t)((double)c5[3] * st / 0.9); gpu_ms += timed_ms_end(); t_kmer += t_p.seconds(); return 2; }
-            est_leaves = (uint64_t)c5[0] * st;
         }
-        size_t fr = 0, tot_mem = 0;
-        (void)hipMemGetInfo(&fr, &tot_mem);
-        uint64_t budget = getenv("UC_LEAF_CACHE_MB") ? strtoull(getenv("UC_LEAF_CACHE_MB"), nullptr, 10) << 20
-                                                     : std::min<uint64_t>(96ull << 30, (uint64_t)((double)tot_mem * 0.35));
-        budget = std::min<uint64_t>(budget, fr > (16ull << 30) ? fr - (16ull << 30) : 0);      // and never the last 16 GiB that are free right now
-        auto refuse = [&](uint64_t leaves) {      // does not fit: ask the caller to cut the queries, or let every chunk enumerate for itself
-            S.leaf_refused = true;
-            if (S.leaf_allow_split && budget >= (1ull << 20)) S.leaf_split = std::max<uint64_t>(2, (leaves * 4 + budget * 3 / 4 - 1) / (budget * 3 / 4));
-        };
-        if (S.leaf_enable && !cached && !S.leaf_refused && est_leaves * 4 > budget + budget / 8) refuse(est_leaves);      // the sample says it cannot fit: do not even count
-        if (S.leaf_split >= 2 && sa == first_query) { gpu_ms += timed_ms_end(); t_kmer += t_p.seconds(); return 1; }
-        // several target chunks ahead (Engine::prefilter said so): enumerate once, keep the leaves — if they fit the budget
-        if (S.leaf_enable && !cached && !S.leaf_refused && nd) {
-            hipLaunchKernelGGL(sim_runs_kernel<1>, sim_grid(nd), dim3(256), 0, stream, ddb, cfg, 0u, 0u, 0u, nd, (const uint32_t *)nullptr, RunList{nullptr, nullptr, 0},
-                               d_counters.p, S.d_dk.p, S.d_nsimk.p, 1u, (const uint64_t *)nullptr, (uint32_t *)nullptr);
-            S.d_leaf_off.reserve((size_t)nd + 1);
-            // exclusive sums over nd + 1 elements: element nd of the input is read, so a copy of the counts carries one zero more
-            S.d_nr.reserve((size_t)nd + 1);
-            UC_HIP(hipMemcpyAsync(S.d_nr.p, S.d_nsimk.p, (size_t)nd * 4, hipMemcpyDeviceToDevice, stream));
-            UC_HIP(hipMemsetAsync(S.d_nr.p + nd, 0, 4, stream));
-            auto lin2 = rocprim::make_transform_iterator(S.d_nr.p, WidenU32());
-            UC_HIP(rocprim::exclusive_scan(nullptr, tb, lin2, S.d_leaf_off.p, (uint64_t)0, (size_t)nd + 1, rocprim::plus<uint64_t>(), stream));
-            temp_reserve(tb);
-            UC_HIP(rocprim::exclusive_scan(d_temp.p, tb, lin2, S.d_leaf_off.p, (uint64_t)0, (size_t)nd + 1, rocprim::plus<uint64_t>(), stream));
-            uint64_t total = 0;
-            UC_HIP(hipMemcpyAsync(&total, S.d_leaf_off.p + nd, 8, hipMemcpyDeviceToHost, stream));
-            UC_HIP(hipStreamSynchronize(stream));
-            if (total * 4 <= budget) {
-                S.d_leaf_v.reserve(std::max<uint64_t>(total, 1));
-                hipLaunchKernelGGL(sim_runs_kernel<2>, sim_grid(nd), dim3(256), 0, stream, ddb, cfg, 0u, 0u, 0u, nd, (const uint32_t *)nullptr, RunList{nullptr, nullptr, 0},
-                                   d_counters.p, S.d_dk.p, S.d_nsimk.p, 1u, (const uint64_t *)S.d_leaf_off.p, S.d_leaf_v.p);
-                S.leaf_valid = true; S.leaf_sa = sa; S.leaf_sb = sb; S.leaf_thr = cfg.thr; S.leaf_nd = nd; S.leaf_total = total;
-                logf(3, "unicore-cluster: prefilter: %llu similar k-mers of %u distinct query k-mers cached (%.1f GiB) for the remaining target chunks\n",
-                     (unsigned long long)total, nd, (double)total * 4 / (double)(1ull << 30));
-            } else {
-                refuse(total);
-                if (S.leaf_split >= 2 && sa == first_query) { gpu_ms += timed_ms_end(); t_kmer += t_p.seconds(); return 1; }
-            }
-        }
-        const bool use_cache = S.leaf_valid && S.leaf_sa == sa && S.leaf_sb == sb && S.leaf_thr == cfg.thr;
         uint64_t n_druns = 0, drun_cap = S.d_drk.cap;
         for (;;) {   // runs of the distinct k-mers, tagged with the k-mer's rank
             drun_cap = std::min<uint64_t>(1ull << 32, std::max<uint64_t>(drun_cap, std::max<uint64_t>(1u << 20, std::min<uint64_t>(DRUN_MAX, (uint64_t)nd * 16))));
@@ -1623,12 +1437,8 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
             UC_HIP(hipMemsetAsync(d_counters.p + 3, 0, 32, stream));
             UC_HIP(hipMemsetAsync(d_counters.p, 0, 8, stream));
             const RunList rl{S.d_drk.p, S.d_drv.p, drun_cap};
-            if (use_cache)
-                hipLaunchKernelGGL(leaf_lookup_kernel, dim3((uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, ((uint64_t)nd + 255) / 256), 8192)), dim3(256), 0, stream,
-                                   (const uint64_t *)S.d_leaf_off.p, (const uint32_t *)S.d_leaf_v.p, nd, d_koff.p, rl, d_counters.p);
-            else
-                hipLaunchKernelGGL(sim_runs_kernel<0>, sim_grid(nd), dim3(256), 0, stream, ddb, cfg, 0u, 0u, 0u, nd, d_koff.p, rl, d_counters.p, S.d_dk.p, S.d_nsimk.p, 1u,
-                                   (const uint64_t *)nullptr, (uint32_t *)nullptr);
+            hipLaunchKernelGGL(sim_runs_kernel, sim_grid(nd), dim3(256), 0, stream, ddb, cfg, 0u, 0u, 0u, nd, d_koff.p, rl, d_counters.p, S.d_dk.p, S.d_nsimk.p, 1u,
+                               (const uint32_t *)S.d_kbits.p);
             unsigned long long c5[5];
             UC_HIP(hipMemcpyAsync(c5, d_counters.p, 40, hipMemcpyDeviceToHost, stream));
             UC_HIP(hipStreamSynchronize(stream));
@@ -1637,7 +1447,7 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
             if (n_druns > drun_cap) {
                 if (n_druns >= (1ull << 32)) fail(UC_ERR_GENERIC, "%u distinct k-mers of query %u produce %llu index ranges", nd, qbegin, (unsigned long long)n_druns);
                 drun_cap = n_druns;
-                if (!use_cache) UC_HIP(hipMemsetAsync(S.d_nsimk.p, 0, (size_t)std::max<uint32_t>(nd, 1) * 4, stream));
+                UC_HIP(hipMemsetAsync(S.d_nsimk.p, 0, (size_t)std::max<uint32_t>(nd, 1) * 4, stream));
                 continue;
             }
             break;
@@ -1751,7 +1561,7 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
             UC_HIP(hipMemsetAsync(d_counters.p + 3, 0, 32, stream));   // run cursor, batch hits, key cursor, candidate cursor
             UC_HIP(hipMemsetAsync(d_counters.p, 0, 8, stream));
             const RunList rl{d_rpidx.p, d_rval.p, run_cap};
-            hipLaunchKernelGGL(sim_runs_kernel<0>, sim_grid(nq_res), dim3(256), 0, stream, ddb, cfg, qa, qb, qp0, qp1, d_koff.p, rl, d_counters.p,
+            hipLaunchKernelGGL(sim_runs_kernel, sim_grid(nq_res), dim3(256), 0, stream, ddb, cfg, qa, qb, qp0, qp1, d_koff.p, rl, d_counters.p,
                                (const uint32_t *)nullptr, (uint32_t *)nullptr, 1u);
             unsigned long long c5[5];
             UC_HIP(hipMemcpyAsync(c5, d_counters.p, 40, hipMemcpyDeviceToHost, stream));

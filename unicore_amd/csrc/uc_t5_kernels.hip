@@ -260,18 +260,18 @@ __global__ void __launch_bounds__(512) t5_gemm256_kernel(const _Float16 *__restr
 // groups' waits.  The K order per output element is unchanged: bit-identical to the other GEMM kernels.
 template <int EPI>
 __global__ void __launch_bounds__(512) t5_gemm256p_kernel(const _Float16 *__restrict__ A, const _Float16 *__restrict__ W, void *__restrict__ out,
-                                                          int M, int N, int K) {
+                                                          int M, int N, int K, int gxm) {
     extern __shared__ __attribute__((aligned(1024))) _Float16 smp[];                // [buffer][A0 | A1 | B0 | B1][128 rows * 64]: 128 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3;
     int m0, n0;
     {
         const int nn = (N + HBN_ - 1) / HBN_, nm = (M + HBM_ - 1) / HBM_;
         const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-        const int g = k / (GXM * nn), r = k % (GXM * nn);
-        const int ml = g * GXM + r % GXM, mt = xcd + 8 * ml;
+        const int g = k / (gxm * nn), r = k % (gxm * nn);
+        const int ml = g * gxm + r % gxm, mt = xcd + 8 * ml;
         if (mt >= nm) return;
         m0 = mt * HBM_;
-        n0 = (r / GXM) * HBN_;
+        n0 = (r / gxm) * HBN_;
     }
     constexpr int HT = 128 * GBK;                                                   // elements of a half-tile
     auto half = [&](int buf, int which) -> _Float16 * { return smp + (size_t)(buf * 4 + which) * HT; };   // which: 0 A0, 1 A1, 2 B0, 3 B1
@@ -430,8 +430,12 @@ static void t5_gemm256p_launch(const void *A, const void *W, void *out, int M, i
         (void)hipFuncSetAttribute((const void *)t5_gemm256p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         once[dev] = true;
     }
-    const int nn = (N + HBN_ - 1) / HBN_, nm = (M + HBM_ - 1) / HBM_, per_xcd = ((nm + 7) / 8 + GXM - 1) / GXM * GXM;
-    hipLaunchKernelGGL(t5_gemm256p_kernel<EPI>, dim3((unsigned)(8 * per_xcd * nn)), dim3(512), LDS, s, (const _Float16 *)A, (const _Float16 *)W, out, M, N, K);
+    // row tiles an XCD keeps in flight beside each other (x 32 / gxm column tiles on its 32 CUs): the A panel gxm x 256 x K should share the
+    // XCD's 4 MB L2 with the W tiles streaming past it
+    static const int gxm_env = getenv("UC_T5_GXM") ? atoi(getenv("UC_T5_GXM")) : 0;
+    const int gxm = gxm_env > 0 ? gxm_env : 2;      // sweep (8-block model, profiles/r03_t5_gxm.log): 1: 866, 2: 882, 4: 871, 8: 849, 16: 861, 32: 823 TFLOP/s
+    const int nn = (N + HBN_ - 1) / HBN_, nm = (M + HBM_ - 1) / HBM_, per_xcd = ((nm + 7) / 8 + gxm - 1) / gxm * gxm;
+    hipLaunchKernelGGL(t5_gemm256p_kernel<EPI>, dim3((unsigned)(8 * per_xcd * nn)), dim3(512), LDS, s, (const _Float16 *)A, (const _Float16 *)W, out, M, N, K, gxm);
 }
 
 template <int EPI>
@@ -450,12 +454,12 @@ static void t5_gemm256_launch(const void *A, const void *W, void *out, int M, in
 
 void t5_gemm(int epi, const void *A, const void *W, void *out, int M, int N, int K, hipStream_t s) {
     if (M <= 0) return;
-    // UC_T5_GEMM256: 0 = 128 x 128 tile only, 1 (default) = 256 x 256 tile with 8 waves of 128 x 64 for large batches.  Both sum K in the same
-    // order: bit-identical results.  (r4, measured and NOT kept in the library: a 256 x 256 tile with FOUR waves of 128 x 128 — accumulators in
+    // UC_T5_GEMM256: 0 = 128 x 128 tile only, 1 = 256 x 256 tile with 8 waves of 128 x 64 for large batches (r3), 3 (default) = the same tile
+    // worked off in phases (t5_gemm256p_kernel, +3 %).  All sum K in the same order: bit-identical results.  (r4, measured and NOT kept in the library: a 256 x 256 tile with FOUR waves of 128 x 128 — accumulators in
     // the 256 AGPRs, 25 % less LDS fragment traffic per FLOP, K loop software-pipelined by hand around one barrier — is bit-identical too but
     // slower: 693 TFLOP/s for the 24-block encoder against 818 with this kernel and 739 with the 128 x 128 one; one wave per SIMD leaves
     // nobody to cover that wave's barrier and wait stalls.  Source: tools/experiments/uc_t5_gemm4w.hip, numbers: profiles/r03_t5_gemm_ab.json.)
-    static const int big = getenv("UC_T5_GEMM256") ? atoi(getenv("UC_T5_GEMM256")) : 1;
+    static const int big = getenv("UC_T5_GEMM256") ? atoi(getenv("UC_T5_GEMM256")) : 3;
     if (big >= 3 && M >= 2048 && N % HBN_ == 0 && (K / GBK) % 2 == 0 && K >= 2 * GBK && (size_t)M * K * 2 < (1ull << 32) && (size_t)N * K * 2 < (1ull << 32)) {
         if (epi == 0) t5_gemm256p_launch<0>(A, W, out, M, N, K, s);
         else if (epi == 1) t5_gemm256p_launch<1>(A, W, out, M, N, K, s);
