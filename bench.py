@@ -22,7 +22,7 @@ N > 1   : one process per GPU (torch.distributed.run).  The data path is inside 
 
           `python bench.py --gpus N` with WORLD_SIZE unset re-executes itself under torch.distributed.run with N ranks.
 also (N = 1, default config): `configs` — sub-records measured in the same run: c3 (BASELINE configs[2] = north_star's quoted
-          1-GPU target size, 500 proteomes: ONE timed pass with its own roofline block and CPU baseline sample) and c5-mini
+          1-GPU target size, 500 proteomes: ONE timed pass after one warm-up pass, with its own roofline block and CPU baseline sample) and c5-mini
           (the ProstT5 encoder's MFMA fraction on one synthetic proteome); `value_one_shot_processes` — what an unmodified
           Unicore experiences: the two spawns of cluster.rs:45-64 (`foldseek cluster` + `foldseek createtsv` through the shim),
           wall from process start to clust.tsv.
@@ -518,9 +518,10 @@ def main():
     if world == 1 and args.config == "c2" and not custom and not args.no_sub_records and not args.no_extra_legs:
         U.lib().uc_release_scratch()
         subs = {}
-        # north_star's quoted 1-GPU target size (BASELINE configs[2] on one GPU): ONE timed pass, its own roofline and CPU sample
+        # north_star's quoted 1-GPU target size (BASELINE configs[2] on one GPU): ONE timed pass after one untimed pass (a cold pass spends
+        # ~6 s of its 46 s in first-touch hipMalloc of ~150 GB of work buffers), its own roofline blocks and CPU sample
         p3 = CONFIGS["c3"]
-        o3, prefix3, n3, _ = run_config(p3[0], p3[1], p3[2], p3[3], p3[4], p3[5], False, 1, 0)
+        o3, prefix3, n3, _ = run_config(p3[0], p3[1], p3[2], p3[3], p3[4], p3[5], False, 1, 1)
         for k in ("metric", "unit", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "value_definition", "rccl_ranks"):
             o3.pop(k, None)
         if not args.no_cpu_baseline:
