@@ -612,7 +612,7 @@ template <> struct TdType<true> { using type = uint32_t; };
 
 // BB (r4): blocked Bloom filter — both hash positions of a key lie in ONE 64-bit word, so marking a key is one ds_or_rtn_b64 (plus a
 // second one for the few positions that were already set) instead of two dependent 32-bit atomic pairs in two unrelated banks
-template <bool C, int RPT, bool BB, bool VG = false>
+template <bool C, int RPT, bool BB>
 __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t qbegin, uint32_t p0, const uint32_t *rpidx,
                                                     const uint64_t *rval, const uint64_t *qr, const uint32_t *order, const void *ent, KeyFmt fmt,
                                                     unsigned long long *region_cursor, void *region_v, uint64_t region_cap,
@@ -706,17 +706,6 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
         return n;
     };
     auto gather = [&](const uint32_t (&idx)[KPT], typename std::conditional<C, uint32_t, uint64_t>::type (&e)[KPT]) {
-        if (C && VG) {
-            // the KPT keys of a thread are consecutive and mostly lie in ONE run, i.e. their index entries are consecutive: one dword-aligned
-            // 16-byte load fetches all four (the entry array is over-allocated by >= 64 entries), single loads only for the keys that
-            // stepped into the next run
-            struct __attribute__((aligned(4))) E4 { uint32_t v[KPT]; };
-            const E4 w = *(const E4 *)((const uint32_t *)ent + idx[0]);
-            e[0] = w.v[0];
-#pragma unroll
-            for (int i = 1; i < KPT; i++) e[i] = idx[i] == idx[0] + (uint32_t)i ? w.v[i] : ((const uint32_t *)ent)[idx[i]];
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < KPT; i++) {
             if (C) e[i] = ((const uint32_t *)ent)[idx[i]];
@@ -1645,22 +1634,22 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
                     // variants for A/B runs: UC_FILTER_VARIANT = 0 (r3: 1024-run tiles, two independent hash positions), 1 (2048-run tiles: the
                     // default — 98.3 -> 95.8 ms of prefilter kernels per configs[1] step), 2 / 3 (the same two with a blocked Bloom filter: one
                     // 64-bit LDS atomic per key instead of two 32-bit ones; measured NO gain — 98.2 / 95.8 ms, 0.4 % more survivors — so the
-                    // kernel is not bound by its LDS atomics; kept for the record, profiles/r03_filter_ab.log)
+                    // kernel is not bound by its LDS atomics; kept for the record, profiles/r03_filter_ab.log.  Also measured and removed: one 16-byte
+                    // load for the four consecutive index entries of a thread instead of four 4-byte loads: 97.4 vs 95.7 ms, profiles/r03_filter_ab2.log)
                     const int variant = getenv("UC_FILTER_VARIANT") ? atoi(getenv("UC_FILTER_VARIANT")) : 1;
                     auto launch = [&](auto kern, int rpt) {
                         static PerDeviceOnce once[8];
-                        const int slot = fmt.compact ? (variant == 4 ? 3 : 4 + (variant & 3)) : (variant & 3);
+                        const int slot = (fmt.compact ? 4 : 0) + (variant & 3);
                         once[slot]([&] { UC_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter_lds(rpt))); });
                         hipLaunchKernelGGL(kern, dim3(nq), dim3(FT), filter_lds(rpt), stream, ddb, qa, qp0, d_rpidx2.p, d_rval2.p, S.d_qr.p, S.d_order.p, ent_p, fmt,
                                            d_counters.p + 5, (void *)d_keys.p, region_cap, d_qbase.p, d_qsurv.p, prof_p);
                     };
                     if (fmt.compact) {
-                        switch (variant) {
+                        switch (variant & 3) {
                             case 0: launch(filter_kernel<true, 1, false>, 1); break;
                             case 1: launch(filter_kernel<true, 2, false>, 2); break;
                             case 2: launch(filter_kernel<true, 1, true>, 1); break;
                             default: launch(filter_kernel<true, 2, true>, 2); break;
-                            case 4: launch(filter_kernel<true, 2, false, true>, 2); break;
                         }
                     } else {
                         switch (variant & 3) {
