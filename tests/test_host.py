@@ -2,6 +2,7 @@
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -247,3 +248,16 @@ def test_synthetic_matrix_needs_an_explicit_opt_in(tmp_path):
     mat = os.path.join(ROOT, "unicore_amd", "data", "mat3di_synthetic.out")
     r = subprocess.run([shim, "cluster", "db", "out", str(tmp_path / "t"), "--mat3di", mat], capture_output=True, text=True, env=env)
     assert r.returncode in (3, 4)          # an explicit matrix is accepted; the run then fails on the missing DB / device
+
+
+def test_bench_launches_itself_for_more_than_one_gpu():
+    """`python bench.py --gpus N` with no WORLD_SIZE (the form the driver uses for its BENCH run) must become a torch.distributed.run launch
+    with N ranks instead of exiting with a usage error.  Without a GPU every rank then stops with the engine's message — what
+    matters here is that N ranks were started."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_multi_gpu.py runs the real thing")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert (r.stdout + r.stderr).count("bench.py needs a GPU") == 2
