@@ -187,7 +187,7 @@ def one_shot_processes(prefix, workdir, options, aln_plain, aln_default):
     outp = os.path.join(workdir, "oneshot_clust")
     tmp = os.path.join(workdir, "tmp")
     res = {"what": "bin/foldseek cluster + bin/foldseek createtsv as two fresh processes (cluster.rs:45-64 argv), first spawn -> clust.tsv; best of 2", "unit": "alignments/s"}
-    T = str(os.cpu_count() or 1)
+    T = str(usable_cores()[0])      # what `unicore --threads 0` would pass on a box whose quota it respects
     for tag, extra, aln in (("plain_step", ["--single-step-clustering"], aln_plain), ("default_workflow", [], aln_default)):
         walls = []
         for _ in range(2):
@@ -509,6 +509,7 @@ def main():
                                        "value": s2["n_gapped_alignments"] / min(walls), "unit": "alignments/s"}
             U.rmdb(outp + "_cluster")
             if not args.no_sub_records:
+                U.lib().uc_release_scratch()     # this process's parked work buffers (tens of GB) go back first: the spawned processes allocate their own
                 out["value_one_shot_processes"] = one_shot_processes(prefix, workdir, options, s1["n_gapped_alignments"], s2["n_gapped_alignments"])
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(prefix, options, n, args.cpu_seconds)

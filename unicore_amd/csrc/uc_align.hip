@@ -682,7 +682,6 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
     uint32_t long_stride = 0;                        // queries beyond the largest systolic class: row-blocked kernel (uc_sw_long.hip)
     if (ngen) work.reserve(sw_long_work_ints(imode, ngen, E.max_len, &long_stride));
     // fork: the classes run concurrently on the auxiliary streams, largest classes first on distinct streams
-    E.ensure_aux();
     UC_HIP(hipEventRecord(E.ev_fork, E.stream));
     for (int i = 0; i < Engine::N_AUX; i++) UC_HIP(hipStreamWaitEvent(E.aux[i], E.ev_fork, 0));
     int slot = 0;

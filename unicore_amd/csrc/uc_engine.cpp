@@ -35,13 +35,10 @@ Engine::Engine(const Params &pp, int dev) : p(pp) {
     UC_HIP(hipEventCreate(&ev0));
     UC_HIP(hipEventCreate(&ev1));
     UC_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-    aux_ready = std::async(std::launch::async, [this] {
-        UC_HIP(hipSetDevice(device));
-        for (int i = 0; i < N_AUX; i++) {
-            UC_HIP(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
-            UC_HIP(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
-        }
-    });
+    for (int i = 0; i < N_AUX; i++) {      // (creating these on a helper thread beside the upload bought nothing: tools/cold_stamps.sh, r4)
+        UC_HIP(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
+        UC_HIP(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+    }
     if (const char *ns = getenv("UC_STREAMS")) n_streams = std::max(1, std::min(N_AUX + 1, atoi(ns)));
     d_S3.reserve(A * A);
     d_SA.reserve(A * A);
@@ -50,12 +47,7 @@ Engine::Engine(const Params &pp, int dev) : p(pp) {
     memset(&stats, 0, sizeof stats);
 }
 
-void Engine::ensure_aux() {
-    if (aux_ready.valid()) aux_ready.get();      // rethrows a failure of the helper thread
-}
-
 Engine::~Engine() {
-    try { ensure_aux(); } catch (...) {}
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     for (int i = 0; i < N_AUX; i++) {

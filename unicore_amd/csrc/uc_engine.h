@@ -4,7 +4,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
-#include <future>
 #include <string>
 #include <utility>
 #include <vector>
@@ -96,10 +95,6 @@ struct Engine {
     hipStream_t aux[N_AUX] = {};
     hipEvent_t ev_fork = nullptr, ev_join[N_AUX] = {};
     int n_streams = N_AUX + 1;   // UC_STREAMS=1 serializes the class kernels on the engine stream (profiling: per-kernel durations then add up to the event time)
-    // the auxiliary streams / events are only needed by the gapped stage: they are created on a helper thread while the database goes up and the
-    // prefilter runs (8 hardware queues cost ~80 ms of a one-shot process; tools/cold_stamps.sh); align() waits for them
-    std::future<void> aux_ready;
-    void ensure_aux();
 
     // host view of the DB
     HostDb hdb;
