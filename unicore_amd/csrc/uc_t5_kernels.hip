@@ -598,15 +598,20 @@ __global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__res
     // through scratch memory
     const int skey = tid >> 4, sdc = (tid & 15) * 8;                 // K: thread -> (key row, dim chunk); + 16 keys per i
     const int sdim = tid >> 3, skc = (tid & 7) * 8;                  // V^T: thread -> (dim row, key chunk); + 32 dims per i
+    // the next block's K / V^T chunks travel in registers while this block is multiplied (T14: issue early, write late)
+    uint4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
+    auto fetch = [&](int k0) {
+        rk0 = *(const uint4 *)(kb + (size_t)min(k0 + skey, L - 1) * ld + sdc);
+        rk1 = *(const uint4 *)(kb + (size_t)min(k0 + skey + 16, L - 1) * ld + sdc);
+        rk2 = *(const uint4 *)(kb + (size_t)min(k0 + skey + 32, L - 1) * ld + sdc);
+        rk3 = *(const uint4 *)(kb + (size_t)min(k0 + skey + 48, L - 1) * ld + sdc);
+        rv0 = *(const uint4 *)(vb + (size_t)sdim * Tp + k0 + skc);
+        rv1 = *(const uint4 *)(vb + (size_t)(sdim + 32) * Tp + k0 + skc);
+        rv2 = *(const uint4 *)(vb + (size_t)(sdim + 64) * Tp + k0 + skc);
+        rv3 = *(const uint4 *)(vb + (size_t)(sdim + 96) * Tp + k0 + skc);
+    };
+    fetch(0);
     for (int k0 = 0; k0 < L; k0 += AKB) {
-        const uint4 rk0 = *(const uint4 *)(kb + (size_t)min(k0 + skey, L - 1) * ld + sdc);
-        const uint4 rk1 = *(const uint4 *)(kb + (size_t)min(k0 + skey + 16, L - 1) * ld + sdc);
-        const uint4 rk2 = *(const uint4 *)(kb + (size_t)min(k0 + skey + 32, L - 1) * ld + sdc);
-        const uint4 rk3 = *(const uint4 *)(kb + (size_t)min(k0 + skey + 48, L - 1) * ld + sdc);
-        const uint4 rv0 = *(const uint4 *)(vb + (size_t)sdim * Tp + k0 + skc);
-        const uint4 rv1 = *(const uint4 *)(vb + (size_t)(sdim + 32) * Tp + k0 + skc);
-        const uint4 rv2 = *(const uint4 *)(vb + (size_t)(sdim + 64) * Tp + k0 + skc);
-        const uint4 rv3 = *(const uint4 *)(vb + (size_t)(sdim + 96) * Tp + k0 + skc);
         *(uint4 *)(sK + skey * SK_LD + sdc) = rk0;
         *(uint4 *)(sK + (skey + 16) * SK_LD + sdc) = rk1;
         *(uint4 *)(sK + (skey + 32) * SK_LD + sdc) = rk2;
@@ -616,6 +621,7 @@ __global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__res
         *(uint4 *)(sV + (sdim + 64) * SV_LD + skc) = rv2;
         *(uint4 *)(sV + (sdim + 96) * SV_LD + skc) = rv3;
         __syncthreads();
+        if (k0 + AKB < L) fetch(k0 + AKB);               // every wave fetches (uniform branch): in flight under the MFMAs below
         if (q0 < L) {                                    // (waves without queries only help with the staging)
             f32x4 sacc[2][4];                            // [query tile][16-key sub-tile]
 #pragma unroll
