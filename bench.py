@@ -104,12 +104,18 @@ def usable_cores():
     may be allowed a fraction of them)"""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     quota = None
-    try:
+    try:                                                   # cgroup v2
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
         if q != "max":
             quota = max(1, int(float(q) / float(per) + 0.5))
     except Exception:
-        pass
+        try:                                               # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = max(1, int(q / per + 0.5))
+        except Exception:
+            pass
     return (min(cores, quota) if quota else cores), cores, quota
 
 

@@ -683,7 +683,7 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
     if (ngen) work.reserve(sw_long_work_ints(imode, ngen, E.max_len, &long_stride));
     // fork: the classes run concurrently on the auxiliary streams, largest classes first on distinct streams
     UC_HIP(hipEventRecord(E.ev_fork, E.stream));
-    for (int i = 0; i < Engine::N_AUX; i++) UC_HIP(hipStreamWaitEvent(E.aux[i], E.ev_fork, 0));
+    for (int i = 0; i < E.n_streams - 1; i++) UC_HIP(hipStreamWaitEvent(E.aux[i], E.ev_fork, 0));
     int slot = 0;
     if (ngen) {                                      // the longest-running launch goes first
         SwArgs al = a;
@@ -705,7 +705,7 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
         UC_HIP(hipGetLastError());
         launches++;
     }
-    for (int i = 0; i < Engine::N_AUX; i++) {   // join
+    for (int i = 0; i < E.n_streams - 1; i++) {   // join
         UC_HIP(hipEventRecord(E.ev_join[i], E.aux[i]));
         UC_HIP(hipStreamWaitEvent(E.stream, E.ev_join[i], 0));
     }
