@@ -15,9 +15,9 @@ workload: --config c2 (default) = BASELINE.json configs[1]: 50 synthetic proteom
           ("-c 0.8 --min-seq-id 0.3 -s 7.5") on 50 proteomes (seed 0x5EED0004); --config c5 = configs[4]: the ProstT5 AA -> 3Di
           encoder (MFMA) fused ahead of the cluster path on --proteomes 5 (its own metric line, see bench_c5).
 N > 1   : one process per GPU (torch.distributed.run).  The data path is inside the library: the target DB is range-
-          partitioned across the ranks (Q x T grid, T = N by default = the north-star layout), the per-shard hit lists are
-          all-gathered with RCCL over xGMI from C (uc_comm_*), merged on the device, every rank aligns the pairs it owns,
-          edges go to rank 0 for the host set cover.  torch.distributed (gloo) only carries the 128-byte RCCL id, the
+          partitioned across the ranks (Q x T grid, T = N by default = the north-star layout), the per-shard hit lists go to the
+          query's home rank with RCCL over xGMI from C (uc_comm_*: ragged all-to-all), are merged there, the surviving pairs go to
+          their owner rank, every rank aligns the pairs it owns, edges go to rank 0 for the host set cover.  torch.distributed (gloo) only carries the 128-byte RCCL id, the
           barriers and the max-over-ranks of the timing.  Total work is fixed -> "strong".
 
           `python bench.py --gpus N` with WORLD_SIZE unset re-executes itself under torch.distributed.run with N ranks.

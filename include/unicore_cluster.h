@@ -66,8 +66,8 @@ typedef struct uc_stats {
     uint64_t n_filtered_hits;                            /* k-mer hits that survive the double-hit filter and get sorted */
     uint64_t n_sw_runs;                                  /* DP problems actually executed over all passes (mutual hits share one, re-runs add) */
     uint64_t cells_run;                                  /* DP cell updates actually executed (cells_* above are the algorithmic counts) */
-    /* multi-GPU exchange: wall seconds of the hit-list all-gather + device merge + edge gather on this rank,
-     * and the bytes this rank received through the collective */
+    /* multi-GPU exchange: wall seconds of the two hit-list exchanges (shard lists to the query's home rank, surviving
+     * pairs to their owner rank) + device merges + edge gather on this rank, and the bytes this rank received from its peers */
     double exchange_seconds;
     uint64_t exchange_bytes;
     uint32_t n_gpus, target_shards;                      /* the Q x T grid the run used: Q = n_gpus / target_shards */
@@ -185,7 +185,8 @@ int uc_engine_hits_import_dev(uc_engine *e, uint64_t n, const uint32_t *d_query,
                               const int32_t *d_diag, uint32_t rank, uint32_t world, uint64_t *n_kept);
 
 /* ---- one process per GPU: the same sharded pass driven from outside (bench.py under torch.distributed.run) ----------
- * The data path stays inside the library: RCCL all-gather of the hit lists, device merge, point-to-point edge gather.
+ * The data path stays inside the library: two ragged RCCL exchanges of the hit lists (grouped ncclSend / ncclRecv), device merges,
+ * point-to-point edge gather.
  * Rank 0 creates an id and ships its 128 bytes to the other ranks by any means (a file, torch.distributed's store);
  * uc_comm_create is collective (ncclCommInitRank) and binds the communicator to HIP device `device`. */
 typedef struct uc_comm uc_comm;
@@ -197,7 +198,7 @@ void uc_comm_destroy(uc_comm *c);
  * it was built over, this rank, its HIP device.  bench.py prints the count in its line; the N > 1 tests assert it == N. */
 int uc_comm_info(const uc_comm *c, int32_t *nccl_ranks, int32_t *nccl_rank, int32_t *device);
 /* One pass of the hot path on this rank: E1-E4 on the rank's cell of the Q x T grid (target_shards = T, 0 = one target
- * shard per GPU: the north-star layout) -> hit-list all-gather + merge + ownership -> E5/E6 on the rank's pairs -> edges
+ * shard per GPU: the north-star layout) -> exchange 1 + merge at the home rank -> exchange 2 to the owner rank -> E5/E6 on the rank's pairs -> edges
  * to rank 0 -> set cover on rank 0.  comm == NULL runs the single-GPU pass.  assign[n_seqs] is written on rank 0 only
  * (may be NULL elsewhere); *n_alignments = gapped alignments of THIS rank. */
 int uc_engine_cluster_step(uc_engine *e, uc_comm *comm, int32_t target_shards, uint32_t *assign, uint64_t *n_alignments);
