@@ -347,7 +347,6 @@ uint64_t exchange_hits(Engine &E, Comm &C) {
     std::vector<uint64_t> soff((size_t)W), scnt((size_t)W), mat((size_t)W * W), roff((size_t)W), rcnt((size_t)W);
 
     // ---- phase 1 (in rounds if a rank would receive more than round_limit() records at once)
-    Timer t1;
     for (int h = 0; h < W; h++) { soff[(size_t)h] = E.hit_off[homes[(size_t)h].first]; scnt[(size_t)h] = E.hit_off[homes[(size_t)h].second] - soff[(size_t)h]; }
     C.all_gather_u64s(E, scnt.data(), W, mat.data());
     uint64_t worst = 0;
@@ -380,8 +379,8 @@ uint64_t exchange_hits(Engine &E, Comm &C) {
             E.import_hits_dev(R, (uint32_t *)S.all.p, (uint32_t *)S.all.p + R, S.all.p + 2 * R, S.all.p + 3 * R, 0, 1);
             t_merge += tg.seconds();
         } else {
-            // the engine's own lists are still the send side of the later rounds: merge into a side engine state is not available, so
-            // the round's slice is merged in place of a scratch copy — park own lists, merge, append, restore
+            // the merge installs its result IN the engine, whose own lists are still the send side of the later rounds: park them, merge
+            // this round's slices, append the result to the accumulator, put the own lists back
             Turn turn(C, &E);
             Timer tg;
             const uint64_t nloc = E.n_hits;
