@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""tools/t5_gemm_ab.py — the three GEMM kernels of the encoder on the same sequences (one process each, UC_T5_GEMM256 = 2: 256 x 256 tile,
-4 waves x (128 x 128), AGPR accumulators; 1: 256 x 256 tile, 8 waves x (128 x 64); 0: 128 x 128 tile): predicted states and logits must
-be IDENTICAL (same K order per output element), plus throughput.
+"""tools/t5_gemm_ab.py — the GEMM kernels of the encoder on the same sequences (one process each; UC_T5_GEMM256 = 2: 256 x 256 tile in two phases per
+K-step, persistent workgroups (the default); 1: 256 x 256 tile, one barrier per K-step; 0: 128 x 128 tile): predicted states and logits must be
+IDENTICAL (same K order per output element), plus throughput.
 usage: t5_gemm_ab.py [n_layers=4] [n_seqs=400]"""
 import json, os, subprocess, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,13 +31,14 @@ if len(sys.argv) > 3:
     work(sys.argv[1], int(sys.argv[2]), int(sys.argv[3])); sys.exit(0)
 nl = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 ns = int(sys.argv[2]) if len(sys.argv) > 2 else 400
-res = []
-for v in ("3", "1", "0"):      # "3" = the phased 256 x 256 kernel (t5_gemm256p_kernel), "1" = the single-phase one, "0" = 128 x 128
-    o = "/tmp/t5_ab_%s.npz" % v
-    subprocess.check_call([sys.executable, os.path.abspath(__file__), o, str(nl), str(ns)], env=dict(os.environ, UC_T5_GEMM256=v))
-    res.append(np.load(o))
-q, a, b = res
-print(json.dumps({"codes_equal": bool((a["codes"] == b["codes"]).all() and (q["codes"] == b["codes"]).all()),
-                  "logits_max_abs_diff": float(max(np.abs(a["logits"] - b["logits"]).max(), np.abs(q["logits"] - b["logits"]).max())),
-                  "tflops_phased_256": float(q["tflops"]), "tflops_8wave_256": float(a["tflops"]), "tflops_128": float(b["tflops"]),
-                  "gpu_ms_phased_256": float(q["gpu_ms"]), "gpu_ms_8wave_256": float(a["gpu_ms"]), "gpu_ms_128": float(b["gpu_ms"])}))
+res = {}
+for name, env in (("twophase_256", {"UC_T5_GEMM256": "2"}), ("8wave_256", {"UC_T5_GEMM256": "1"}), ("128", {"UC_T5_GEMM256": "0"})):
+    o = "/tmp/t5_ab_%s.npz" % name
+    subprocess.check_call([sys.executable, os.path.abspath(__file__), o, str(nl), str(ns)], env=dict(os.environ, **env))
+    res[name] = np.load(o)
+b = res["128"]
+out = {"codes_equal": bool(all((r["codes"] == b["codes"]).all() for r in res.values())),
+       "logits_max_abs_diff": float(max(np.abs(r["logits"] - b["logits"]).max() for r in res.values())), "n_layers": nl, "n_seqs": ns}
+for k, r in res.items():
+    out["tflops_" + k] = float(r["tflops"]); out["gpu_ms_" + k] = float(r["gpu_ms"])
+print(json.dumps(out))

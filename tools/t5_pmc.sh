@@ -1,10 +1,10 @@
 #!/bin/bash
 # tools/t5_pmc.sh — PMC counters of the encoder's GEMM kernels (4-layer model, 400 sequences) for the GEMM variants 1 (single-phase 256 tile)
-# and 3 (phased 256 tile): where do the cycles go?  Counter passes only (no trace domains beside the kernel dispatch records).
+# and 2 (two-phase persistent 256 tile): where do the cycles go?  Counter passes only (no trace domains beside the kernel dispatch records).
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
-for v in 1 3; do
+for v in 1 2; do
   for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" \
              "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE"; do
     tag=$(echo $set | cut -d' ' -f1)

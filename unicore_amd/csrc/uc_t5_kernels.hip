@@ -15,7 +15,9 @@
 //   C (16 x 16): lane l, register r holds C[(l >> 4) * 4 + r][l & 15].
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 #include "uc_t5.h"
 
@@ -128,14 +130,13 @@ __global__ void __launch_bounds__(256) t5_gemm_kernel(const _Float16 *__restrict
 }
 
 // ---- the large-tile variant: 256 x 256 x 64, 8 waves x (128 x 64) -------------------------------------------------------
-// With 64 x 64 per wave the 128^2 kernel reads 16 fragments (16 B per lane) from LDS per 32 MFMAs: at 128 B / cycle / CU that
-// is as many cycles as the MFMAs themselves take, so the two pipes cannot both be full.  A wave tile of 128 x 64 reads 24
-// fragments per 64 MFMAs (0.375 instead of 0.5 per MFMA); the 256 x 256 workgroup tile also halves the global -> LDS traffic
-// per FLOP.  Same staging (global_load_lds into a double-buffered XOR-swizzled tile, one barrier per K-step), 128 KB of LDS,
-// one workgroup of 8 waves per CU, accumulators 128 VGPRs.  Measured (r3d): whole encoder 746 -> 835 TFLOP/s; with the global
-// loads switched off the same loop reaches ~1.2 PFLOP/s inside the GEMM (the chip's tuned f16 GEMMs: 1.3-1.5), L2 hit rate
-// 79 % (rocprofv3 TCC_HIT / TCC_MISS): what is left is the LDS port - 192 KB of fragment reads + 64 KB of DMA writes per K-step
-// are 2048 cycles at 128 B / cycle, exactly the MFMA time of the step - not the schedule and not the L2.
+// A wave tile of 128 x 64 reads 24 LDS fragments per 64 MFMAs (0.375 per MFMA instead of the 0.5 of the 128^2 kernel's 64 x 64),
+// and the 256 x 256 workgroup tile halves the global -> LDS traffic per FLOP.  Same staging (global_load_lds into a
+// double-buffered XOR-swizzled tile, one barrier per K-step), 128 KB of LDS, one workgroup of 8 waves per CU, accumulators 128
+// VGPRs.  Measured (r3d): whole encoder 746 -> 835 TFLOP/s, L2 hit rate 79 % (rocprofv3 TCC_HIT / TCC_MISS).  (The r3 reading
+// "the LDS port is saturated" assumed 128 B / clock; ds_read_b128 moves 256 B / clock on gfx950 and the fragment rows are
+// conflict-free in its 16-lane groups - the decomposition that replaced it stands at t5_gemm256x_kernel.)  Kept as the
+// fallback where the two-phase kernel's 32-bit staging offsets do not reach, and as the baseline of tools/t5_gemm_ab.py.
 constexpr int HBM_ = 256, HBN_ = 256;
 
 template <int EPI>
@@ -241,59 +242,69 @@ __global__ void __launch_bounds__(512) t5_gemm256_kernel(const _Float16 *__restr
     }
 }
 
-// ---- the phased variant of the 256 x 256 tile (r4) ---------------------------------------------------------------------------
-// Same tile, same 8 waves of 128 x 64 and the same bytes through LDS as t5_gemm256_kernel, but the K-step is no longer "wait for the whole
-// tile, barrier, read, multiply".  A K-tile is staged as FOUR half-tiles of 16 KB, chosen so that each is dead as early as possible:
-//   A-half h = the rows of sub-block h (64 rows) of BOTH row-waves, B-half h = the columns of sub-block h (32 columns) of all four column-waves;
-//   the wave tile is worked off in four C-quadrants (64 x 32, 16 MFMAs each) in the order (0,0) (0,1) (1,1) (1,0):
-//   phase 1 reads A-half 0 + B-half 0 into registers, phase 2 B-half 1, phase 3 A-half 1, phase 4 B-half 0 again.
-// A-half 0 of a buffer is therefore free after phase 1, B-half 1 after phase 2, A-half 1 after phase 3, B-half 0 after phase 4, and every
-// phase re-stages exactly one half-tile: phases 2 / 3 / 4 of tile t load A-half 0 / B-half 1 / A-half 1 of tile t + 2 into the buffer tile t
-// is still being read from, phase 1 of tile t + 1 its B-half 0.  Loads stay in flight ACROSS barriers: the only wait is a counted
-// s_waitcnt vmcnt(6) in phase 4 (three half-tiles = 6 instructions may still be under way; everything tile t + 1 needs has landed), raw
-// s_barrier instead of __syncthreads (whose fence would drain the DMA queue).  A phase is {LDS reads + one stage; lgkmcnt(0); barrier;
-// 16 MFMAs at raised priority; barrier}, and the two row-waves of a SIMD run ONE BARRIER APART (the second row-wave executes one extra
-// barrier up front, the first one extra at the end), so on every SIMD one wave multiplies while the other reads and stages: the matrix
-// pipe and the LDS port work side by side instead of taking turns.  Hazards: a half-tile is re-staged in the phase after its last read,
-// and every read is retired (lgkmcnt(0)) before the barrier that ends its interval — both wave groups included (the later group reads one
-// interval later and stages one interval later); data waited for in phase 4 is read from phase 1 of the next tile on, a barrier after both
-// groups' waits.  The K order per output element is unchanged: bit-identical to the other GEMM kernels.
+// ---- the two-phase persistent variant of the 256 x 256 tile (r4) ------------------------------------------------------------------------------
+// Same tile, same 8 waves of 128 x 64 and the same bytes through LDS as t5_gemm256_kernel, but a K-step is no longer "wait for the whole tile, barrier,
+// read, multiply".  A K-tile is staged as FOUR half-tiles ("pieces") of 16 KB - A-half h = the rows of sub-block h (64 rows) of BOTH row-waves, B-half h =
+// the columns of sub-block h (32 columns) of all four column-waves - and worked off in TWO phases of 32 MFMAs:
+//   X: stage A-half 1 of step kt + 1 | read A-half 0 and both B halves (16 fragments) | wave-tile rows 0 .. 63
+//   Y: stage A-half 0, B-half 0, B-half 1 of step kt + 2 (the pieces X has just freed, in the buffer step kt is still read from) | read A-half 1 (8 fragments) | rows 64 .. 127
+// B fragments stay in registers for the whole K-step.  A phase is {stage; LDS reads; counted s_waitcnt vmcnt(8) (four pieces may still be in flight: what the
+// NEXT phase reads has landed) + lgkmcnt(0); barrier; 32 MFMAs at raised priority; barrier}, raw s_barrier instead of __syncthreads (whose fence would drain
+// the DMA queue), loads in flight ACROSS barriers.  The two row-waves of a SIMD run ONE BARRIER APART (the second executes one extra barrier up front, the first one
+// extra at the end), so on every SIMD one wave multiplies while the other reads and stages: the matrix pipe and the LDS port work side by side.  Hazards: a piece
+// is re-staged in the phase after its last read, every read is retired (lgkmcnt(0)) before the barrier that ends its interval - both wave groups included (the
+// later group reads and stages one interval later); a wait in phase q is followed by both groups' barriers before anybody reads in phase q + 1.
+// PERSISTENT: one workgroup per CU (128 KB of LDS) walks its tiles; the K-steps of consecutive tiles form ONE stream - the last steps of a tile stage the first of
+// the next (the pieces' staging offsets move on one at a time), so only a workgroup's first tile pays the load latency, and a tile's stores drain under the next tile.
+// Where the time goes (tools/ubench/gemm_supply.hip = this kernel with parts switched off; TFLOP/s-equivalent at 65,536 tokens, K = 1024 / 16384;
+// profiles/r03_gemm_supply.log): MFMA loop alone 1.8 / 2.05 P (the clock under MFMA load is ~2.0 GHz: 2.05 P IS the matrix pipe), + epilogue stores 1.46 / 2.05,
+// + LDS fragment reads 1.26 / 1.76, + the global -> LDS stream 0.9-1.1 / 1.34.  The stream alone runs at 12-14 TB/s (20-23 B / clock / CU) and 1.3-1.8x faster
+// when every load hits L2; more bytes in flight do not speed it up (bandwidth-, not latency-bound).  The K order per output element is unchanged: bit-identical
+// to the other GEMM kernels.
 template <int EPI>
-__global__ void __launch_bounds__(512) t5_gemm256p_kernel(const _Float16 *__restrict__ A, const _Float16 *__restrict__ W, void *__restrict__ out,
-                                                          int M, int N, int K, int gxm) {
-    extern __shared__ __attribute__((aligned(1024))) _Float16 smp[];                // [buffer][A0 | A1 | B0 | B1][128 rows * 64]: 128 KB
+__global__ void __launch_bounds__(512) t5_gemm256x_kernel(const _Float16 *__restrict__ A, const _Float16 *__restrict__ W, void *__restrict__ out,
+                                                          int M, int N, int K, int gxm, int slots) {
+    extern __shared__ __attribute__((aligned(1024))) _Float16 smx[];                // [buffer][A0 | A1 | B0 | B1][128 rows * 64]: 128 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3;
-    int m0, n0;
-    {
-        const int nn = (N + HBN_ - 1) / HBN_, nm = (M + HBM_ - 1) / HBM_;
-        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int nn = N / HBN_, nm = (M + HBM_ - 1) / HBM_, xcd = blockIdx.x & 7;
+    const int n_local = ((nm + 7) / 8 + gxm - 1) / gxm * gxm * nn;
+    auto decode = [&](int k, int &tm0, int &tn0) -> bool {
         const int g = k / (gxm * nn), r = k % (gxm * nn);
-        const int ml = g * gxm + r % gxm, mt = xcd + 8 * ml;
-        if (mt >= nm) return;
-        m0 = mt * HBM_;
-        n0 = (r / gxm) * HBN_;
-    }
-    constexpr int HT = 128 * GBK;                                                   // elements of a half-tile
-    auto half = [&](int buf, int which) -> _Float16 * { return smp + (size_t)(buf * 4 + which) * HT; };   // which: 0 A0, 1 A1, 2 B0, 3 B1
+        const int mt = xcd + 8 * (g * gxm + r % gxm);
+        tm0 = mt * HBM_;
+        tn0 = (r / gxm) * HBN_;
+        return mt < nm;
+    };
+    auto seek = [&](int k, int &tm0, int &tn0) -> int {
+        while (k < n_local && !decode(k, tm0, tn0)) k += slots;
+        return k;
+    };
+    int m0 = 0, n0 = 0, kcur = seek((int)(blockIdx.x >> 3), m0, n0);
+    if (kcur >= n_local) return;
+    constexpr int HT = 128 * GBK;
+    auto half = [&](int buf, int which) -> _Float16 * { return smx + (size_t)(buf * 4 + which) * HT; };   // which: 0 A0, 1 A1, 2 B0, 3 B1
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // staging: a half-tile = 16 wave-instructions of 8 rows; wave w issues instructions 2 w and 2 w + 1.  Half-tile row r of A-half h is
-    // tile row (r >> 6) * 128 + h * 64 + (r & 63); of B-half h it is tile column (r >> 5) * 64 + h * 32 + (r & 31).  32-bit byte offsets
-    // against the (wave-uniform) operand bases.
     uint32_t oa[2][2], ob[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; h++)
+    auto set_a = [&](int h, int tm0) {
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int r = (wave * 2 + i) * 8 + (lane >> 3), kc = ((lane & 7) ^ (r & 7)) * 8;
-            const int arow = (r >> 6) * 128 + h * 64 + (r & 63), bcol = (r >> 5) * 64 + h * 32 + (r & 31);
-            oa[h][i] = (uint32_t)(((size_t)min(m0 + arow, M - 1) * K + kc) * 2);
-            ob[h][i] = (uint32_t)(((size_t)min(n0 + bcol, N - 1) * K + kc) * 2);
+            oa[h][i] = (uint32_t)(((size_t)min(tm0 + (r >> 6) * 128 + h * 64 + (r & 63), M - 1) * K + kc) * 2);
         }
-    auto stage = [&](int kt, int buf, int which) {   // which as in half(); compile-time after unrolling
+    };
+    auto set_b = [&](int h, int tn0) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int r = (wave * 2 + i) * 8 + (lane >> 3), kc = ((lane & 7) ^ (r & 7)) * 8;
+            ob[h][i] = (uint32_t)(((size_t)(tn0 + (r >> 5) * 64 + h * 32 + (r & 31)) * K + kc) * 2);
+        }
+    };
+    set_a(0, m0); set_a(1, m0); set_b(0, n0); set_b(1, n0);
+    auto stage = [&](int kt, int buf, int which) {
         const char *base = (which < 2 ? (const char *)A : (const char *)W) + (size_t)kt * (GBK * 2);
         _Float16 *dst = half(buf, which);
 #pragma unroll
@@ -302,36 +313,45 @@ __global__ void __launch_bounds__(512) t5_gemm256p_kernel(const _Float16 *__rest
             __builtin_amdgcn_global_load_lds((gbl_void *)(base + o), (lds_void *)(dst + (wave * 2 + i) * 8 * GBK), 16, 0, 0);
         }
     };
-    // fragment (16 rows x 32 k) of a half-tile: rows r0 .. r0 + 15, k-slice ks
     auto frag = [&](const _Float16 *s, int r0, int ks) -> half8 {
         const int r = r0 + (lane & 15);
         return *(const half8 *)(s + r * GBK + (((ks * 4 + (lane >> 4)) ^ (r & 7)) * 8));
     };
-    const int nk = K / GBK;                                                         // even and >= 2 (the launcher checks)
-    // prologue: all of tile 0, and of tile 1 what the steady state would have staged by now (its B-half 0 follows in phase 1 of tile 0)
-    stage(0, 0, 0); stage(0, 0, 3); stage(0, 0, 1); stage(0, 0, 2);
-    stage(1, 1, 0); stage(1, 1, 3); stage(1, 1, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    const int nk = K / GBK;                                                         // >= 2 (the launcher checks)
+    // prologue: step 0 and, of step 1, what phase Y of "step -1" would have staged
+    stage(0, 0, 0); stage(0, 0, 2); stage(0, 0, 3); stage(0, 0, 1);
+    stage(1, 1, 0); stage(1, 1, 2); stage(1, 1, 3);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();                                      // the second row-wave of every SIMD runs one barrier behind
 
-    half8 fa[4][2], fb0[2][2], fb1[2][2];
-    for (int kt = 0; kt < nk; kt++) {
-        const int buf = kt & 1;
+    half8 fa[4][2], fb[4][2];
+    int buf = 0;
+    for (;;) {                                                                      // this workgroup's tiles
+    int m0n = 0, n0n = 0;
+    const int knext = seek(kcur + slots, m0n, n0n);
+    const bool has_next = knext < n_local;
+    for (int kt = 0; kt < nk; kt++, buf ^= 1) {
+        // the staging offsets move on to the next tile piece by piece: phase Y stages two steps ahead, phase X one
+        if (has_next && kt == nk - 2) { set_a(0, m0n); set_b(0, n0n); set_b(1, n0n); }
+        if (has_next && kt == nk - 1) set_a(1, m0n);
+        const bool more1 = kt + 1 < nk || has_next, more2 = kt + 2 < nk || has_next;
+        const int kt1 = kt + 1 < nk ? kt + 1 : 0, kt2 = kt + 2 < nk ? kt + 2 : kt + 2 - nk;
+        const bool tail = !has_next && kt + 2 >= nk;                               // the stream ends: nothing is staged behind what is waited for
         const _Float16 *sA0 = half(buf, 0) + wr * 64 * GBK, *sA1 = half(buf, 1) + wr * 64 * GBK;
         const _Float16 *sB0 = half(buf, 2) + wc * 32 * GBK, *sB1 = half(buf, 3) + wc * 32 * GBK;
-        // ---- phase 1: A-half 0 + B-half 0 -> registers; stage B-half 0 of tile kt + 1; quadrant (0, 0)
+        // ---- phase X
+        if (more1) stage(kt1, buf ^ 1, 1);
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) fb0[j][ks] = frag(sB0, j * 16, ks);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int ks = 0; ks < 2; ks++) { fb[j][ks] = frag(sB0, j * 16, ks); fb[2 + j][ks] = frag(sB1, j * 16, ks); }
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) fa[i][ks] = frag(sA0, i * 16, ks);
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1, 2);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (tail) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -339,33 +359,17 @@ __global__ void __launch_bounds__(512) t5_gemm256p_kernel(const _Float16 *__rest
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb0[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
-        // ---- phase 2: B-half 1 -> registers; stage A-half 0 of tile kt + 2 (this buffer); quadrant (0, 1)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++) fb1[j][ks] = frag(sB1, j * 16, ks);
-        if (kt + 2 < nk) stage(kt + 2, buf, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb1[j][ks], fa[i][ks], acc[i][2 + j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();
-        // ---- phase 3: A-half 1 -> registers; stage B-half 1 of tile kt + 2; quadrant (1, 1)
+        // ---- phase Y
+        if (more2) { stage(kt2, buf, 0); stage(kt2, buf, 2); stage(kt2, buf, 3); }
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) fa[i][ks] = frag(sA1, i * 16, ks);
-        if (kt + 2 < nk) stage(kt + 2, buf, 3);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (tail) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -373,69 +377,79 @@ __global__ void __launch_bounds__(512) t5_gemm256p_kernel(const _Float16 *__rest
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int j = 0; j < 2; j++) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb1[j][ks], fa[i][ks], acc[4 + i][2 + j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();
-        // ---- phase 4: B-half 0 -> registers again; stage A-half 1 of tile kt + 2; counted wait: tile kt + 1 is complete; quadrant (1, 0)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++) fb0[j][ks] = frag(sB0, j * 16, ks);
-        if (kt + 2 < nk) {
-            stage(kt + 2, buf, 1);
-            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb0[j][ks], fa[i][ks], acc[4 + i][j], 0, 0, 0);
+                for (int j = 0; j < 4; j++) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][ks], fa[i][ks], acc[4 + i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     }
-    if (wr == 0) __builtin_amdgcn_s_barrier();                                      // barrier counts of the two groups match again
+    // epilogue (no barrier inside: the wave groups stay one barrier apart; one group stores while the other multiplies).  A lane holds out[row l & 15][4
+    // consecutive columns (l >> 4) * 4 ..] of each 16 x 16 tile: stored as they are, the f16 results leave as 8 bytes per lane = 32-byte pieces of 16 rows per
+    // instruction, and such stores cost the K = 1024 layers a quarter of their time (gemm_supply: 0.95 -> 1.17-1.22 P with 64- / 128-byte row pieces).  So two
+    // neighbouring tiles are interleaved first: v_permlane16_swap hands lane group 1's quarter of tile j to group 0 and group 0's quarter of tile j + 1 to
+    // group 1 (likewise 3 <-> 2), after which every lane owns 8 consecutive columns = 16 bytes, and an instruction writes 64 contiguous bytes of 16 rows.
+    if (EPI == 2) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int row = m0 + wr * 128 + i * 16 + (lane & 15);
-        if (row >= M) continue;
+        for (int i = 0; i < 8; i++) {
+            const int row = m0 + wr * 128 + i * 16 + (lane & 15);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int col = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
-            if (col >= N) continue;
-            f32x4 v = acc[i][j];
-            if (EPI == 2) {
+            for (int j = 0; j < 4; j++) {
+                const int col = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+                const f32x4 v = acc[i][j];
+                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (row >= M) continue;
                 f32x4 *o = (f32x4 *)((float *)out + (size_t)row * N + col);
                 *o = *o + v;
-            } else {
-                if (EPI == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                *(h4 *)((_Float16 *)out + (size_t)row * N + col) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            }
+        }
+    } else {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const int g = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int row = m0 + wr * 128 + i * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                f32x4 v0 = acc[i][j], v1 = acc[i][j + 1];
+                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[i][j + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (EPI == 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+                }
+                const uint32_t ax = __builtin_bit_cast(uint32_t, h2{(_Float16)v0[0], (_Float16)v0[1]}), ay = __builtin_bit_cast(uint32_t, h2{(_Float16)v0[2], (_Float16)v0[3]});
+                const uint32_t bx = __builtin_bit_cast(uint32_t, h2{(_Float16)v1[0], (_Float16)v1[1]}), by = __builtin_bit_cast(uint32_t, h2{(_Float16)v1[2], (_Float16)v1[3]});
+                const auto sx = __builtin_amdgcn_permlane16_swap(ax, bx, false, false), sy = __builtin_amdgcn_permlane16_swap(ay, by, false, false);
+                // group g now holds tile j + (g & 1), columns (g >> 1) * 8 .. + 7: first result = the lower four, second = the upper four
+                const int col = n0 + wc * 64 + (j + (g & 1)) * 16 + (g >> 1) * 8;
+                if (row < M) *(u32x4 *)((_Float16 *)out + (size_t)row * N + col) = u32x4{sx[0], sy[0], sx[1], sy[1]};
             }
         }
     }
+    if (!has_next) break;
+    m0 = m0n; n0 = n0n; kcur = knext;
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
 }
 
 template <int EPI>
-static void t5_gemm256p_launch(const void *A, const void *W, void *out, int M, int N, int K, hipStream_t s) {
+static void t5_gemm256x_launch(const void *A, const void *W, void *out, int M, int N, int K, hipStream_t s) {
     constexpr int LDS = 2 * 4 * 128 * GBK * 2;
     static bool once[64] = {};
+    static int cus[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !once[dev]) {
-        (void)hipFuncSetAttribute((const void *)t5_gemm256p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (!once[dev]) {
+        (void)hipFuncSetAttribute((const void *)t5_gemm256x_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipDeviceProp_t pr;
+        cus[dev] = hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount >= 8 ? pr.multiProcessorCount : 256;
         once[dev] = true;
     }
-    // row tiles an XCD keeps in flight beside each other (x 32 / gxm column tiles on its 32 CUs): the A panel gxm x 256 x K should share the
-    // XCD's 4 MB L2 with the W tiles streaming past it
     static const int gxm_env = getenv("UC_T5_GXM") ? atoi(getenv("UC_T5_GXM")) : 0;
-    const int gxm = gxm_env > 0 ? gxm_env : 2;      // sweep (8-block model, profiles/r03_t5_gxm.log): 1: 866, 2: 882, 4: 871, 8: 849, 16: 861, 32: 823 TFLOP/s
-    const int nn = (N + HBN_ - 1) / HBN_, nm = (M + HBM_ - 1) / HBM_, per_xcd = ((nm + 7) / 8 + gxm - 1) / gxm * gxm;
-    hipLaunchKernelGGL(t5_gemm256p_kernel<EPI>, dim3((unsigned)(8 * per_xcd * nn)), dim3(512), LDS, s, (const _Float16 *)A, (const _Float16 *)W, out, M, N, K, gxm);
+    const int gxm = gxm_env > 0 ? gxm_env : 2;
+    const int nn = N / HBN_, nm = (M + HBM_ - 1) / HBM_, n_local = ((nm + 7) / 8 + gxm - 1) / gxm * gxm * nn;
+    const int slots = std::min(n_local, std::max(1, cus[dev] / 8));
+    hipLaunchKernelGGL(t5_gemm256x_kernel<EPI>, dim3((unsigned)(8 * slots)), dim3(512), LDS, s, (const _Float16 *)A, (const _Float16 *)W, out, M, N, K, gxm, slots);
 }
 
 template <int EPI>
@@ -454,16 +468,18 @@ static void t5_gemm256_launch(const void *A, const void *W, void *out, int M, in
 
 void t5_gemm(int epi, const void *A, const void *W, void *out, int M, int N, int K, hipStream_t s) {
     if (M <= 0) return;
-    // UC_T5_GEMM256: 0 = 128 x 128 tile only, 1 = 256 x 256 tile with 8 waves of 128 x 64 for large batches (r3), 3 (default) = the same tile
-    // worked off in phases (t5_gemm256p_kernel, +3 %).  All sum K in the same order: bit-identical results.  (r4, measured and NOT kept in the library: a 256 x 256 tile with FOUR waves of 128 x 128 — accumulators in
-    // the 256 AGPRs, 25 % less LDS fragment traffic per FLOP, K loop software-pipelined by hand around one barrier — is bit-identical too but
-    // slower: 693 TFLOP/s for the 24-block encoder against 818 with this kernel and 739 with the 128 x 128 one; one wave per SIMD leaves
-    // nobody to cover that wave's barrier and wait stalls.  Source: tools/experiments/uc_t5_gemm4w.hip, numbers: profiles/r03_t5_gemm_ab.json.)
-    static const int big = getenv("UC_T5_GEMM256") ? atoi(getenv("UC_T5_GEMM256")) : 3;
-    if (big >= 3 && M >= 2048 && N % HBN_ == 0 && (K / GBK) % 2 == 0 && K >= 2 * GBK && (size_t)M * K * 2 < (1ull << 32) && (size_t)N * K * 2 < (1ull << 32)) {
-        if (epi == 0) t5_gemm256p_launch<0>(A, W, out, M, N, K, s);
-        else if (epi == 1) t5_gemm256p_launch<1>(A, W, out, M, N, K, s);
-        else t5_gemm256p_launch<2>(A, W, out, M, N, K, s);
+    // UC_T5_GEMM256: 0 = 128 x 128 tile only, 1 = 256 x 256 tile, 8 waves of 128 x 64, one barrier per K-step (r3), 2 (default) = the same tile worked off in
+    // two phases per K-step by persistent workgroups (t5_gemm256x_kernel).  All sum K in the same order: bit-identical results (tools/t5_gemm_ab.py).
+    // Measured and NOT kept in the library (r4; numbers in profiles/r03_t5_gemm_ab*.json, profiles/r03_gemm_supply.log): a 256 x 256 tile with FOUR waves of
+    // 128 x 128 and AGPR accumulators (tools/experiments/uc_t5_gemm4w.hip: 693 TFLOP/s for the 24-block encoder against 739 with the 128 x 128 tile - one wave
+    // per SIMD leaves nobody to cover its barrier and wait stalls); four phases of 16 MFMAs per K-step (+3 % over the one-barrier kernel, +5.5 % persistent;
+    // superseded by the two-phase kernel, +8.5 %); a ten-slot ring of half-tiles over all 160 KB of LDS (seven half-tiles in flight: 5 % slower); a start skew
+    // between the workgroups of an XCD (no effect); a wait that names the epilogue's stores so that loads issued before them are not held up (no effect).
+    static const int big = getenv("UC_T5_GEMM256") ? atoi(getenv("UC_T5_GEMM256")) : 2;
+    if (big >= 2 && M >= 2048 && N % HBN_ == 0 && K % GBK == 0 && K >= 2 * GBK && (size_t)M * K * 2 < (1ull << 32) && (size_t)N * K * 2 < (1ull << 32)) {
+        if (epi == 0) t5_gemm256x_launch<0>(A, W, out, M, N, K, s);
+        else if (epi == 1) t5_gemm256x_launch<1>(A, W, out, M, N, K, s);
+        else t5_gemm256x_launch<2>(A, W, out, M, N, K, s);
         return;
     }
     if (big && M >= 2048 && N % HBN_ == 0) {     // large batches: the 256 x 256 tile (small ones would leave most CUs without a tile)
