@@ -546,9 +546,9 @@ void t5_rmsnorm(const float *x, const float *w, void *y, int T, int D, float eps
 //         -> lane holds O[query l & 15][dims (l >> 4) * 4 + r]: the same query as its statistics, so the online-softmax
 //            rescale is a plain per-lane multiply and the result leaves as 8-byte stores.
 // The 32 keys of a block enter the second contraction in the order the first one produced them (k = g * 8 + e <-> key
-// g * 4 + e for e < 4, 16 + g * 4 + e - 4 otherwise); V^T is read in the same order, a sum does not care.
+// g * 4 + e for e < 4, 16 + g * 4 + e - 4 otherwise); a sum does not care.
 // V^T comes from a per-layer transpose of the V third of qkv into vt[H * 128][Tp] (every sequence padded to a multiple of
-// 64 keys with zeros), so its A fragments are contiguous.
+// 64 keys with zeros) that stores every group of 32 keys IN THAT ORDER, so an A fragment is 16 contiguous bytes.
 constexpr int ADK = 128, AQW = 32;            // head dim, keys per block, queries per wave (2 tiles of 16)
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // dword-aligned 16-byte access
@@ -568,11 +568,13 @@ __global__ void __launch_bounds__(256) t5_vt_kernel(const _Float16 *__restrict__
     }
     __syncthreads();
     {
-        const int d = tid >> 2, tc = (tid & 3) * 8;
+        // position g * 8 + e of a group of 32 keys holds key g * 4 + e (e < 4) or 16 + g * 4 + e - 4: the order in which the first contraction leaves
+        // the keys in a lane's registers (see below), so that the A fragment of V^T is ONE 16-byte LDS read
+        const int d = tid >> 2, gq = tid & 3;
         half8 o;
 #pragma unroll
-        for (int e = 0; e < 8; e++) o[e] = sm[tc + e][d];
-        *(half8 *)(vt + (size_t)(d0 + d) * Tp + tl.dst + tc) = o;
+        for (int e = 0; e < 8; e++) o[e] = sm[e < 4 ? gq * 4 + e : 16 + gq * 4 + e - 4][d];
+        *(half8 *)(vt + (size_t)(d0 + d) * Tp + tl.dst + gq * 8) = o;
     }
 }
 
@@ -581,13 +583,15 @@ __global__ void __launch_bounds__(256) t5_vt_kernel(const _Float16 *__restrict__
 // while this one is multiplied) and shared through LDS: per-wave fragment loads straight from L2 re-read every block once
 // per 32 queries and were bandwidth / address-bound (77 TFLOP/s; profiles/round2/r3_t5).
 constexpr int AKB = 64;                                  // keys per block
-constexpr int SK_LD = ADK + 8, SV_LD = AKB + 8;          // LDS row strides in halves (272 B / 144 B: conflict-free fragment reads)
+constexpr int SK_LD = ADK + 8, SV_LD = AKB;              // LDS row strides in halves.  K: 272 B (padded); V^T: 128 B, the 16-byte chunk x of row r sits in
+                                                         // slot x ^ ((r >> 1) & 7): conflict-free in the 16-lane groups of ds_read_b128 (rows 0-3 + 12-15 at chunk x, rows 4-11 at x + 1)
 
 __global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__restrict__ qkv, const _Float16 *__restrict__ vt, size_t Tp,
                                                            const T5AttnTile *__restrict__ tiles, const float *__restrict__ bias, int bias_span, int H,
                                                            _Float16 *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) _Float16 sK[AKB * SK_LD];
     __shared__ __attribute__((aligned(16))) _Float16 sV[ADK * SV_LD];
+    __shared__ float sB[192];                             // the bias entries this workgroup needs for one key block: (key - query) = k0 - q0 - 127 .. k0 - q0 + 63
     const T5AttnTile tl = tiles[blockIdx.x];
     const int h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     const int L = tl.len, q0 = tl.q0 + w * AQW;
@@ -614,9 +618,14 @@ __global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__res
     // through scratch memory
     const int skey = tid >> 4, sdc = (tid & 15) * 8;                 // K: thread -> (key row, dim chunk); + 16 keys per i
     const int sdim = tid >> 3, skc = (tid & 7) * 8;                  // V^T: thread -> (dim row, key chunk); + 32 dims per i
+    const int svw = sdim * SV_LD + (((tid & 7) ^ ((sdim >> 1) & 7)) * 8);   // its (swizzled) place in sV; rows + 32 i have the same swizzle
     // the next block's K / V^T chunks travel in registers while this block is multiplied (T14: issue early, write late)
     uint4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
+    float rb = 0.f;                                      // thread t < 192: bias of (key - query) = k0 - tl.q0 - 127 + t.  (Read per lane from global memory
+    // inside the softmax, 8 x 16 bytes per block, the bias loads sat BEHIND the next block's K / V^T prefetch in the in-order vmcnt queue: every block waited for
+    // its successor's loads - 311 TFLOP/s.)
     auto fetch = [&](int k0) {
+        if (tid < 192) rb = bh[max(-(bias_span - 1), min(bias_span - 1, k0 - tl.q0 - 127 + tid))];
         rk0 = *(const uint4 *)(kb + (size_t)min(k0 + skey, L - 1) * ld + sdc);
         rk1 = *(const uint4 *)(kb + (size_t)min(k0 + skey + 16, L - 1) * ld + sdc);
         rk2 = *(const uint4 *)(kb + (size_t)min(k0 + skey + 32, L - 1) * ld + sdc);
@@ -632,10 +641,11 @@ __global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__res
         *(uint4 *)(sK + (skey + 16) * SK_LD + sdc) = rk1;
         *(uint4 *)(sK + (skey + 32) * SK_LD + sdc) = rk2;
         *(uint4 *)(sK + (skey + 48) * SK_LD + sdc) = rk3;
-        *(uint4 *)(sV + sdim * SV_LD + skc) = rv0;
-        *(uint4 *)(sV + (sdim + 32) * SV_LD + skc) = rv1;
-        *(uint4 *)(sV + (sdim + 64) * SV_LD + skc) = rv2;
-        *(uint4 *)(sV + (sdim + 96) * SV_LD + skc) = rv3;
+        *(uint4 *)(sV + svw) = rv0;
+        *(uint4 *)(sV + svw + 32 * SV_LD) = rv1;
+        *(uint4 *)(sV + svw + 64 * SV_LD) = rv2;
+        *(uint4 *)(sV + svw + 96 * SV_LD) = rv3;
+        if (tid < 192) sB[tid] = rb;
         __syncthreads();
         if (k0 + AKB < L) fetch(k0 + AKB);               // every wave fetches (uniform branch): in flight under the MFMAs below
         if (q0 < L) {                                    // (waves without queries only help with the staging)
@@ -655,20 +665,27 @@ __global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__res
             float alpha[2];
 #pragma unroll
             for (int qt = 0; qt < 2; qt++) {
-                const int qi = min(q0 + qt * 16 + c, L - 1);
                 float p[16], mx = -INFINITY;
+                // sB index of (key k0 + st * 16 + g * 4 + r, query tl.q0 + w * 32 + qt * 16 + c): it depends on st - qt only, five distinct groups of 4
+                const float *bq = sB + (127 + g * 4 - w * AQW - c);
+                if (k0 + AKB <= L) {                     // (uniform) a full block: nothing to mask
 #pragma unroll
-                for (int st = 0; st < 4; st++) {
-                    // the lane's 4 keys are consecutive: one unconditional 16-byte (dword-aligned) load of their biases — a
-                    // load per key under `kj < L` became 32 branchy, serialized loads per block and cost 10x the MFMA time
-                    const int kb0 = k0 + st * 16 + g * 4;
-                    const f32x4u bv = *(const f32x4u *)(bh + (min(kb0, L - 1) - qi));      // (the table is padded by 4 entries)
+                    for (int st = 0; st < 4; st++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const float sv = kb0 + r < L ? sacc[qt][st][r] + bv[r] : -INFINITY;
-                        p[st * 4 + r] = sv;
-                        mx = fmaxf(mx, sv);
-                    }
+                        for (int r = 0; r < 4; r++) {
+                            const float sv = sacc[qt][st][r] + bq[(st - qt) * 16 + r];
+                            p[st * 4 + r] = sv;
+                            mx = fmaxf(mx, sv);
+                        }
+                } else {
+#pragma unroll
+                    for (int st = 0; st < 4; st++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const float sv = k0 + st * 16 + g * 4 + r < L ? sacc[qt][st][r] + bq[(st - qt) * 16 + r] : -INFINITY;
+                            p[st * 4 + r] = sv;
+                            mx = fmaxf(mx, sv);
+                        }
                 }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -690,10 +707,8 @@ __global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__res
                     for (int r = 0; r < 4; r++) o[qt][d][r] *= alpha[qt];
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {
-                    // A fragment of V^T: dim d * 16 + c, keys in the order of pf: [32 hf + g*4 .. +3 | 32 hf + 16 + g*4 .. +3]
-                    const _Float16 *vr = sV + (d * 16 + c) * SV_LD + 32 * hf + g * 4;
-                    const half4 v0 = *(const half4 *)vr, v1 = *(const half4 *)(vr + 16);
-                    const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    // A fragment of V^T: dim d * 16 + c, keys in the order of pf: [32 hf + g*4 .. +3 | 32 hf + 16 + g*4 .. +3] = positions 32 hf + g * 8 .. + 7 of vt
+                    const half8 vf = *(const half8 *)(sV + (d * 16 + c) * SV_LD + (((4 * hf + g) ^ ((c >> 1) & 7)) * 8));
                     o[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[0][hf], o[0][d], 0, 0, 0);
                     o[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[1][hf], o[1][d], 0, 0, 0);
                 }
