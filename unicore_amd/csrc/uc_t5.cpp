@@ -152,8 +152,8 @@ int rel_bucket(int rel /* key - query */, int num_buckets, int max_distance) {
 T5Model::~T5Model() {
     (void)hipSetDevice(device);
     for (void *p : allocs) (void)hipFree(p);
-    for (void *p : {(void *)hidden, (void *)h1, (void *)logits, (void *)bias_tab, xn, qkv, ao, ff, ycnn, vt, (void *)d_tok, (void *)d_seq_of, (void *)d_seq_off,
-                    (void *)d_tiles, (void *)d_vt_tiles, (void *)d_codes})
+    for (void *p : {(void *)hidden, (void *)h1, (void *)logits, (void *)bias_tab, xn, qkv, ao, ff, ycnn, (void *)d_tok, (void *)d_seq_of, (void *)d_seq_off,
+                    (void *)d_tiles, (void *)d_codes})
         if (p) (void)hipFree(p);
     if (ev[0]) (void)hipEventDestroy(ev[0]);
     if (ev[1]) (void)hipEventDestroy(ev[1]);
@@ -321,8 +321,6 @@ void T5Model::encode_batch(const std::vector<const std::string *> &seqs, std::ve
     const size_t ns = seqs.size();
     std::vector<int32_t> tok, seq_of, seq_off(ns + 1, 0);
     std::vector<T5AttnTile> tiles;
-    std::vector<T5VtTile> vt_tiles;
-    int64_t Tp = 0;                                          // tokens of vt: every sequence padded to a multiple of 32
     int maxL = 1;
     for (size_t s = 0; s < ns; s++) {
         const std::string &a = *seqs[s];
@@ -332,9 +330,7 @@ void T5Model::encode_batch(const std::vector<const std::string *> &seqs, std::ve
         for (char c : a) tok.push_back(aa_token[(unsigned char)c]);
         tok.push_back(cfg.eos_token);
         for (int i = 0; i < L; i++) seq_of.push_back((int32_t)s);
-        for (int q0 = 0; q0 < L; q0 += 128) tiles.push_back({seq_off[s], L, q0, Tp});
-        for (int k0 = 0; k0 < (L + 63) / 64 * 64; k0 += 32) vt_tiles.push_back({seq_off[s] + std::min(k0, L - 1), std::max(0, std::min(32, L - k0)), Tp + k0});
-        Tp += (L + 63) / 64 * 64;                            // the attention kernel walks 64-key blocks: the pad tiles below are zero-filled
+        for (int q0 = 0; q0 < L; q0 += 128) tiles.push_back({seq_off[s], L, q0});
         maxL = std::max(maxL, L);
     }
     seq_off[ns] = (int32_t)tok.size();
@@ -351,9 +347,7 @@ void T5Model::encode_batch(const std::vector<const std::string *> &seqs, std::ve
     }
     if (ns + 1 > cap_seqs) { cap_seqs = ns + ns / 8 + 64; grow((void **)&d_seq_off, cap_seqs * 4); }
     if (tiles.size() > cap_tiles) { cap_tiles = tiles.size() + tiles.size() / 8 + 64; grow((void **)&d_tiles, cap_tiles * sizeof(T5AttnTile)); }
-    if (vt_tiles.size() > cap_vt_tiles) { cap_vt_tiles = vt_tiles.size() + vt_tiles.size() / 8 + 64; grow((void **)&d_vt_tiles, cap_vt_tiles * sizeof(T5VtTile)); }
-    if ((size_t)Tp + 64 > cap_vt) { cap_vt = ((size_t)Tp + (size_t)Tp / 8 + 256 + 31) / 32 * 32; grow(&vt, cap_vt * HD * 2); }      // row stride of vt: a multiple of 32 keeps its 8 / 16-byte accesses aligned
-    if (maxL > bias_span) { bias_span = maxL + maxL / 4 + 64; grow((void **)&bias_tab, ((size_t)H * (2 * bias_span - 1) + 8) * 4); }   // + 8: the kernel reads 4 entries at a time
+    if (maxL > bias_span) { bias_span = maxL + maxL / 4 + 64; grow((void **)&bias_tab, ((size_t)H * (2 * bias_span - 1) + 8) * 4); }
     {   // bias table per head over key - query in (-span, span): built from the model's bucket table (small: H x (2 span - 1) floats)
         std::vector<float> hb((size_t)H * cfg.rel_buckets);
         UC_HIP(hipMemcpy(hb.data(), rel_bias, hb.size() * 4, hipMemcpyDeviceToHost));
@@ -369,7 +363,6 @@ void T5Model::encode_batch(const std::vector<const std::string *> &seqs, std::ve
     UC_HIP(hipMemcpyAsync(d_seq_of, seq_of.data(), (size_t)T * 4, hipMemcpyHostToDevice, stream));
     UC_HIP(hipMemcpyAsync(d_seq_off, seq_off.data(), (ns + 1) * 4, hipMemcpyHostToDevice, stream));
     UC_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(T5AttnTile), hipMemcpyHostToDevice, stream));
-    UC_HIP(hipMemcpyAsync(d_vt_tiles, vt_tiles.data(), vt_tiles.size() * sizeof(T5VtTile), hipMemcpyHostToDevice, stream));
 
     UC_HIP(hipEventRecord(ev[0], stream));
     t5_embed(d_tok, emb, hidden, T, D, cfg.vocab, stream);
@@ -381,7 +374,7 @@ void T5Model::encode_batch(const std::vector<const std::string *> &seqs, std::ve
         if (!(dbg_part & 1)) goto ffn_half;
         t5_rmsnorm(hidden, L.attn_norm, xn, T, D, cfg.eps, stream);
         t5_gemm(0, xn, L.wqkv, qkv, T, 3 * HD, D, stream);
-        t5_attention(qkv, vt, cap_vt, d_vt_tiles, (int)vt_tiles.size(), d_tiles, (int)tiles.size(), bias_tab, bias_span, H, ao, stream);
+        t5_attention(qkv, d_tiles, (int)tiles.size(), bias_tab, bias_span, H, ao, stream);
         t5_gemm(2, ao, L.wo, hidden, T, D, HD, stream);
     ffn_half:
         if (!(dbg_part & 2)) continue;

@@ -23,8 +23,7 @@ struct T5Config {
     int eos_in_head = 0, uzob_to_x = 1;
 };
 
-struct T5AttnTile { int32_t tok0, len, q0; int64_t poff; };    // sequence start token, its length, first query row of the workgroup (128 rows), start of the sequence in vt
-struct T5VtTile { int32_t src, count; int64_t dst; };          // 32 padded tokens of one sequence: first source token, valid tokens, position in vt
+struct T5AttnTile { int32_t tok0, len, q0; };                  // sequence start token, its length, first query row of the workgroup (128 rows)
 
 // ---- GGUF (v3) container: what llama.cpp / ggml and Foldseek's ProstT5 weights use --------------------------------------
 struct GgufTensor {
@@ -49,8 +48,7 @@ void gguf_read_header(const std::string &path, GgufFile &g);
 void t5_gemm(int epi, const void *A, const void *W, void *out, int M, int N, int K, hipStream_t s);
 void t5_embed(const int32_t *tok, const void *emb, float *hidden, int T, int D, int vocab, hipStream_t s);
 void t5_rmsnorm(const float *x, const float *w, void *y, int T, int D, float eps, hipStream_t s);
-void t5_attention(const void *qkv, void *vt, size_t Tp, const T5VtTile *vt_tiles, int n_vt_tiles, const T5AttnTile *tiles, int n_tiles, const float *bias,
-                  int bias_span, int H, void *out, hipStream_t s);
+void t5_attention(const void *qkv, const T5AttnTile *tiles, int n_tiles, const float *bias, int bias_span, int H, void *out, hipStream_t s);
 void t5_cnn_head(const void *y, int ldy, const int32_t *seq_of, const int32_t *seq_off, const float *b1, const float *w2, const float *b2, float *h1,
                  uint8_t *codes, float *logits, int T, int C1, int KW, int NO, int eos_in_head, hipStream_t s);
 void t5_f32_to_f16(const float *x, void *y, size_t n, hipStream_t s);
@@ -81,9 +79,7 @@ struct T5Model {
     // activations (grown on demand)
     size_t cap_tokens = 0;
     float *hidden = nullptr, *h1 = nullptr, *logits = nullptr, *bias_tab = nullptr;
-    void *xn = nullptr, *qkv = nullptr, *ao = nullptr, *ff = nullptr, *ycnn = nullptr, *vt = nullptr;
-    T5VtTile *d_vt_tiles = nullptr;
-    size_t cap_vt = 0, cap_vt_tiles = 0;
+    void *xn = nullptr, *qkv = nullptr, *ao = nullptr, *ff = nullptr, *ycnn = nullptr;
     int32_t *d_tok = nullptr, *d_seq_of = nullptr, *d_seq_off = nullptr;
     T5AttnTile *d_tiles = nullptr;
     uint8_t *d_codes = nullptr;

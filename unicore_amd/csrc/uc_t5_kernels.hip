@@ -547,57 +547,33 @@ void t5_rmsnorm(const float *x, const float *w, void *y, int T, int D, float eps
 //            rescale is a plain per-lane multiply and the result leaves as 8-byte stores.
 // The 32 keys of a block enter the second contraction in the order the first one produced them (k = g * 8 + e <-> key
 // g * 4 + e for e < 4, 16 + g * 4 + e - 4 otherwise); a sum does not care.
-// V^T comes from a per-layer transpose of the V third of qkv into vt[H * 128][Tp] (every sequence padded to a multiple of
-// 64 keys with zeros) that stores every group of 32 keys IN THAT ORDER, so an A fragment is 16 contiguous bytes.
+// V is consumed ROW-MAJOR, as the q|k|v GEMM wrote it: the A fragment of V^T (16 dims x those 8 keys per lane) comes out of two
+// ds_read_b64_tr_b16 - gfx950's transposing LDS read: within a 16-lane group, lane i receives element i % 4 of what lanes i / 4, 4 + i / 4,
+// 8 + i / 4, 12 + i / 4 address (checked on the hardware), i.e. column i of the 4 keys x 16 dims block whose row j the lanes 4 j .. 4 j + 3
+// point at.  (Until r4 a separate pass wrote a transposed, padded copy V^T[H * 128][tokens] per layer: 3.6 % of the encoder, at HBM speed.)
 constexpr int ADK = 128, AQW = 32;            // head dim, keys per block, queries per wave (2 tiles of 16)
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // dword-aligned 16-byte access
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) fp16x4 lds_fp16x4;
 
-// V third of qkv -> vt[H * 128][Tp]; one workgroup = 32 padded tokens x 64 dims
-__global__ void __launch_bounds__(256) t5_vt_kernel(const _Float16 *__restrict__ qkv, const T5VtTile *__restrict__ tiles, int H, size_t Tp,
-                                                    _Float16 *__restrict__ vt) {
-    __shared__ _Float16 sm[32][72];
-    const T5VtTile tl = tiles[blockIdx.x];
-    const int d0 = blockIdx.y * 64, tid = threadIdx.x;
-    const size_t ld = (size_t)3 * H * ADK;
-    {
-        const int t = tid >> 3, dc = (tid & 7) * 8;
-        uint4 v = {0, 0, 0, 0};
-        if (t < tl.count) v = *(const uint4 *)(qkv + (size_t)(tl.src + t) * ld + (size_t)2 * H * ADK + d0 + dc);
-        *(uint4 *)(&sm[t][dc]) = v;
-    }
-    __syncthreads();
-    {
-        // position g * 8 + e of a group of 32 keys holds key g * 4 + e (e < 4) or 16 + g * 4 + e - 4: the order in which the first contraction leaves
-        // the keys in a lane's registers (see below), so that the A fragment of V^T is ONE 16-byte LDS read
-        const int d = tid >> 2, gq = tid & 3;
-        half8 o;
-#pragma unroll
-        for (int e = 0; e < 8; e++) o[e] = sm[e < 4 ? gq * 4 + e : 16 + gq * 4 + e - 4][d];
-        *(half8 *)(vt + (size_t)(d0 + d) * Tp + tl.dst + gq * 8) = o;
-    }
-}
-
-// One workgroup = 128 queries of one (sequence, head): 4 waves x 32 queries.  The K block (64 keys x 128 dims) and the V^T
-// block (128 dims x 64 keys) are loaded ONCE per workgroup with coalesced 16-byte loads (the next block travels in registers
+// One workgroup = 128 queries of one (sequence, head): 4 waves x 32 queries.  The K block and the V block (64 keys x 128 dims
+// each) are loaded ONCE per workgroup with coalesced 16-byte loads (the next block travels in registers
 // while this one is multiplied) and shared through LDS: per-wave fragment loads straight from L2 re-read every block once
 // per 32 queries and were bandwidth / address-bound (77 TFLOP/s; profiles/round2/r3_t5).
 constexpr int AKB = 64;                                  // keys per block
-constexpr int SK_LD = ADK + 8, SV_LD = AKB;              // LDS row strides in halves.  K: 272 B (padded); V^T: 128 B, the 16-byte chunk x of row r sits in
-                                                         // slot x ^ ((r >> 1) & 7): conflict-free in the 16-lane groups of ds_read_b128 (rows 0-3 + 12-15 at chunk x, rows 4-11 at x + 1)
+constexpr int SK_LD = ADK + 8, SV_LD = ADK + 16;         // LDS row strides in halves: K 272 B; V 288 B = 32 (mod 256): the 8 keys x 32 bytes a half-wave's
+                                                         // transposing read touches fall into 8 different 32-byte bank groups
 
-__global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__restrict__ qkv, const _Float16 *__restrict__ vt, size_t Tp,
-                                                           const T5AttnTile *__restrict__ tiles, const float *__restrict__ bias, int bias_span, int H,
+__global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__restrict__ qkv, const T5AttnTile *__restrict__ tiles, const float *__restrict__ bias, int bias_span, int H,
                                                            _Float16 *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) _Float16 sK[AKB * SK_LD];
-    __shared__ __attribute__((aligned(16))) _Float16 sV[ADK * SV_LD];
+    __shared__ __attribute__((aligned(16))) _Float16 sV[AKB * SV_LD];
     __shared__ float sB[192];                             // the bias entries this workgroup needs for one key block: (key - query) = k0 - q0 - 127 .. k0 - q0 + 63
     const T5AttnTile tl = tiles[blockIdx.x];
     const int h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     const int L = tl.len, q0 = tl.q0 + w * AQW;
     const size_t ld = (size_t)3 * H * ADK;
-    const _Float16 *qb = qkv + (size_t)tl.tok0 * ld + (size_t)h * ADK, *kb = qb + (size_t)H * ADK;
-    const _Float16 *vb = vt + (size_t)h * ADK * Tp + tl.poff;
+    const _Float16 *qb = qkv + (size_t)tl.tok0 * ld + (size_t)h * ADK, *kb = qb + (size_t)H * ADK, *vb = kb + (size_t)H * ADK;
     const float *bh = bias + (size_t)h * (2 * bias_span - 1) + (bias_span - 1);
     half8 qf[2][4];                                      // B fragments of Q^T: query q0 + qt * 16 + c, dims kk * 32 + g * 8 ..
 #pragma unroll
@@ -612,14 +588,11 @@ __global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__res
 #pragma unroll
         for (int d = 0; d < 8; d++) o[qt][d] = f32x4{0.f, 0.f, 0.f, 0.f};
     float mrow[2] = {-INFINITY, -INFINITY}, lrow[2] = {0.f, 0.f};
-    // staging: K block = 64 rows x 16 chunks of 16 B, V^T block = 128 rows x 8 chunks: 4 + 4 chunks per thread.  All eight
-    // loads are unconditional (key rows clamped: keys >= L are masked in the softmax anyway; V^T is zero-padded) and issued
-    // back to back - as lambdas over register arrays under `key < L` they were compiled to branchy, serialized loads spilled
-    // through scratch memory
-    const int skey = tid >> 4, sdc = (tid & 15) * 8;                 // K: thread -> (key row, dim chunk); + 16 keys per i
-    const int sdim = tid >> 3, skc = (tid & 7) * 8;                  // V^T: thread -> (dim row, key chunk); + 32 dims per i
-    const int svw = sdim * SV_LD + (((tid & 7) ^ ((sdim >> 1) & 7)) * 8);   // its (swizzled) place in sV; rows + 32 i have the same swizzle
-    // the next block's K / V^T chunks travel in registers while this block is multiplied (T14: issue early, write late)
+    // staging: K block and V block = 64 rows x 16 chunks of 16 B each: 4 + 4 chunks per thread.  All eight loads are unconditional (key rows
+    // clamped: keys >= L are masked in the softmax and their P is exactly 0) and issued back to back - as lambdas over register arrays under
+    // `key < L` they were compiled to branchy, serialized loads spilled through scratch memory
+    const int skey = tid >> 4, sdc = (tid & 15) * 8;                 // thread -> (key row, dim chunk); + 16 keys per i
+    // the next block's K / V chunks travel in registers while this block is multiplied (T14: issue early, write late)
     uint4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
     float rb = 0.f;                                      // thread t < 192: bias of (key - query) = k0 - tl.q0 - 127 + t.  (Read per lane from global memory
     // inside the softmax, 8 x 16 bytes per block, the bias loads sat BEHIND the next block's K / V^T prefetch in the in-order vmcnt queue: every block waited for
@@ -630,10 +603,10 @@ __global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__res
         rk1 = *(const uint4 *)(kb + (size_t)min(k0 + skey + 16, L - 1) * ld + sdc);
         rk2 = *(const uint4 *)(kb + (size_t)min(k0 + skey + 32, L - 1) * ld + sdc);
         rk3 = *(const uint4 *)(kb + (size_t)min(k0 + skey + 48, L - 1) * ld + sdc);
-        rv0 = *(const uint4 *)(vb + (size_t)sdim * Tp + k0 + skc);
-        rv1 = *(const uint4 *)(vb + (size_t)(sdim + 32) * Tp + k0 + skc);
-        rv2 = *(const uint4 *)(vb + (size_t)(sdim + 64) * Tp + k0 + skc);
-        rv3 = *(const uint4 *)(vb + (size_t)(sdim + 96) * Tp + k0 + skc);
+        rv0 = *(const uint4 *)(vb + (size_t)min(k0 + skey, L - 1) * ld + sdc);
+        rv1 = *(const uint4 *)(vb + (size_t)min(k0 + skey + 16, L - 1) * ld + sdc);
+        rv2 = *(const uint4 *)(vb + (size_t)min(k0 + skey + 32, L - 1) * ld + sdc);
+        rv3 = *(const uint4 *)(vb + (size_t)min(k0 + skey + 48, L - 1) * ld + sdc);
     };
     fetch(0);
     for (int k0 = 0; k0 < L; k0 += AKB) {
@@ -641,10 +614,10 @@ __global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__res
         *(uint4 *)(sK + (skey + 16) * SK_LD + sdc) = rk1;
         *(uint4 *)(sK + (skey + 32) * SK_LD + sdc) = rk2;
         *(uint4 *)(sK + (skey + 48) * SK_LD + sdc) = rk3;
-        *(uint4 *)(sV + svw) = rv0;
-        *(uint4 *)(sV + svw + 32 * SV_LD) = rv1;
-        *(uint4 *)(sV + svw + 64 * SV_LD) = rv2;
-        *(uint4 *)(sV + svw + 96 * SV_LD) = rv3;
+        *(uint4 *)(sV + skey * SV_LD + sdc) = rv0;
+        *(uint4 *)(sV + (skey + 16) * SV_LD + sdc) = rv1;
+        *(uint4 *)(sV + (skey + 32) * SV_LD + sdc) = rv2;
+        *(uint4 *)(sV + (skey + 48) * SV_LD + sdc) = rv3;
         if (tid < 192) sB[tid] = rb;
         __syncthreads();
         if (k0 + AKB < L) fetch(k0 + AKB);               // every wave fetches (uniform branch): in flight under the MFMAs below
@@ -707,8 +680,12 @@ __global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__res
                     for (int r = 0; r < 4; r++) o[qt][d][r] *= alpha[qt];
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {
-                    // A fragment of V^T: dim d * 16 + c, keys in the order of pf: [32 hf + g*4 .. +3 | 32 hf + 16 + g*4 .. +3] = positions 32 hf + g * 8 .. + 7 of vt
-                    const half8 vf = *(const half8 *)(sV + (d * 16 + c) * SV_LD + (((4 * hf + g) ^ ((c >> 1) & 7)) * 8));
+                    // A fragment of V^T: dim d * 16 + c, keys in the order of pf: [32 hf + g*4 .. +3 | 32 hf + 16 + g*4 .. +3].  This lane points at
+                    // key 32 hf (+ 16) + g * 4 + c / 4, dims d * 16 + (c % 4) * 4 .. + 3 and receives dim d * 16 + c of the group's four keys
+                    const _Float16 *vr = sV + (32 * hf + g * 4 + (c >> 2)) * SV_LD + d * 16 + (c & 3) * 4;
+                    const half4 v0 = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4 *)vr));
+                    const half4 v1 = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4 *)(vr + 16 * SV_LD)));
+                    const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     o[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[0][hf], o[0][d], 0, 0, 0);
                     o[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[1][hf], o[1][d], 0, 0, 0);
                 }
@@ -730,12 +707,9 @@ __global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__res
         }
     }
 }
-void t5_attention(const void *qkv, void *vt, size_t Tp, const T5VtTile *vt_tiles, int n_vt_tiles, const T5AttnTile *tiles, int n_tiles, const float *bias,
-                  int bias_span, int H, void *out, hipStream_t s) {
+void t5_attention(const void *qkv, const T5AttnTile *tiles, int n_tiles, const float *bias, int bias_span, int H, void *out, hipStream_t s) {
     if (n_tiles <= 0) return;
-    hipLaunchKernelGGL(t5_vt_kernel, dim3(n_vt_tiles, H * ADK / 64), dim3(256), 0, s, (const _Float16 *)qkv, vt_tiles, H, Tp, (_Float16 *)vt);
-    hipLaunchKernelGGL(t5_attention_kernel, dim3(n_tiles, H), dim3(256), 0, s, (const _Float16 *)qkv, (const _Float16 *)vt, Tp, tiles, bias, bias_span, H,
-                       (_Float16 *)out);
+    hipLaunchKernelGGL(t5_attention_kernel, dim3(n_tiles, H), dim3(256), 0, s, (const _Float16 *)qkv, tiles, bias, bias_span, H, (_Float16 *)out);
 }
 
 // ---------------------------------------------------------------------------------------------- 3Di CNN head
