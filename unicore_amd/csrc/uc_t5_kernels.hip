@@ -641,32 +641,28 @@ __global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__res
                 float p[16], mx = -INFINITY;
                 // sB index of (key k0 + st * 16 + g * 4 + r, query tl.q0 + w * 32 + qt * 16 + c): it depends on st - qt only, five distinct groups of 4
                 const float *bq = sB + (127 + g * 4 - w * AQW - c);
-                if (k0 + AKB <= L) {                     // (uniform) a full block: nothing to mask
+#pragma unroll
+                for (int st = 0; st < 4; st++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) p[st * 4 + r] = sacc[qt][st][r] + bq[(st - qt) * 16 + r];     // (unconditional LDS reads: no branches)
+                if (k0 + AKB > L) {                      // (uniform) only a sequence's last block has keys to mask
+                    asm volatile("" ::: "memory");       // (keeps this a branch: if-converted, the 32 compares + selects ran for every block)
 #pragma unroll
                     for (int st = 0; st < 4; st++)
 #pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const float sv = sacc[qt][st][r] + bq[(st - qt) * 16 + r];
-                            p[st * 4 + r] = sv;
-                            mx = fmaxf(mx, sv);
-                        }
-                } else {
-#pragma unroll
-                    for (int st = 0; st < 4; st++)
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const float sv = k0 + st * 16 + g * 4 + r < L ? sacc[qt][st][r] + bq[(st - qt) * 16 + r] : -INFINITY;
-                            p[st * 4 + r] = sv;
-                            mx = fmaxf(mx, sv);
-                        }
+                        for (int r = 0; r < 4; r++) p[st * 4 + r] = k0 + st * 16 + g * 4 + r < L ? p[st * 4 + r] : -INFINITY;
                 }
+#pragma unroll
+                for (int e = 0; e < 16; e++) mx = fmaxf(mx, p[e]);
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 const float mnew = fmaxf(mrow[qt], mx);
                 alpha[qt] = __expf(mrow[qt] - mnew);      // first block: exp(-inf) = 0
+                constexpr float LOG2E = 1.44269504088896340736f;
+                const float mneg = -mnew * LOG2E;
                 float sum = 0.f;
 #pragma unroll
-                for (int e = 0; e < 16; e++) { p[e] = __expf(p[e] - mnew); sum += p[e]; pf[qt][e >> 3][e & 7] = (_Float16)p[e]; }
+                for (int e = 0; e < 16; e++) { p[e] = __builtin_amdgcn_exp2f(fmaf(p[e], LOG2E, mneg)); sum += p[e]; pf[qt][e >> 3][e & 7] = (_Float16)p[e]; }   // exp(p - mnew): one FMA + v_exp_f32
                 sum += __shfl_xor(sum, 16, 64);
                 sum += __shfl_xor(sum, 32, 64);
                 lrow[qt] = lrow[qt] * alpha[qt] + sum;
