@@ -1365,4 +1365,5 @@ void Engine::set_cover_graph(uint32_t n, const uint32_t *h_edges, const uint32_t
     if (timing) fprintf(stderr, "set_cover_device: greedy on the host %.2f ms\n", t_greedy.seconds() * 1e3);
 }
 
+void preload_align_module() { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, (const void *)plan_key_kernel); }
 }  // namespace uc

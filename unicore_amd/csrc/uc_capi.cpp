@@ -431,6 +431,17 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
             return;
         }
         const int pre = p.linclust ? 1 : 0;     // E8a: one linear-time pre-clustering round in front of the cascade rounds
+        // the kernels' code objects are uploaded on a helper thread beside engine construction, database upload and prefilter (uc_sw.hip:preload_modules);
+        // UC_PRELOAD=0 leaves it to HIP's lazy loading.  (The future's destructor joins the thread on every way out of this function.)
+        std::future<void> preload;
+        if (W == 1 && !(getenv("UC_PRELOAD") && atoi(getenv("UC_PRELOAD")) == 0)) {
+            const int d0 = devices[0];
+            const bool lc = pre != 0, st = stamp;
+            preload = std::async(std::launch::async, [d0, lc, st]() {
+                preload_modules(d0, lc);
+                if (st) fprintf(stderr, "unicore-cluster[timing]: t+%7.1f ms  (helper thread) code objects of the prefilter / alignment / SW modules loaded\n", 1e3 * g_library_loaded.seconds());
+            });
+        }
         logf(3, "unicore-cluster: %u sequences, %llu residues, %d GPU(s)%s [%d query group(s) x %d target shard(s)], %s%d clustering step(s)\n", n,
              (unsigned long long)full.residues(), W, virtual_gpus ? " (virtual: several ranks per device)" : "", gQ, gT,
              pre ? "linear-time pre-step + " : "", p.cluster_steps);

@@ -183,4 +183,5 @@ void merge_hits(uint32_t n, int max_seqs, int n_parts, const uint32_t *const *co
                 std::vector<uint32_t> &out_cnt, std::vector<uc_hit> &out_hits);
 const char *last_error_cstr();
 
+void preload_modules(int device, bool linclust);      // uc_sw.hip: forces the code objects of the cluster path onto the device (cold start)
 }  // namespace uc

@@ -209,4 +209,5 @@ uint64_t Engine::linclust_hits() {
     return np;
 }
 
+void preload_linclust_module() { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, (const void *)lc_select_kernel); }
 }  // namespace uc

@@ -1893,4 +1893,5 @@ uint64_t Engine::import_hits_dev(uint64_t n_in, const uint32_t *dq, const uint32
     return keep;
 }
 
+void preload_prefilter_module() { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, (const void *)kmer_extract_kernel); }
 }  // namespace uc

@@ -123,4 +123,18 @@ void launch_ungapped(const DeviceDb &db, uint64_t n, const uint32_t *q, const ui
     hipLaunchKernelGGL(ungapped_kernel, dim3((uint32_t)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, db, n, q, t, diag, score, overlap_sum);
 }
 
+// Module preloading (cold start of a one-shot process, tools/cold_stamps.sh): HIP uploads a translation unit's code object when one of its kernels is first
+// used - tens of milliseconds each for the SW classes, paid in the middle of the first pass.  A helper thread touches one kernel per module while the main
+// thread builds the engine, uploads the database and runs the prefilter.
+void preload_sw_pk_m0(); void preload_sw_pk_m1(); void preload_sw_pk_m4(); void preload_sw_pk_m6();
+void preload_prefilter_module(); void preload_align_module(); void preload_linclust_module();
+void preload_modules(int device, bool linclust) {
+    if (hipSetDevice(device) != hipSuccess) return;
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, (const void *)db_pad_kernel);
+    preload_prefilter_module();
+    if (linclust) preload_linclust_module();
+    preload_align_module();
+    preload_sw_pk_m0(); preload_sw_pk_m1(); preload_sw_pk_m6(); preload_sw_pk_m4();
+}
 }  // namespace uc

@@ -467,4 +467,11 @@ void launch_sw_pk_class_mode(int G, int R, const SwArgs &a, uint32_t n_tasks, hi
     abort();
 }
 
+// forces this translation unit's code object onto the current device (HIP loads a module lazily at the first use of one of its kernels): see preload_modules()
+template <int MODE>
+void preload_sw_pk_mode() {
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, (const void *)sw_pk_kernel<64, 14, MODE, 8>);
+}
+
 }  // namespace uc

@@ -4,4 +4,5 @@ namespace uc {
 void launch_sw_pk_class_m0(int G, int R, const SwArgs &a, uint32_t n_tasks, hipStream_t s) {
     launch_sw_pk_class_mode<0>(G, R, a, n_tasks, s);
 }
+void preload_sw_pk_m0() { preload_sw_pk_mode<0>(); }
 }  // namespace uc
