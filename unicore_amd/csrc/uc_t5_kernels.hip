@@ -566,9 +566,10 @@ constexpr int SK_LD = ADK + 8, SV_LD = ADK + 16;         // LDS row strides in h
 
 __global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__restrict__ qkv, const T5AttnTile *__restrict__ tiles, const float *__restrict__ bias, int bias_span, int H,
                                                            _Float16 *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) _Float16 sK[AKB * SK_LD];
-    __shared__ __attribute__((aligned(16))) _Float16 sV[AKB * SV_LD];
-    __shared__ float sB[192];                             // the bias entries this workgroup needs for one key block: (key - query) = k0 - q0 - 127 .. k0 - q0 + 63
+    // two buffers: while a block is multiplied, the next one's registers are written into the other buffer as soon as its loads have landed - ONE barrier per block
+    __shared__ __attribute__((aligned(16))) _Float16 sK2[2][AKB * SK_LD];
+    __shared__ __attribute__((aligned(16))) _Float16 sV2[2][AKB * SV_LD];
+    __shared__ float sB2[2][192];                         // the bias entries this workgroup needs for one key block: (key - query) = k0 - q0 - 127 .. k0 - q0 + 63
     const T5AttnTile tl = tiles[blockIdx.x];
     const int h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     const int L = tl.len, q0 = tl.q0 + w * AQW;
@@ -608,18 +609,25 @@ __global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__res
         rv2 = *(const uint4 *)(vb + (size_t)min(k0 + skey + 32, L - 1) * ld + sdc);
         rv3 = *(const uint4 *)(vb + (size_t)min(k0 + skey + 48, L - 1) * ld + sdc);
     };
+    auto stash = [&](int b) {                            // the fetched registers -> buffer b
+        _Float16 *dK = sK2[b], *dV = sV2[b];
+        *(uint4 *)(dK + skey * SK_LD + sdc) = rk0;
+        *(uint4 *)(dK + (skey + 16) * SK_LD + sdc) = rk1;
+        *(uint4 *)(dK + (skey + 32) * SK_LD + sdc) = rk2;
+        *(uint4 *)(dK + (skey + 48) * SK_LD + sdc) = rk3;
+        *(uint4 *)(dV + skey * SV_LD + sdc) = rv0;
+        *(uint4 *)(dV + (skey + 16) * SV_LD + sdc) = rv1;
+        *(uint4 *)(dV + (skey + 32) * SV_LD + sdc) = rv2;
+        *(uint4 *)(dV + (skey + 48) * SV_LD + sdc) = rv3;
+        if (tid < 192) sB2[b][tid] = rb;
+    };
     fetch(0);
-    for (int k0 = 0; k0 < L; k0 += AKB) {
-        *(uint4 *)(sK + skey * SK_LD + sdc) = rk0;
-        *(uint4 *)(sK + (skey + 16) * SK_LD + sdc) = rk1;
-        *(uint4 *)(sK + (skey + 32) * SK_LD + sdc) = rk2;
-        *(uint4 *)(sK + (skey + 48) * SK_LD + sdc) = rk3;
-        *(uint4 *)(sV + skey * SV_LD + sdc) = rv0;
-        *(uint4 *)(sV + (skey + 16) * SV_LD + sdc) = rv1;
-        *(uint4 *)(sV + (skey + 32) * SV_LD + sdc) = rv2;
-        *(uint4 *)(sV + (skey + 48) * SV_LD + sdc) = rv3;
-        if (tid < 192) sB[tid] = rb;
-        __syncthreads();
+    stash(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < L; k0 += AKB, cur ^= 1) {
+        const _Float16 *sK = sK2[cur], *sV = sV2[cur];
+        const float *sB = sB2[cur];
         if (k0 + AKB < L) fetch(k0 + AKB);               // every wave fetches (uniform branch): in flight under the MFMAs below
         if (q0 < L) {                                    // (waves without queries only help with the staging)
             f32x4 sacc[2][4];                            // [query tile][16-key sub-tile]
@@ -687,6 +695,7 @@ __global__ void __launch_bounds__(256) t5_attention_kernel(const _Float16 *__res
                 }
             }
         }
+        if (k0 + AKB < L) stash(cur ^ 1);                // nobody reads that buffer any more: its last readers passed the previous barrier
         __syncthreads();
     }
     if (q0 >= L) return;
