@@ -261,3 +261,14 @@ def test_bench_launches_itself_for_more_than_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0
     assert (r.stdout + r.stderr).count("bench.py needs a GPU") == 2
+
+
+def test_gemm_supply_microbenchmark_generator_still_matches_the_kernel_text(tmp_path):
+    """tools/ubench/make_gemm_supply.py cuts the library's GEMM kernel out of uc_t5_kernels.hip by text anchors and switches parts of it off: every
+    anchor must still be there (the generator asserts each substitution), and the committed gemm_supply.hip must be what it generates"""
+    gen = os.path.join(ROOT, "tools", "ubench", "make_gemm_supply.py")
+    committed = open(os.path.join(ROOT, "tools", "ubench", "gemm_supply.hip")).read()
+    src = open(gen).read().replace('HERE = os.path.dirname(os.path.abspath(__file__))', 'HERE = %r' % os.path.join(ROOT, "tools", "ubench"))
+    src = src.replace('open(os.path.join(HERE, "gemm_supply.hip"), "w")', 'open(%r, "w")' % str(tmp_path / "gemm_supply.hip"))
+    exec(compile(src, gen, "exec"), {"__name__": "gen"})
+    assert open(tmp_path / "gemm_supply.hip").read() == committed
