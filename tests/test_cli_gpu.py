@@ -153,14 +153,13 @@ def test_prefilter_execution_variants_give_identical_tsv(synth_db, opts, tmp_pat
     (UC_SIM_PER_POSITION=1) may change a byte of the result or any of the prefilter counts."""
     ref, st1 = _tsv(synth_db, tmp_path, "v0", opts, 1)
     keys = ("n_sim_kmers", "n_kmer_hits", "n_filtered_hits", "n_candidates", "n_prefilter_hits", "n_gapped_alignments", "n_clusters")
-    # ... nor may the cut of the targets into index chunks, with the similar k-mers enumerated once and their leaves kept for the
-    # later chunks (r4: the leaf cache), with the cache switched off, or with a budget it does not fit (every chunk enumerates)
+    # ... nor may the cut of the targets into index chunks, the filter kernel variant (tile size, blocked Bloom filter), or the way the kernels' code
+    # objects reach the device (helper-thread preload / HIP's lazy loading)
     small = {"UC_PREFILTER_CHUNK_RES": "20000"}
     for tag, env in (("v1", {"UC_DRUN_MAX": "20000"}), ("v2", {"UC_DRUN_MAX": "3000"}), ("v3", {"UC_SIM_PER_POSITION": "1"}),
-                     ("v4", small), ("v5", dict(small, UC_LEAF_CACHE="0")), ("v6", dict(small, UC_LEAF_CACHE_MB="0")),
-                     ("v7", dict(small, UC_DRUN_MAX="20000")),
-                     ("v11", dict(small, UC_LEAF_CACHE_MB="1")),          # a cache that only fits a part of the queries: the queries are cut into parts ("v8", {"UC_FILTER_VARIANT": "0"}), ("v9", {"UC_FILTER_VARIANT": "1"}),
-                     ("v10", {"UC_FILTER_VARIANT": "2"})):
+                     ("v4", small), ("v7", dict(small, UC_DRUN_MAX="20000")),
+                     ("v8", {"UC_FILTER_VARIANT": "0"}), ("v9", {"UC_FILTER_VARIANT": "2"}), ("v10", {"UC_FILTER_VARIANT": "3"}),
+                     ("v12", {"UC_PRELOAD": "0"})):
         got, st = _tsv(synth_db, tmp_path, tag, opts, 1, env=env)
         assert got == ref, (tag, opts)
         kk = [k for k in keys if not (tag in ("v9", "v10") and k == "n_filtered_hits")]      # the blocked Bloom filter lets a few more single hits through to the sort
