@@ -43,6 +43,13 @@ typedef struct uc_opts {
                                     mat3di.out the call fails unless UC_ALLOW_SYNTHETIC=1 opts into the seeded stand-in */
 } uc_opts;
 
+/* ABI revision of this header: bumped whenever a struct below grows or an entry point changes meaning.  uc_stats is written in full by
+ * uc_cluster / uc_search / uc_engine_stats and carries no size field of its own, so a caller built against an older header must check
+ * uc_abi_version() == UC_ABI_VERSION (or uc_stats_size() == sizeof(uc_stats)) before passing one in. */
+#define UC_ABI_VERSION 4
+uint32_t uc_abi_version(void);
+size_t uc_stats_size(void);
+
 #define UC_NSTAGE 8
 enum { UC_ST_LOAD = 0, UC_ST_INDEX = 1, UC_ST_KMER = 2, UC_ST_UNGAPPED = 3, UC_ST_SELECT = 4,
        UC_ST_GAPPED = 5, UC_ST_SETCOVER = 6, UC_ST_OUTPUT = 7 };
@@ -87,6 +94,18 @@ int uc_createtsv(const char *db, const char *cluster_db, const char *out_tsv, co
 /* == `foldseek rmdb <out>_cluster -v V`                                         (cluster.rs:67-76) */
 int uc_rmdb(const char *db_prefix);
 
+/* Workflow observer (optional).  A bare "-c 0.8" — what cluster.rs:35,49 forwards — runs the DEFAULT workflow: a linear-time pre-step and a
+ * 3-step cascade, each round on the representatives of the one before.  A registered hook is called by uc_cluster once per round, after the
+ * round's gapped stage and before its set cover, on the calling thread (single-GPU runs; with N GPUs: rank 0's thread, and `round_engine`
+ * holds rank 0's share of the pairs only).  round = -1 for the pre-step, 0.. for the cascade rounds; the round works on n_round_seqs
+ * sequences, round-local index i = database sequence seq_ids[i]; kmer_thr is the round's k-mer score threshold (the sensitivity rises from
+ * 1 to the target over the rounds).  round_engine is valid only during the call: its hit lists and alignment records are the round's
+ * (uc_engine_hits_get_range / uc_engine_alns_get / uc_engine_stats, round-local indices).  The at-size parity tests sample every round
+ * against the CPU oracle through this; bench.py uses it to size the CPU baseline of the workflow round by round.  NULL unregisters. */
+typedef struct uc_engine uc_engine;
+typedef void (*uc_round_hook)(void *user, int32_t round, uint32_t n_round_seqs, const uint32_t *seq_ids, int32_t kmer_thr, uc_engine *round_engine);
+void uc_set_round_hook(uc_round_hook hook, void *user);
+
 /* ---- the calls of src/modules/search.rs, same kernels, query DB vs target DB --------------- */
 /* == `foldseek search --threads T <queryDB> <targetDB> <out>_aln <tmp> <opts...>`  (search.rs:44-50; note that Unicore
  *    passes its TARGET argument first, i.e. as Foldseek's query DB).  Defaults as for cluster except -e 10 and
@@ -128,7 +147,6 @@ int uc_option_arity(const char *flag);
 void uc_release_scratch(void);
 
 /* ---- staged engine API (multi-GPU driver, bench, parity tests) -------------------------------- */
-typedef struct uc_engine uc_engine;
 
 typedef struct uc_hit {          /* one prefilter result (stage E4 output) */
     uint32_t target;

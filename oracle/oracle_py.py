@@ -101,6 +101,8 @@ def lib():
     L.uco_simd_sample_run.argtypes = [C.POINTER(Db), C.POINTER(Index), C.POINTER(Params), C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_double),
                                       C.c_void_p, C.c_void_p, C.c_void_p]
     L.uco_simd_sample_run.restype = C.c_uint64
+    L.uco_simd_sample_run_counts.argtypes = L.uco_simd_sample_run.argtypes + [C.POINTER(Counts)]
+    L.uco_simd_sample_run_counts.restype = C.c_uint64
     L.uco_align_pair.argtypes = [C.POINTER(Db), C.c_uint32, C.c_uint32, C.POINTER(Params), C.c_int32, C.c_void_p]
     L.uco_align_pair.restype = None
     L.uco_min_score.argtypes = [C.POINTER(Params), C.c_int, C.c_uint64]
@@ -170,6 +172,40 @@ class OracleDb:
             self.db.sa = cata.ctypes.data_as(C.POINTER(C.c_uint8))
             self.db.names = C.cast(arr, C.POINTER(C.c_char_p))
             self._owned = False
+
+    @classmethod
+    def from_flat(cls, off, c3, ca):
+        """from concatenated code arrays + n+1 offsets (no names: enough for everything but the TSV / m8 writers)"""
+        self = cls.__new__(cls)
+        self.db = Db()
+        off = np.ascontiguousarray(off, np.uint64)
+        tot = int(off[-1])
+        cat3 = np.concatenate([np.asarray(c3[:tot], np.uint8), np.zeros(1, np.uint8)])
+        cata = np.concatenate([np.asarray(ca[:tot], np.uint8), np.zeros(1, np.uint8)])
+        self._keep = [off, cat3, cata]
+        self.db.n = len(off) - 1
+        self.db.off = off.ctypes.data_as(C.POINTER(C.c_uint64))
+        self.db.s3 = cat3.ctypes.data_as(C.POINTER(C.c_uint8))
+        self.db.sa = cata.ctypes.data_as(C.POINTER(C.c_uint8))
+        self.db.names = None
+        self._owned = False
+        return self
+
+    def subset(self, ids):
+        """the sub-database of sequences `ids` (in that order): what a cascade round works on"""
+        ids = np.asarray(ids, np.int64)
+        off = self.offsets().astype(np.int64)
+        if len(ids) == self.n and np.array_equal(ids, np.arange(self.n)):
+            c3, ca = self.codes()
+            return OracleDb.from_flat(off, c3, ca)
+        lens = off[ids + 1] - off[ids]
+        noff = np.zeros(len(ids) + 1, np.int64)
+        noff[1:] = np.cumsum(lens)
+        idx = np.repeat(off[ids] - noff[:-1], lens) + np.arange(int(noff[-1]), dtype=np.int64)
+        tot = int(off[-1])
+        s3 = np.ctypeslib.as_array(self.db.s3, shape=(tot,))
+        sa = np.ctypeslib.as_array(self.db.sa, shape=(tot,))
+        return OracleDb.from_flat(noff, s3[idx], sa[idx])
 
     @property
     def n(self):
@@ -342,6 +378,18 @@ def simd_sample_run(odb, ix, p, queries, threads=0, records=False):
     n = lib().uco_simd_sample_run(C.byref(odb.db), C.byref(ix), C.byref(p), threads, q.ctypes.data, len(q), sec,
                                   hits.ctypes.data, cnt.ctypes.data, alns.ctypes.data)
     return int(n), sec[0], sec[1], cnt, hits, alns
+
+
+def simd_run_counts(odb, ix, p, queries, threads=0):
+    """simd_sample_run(records=True) plus the prefilter's stage counters of these queries (dict)"""
+    q = np.ascontiguousarray(queries, np.uint32)
+    sec = (C.c_double * 2)()
+    M = p.max_seqs
+    cnt, hits, alns = np.zeros(len(q), np.uint32), np.zeros((len(q), M), HIT_DTYPE), np.zeros((len(q), M), ALN_DTYPE)
+    pc = Counts()
+    n = lib().uco_simd_sample_run_counts(C.byref(odb.db), C.byref(ix), C.byref(p), threads, q.ctypes.data, len(q), sec,
+                                         hits.ctypes.data, cnt.ctypes.data, alns.ctypes.data, C.byref(pc))
+    return int(n), sec[0], sec[1], cnt, hits, alns, {f: int(getattr(pc, f)) for f, _ in Counts._fields_}
 
 
 def simd_cells():

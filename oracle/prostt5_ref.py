@@ -10,12 +10,14 @@ time, createdb.rs:148-155) are absent here, so what is restated is the PUBLISHED
   * ProstT5's 3Di head (Heinzinger et al. 2023, github.com/mheinzinger/ProstT5 `CNN`): Conv(1024 -> 32, k = 7, pad 3),
     ReLU, Conv(32 -> 20, k = 7, pad 3), argmax over the 20 classes = 3Di states in alphabetical letter order;
   * input = "<AA2fold>" + residues + "</s>", the prediction of the residue positions is kept.
-  * head convention (EXT-UNVERIFIED for Foldseek; default = the published predict_3Di script run on ONE sequence): </s> takes
-    part in the encoder's attention, its final hidden state is ZEROED before the CNN, the <AA2fold> position is sliced off
-    before the CNN (zero padding on the left), the CNN runs over residues + the zeroed </s> position (whose conv1 output —
-    ReLU(bias + the taps that reach back into the last residues) — is seen by conv2), and rare residues U/Z/O/B are mapped
-    to X before tokenisation.  `eos_in_head=True` / `uzob_to_x=False` give the r2 convention (</s>'s hidden state feeds the
-    CNN, B/O/U/Z keep their own ids); the product mirrors both switches (UC_T5_EOS_IN_HEAD=1, UC_T5_KEEP_UZOB=1).
+  * head convention (EXT-UNVERIFIED for Foldseek).  DEFAULT = the reading this repository has used since its first createdb
+    (`eos_in_head=True`, `uzob_to_x=False`): </s> takes part in the encoder's attention and its final hidden state feeds the
+    CNN like any other position; the <AA2fold> position is sliced off before the CNN (zero padding on the left); B/O/U/Z are
+    looked up in the vocabulary like every other letter.  The OTHER reading (`eos_in_head=False`, `uzob_to_x=True`) is
+    ProstT5's published predict_3Di script run on ONE sequence: </s>'s hidden state is ZEROED before the CNN (its position
+    stays: conv1's output there — ReLU(bias + the taps reaching back into the last residues) — is seen by conv2) and
+    U/Z/O/B are read as X.  The product mirrors both switches (UC_T5_EOS_IN_HEAD=0, UC_T5_KEEP_UZOB=0 select the other
+    reading); both have committed fixtures (tests/golden/t5_*.npz: keys `*` and `*_p3d`).
 The weights used by the tests and the benchmark are SEEDED SYNTHETIC ones written as GGUF by write_synthetic_gguf();
 a real prostt5-f16.gguf drops into the same loader (tensor names: llama.cpp's t5encoder convention, aliases in
 unicore_amd/csrc/uc_t5.cpp; the CNN head's tensor names inside Foldseek's file are EXT-UNVERIFIED).
@@ -182,7 +184,7 @@ def write_synthetic_gguf(path, cfg, seed=0x5EED0005, f16=True, with_vocab=True, 
 
 
 # ---------------------------------------------------------------------------------------------- the fp32 restatement
-def tokenize(seq, cfg, uzob_to_x=True):
+def tokenize(seq, cfg, uzob_to_x=False):
     ids = {c: 3 + i for i, c in enumerate(AA_ORDER)}
     x = ids["X"]
     if uzob_to_x:
@@ -211,7 +213,7 @@ def prepare(weights, dtype=None):
     return {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.array(v, dtype=np.float32))).to(dt) for k, v in weights.items()}
 
 
-def forward(weights, cfg, seq, dtype=None, run_layers=None, part=3, eos_in_head=False, uzob_to_x=True):
+def forward(weights, cfg, seq, dtype=None, run_layers=None, part=3, eos_in_head=True, uzob_to_x=False):
     """fp32 (or `dtype`) forward of one sequence -> (logits [L, n_out] float32 numpy, codes uint8 [L])"""
     import torch
     dt = dtype or torch.float32

@@ -216,6 +216,10 @@ void uco_simd_align_query(const uco_db *db, uint32_t q, const uint32_t *targets,
 uint64_t uco_simd_sample_run(const uco_db *db, const uco_index *ix, const uco_params *p, int threads,
                              const uint32_t *queries, uint32_t n_queries, double seconds[2],
                              uco_hit *hit_out, uint32_t *cnt_out, uco_aln *aln_out);
+/* ... plus the prefilter stage counters of these queries added to *pc (may be NULL) */
+uint64_t uco_simd_sample_run_counts(const uco_db *db, const uco_index *ix, const uco_params *p, int threads,
+                                    const uint32_t *queries, uint32_t n_queries, double seconds[2],
+                                    uco_hit *hit_out, uint32_t *cnt_out, uco_aln *aln_out, uco_counts *pc);
 /* DP cells since the last call: out[0] = rows x columns of the problems handed to the SIMD kernel (forward, reversed and start
  * passes), out[1] = cells the 16-lane batches swept including lane padding; resets both */
 void uco_simd_cells(uint64_t out[2]);

@@ -203,6 +203,14 @@ static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &
 uint64_t uco_simd_sample_run(const uco_db *db, const uco_index *ix, const uco_params *p, int threads,
                              const uint32_t *queries, uint32_t n_queries, double seconds[2],
                              uco_hit *hit_out, uint32_t *cnt_out, uco_aln *aln_out) {
+    return uco_simd_sample_run_counts(db, ix, p, threads, queries, n_queries, seconds, hit_out, cnt_out, aln_out, NULL);
+}
+
+/* the same with the prefilter's stage counters of these queries (similar k-mers, k-mer hits, candidates, prefilter hits) added
+ * to *pc: tools/oracle_at_size.py sums them over query chunks to get the whole-database counters of uco_cluster */
+uint64_t uco_simd_sample_run_counts(const uco_db *db, const uco_index *ix, const uco_params *p, int threads,
+                                    const uint32_t *queries, uint32_t n_queries, double seconds[2],
+                                    uco_hit *hit_out, uint32_t *cnt_out, uco_aln *aln_out, uco_counts *pc) {
     const int M = p->max_seqs;
     uco_hit *hits = hit_out ? hit_out : (uco_hit *)malloc((size_t)n_queries * M * sizeof(uco_hit));
     uint32_t *hcnt = cnt_out ? cnt_out : (uint32_t *)calloc(n_queries, sizeof(uint32_t));
@@ -211,9 +219,20 @@ uint64_t uco_simd_sample_run(const uco_db *db, const uco_index *ix, const uco_pa
     if (threads > 0) omp_set_num_threads(threads);
 #endif
     const double t0 = now_s();
-#pragma omp parallel for schedule(dynamic, 4)
-    for (int64_t k = 0; k < (int64_t)n_queries; k++)
-        hcnt[k] = (uint32_t)uco_prefilter_query(db, ix, queries[k], p, hits + (size_t)k * M, NULL);
+#pragma omp parallel
+    {
+        uco_counts loc; memset(&loc, 0, sizeof loc);
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t k = 0; k < (int64_t)n_queries; k++)
+            hcnt[k] = (uint32_t)uco_prefilter_query(db, ix, queries[k], p, hits + (size_t)k * M, pc ? &loc : NULL);
+        if (pc) {
+#pragma omp critical
+            {
+                pc->n_sim_kmers += loc.n_sim_kmers; pc->n_kmer_hits += loc.n_kmer_hits;
+                pc->n_candidates += loc.n_candidates; pc->n_prefilter_hits += loc.n_prefilter_hits;
+            }
+        }
+    }
     const double t1 = now_s();
     const uint64_t dbres = db->off[db->n];
     uint64_t pairs = 0;

@@ -33,9 +33,12 @@ def main():
     _, w = R.read_gguf(ensure_gguf())
     out = {}
     for i, s in enumerate(SEQS):
-        lg, codes = R.forward(w, cfg, s)
+        lg, codes = R.forward(w, cfg, s)                                          # the default head convention
         out["logits%d" % i] = lg.astype(np.float32)
         out["codes%d" % i] = codes
+        lg, codes = R.forward(w, cfg, s, eos_in_head=False, uzob_to_x=True)       # the predict_3Di reading (UC_T5_EOS_IN_HEAD=0 UC_T5_KEEP_UZOB=0)
+        out["logits%d_p3d" % i] = lg.astype(np.float32)
+        out["codes%d_p3d" % i] = codes
     np.savez_compressed(os.path.join(HERE, "t5_full_depth.npz"), seqs=np.array(SEQS), **out)
     print({k: v.shape for k, v in out.items()})
 

@@ -60,10 +60,10 @@ def test_oracle_reproduces_the_committed_fixture(tmp_path):
         assert np.array_equal(codes, z["codes%d" % i])
 
 
-def _forward_numpy(w, cfg, seq):
+def _forward_numpy(w, cfg, seq, eos_in_head=True, uzob_to_x=False):
     """second, torch-free restatement (float64 numpy, explicit loops for the bucket rule and the convolutions)"""
     W = {k: np.asarray(v, np.float64) for k, v in w.items()}
-    tok = R.tokenize(seq, cfg)
+    tok = R.tokenize(seq, cfg, uzob_to_x)
     L, H, dk = len(tok), cfg["n_heads"], cfg["d_kv"]
     h = W["token_embd.weight"][tok]
 
@@ -92,7 +92,8 @@ def _forward_numpy(w, cfg, seq):
         x = rms(h, W[b + "ffn_norm.weight"])
         h = h + np.maximum(x @ W[b + "ffn_up.weight"].T, 0) @ W[b + "ffn_down.weight"].T
     x = rms(h, W["enc.output_norm.weight"])[1:]                      # <AA2fold> off before the head
-    x[-1] = 0                                                        # </s> masked to zero, its position stays
+    if not eos_in_head:
+        x[-1] = 0                                                    # predict_3Di reading: </s> masked to zero, its position stays
     KW = cfg["cnn_kernel"]
 
     def conv(x, w_, b_):                                             # x [n, cin], w_ [cout, cin, k]: cross-correlation, zero padding
@@ -110,15 +111,20 @@ def _forward_numpy(w, cfg, seq):
 
 def test_oracle_against_a_second_independent_restatement(tmp_path):
     """the torch restatement (the checker of the GPU tests) agrees with a torch-free float64 numpy one: bucket rule, shared
-    bias of block 0, un-scaled attention, pre-norm residual blocks, and the head's slicing convention (prefix off before
-    the convolutions, </s> zeroed before and dropped after: ProstT5 predict_3Di; U/Z/O/B -> X)"""
+    bias of block 0, un-scaled attention, pre-norm residual blocks, and BOTH head conventions (prefix off before the convolutions,
+    </s> dropped after them; default: </s>'s hidden state feeds the CNN, B/O/U/Z keep their ids; the predict_3Di reading: </s>
+    zeroed before the CNN, U/Z/O/B -> X)"""
     cfg, path = _tiny(tmp_path)
     _, w = R.read_gguf(path)
     for seq in ("M", "MKTAYIAKQRQISFVKSH", "ACDEFGHIKLMNPQRSTVWYXBZ" * 7):
-        lg, codes = R.forward(w, cfg, seq)
-        ref = _forward_numpy(w, cfg, seq)
-        assert ref.shape == lg.shape and np.abs(ref - lg).max() <= 2e-4 * max(np.abs(ref).max(), 1.0), seq
-        assert (ref.argmax(1) == codes).mean() > 0.99
+        for conv in (dict(eos_in_head=True, uzob_to_x=False), dict(eos_in_head=False, uzob_to_x=True)):
+            lg, codes = R.forward(w, cfg, seq, **conv)
+            ref = _forward_numpy(w, cfg, seq, **conv)
+            assert ref.shape == lg.shape and np.abs(ref - lg).max() <= 2e-4 * max(np.abs(ref).max(), 1.0), (seq, conv)
+            assert (ref.argmax(1) == codes).mean() > 0.99
+    a, _ = R.forward(w, cfg, "MKTAYIAKQRUZOBQISFVKSH")
+    b, _ = R.forward(w, cfg, "MKTAYIAKQRUZOBQISFVKSH", eos_in_head=False, uzob_to_x=True)
+    assert np.abs(a - b).max() > 1e-3                                  # the two readings do differ
 
 
 def test_encoder_fails_loudly_without_a_gpu(tmp_path):
@@ -255,16 +261,20 @@ def test_hip_encoder_full_depth_24_blocks(full_model):
         _check(c, lg, rl, rc, ("24 blocks", len(s)))
         worst = max(worst, float(np.abs(lg - rl).max() / np.abs(rl).max()))
     print("full depth: worst relative logit error %.2e" % worst)
-    # the head-convention switches reach the product the same way they reach the oracle (EXT-UNVERIFIED table)
+    # the head-convention switches reach the product the same way they reach the oracle (EXT-UNVERIFIED table): the OTHER
+    # reading (ProstT5's predict_3Di script) against its own committed fixture and against the restatement
     enc.close()
-    os.environ["UC_T5_EOS_IN_HEAD"] = "1"
-    os.environ["UC_T5_KEEP_UZOB"] = "1"
+    os.environ["UC_T5_EOS_IN_HEAD"] = "0"
+    os.environ["UC_T5_KEEP_UZOB"] = "0"
     try:
         enc2 = U.T5Encoder(path)
+        codes, logits = enc2.encode(F.SEQS, logits=True)
+        for i in range(len(F.SEQS)):
+            _check(codes[i], logits[i], z["logits%d_p3d" % i], z["codes%d_p3d" % i], "full-depth fixture %d, predict_3Di reading" % i)
         s = "MKTAYIAKQRUZOBQISFVKSH"
         c2, l2 = enc2.encode([s], logits=True)
-        rl, rc = R.forward(W, cfg, s, eos_in_head=True, uzob_to_x=False)
-        _check(c2[0], l2[0], rl, rc, "r2 head convention")
+        rl, rc = R.forward(W, cfg, s, eos_in_head=False, uzob_to_x=True)
+        _check(c2[0], l2[0], rl, rc, "predict_3Di head convention")
         rl1, _ = R.forward(W, cfg, s)
         assert np.abs(rl - rl1).max() > 1e-3                     # the two conventions do differ (last residues, U/Z/O/B)
         enc2.close()

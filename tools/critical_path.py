@@ -60,19 +60,26 @@ LINK, EFF = 153e9, 0.6
 per_rank_rx = stn["exchange_bytes"] / N          # uc_cluster sums the ranks' counters
 x_model = per_rank_rx / ((N - 1) * LINK * EFF)
 one_gpu = sum(st1["stage_seconds"][1:7])         # index .. setcover of the 1-GPU pass (no load, no output)
-scaling = {k: ph[k] for k in ("prefilter", "merge_at_home", "install_owned", "gapped")}
+# EVERY measured phase of the slowest rank is on the critical path (the first version of this tool dropped "exchange_pairs_to_owner"
+# — which holds the device partition-by-owner radix sort, not only copies — and "edge_gather"): the sum below leaves nothing out.  The two
+# exchange phases contain this emulation's device copies in place of the xGMI transfers, so "with model" adds the modelled transfer time on top
+# (slightly pessimistic: the copies stay in), "measured only" does not.
+measured = sum(ph[k] for k in U.PHASES)
+critical = measured + x_model
+scaling = {k: ph[k] for k in ("prefilter", "exchange_lists_to_home", "merge_at_home", "exchange_pairs_to_owner", "install_owned", "gapped")}
 serial = {"rank0_serial_cover": ph["rank0_serial_cover"], "edge_gather_measured_in_process": ph["edge_gather"], "exchanges_modelled": x_model}
-critical = sum(scaling.values()) + ph["rank0_serial_cover"] + x_model
-# what does not shrink with N: the similar-k-mer enumeration every rank repeats for ALL queries is inside "prefilter"; estimate it
-# from the 1-GPU run's per-stage split is not possible here, so the non-scaling share is reported as (critical - one_gpu / N)
 out = {
     "what": "EMULATION on one GPU (virtual ranks, serialized compute phases): per-phase time of the slowest rank; exchanges modelled from bytes",
     "config": "%s: %d proteomes, %d sequences, options '%s'" % (label, proteomes, st1["n_seqs"], opts), "ranks": N,
     "one_gpu_pass_s": one_gpu, "one_gpu_wall_s_disk_to_cluster_db": wall1, "one_gpu_stage_seconds": dict(zip(U.STAGES, st1["stage_seconds"])),
     "slowest_rank_phase_s": ph, "exchange_bytes_received_per_rank": per_rank_rx,
     "exchange_model": {"links": N - 1, "GBps_per_link": LINK / 1e9, "assumed_efficiency": EFF, "seconds": x_model},
-    "emulated_critical_path_s": critical, "ideal_s": one_gpu / N, "emulated_speedup": one_gpu / critical if critical > 0 else None,
+    "emulated_critical_path_s": critical, "emulated_critical_path_measured_phases_only_s": measured,
+    "ideal_s": one_gpu / N, "emulated_speedup": one_gpu / critical if critical > 0 else None,
+    "emulated_speedup_measured_phases_only": one_gpu / measured if measured > 0 else None,
     "emulated_efficiency": one_gpu / N / critical if critical > 0 else None,
+    "rank0_serial_tail_s": ph["rank0_serial_cover"] + ph["edge_gather"],
+    "rank0_serial_tail_share_of_critical_path": (ph["rank0_serial_cover"] + ph["edge_gather"]) / critical if critical > 0 else None,
     "non_scaling_s": critical - one_gpu / N, "non_scaling_share_of_one_gpu_pass": (critical - one_gpu / N) / one_gpu if one_gpu > 0 else None,
     "serial_terms_s": serial,
     "alignments": {"one_gpu": st1["n_gapped_alignments"], "ranks": stn["n_gapped_alignments"]}, "clusters": {"one_gpu": st1["n_clusters"], "ranks": stn["n_clusters"]},

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""tools/oracle_at_size.py --config c3 [--threads N] [--chunk Q] [--work DIR] [--out tests/golden/c3_sha.json]
+
+The CPU oracle END TO END at a BASELINE configuration's full size (north_star's "byte-identical clust.tsv
+on 500 proteomes at 1 GPU" needs a whole-TSV answer from the CPU side, not a query sample).  Runs in the BUILD container (no GPU):
+the plain all-vs-all step of spec UC-1.1 — E1 index, E2-E4 per query (the scalar oracle's prefilter), E5/E6 through the AVX2
+inter-sequence leg `oracle/uc_simd.c` (record for record equal to the scalar oracle: tests/test_oracle_kat.py), E7 `uco_setcover`,
+E9 `uco_write_tsv` — in query chunks with a checkpoint per chunk (a killed run resumes), and writes
+
+    {sha256 of clust.tsv, bytes, clusters, every stage counter of uco_cluster, per-chunk edge checksum}
+
+as a small golden fixture.  `tests/test_configs_gpu.py::test_config_at_size[c3]` asserts the HIP path's TSV hash and counters
+against it on the GPU box.  `--selfcheck` compares this chunked driver with `uco_cluster` itself on a small database first."""
+import argparse, hashlib, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("UC_ALLOW_SYNTHETIC", "1")
+import numpy as np
+import util
+from oracle import oracle_py as O
+
+CONFIGS = {  # == bench.py CONFIGS / tests/test_configs_gpu.py
+    "c2": (50, 6000, 1.0, 0x5EED0002, "-c 0.8"),
+    "c3": (500, 6000, 1.0, 0x5EED0003, "-c 0.8"),
+}
+
+
+def run_chunked(odb, p, threads, chunk, work, log=None):
+    """-> (assign, counts) of the plain step, computed chunk by chunk (checkpointed under `work` if given)"""
+    n = odb.n
+    off = odb.offsets().astype(np.int64)
+    lens = off[1:] - off[:-1]
+    dbres = int(off[n])
+    ix = None
+    tot = dict(n_sim_kmers=0, n_kmer_hits=0, n_candidates=0, n_prefilter_hits=0, n_alignments=0, n_edges=0,
+               cells_fwd=0, cells_rev=0, cells_start=0)
+    edge_parts, t_pre, t_aln = [], 0.0, 0.0
+    ms_all = None
+    for c0 in range(0, n, chunk):
+        c1 = min(n, c0 + chunk)
+        ck = os.path.join(work, "chunk_%09d_%09d.npz" % (c0, c1)) if work else None
+        if ck and os.path.exists(ck):
+            z = np.load(ck)
+            e, cn = z["edges"], json.loads(str(z["counts"]))
+        else:
+            if ix is None:
+                t = time.perf_counter()
+                ix = O.build_index(odb, p)
+                if log: log("index built in %.1f s" % (time.perf_counter() - t))
+            q = np.arange(c0, c1, dtype=np.uint32)
+            npairs, s0, s1, cnt, hits, alns, pc = O.simd_run_counts(odb, ix, p, q, threads=threads)
+            t_pre += s0; t_aln += s1
+            M = hits.shape[1]
+            valid = np.arange(M)[None, :] < cnt[:, None]
+            lq = lens[c0:c1][:, None]
+            lt = lens[hits["t"]] * valid
+            ms = np.array([O.lib().uco_min_score(p, int(l), dbres) for l in lens[c0:c1]], np.int64)[:, None]
+            acc = valid & (alns["accepted"] == 1)
+            qq = np.broadcast_to(q[:, None], acc.shape)
+            e = np.stack([qq[acc], hits["t"][acc]], axis=1).astype(np.uint32)      # (q asc, list order) == uco_cluster's edge order
+            cn = dict(pc)
+            cn["n_alignments"] = int(cnt.sum()); cn["n_edges"] = int(len(e))
+            cn["cells_fwd"] = int((lq * lt).sum())
+            cn["cells_rev"] = int((lq * lt * (valid & (alns["score"] >= ms))).sum()) if p.rev_correction else 0
+            cn["cells_start"] = int((((alns["qend"].astype(np.int64) + 1) * (alns["tend"].astype(np.int64) + 1)) * (valid & (alns["pass_evalue"] == 1))).sum())
+            assert npairs == cn["n_alignments"]
+            if ck:
+                np.savez(ck + ".tmp.npz", edges=e, counts=json.dumps(cn))
+                os.replace(ck + ".tmp.npz", ck)
+            if log: log("queries [%d, %d): %d alignments, %d edges, prefilter %.0f s, gapped %.0f s" % (c0, c1, cn["n_alignments"], len(e), s0, s1))
+        edge_parts.append(e)
+        for k in tot:
+            tot[k] += int(cn.get(k, 0))
+    if ix is not None:
+        O.free_index(ix)
+    edges = np.concatenate(edge_parts) if edge_parts else np.zeros((0, 2), np.uint32)
+    assign = O.setcover(n, edges)
+    tot["n_clusters"] = int((assign == np.arange(n)).sum())
+    tot["edge_sha256"] = hashlib.sha256(np.ascontiguousarray(edges).tobytes()).hexdigest()
+    return assign, tot, (t_pre, t_aln)
+
+
+def selfcheck():
+    """the chunked driver == uco_cluster (assignment and all counters) on a family database"""
+    s3, sa = util.family_db(11, n_fam=40, members=6, extra=(700, 900))
+    odb = O.OracleDb(s3=s3, sa=sa)
+    p = util.oracle_params(O, "-c 0.8")
+    ref = O.cluster(odb, p, threads=4, dumps=False)
+    assign, tot, _ = run_chunked(odb, p, 4, 37, None)
+    assert np.array_equal(assign, ref["assign"])
+    for k, v in ref["counts"].items():
+        assert int(v) == tot[k], (k, int(v), tot[k])
+    return True
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c3")
+    ap.add_argument("--threads", type=int, default=max(1, len(os.sched_getaffinity(0)) - 1))
+    ap.add_argument("--chunk", type=int, default=20000)
+    ap.add_argument("--work", default=None)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--selfcheck", action="store_true")
+    a = ap.parse_args()
+    if a.selfcheck:
+        print("selfcheck", selfcheck()); return
+    prot, fam, scale, seed, opts = CONFIGS[a.config]
+    work = a.work or "/tmp/uc_oracle_%s" % a.config
+    os.makedirs(work, exist_ok=True)
+    t0 = time.perf_counter()
+    def log(m): print("[%7.0f s] %s" % (time.perf_counter() - t0, m), file=sys.stderr, flush=True)
+    db = os.path.join(work, "db")
+    if not os.path.exists(db + ".map"):
+        util.gen_synth_db(db, prot, seed, fam, scale)
+    odb = O.OracleDb(db)
+    p = util.oracle_params(O, opts)
+    log("%d sequences, %d residues, options %r, %d threads" % (odb.n, int(odb.offsets()[-1]), opts, a.threads))
+    assign, tot, (tp, ta) = run_chunked(odb, p, a.threads, a.chunk, work, log)
+    tsv = os.path.join(work, "clust.tsv")
+    O.write_tsv(tsv, odb, assign)
+    data = open(tsv, "rb").read()
+    res = {"config": a.config, "proteomes": prot, "seed": hex(seed), "options": opts + " --single-step-clustering",
+           "sequences": int(odb.n), "residues": int(odb.offsets()[-1]),
+           "tsv_sha256": hashlib.sha256(data).hexdigest(), "tsv_bytes": len(data), "counts": tot,
+           "made_by": "tools/oracle_at_size.py (build container, %d threads; prefilter %.0f s + gapped %.0f s of this process, checkpointed chunks not included)" % (a.threads, tp, ta)}
+    out = a.out or os.path.join(ROOT, "tests", "golden", "%s_sha.json" % a.config)
+    json.dump(res, open(out, "w"), indent=1)
+    log("wrote " + out)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

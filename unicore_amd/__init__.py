@@ -60,8 +60,10 @@ SYMBOLS = (
     "uc_engine_hits_export_dev", "uc_engine_hits_import_dev", "uc_engine_setcover",
     "uc_hits_merge", "uc_engine_align", "uc_engine_alns_get", "uc_engine_edges_size", "uc_engine_edges_get",
     "uc_engine_stats", "uc_engine_reset_stats", "uc_setcover", "uc_write_cluster_db",
-    "uc_engine_ungapped_batch", "uc_engine_sw_batch",
+    "uc_engine_ungapped_batch", "uc_engine_sw_batch", "uc_abi_version", "uc_stats_size", "uc_set_round_hook",
 )
+ABI_VERSION = 4      # == UC_ABI_VERSION of include/unicore_cluster.h this binding mirrors
+ROUND_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32), C.c_int32, C.c_void_p)
 
 _lib = None
 
@@ -131,6 +133,14 @@ def lib():
     L.uc_write_cluster_db.argtypes = [C.c_char_p, u32, vp]
     L.uc_engine_ungapped_batch.argtypes = [vp, u64, vp, vp, vp, vp]
     L.uc_engine_sw_batch.argtypes = [vp, C.c_int, u64, vp, vp, vp, vp, vp, vp, vp]
+    L.uc_abi_version.restype = u32
+    L.uc_stats_size.restype = C.c_size_t
+    L.uc_set_round_hook.argtypes = [ROUND_HOOK, vp]
+    L.uc_set_round_hook.restype = None
+    # uc_stats carries no size field: a binding that disagrees with the library about its layout would be overrun silently
+    if L.uc_abi_version() != ABI_VERSION or L.uc_stats_size() != C.sizeof(UcStats):
+        raise ImportError("libunicore_cluster.so has ABI %d / uc_stats of %d bytes; this binding mirrors ABI %d / %d bytes — rebuild (`make product`)"
+                          % (L.uc_abi_version(), L.uc_stats_size(), ABI_VERSION, C.sizeof(UcStats)))
     _lib = L
     return L
 
@@ -217,6 +227,31 @@ def createdb(fasta_paths, out_db, model, verbosity=1, device=-1):
     o, st = make_opts("", 1, verbosity, device), UcT5Stats()
     _check(lib().uc_createdb(arr, len(fasta_paths), out_db.encode(), model.encode(), C.byref(o), C.byref(st)))
     return {k: getattr(st, k) for k, _ in UcT5Stats._fields_}
+
+
+_round_hook_keepalive = None
+
+
+def set_round_hook(fn):
+    """uc_set_round_hook: fn(round, ids, kmer_thr, view) is called once per workflow round of uc_cluster — after the round's gapped stage,
+    before its set cover — with round = -1 for the linear-time pre-step, ids = database sequence number of every round-local index (a copy)
+    and view = an Engine facade over the round's engine (hits_range / alns_range / stats; valid only during the call).  None unregisters."""
+    global _round_hook_keepalive
+    if fn is None:
+        lib().uc_set_round_hook(ROUND_HOOK(), None)
+        _round_hook_keepalive = None
+        return
+
+    def tramp(_user, rnd, m, ids, kthr, eng):
+        view = Engine.__new__(Engine)
+        view._h = C.c_void_p(eng)
+        try:
+            fn(int(rnd), np.ctypeslib.as_array(ids, shape=(int(m),)).copy(), int(kthr), view)
+        finally:
+            view._h = C.c_void_p()      # a view never destroys the engine it looked at
+    cb = ROUND_HOOK(tramp)
+    _round_hook_keepalive = cb
+    lib().uc_set_round_hook(cb, None)
 
 
 class T5Encoder:

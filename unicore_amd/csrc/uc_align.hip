@@ -901,6 +901,7 @@ AlignScratch *take_align_scratch(int device) {
 
 // ---- kernel-level entry point: arbitrary pair list from the host -----------------------------------
 void Engine::sw_batch(int mode, const std::vector<PairIn> &pairs, int32_t *score, int32_t *qe, int32_t *te) {
+    PressureScope ps(*this, 1);
     if (!have_db) fail(UC_ERR_ARGS, "no database loaded");
     const size_t n = pairs.size();
     if (n == 0) return;
@@ -943,6 +944,7 @@ void Engine::sw_batch(int mode, const std::vector<PairIn> &pairs, int32_t *score
 
 // ---- stage E5 + E6 for queries [qbegin, qend) of the device-resident hit lists ----------------------
 void Engine::align(uint32_t qbegin, uint32_t qend) {
+    PressureScope ps(*this, 1);
     if (!have_db) fail(UC_ERR_ARGS, "no database loaded");
     if (qbegin > qend || qend > hdb.n) fail(UC_ERR_ARGS, "align: bad query range");
     UC_HIP(hipSetDevice(device));
@@ -1317,6 +1319,7 @@ void Engine::set_cover_device(uint32_t n, const uint32_t *h_edges, uint64_t n_ed
 // the graph (CSR, both directions, duplicates and self loops removed) on the device from a host or a device edge list, the
 // greedy cover on the host
 void Engine::set_cover_graph(uint32_t n, const uint32_t *h_edges, const uint32_t *dev_edges, uint64_t n_edges, uint32_t *assign) {
+    PressureScope ps(*this, 1);
     UC_HIP(hipSetDevice(device));
     Timer t_graph;
     AlignScratch &A = scratch_of(*this);

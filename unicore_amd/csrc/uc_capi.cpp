@@ -8,6 +8,7 @@
 #include <cstring>
 #include <future>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 #include "uc_engine.h"
@@ -73,6 +74,21 @@ void mkdir_p(const std::string &path) {
     }
 }
 
+// workflow observer (uc_set_round_hook): read once per round by rank 0's thread
+std::mutex g_hook_mu;
+uc_round_hook g_round_hook = nullptr;
+void *g_round_hook_user = nullptr;
+
+void call_round_hook(Engine &E, int round, const std::vector<uint32_t> &ids) {
+    uc_round_hook h; void *u;
+    { std::lock_guard<std::mutex> lk(g_hook_mu); h = g_round_hook; u = g_round_hook_user; }
+    if (!h) return;
+    uc_engine view;                       // a non-owning view of the round's engine for the duration of the call
+    view.e.reset(&E);
+    struct Release { uc_engine &v; ~Release() { (void)v.e.release(); } } rel{view};
+    h(u, round, E.hdb.n, ids.data(), E.p.kmer_thr, &view);
+}
+
 void require(const void *p, const char *what) {
     if (!p) fail(UC_ERR_ARGS, "%s must not be NULL", what);
 }
@@ -90,6 +106,13 @@ const char *uc_version(void) {
     v = std::string("unicore-cluster-mi355x 0.2.0 (spec UC-1.1, gfx950; default workflow: linclust pre-step + 3-step cascade; 3Di matrix: ") +
         (real ? "data/mat3di.out" : "MISSING - only the synthetic stand-in is shipped, runs need UC_ALLOW_SYNTHETIC=1 or --mat3di") + ")";
     return v.c_str();
+}
+
+uint32_t uc_abi_version(void) { return UC_ABI_VERSION; }
+size_t uc_stats_size(void) { return sizeof(uc_stats); }
+void uc_set_round_hook(uc_round_hook hook, void *user) {
+    std::lock_guard<std::mutex> lk(g_hook_mu);
+    g_round_hook = hook; g_round_hook_user = user;
 }
 
 int uc_option_arity(const char *flag) { return flag ? option_arity(flag) : -1; }
@@ -563,15 +586,21 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
                     E.stats.phase_seconds[5] += ta.seconds();
                 }
                 phase("align", rr);
-                std::vector<uint32_t> all;
+                if (r == 0) call_round_hook(E, rd, cur);
                 Timer te;
                 uint64_t n_acc = 0;                  // accepted pairs of the round (all ranks)
-                if (W > 1) { C.gather_edges(E, all); n_acc = all.size() / 2; E.stats.exchange_seconds += te.seconds(); }
+                const uint32_t *dev_all = nullptr;   // rank 0: every rank's edges in one device buffer (gathered device to device)
+                if (W > 1) { n_acc = C.gather_edges_dev(E, &dev_all); E.stats.exchange_seconds += te.seconds(); }
                 else n_acc = E.edges_on_host ? E.edges.size() / 2 : E.n_edges_dev;
                 if (r == 0) {
                     Timer tc;
                     std::vector<uint32_t> sa(m);
-                    if (W > 1) E.set_cover_device(m, all.data(), all.size() / 2, sa.data());
+                    if (W > 1 && n_acc < (1ull << 31)) E.set_cover_graph(m, nullptr, dev_all, n_acc, sa.data());
+                    else if (W > 1) {   // beyond the 32-bit positions of the device graph build: the all-host cover
+                        std::vector<uint32_t> all(2 * n_acc);
+                        UC_HIP(hipMemcpy(all.data(), dev_all, 2 * n_acc * 4, hipMemcpyDeviceToHost));
+                        set_cover(m, all.data(), n_acc, sa.data());
+                    }
                     else E.set_cover_own_edges(m, sa.data());      // one rank: graph straight from the device-resident edge list
                     // mergeclusters: the representative of a sequence is the representative of its representative
                     for (uint32_t i = 0; i < cur.size(); i++) posmap[cur[i]] = i;

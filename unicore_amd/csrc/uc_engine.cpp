@@ -114,6 +114,7 @@ void Engine::finish_db_install(Timer &tm) {
 }
 
 void Engine::upload_db(bool keep_raw) {
+    PressureScope ps(*this, 2);
     Timer tm;
     UC_HIP(hipSetDevice(device));
     const uint32_t n = hdb.n;
@@ -144,6 +145,7 @@ void Engine::upload_db(bool keep_raw) {
 // the sequences `cur` (ascending ids of the database uploaded with keep_raw) become the engine's database: offsets on the
 // host (full_off = raw offsets of that database), the sequence data gathered on the device from the resident raw copy
 void Engine::upload_sub_db(const std::vector<uint32_t> &cur, const std::vector<uint64_t> &full_off) {
+    PressureScope ps(*this, 2);
     Timer tm;
     UC_HIP(hipSetDevice(device));
     if (!raw_resident || full_off.size() != (size_t)raw_n + 1) fail(UC_ERR_GENERIC, "upload_sub_db: no resident raw database");
@@ -176,6 +178,21 @@ void Engine::drop_scratch() {
     // tens of GB of hipMalloc inside its timed phase
     if (pre) { park_prefilter_scratch(pre, device); pre = nullptr; }
     if (aln) { park_align_scratch(aln, device); aln = nullptr; }
+}
+
+bool Engine::relieve_pressure(int stage) {
+    (void)hipStreamSynchronize(stream);
+    size_t f0 = 0, f1 = 0, tot = 0;
+    (void)hipMemGetInfo(&f0, &tot);
+    bool freed = false;
+    if (stage != 1 && aln) { free_align_scratch(aln); aln = nullptr; freed = true; }
+    if (stage != 0 && pre) { free_prefilter_scratch(pre); pre = nullptr; freed = true; }
+    if (PrefilterScratch *x = take_parked_prefilter_scratch(device)) { free_prefilter_scratch(x); freed = true; }
+    if (AlignScratch *x = take_parked_align_scratch(device)) { free_align_scratch(x); freed = true; }
+    (void)hipMemGetInfo(&f1, &tot);
+    logf(2, "unicore-cluster: device memory ran out in the %s; %s work buffers released (%.1f -> %.1f GiB free)\n",
+         stage == 0 ? "prefilter" : stage == 1 ? "gapped stage" : "database upload", freed ? "the other stage's" : "no", (double)f0 / (1ull << 30), (double)f1 / (1ull << 30));
+    return freed;
 }
 
 void Engine::ungapped_batch(uint64_t n, const uint32_t *q, const uint32_t *t, const int32_t *diag, int32_t *out) {

@@ -16,6 +16,24 @@
 
 namespace uc {
 
+// Memory pressure.  Both stages keep their work buffers between calls (re-allocating tens of GB per step costs more than the step at small
+// sizes), and each sizes its big batches by what is free — but the fixed allocations of one stage can still meet the other stage's leftovers
+// (the default workflow at 1000+ proteomes: 100+ GB of traceback matrices from the pre-step's gapped stage, then the next round's prefilter).
+// A hipMalloc that fails with out-of-memory therefore asks the engine at work on this thread to give back what it is NOT using right now
+// (the other stage's scratch, buffers a destroyed engine parked on the device) and is tried once more.  Engine::PressureScope registers the
+// handler for the duration of a stage.
+struct OomRelief { bool (*fn)(void *) = nullptr; void *ctx = nullptr; };
+inline OomRelief &oom_relief_slot() { static thread_local OomRelief r; return r; }
+inline hipError_t malloc_with_relief(void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {
+        const OomRelief r = oom_relief_slot();
+        (void)hipGetLastError();
+        if (r.fn && r.fn(r.ctx)) e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+
 template <typename T>
 struct DevBuf {   // plain owning device allocation (hipMalloc), grows geometrically
     T *p = nullptr;
@@ -36,7 +54,7 @@ struct DevBuf {   // plain owning device allocation (hipMalloc), grows geometric
             fprintf(stderr, "unicore-cluster[alloc]: %.2f GiB (%zu x %zu B), %.1f GiB free before\n", (double)(want * sizeof(T)) / (1ull << 30), want, sizeof(T),
                     (double)fr / (1ull << 30));
         }
-        UC_HIP(hipMalloc((void **)&p, want * sizeof(T)));
+        UC_HIP(malloc_with_relief((void **)&p, want * sizeof(T)));
         cap = want;
     }
     // keeps the first `used` elements.  The copy runs ON `s`, behind whatever that stream still has in flight for the old
@@ -45,7 +63,7 @@ struct DevBuf {   // plain owning device allocation (hipMalloc), grows geometric
         if (n <= cap) return;
         size_t want = n + n / 2 + 64;
         T *np = nullptr;
-        UC_HIP(hipMalloc((void **)&np, want * sizeof(T)));
+        UC_HIP(malloc_with_relief((void **)&np, want * sizeof(T)));
         if (used && p) UC_HIP(hipMemcpyAsync(np, p, used * sizeof(T), hipMemcpyDeviceToDevice, s));
         UC_HIP(hipStreamSynchronize(s));
         if (p) (void)hipFree(p);
@@ -148,7 +166,20 @@ struct Engine {
                        double *density_out = nullptr);   // one target chunk
     PrefilterScratch *pre = nullptr;                       // work buffers kept between prefilter calls
     AlignScratch *aln = nullptr;                           // ... and between align calls
-    void drop_scratch();                                   // frees both (results stay): virtual-rank emulation, memory pressure
+    void drop_scratch();                                   // parks both (results stay): virtual-rank emulation
+    // out-of-memory handler of a stage (see OomRelief): stage 0 = the prefilter is at work (gives back the gapped stage's scratch), 1 = the gapped
+    // stage / set cover is at work (gives back the prefilter's), 2 = neither (database upload: both); parked sets of the device go in every case
+    bool relieve_pressure(int stage);
+    struct PressureScope {
+        OomRelief saved;
+        struct Ctx { Engine *e; int stage; } ctx;
+        PressureScope(Engine &E, int stage) : saved(oom_relief_slot()), ctx{&E, stage} {
+            oom_relief_slot() = OomRelief{[](void *c) { return ((Ctx *)c)->e->relieve_pressure(((Ctx *)c)->stage); }, &ctx};
+        }
+        ~PressureScope() { oom_relief_slot() = saved; }
+        PressureScope(const PressureScope &) = delete;
+        PressureScope &operator=(const PressureScope &) = delete;
+    };
     uint64_t prefilter_chunk_residues = 96ull << 20;   // target residues per index chunk (keeps hits/query inside the LDS filter)
     void set_hits(const uint32_t *counts, const uc_hit *h, bool check_max_seqs = true);
     void get_hits(uc_hit *out) const;                        // D2H of the device hit arrays

@@ -120,6 +120,7 @@ inline dim3 lc_grid(uint64_t n) { return dim3((uint32_t)std::min<uint64_t>(std::
 // (centre, member) candidate pairs of the linear-time pre-step for the database resident on this engine's device, sorted by
 // (centre, member), unique
 std::vector<uint32_t> Engine::linclust_pairs_impl(uint64_t *install) {
+    PressureScope ps(*this, 0);
     if (!have_db) fail(UC_ERR_ARGS, "no database loaded");
     UC_HIP(hipSetDevice(device));
     const uint32_t n = hdb.n;

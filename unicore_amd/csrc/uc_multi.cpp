@@ -48,23 +48,41 @@ struct CommScratch {
 Comm::Comm() : scratch(new CommScratch) {}
 Comm::~Comm() {
     scratch.reset();
-    if (nccl) (void)ncclCommDestroy(nccl);
+    if (ncclComm *h = nccl.exchange(nullptr)) (void)ncclCommDestroy(h);
 }
 
 void Comm::abort() {
-    std::lock_guard<std::mutex> lk(nccl_mu);
-    aborted = true;
-    if (nccl) { (void)ncclCommAbort(nccl); nccl = nullptr; }
+    aborted.store(true);
+    // whoever takes the handle out aborts it, exactly once; no lock: the thread that owns this communicator may be blocked inside
+    // ncclGroupEnd / a first-use connect waiting for the very peer that is calling us
+    if (ncclComm *h = nccl.exchange(nullptr)) (void)ncclCommAbort(h);
 }
 
 namespace {
-// RCCL enqueue under the communicator's lock: abort() cannot free the handle between the check and the call; the blocking
-// part of a collective is the stream synchronisation AFTER the enqueue, which runs unlocked (that is what abort() interrupts)
+// ncclGroupStart ... ncclGroupEnd as a scope: an exception between the two (a failed ncclSend, an injected failure) must not leave the
+// calling thread's group open — the abort that follows would run INSIDE that group
+struct GroupScope {
+    bool open = false;
+    GroupScope() { UC_NCCL(ncclGroupStart()); open = true; }
+    void end() { open = false; UC_NCCL(ncclGroupEnd()); }
+    ~GroupScope() { if (open) (void)ncclGroupEnd(); }
+};
+
+// test hook: UC_FAIL_RANK="<rank>:<stage>"; stage 2 = inside the grouped point-to-point exchange, between ncclGroupStart and ncclGroupEnd
+bool inject_failure(int rank, int stage) {
+    int fr = -1, fs = -1;
+    if (const char *e = getenv("UC_FAIL_RANK")) sscanf(e, "%d:%d", &fr, &fs);
+    return fr == rank && fs == stage;
+}
+
+// RCCL enqueue: the handle is read once; an abort() that lands between the read and the call makes the call fail (or return early) — both
+// surface as an error of this rank, which is what the caller wants to hear
 template <class F>
 void nccl_enqueue(Comm &C, F &&f) {
-    std::lock_guard<std::mutex> lk(C.nccl_mu);
-    if (C.aborted || !C.nccl) fail(UC_ERR_DEVICE, "RCCL communicator of rank %d was aborted (another GPU rank of this run failed)", C.rank);
-    f(C.nccl);
+    ncclComm *h = C.nccl.load();
+    if (C.aborted.load() || !h) fail(UC_ERR_DEVICE, "RCCL communicator of rank %d was aborted (another GPU rank of this run failed)", C.rank);
+    f(h);
+    if (C.aborted.load()) fail(UC_ERR_DEVICE, "RCCL communicator of rank %d was aborted (another GPU rank of this run failed)", C.rank);
 }
 }  // namespace
 
@@ -81,34 +99,38 @@ void comm_init_rank(Comm &C, const uint8_t id[128], int rank, int world, int dev
     UC_HIP(hipSetDevice(device));
     C.rank = rank;
     C.world = world;
-    UC_NCCL(ncclCommInitRank(&C.nccl, world, u, rank));
+    ncclComm *h = nullptr;
+    UC_NCCL(ncclCommInitRank(&h, world, u, rank));
+    C.nccl.store(h);
+    C.uses_rccl = true;
 }
 
 void comm_info(const Comm &C, int *count, int *rank, int *device) {
-    if (!C.nccl) fail(UC_ERR_ARGS, "communicator has no RCCL handle");
-    UC_NCCL(ncclCommCount(C.nccl, count));
-    UC_NCCL(ncclCommUserRank(C.nccl, rank));
-    UC_NCCL(ncclCommCuDevice(C.nccl, device));
+    ncclComm *h = C.nccl.load();
+    if (!h) fail(UC_ERR_ARGS, "communicator has no RCCL handle");
+    UC_NCCL(ncclCommCount(h, count));
+    UC_NCCL(ncclCommUserRank(h, rank));
+    UC_NCCL(ncclCommCuDevice(h, device));
 }
 
 void comm_init_all(const std::vector<Comm *> &comms, const std::vector<int> &devices) {
     const int W = (int)comms.size();
     std::vector<ncclComm_t> h((size_t)W, nullptr);
     UC_NCCL(ncclCommInitAll(h.data(), W, devices.data()));
-    for (int r = 0; r < W; r++) { comms[(size_t)r]->rank = r; comms[(size_t)r]->world = W; comms[(size_t)r]->nccl = h[(size_t)r]; }
+    for (int r = 0; r < W; r++) { comms[(size_t)r]->rank = r; comms[(size_t)r]->world = W; comms[(size_t)r]->nccl.store(h[(size_t)r]); comms[(size_t)r]->uses_rccl = true; }
 }
 
 // A communicator that owns an RCCL handle always goes through RCCL, even with one rank: a 1-rank communicator on the
 // single-GPU test box exercises exactly the calls an 8-rank run makes.
 void Comm::barrier(Engine &E) {
-    if (world == 1 && !nccl) return;
+    if (world == 1 && !uses_rccl) return;
     if (grp) { grp->barrier(); return; }
     std::vector<uint64_t> dummy((size_t)world);
     all_gather_u64(E, 0, dummy.data());   // cross-process: the smallest collective doubles as the barrier
 }
 
 void Comm::all_gather_u64(Engine &E, uint64_t v, uint64_t *out) {
-    if (world == 1 && !nccl) { out[0] = v; return; }
+    if (world == 1 && !uses_rccl) { out[0] = v; return; }
     if (grp) {
         grp->val[(size_t)rank] = v;
         grp->barrier();
@@ -126,12 +148,12 @@ void Comm::all_gather_u64(Engine &E, uint64_t v, uint64_t *out) {
 }
 
 void Comm::all_gather_dev(Engine &E, const void *send, void *recv, size_t bytes) {
-    if (world == 1 && !nccl) {
+    if (world == 1 && !uses_rccl) {
         if (bytes) UC_HIP(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, E.stream));
         UC_HIP(hipStreamSynchronize(E.stream));
         return;
     }
-    if (nccl || aborted) {
+    if (uses_rccl) {
         if (grp) grp->barrier();   // a rank that failed earlier must not leave its peers inside the collective
         nccl_enqueue(*this, [&](ncclComm *h) { UC_NCCL(ncclAllGather(send, recv, bytes, ncclUint8, h, E.stream)); });
         UC_HIP(hipStreamSynchronize(E.stream));
@@ -150,8 +172,8 @@ void Comm::all_gather_dev(Engine &E, const void *send, void *recv, size_t bytes)
 }
 
 void Comm::broadcast_dev(Engine &E, void *buf, size_t bytes, int root) {
-    if (world == 1 && !nccl) return;
-    if (nccl || aborted) {
+    if (world == 1 && !uses_rccl) return;
+    if (uses_rccl) {
         if (grp) grp->barrier();
         nccl_enqueue(*this, [&](ncclComm *h) { UC_NCCL(ncclBroadcast(buf, buf, bytes, ncclUint8, root, h, E.stream)); });
         UC_HIP(hipStreamSynchronize(E.stream));
@@ -166,58 +188,65 @@ void Comm::broadcast_dev(Engine &E, void *buf, size_t bytes, int root) {
     grp->barrier();
 }
 
-void Comm::gather_edges(Engine &E, std::vector<uint32_t> &out) {
-    out.clear();
-    E.host_edges();                     // the exchange below works on the host copies
-    if (world == 1 && !nccl) { out = E.edges; return; }
-    if (grp) {   // threads of one process: rank 0 reads its peers' host vectors ("edges are copied D2H per GPU ... the host runs set cover once")
-        grp->ptr[(size_t)rank] = &E.edges;
-        grp->barrier();
-        Timer tg;   // phase 6 = the gather itself; the wait for the slowest rank's gapped stage above belongs to that rank's phase 5
-        if (rank == 0) {
-            size_t tot = 0;
-            for (int r = 0; r < world; r++) tot += ((const std::vector<uint32_t> *)grp->ptr[(size_t)r])->size();
-            out.reserve(tot);
-            for (int r = 0; r < world; r++) {
-                const std::vector<uint32_t> &v = *(const std::vector<uint32_t> *)grp->ptr[(size_t)r];
-                out.insert(out.end(), v.begin(), v.end());
-            }
-        }
-        grp->barrier();
-        E.stats.phase_seconds[6] += tg.seconds();
-        return;
-    }
-    // one process per GPU: sizes, then every rank sends its list to rank 0 (grouped point-to-point over xGMI)
+uint64_t Comm::gather_edges_dev(Engine &E, const uint32_t **dev_out) {
     Timer tg;
-    std::vector<uint64_t> sz((size_t)world);
-    all_gather_u64(E, E.edges.size(), sz.data());
     CommScratch &S = *scratch;
-    const size_t mine = E.edges.size();
-    S.e_send.reserve(std::max<size_t>(mine, 1));
-    if (mine) UC_HIP(hipMemcpyAsync(S.e_send.p, E.edges.data(), mine * 4, hipMemcpyHostToDevice, E.stream));
-    size_t tot = 0;
-    for (uint64_t s : sz) tot += s;
-    if (rank == 0) S.e_recv.reserve(std::max<size_t>(tot, 1));
-    nccl_enqueue(*this, [&](ncclComm *h) {
-        UC_NCCL(ncclGroupStart());
+    if (dev_out) *dev_out = nullptr;
+    // this rank's list as a device array (align() leaves it on the device; a list that only exists on the host is staged once)
+    const uint64_t mine = E.edges_on_host ? E.edges.size() / 2 : E.n_edges_dev;
+    const uint32_t *src = E.d_edges.p;
+    if (E.edges_on_host && mine) {
+        S.e_send.reserve(2 * mine);
+        UC_HIP(hipMemcpyAsync(S.e_send.p, E.edges.data(), 2 * mine * 4, hipMemcpyHostToDevice, E.stream));
+        src = S.e_send.p;
+    }
+    if (world == 1 && !uses_rccl) {
+        UC_HIP(hipStreamSynchronize(E.stream));
+        if (dev_out) *dev_out = src;
+        return mine;
+    }
+    std::vector<uint64_t> sz((size_t)world);
+    all_gather_u64(E, mine, sz.data());
+    uint64_t tot = 0;
+    for (uint64_t c : sz) tot += c;
+    if (rank == 0) S.e_recv.reserve(std::max<uint64_t>(2 * tot, 1));
+    if (uses_rccl) {
+        if (grp) grp->barrier();
+        nccl_enqueue(*this, [&](ncclComm *h) {
+            GroupScope g;
+            if (rank == 0) {
+                uint64_t o = sz[0];
+                for (int r = 1; r < world; r++) {
+                    if (sz[(size_t)r]) UC_NCCL(ncclRecv(S.e_recv.p + 2 * o, 2 * sz[(size_t)r], ncclUint32, r, h, E.stream));
+                    o += sz[(size_t)r];
+                }
+            } else if (mine) {
+                UC_NCCL(ncclSend(src, 2 * mine, ncclUint32, 0, h, E.stream));
+            }
+            g.end();
+        });
+        if (rank == 0 && mine) UC_HIP(hipMemcpyAsync(S.e_recv.p, src, 2 * mine * 4, hipMemcpyDeviceToDevice, E.stream));
+        UC_HIP(hipStreamSynchronize(E.stream));
+        if (grp) grp->barrier();
+    } else {
+        // virtual ranks (several engines on one device): publish the list, rank 0 copies
+        UC_HIP(hipStreamSynchronize(E.stream));
+        grp->ptr[(size_t)rank] = src;
+        grp->barrier();
         if (rank == 0) {
-            size_t o = sz[0];
-            for (int r = 1; r < world; r++) {
-                if (sz[(size_t)r]) UC_NCCL(ncclRecv(S.e_recv.p + o, sz[(size_t)r], ncclUint32, r, h, E.stream));
+            uint64_t o = 0;
+            for (int r = 0; r < world; r++) {
+                if (sz[(size_t)r]) UC_HIP(hipMemcpyAsync(S.e_recv.p + 2 * o, grp->ptr[(size_t)r], 2 * sz[(size_t)r] * 4, hipMemcpyDefault, E.stream));
                 o += sz[(size_t)r];
             }
-        } else if (mine) {
-            UC_NCCL(ncclSend(S.e_send.p, mine, ncclUint32, 0, h, E.stream));
+            UC_HIP(hipStreamSynchronize(E.stream));
         }
-        UC_NCCL(ncclGroupEnd());
-    });
-    if (rank == 0) {
-        out.resize(tot);
-        if (mine) memcpy(out.data(), E.edges.data(), mine * 4);
-        if (tot > mine) UC_HIP(hipMemcpyAsync(out.data() + mine, S.e_recv.p + mine, (tot - mine) * 4, hipMemcpyDeviceToHost, E.stream));
+        grp->barrier();   // the peers' lists may change only now
     }
-    UC_HIP(hipStreamSynchronize(E.stream));
+    if (rank == 0 && dev_out) *dev_out = S.e_recv.p;
+    E.stats.exchange_bytes += rank == 0 ? 8 * (tot - mine) : 0;
     E.stats.phase_seconds[6] += tg.seconds();
+    return tot;
 }
 
 // ---------------------------------------------------------------------------------------------- grid plan
@@ -265,7 +294,7 @@ uint64_t round_limit() {   // records a rank receives per round of exchange 1 (b
 }  // namespace
 
 void Comm::all_gather_u64s(Engine &E, const uint64_t *v, int k, uint64_t *out) {
-    if (world == 1 && !nccl) { memcpy(out, v, (size_t)k * 8); return; }
+    if (world == 1 && !uses_rccl) { memcpy(out, v, (size_t)k * 8); return; }
     if (grp) {
         grp->ptr[(size_t)rank] = v;
         grp->barrier();
@@ -290,24 +319,26 @@ void Comm::all_to_all_dev(Engine &E, int na, const void *const *send, const uint
                           void *const *recv, const uint64_t *recv_off, const uint64_t *recv_cnt) {
     const int me = rank;
     if (send_cnt[me] != recv_cnt[me]) fail(UC_ERR_GENERIC, "all_to_all_dev: inconsistent self segment");
-    if (world == 1 && !nccl) {
+    if (world == 1 && !uses_rccl) {
         for (int k = 0; k < na && send_cnt[0]; k++)
             UC_HIP(hipMemcpyAsync((char *)recv[k] + 4 * recv_off[0], (const char *)send[k] + 4 * send_off[0], 4 * send_cnt[0], hipMemcpyDeviceToDevice, E.stream));
         UC_HIP(hipStreamSynchronize(E.stream));
         return;
     }
-    if (nccl || aborted) {
+    if (uses_rccl) {
         if (grp) grp->barrier();   // a rank that failed earlier must not leave its peers inside the exchange
         nccl_enqueue(*this, [&](ncclComm *h) {
-            UC_NCCL(ncclGroupStart());
+            GroupScope g;
             for (int p = 0; p < world; p++) {
                 if (p == me) continue;
                 for (int k = 0; k < na; k++) {
                     if (send_cnt[p]) UC_NCCL(ncclSend((const char *)send[k] + 4 * send_off[p], send_cnt[p], ncclUint32, p, h, E.stream));
                     if (recv_cnt[p]) UC_NCCL(ncclRecv((char *)recv[k] + 4 * recv_off[p], recv_cnt[p], ncclUint32, p, h, E.stream));
                 }
+                if (p >= world / 2 && inject_failure(me, 2)) fail(UC_ERR_DEVICE, "injected failure of rank %d inside the grouped exchange (UC_FAIL_RANK)", me);
             }
-            UC_NCCL(ncclGroupEnd());
+            if (inject_failure(me, 2)) fail(UC_ERR_DEVICE, "injected failure of rank %d inside the grouped exchange (UC_FAIL_RANK)", me);
+            g.end();
         });
         for (int k = 0; k < na && send_cnt[me]; k++)
             UC_HIP(hipMemcpyAsync((char *)recv[k] + 4 * recv_off[me], (const char *)send[k] + 4 * send_off[me], 4 * send_cnt[me], hipMemcpyDeviceToDevice, E.stream));
@@ -465,14 +496,14 @@ uint64_t cluster_step(Engine &E, Comm &C, int target_shards, uint32_t *assign) {
         E.stats.phase_seconds[0] += tp.seconds();
     }
     uint64_t n_aln = E.n_hits;
-    if (C.world > 1 || C.nccl) n_aln = exchange_hits(E, C);
+    if (C.world > 1 || C.uses_rccl) n_aln = exchange_hits(E, C);
     {
         Turn turn(C, &E);
         Timer ta;
         E.align(0, n);
         E.stats.phase_seconds[5] += ta.seconds();
     }
-    if (C.world == 1 && !C.nccl) {   // one rank: the graph is built straight from the device-resident edge list
+    if (C.world == 1 && !C.uses_rccl) {   // one rank: the graph is built straight from the device-resident edge list
         if (!assign && n) fail(UC_ERR_ARGS, "cluster_step: rank 0 needs an assignment buffer");
         Timer tc;
         const uint64_t ne = E.edges_on_host ? E.edges.size() / 2 : E.n_edges_dev;
@@ -481,15 +512,20 @@ uint64_t cluster_step(Engine &E, Comm &C, int target_shards, uint32_t *assign) {
         E.stats.stage_seconds[UC_ST_SETCOVER] += tc.seconds();
         return n_aln;
     }
-    std::vector<uint32_t> all;
     Timer te;
-    C.gather_edges(E, all);
+    const uint32_t *dev_all = nullptr;
+    const uint64_t n_all = C.gather_edges_dev(E, &dev_all);
     E.stats.exchange_seconds += C.world > 1 ? te.seconds() : 0.0;
     if (C.rank == 0) {
         if (!assign && n) fail(UC_ERR_ARGS, "cluster_step: rank 0 needs an assignment buffer");
         Timer tc;
-        E.set_cover_device(n, all.data(), all.size() / 2, assign);
-        E.stats.algorithmic_bytes[UC_ST_SETCOVER] += 8ull * (all.size() / 2) + 4ull * n;
+        if (n_all < (1ull << 31)) E.set_cover_graph(n, nullptr, dev_all, n_all, assign);     // the graph is built from the buffer the edges landed in
+        else {   // beyond the 32-bit positions of the device graph build: the all-host cover
+            std::vector<uint32_t> all(2 * n_all);
+            UC_HIP(hipMemcpy(all.data(), dev_all, 2 * n_all * 4, hipMemcpyDeviceToHost));
+            set_cover(n, all.data(), n_all, assign);
+        }
+        E.stats.algorithmic_bytes[UC_ST_SETCOVER] += 8ull * n_all + 4ull * n;
         E.stats.stage_seconds[UC_ST_SETCOVER] += tc.seconds();
         E.stats.phase_seconds[7] += tc.seconds();
     }

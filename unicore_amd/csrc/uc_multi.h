@@ -9,6 +9,7 @@
 //               hits share their DP on one rank) -> E5/E6 on its share
 //   rank 0 : accepted edges of all ranks -> host set cover (E7)
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <memory>
@@ -47,17 +48,20 @@ struct CommScratch;   // device staging buffers of the exchange (uc_multi.cpp)
 struct Comm {
     int rank = 0, world = 1;
     LocalGroup *grp = nullptr;       // set when all ranks are threads of this process
-    ncclComm *nccl = nullptr;        // set when the ranks sit on distinct devices (RCCL); null = in-process copies (virtual GPUs of the tests)
+    // set when the ranks sit on distinct devices (RCCL); null = in-process copies (virtual GPUs of the tests).  Atomic: abort() takes the handle
+    // from any thread WITHOUT waiting for an enqueue in flight (an enqueue can block inside ncclGroupEnd on a peer — the very call an abort
+    // has to interrupt; ncclCommAbort is the one RCCL call that may run beside a blocked call on the same communicator)
+    std::atomic<ncclComm *> nccl{nullptr};
     std::unique_ptr<CommScratch> scratch;
-    std::mutex nccl_mu;              // serializes RCCL enqueues of this communicator against abort()
-    bool aborted = false;
+    std::atomic<bool> aborted{false};
+    bool uses_rccl = false;          // the communicator was created over RCCL (stays true after an abort took the handle)
     Comm();
     ~Comm();
     Comm(const Comm &) = delete;
     Comm &operator=(const Comm &) = delete;
 
     // failure path: ncclCommAbort, so that a peer blocked inside a collective of this communicator returns (its next barrier
-    // then throws); the handle is gone afterwards.  Safe to call from any thread, once or more.
+    // then throws); the handle is gone afterwards.  Safe to call from any thread, once or more; never waits for another thread.
     void abort();
     void barrier(Engine &E);
     void all_gather_u64(Engine &E, uint64_t v, uint64_t *out /* world */);
@@ -68,8 +72,10 @@ struct Comm {
     // recv holds world x bytes; send/recv are device buffers of E's device
     void all_gather_dev(Engine &E, const void *send, void *recv, size_t bytes);
     void broadcast_dev(Engine &E, void *buf, size_t bytes, int root);
-    // accepted edges of every rank, concatenated in rank order, on rank 0 (empty elsewhere)
-    void gather_edges(Engine &E, std::vector<uint32_t> &out);
+    // accepted edges of every rank, concatenated in rank order, on rank 0 — device to device: every rank's device-resident edge list goes straight into ONE device buffer of rank 0 (grouped ncclSend / ncclRecv over
+    // xGMI; virtual ranks: device copies) — no D2H on the senders, no host concatenation, no H2D on rank 0, whose graph build reads the buffer where it
+    // lands.  Returns the total number of edges (pairs) over all ranks on EVERY rank; *dev_out (rank 0 only) stays valid until the next gather.
+    uint64_t gather_edges_dev(Engine &E, const uint32_t **dev_out);
 };
 
 // emulation aid (UC_VIRTUAL_SERIAL=1, virtual ranks only): the compute phases of the ranks take turns on the one physical GPU,
@@ -79,7 +85,8 @@ struct Turn {
     Engine *e = nullptr;
     explicit Turn(Comm &C, Engine *E = nullptr) : g(C.grp && C.grp->serialize ? C.grp : nullptr), e(E) { if (g) g->turn.lock(); }
     // eight engines' work buffers do not fit one GPU at BASELINE configs[2] size: a rank gives its scratch back at the end of its turn
-    ~Turn() { if (g) { if (e) e->drop_scratch(); g->turn.unlock(); } }
+    // (a destructor must not throw: a HIP error while handing buffers back is dropped here and surfaces at the rank's next HIP call)
+    ~Turn() { if (g) { if (e) { try { e->drop_scratch(); } catch (...) {} } g->turn.unlock(); } }
     Turn(const Turn &) = delete;
     Turn &operator=(const Turn &) = delete;
 };

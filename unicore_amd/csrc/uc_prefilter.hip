@@ -1210,6 +1210,7 @@ static size_t scratch_trim_limit() {
 // i.e. up to ~100 M target residues per chunk at default sensitivity (at 760 M residues in one chunk 75 % of the
 // hits survived the filter and the key sort took 2/3 of the run).
 void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend) {
+    PressureScope ps(*this, 0);
     if (!have_db) fail(UC_ERR_ARGS, "no database loaded");
     if (tbegin > tend || tend > hdb.n) fail(UC_ERR_ARGS, "prefilter: bad target range");
     if (qend == UINT32_MAX) qend = hdb.n;
@@ -1807,6 +1808,7 @@ void Engine::export_hits_dev(uint32_t *dq, uint32_t *dt, int32_t *ds, int32_t *d
 // STABLE radix sort on ceil(log2 world) bits, so every owner's segment keeps the list order (query, score desc, target asc).
 // dq..dd: caller-owned device arrays of n_hits elements; counts[world] on the host.
 void Engine::partition_hits_by_owner(uint32_t world, uint32_t *dq, uint32_t *dt, int32_t *ds, int32_t *dd, uint64_t *counts) {
+    PressureScope ps(*this, 0);
     for (uint32_t w = 0; w < world; w++) counts[w] = 0;
     if (!n_hits) return;
     if (n_hits >= (1ull << 32)) fail(UC_ERR_GENERIC, "partition_hits_by_owner: %llu records exceed the 32-bit index", (unsigned long long)n_hits);
@@ -1834,6 +1836,7 @@ void Engine::partition_hits_by_owner(uint32_t world, uint32_t *dq, uint32_t *dt,
 
 uint64_t Engine::import_hits_dev(uint64_t n_in, const uint32_t *dq, const uint32_t *dt, const int32_t *ds, const int32_t *dd,
                                  uint32_t rank, uint32_t world) {
+    PressureScope ps(*this, 0);
     if (!have_db) fail(UC_ERR_ARGS, "no database loaded");
     UC_HIP(hipSetDevice(device));
     const uint32_t n = hdb.n;

@@ -17,10 +17,13 @@ struct T5Config {
     float eps = 1e-6f;
     int cnn_hidden = 32, cnn_kernel = 7, n_out = 20;
     int prefix_token = 149, eos_token = 1, unk_token = 2;      // "<AA2fold>", "</s>", "<unk>"
-    // head convention (EXT-UNVERIFIED for Foldseek; default = ProstT5's published predict_3Di script on one sequence): </s> is attended
-    // by the encoder but its final hidden state is masked to zero before the CNN, and U/Z/O/B are read as X.
-    // UC_T5_EOS_IN_HEAD=1 / UC_T5_KEEP_UZOB=1 select the other reading (the r2 behaviour of this library).
-    int eos_in_head = 0, uzob_to_x = 1;
+    // head convention — EXT-UNVERIFIED for Foldseek, so the DEFAULT is the reading this library has produced since its first createdb (ADVICE r3:
+    // do not move every 3Di database on unverified grounds): </s>'s final hidden state feeds the CNN like any other position, and B/O/U/Z are
+    // looked up in the vocabulary like every other letter (the GGUF vocabulary holds them; only letters it lacks fall back to X).
+    // UC_T5_EOS_IN_HEAD=0 / UC_T5_KEEP_UZOB=0 select the other reading — ProstT5's published predict_3Di script run on one sequence: </s> is
+    // attended by the encoder but masked to zero before the CNN, U/Z/O/B are read as X.  Both are tested against the oracle at full depth and
+    // both have committed fixtures; INTEGRATION.md section D names what to diff once a Foldseek binary is at hand.
+    int eos_in_head = 1, uzob_to_x = 0;
 };
 
 struct T5AttnTile { int32_t tok0, len, q0; };                  // sequence start token, its length, first query row of the workgroup (128 rows)
