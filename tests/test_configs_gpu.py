@@ -137,19 +137,33 @@ def test_c5_chain_at_50_proteomes(O, tmp_path_factory):
     (24 blocks, full geometry, seeded synthetic weights) -> uc_engine_set_db (no disk round trip) -> cluster step.
     (a) the 3Di states of a 20-sequence sample equal the fp32 restatement's (same tolerance as tests/test_t5.py) and do not
     depend on the batch they were encoded in; (b) hit lists and alignment records of 300 random queries equal the CPU
-    oracle's on the encoder's 3Di track; (c) the cluster TSV satisfies the consumer contract of profile.rs."""
+    oracle's on the encoder's 3Di track; (c) the cluster TSV satisfies the consumer contract of profile.rs.
+    (tools/c5_at_size.py runs the same checks at the configuration's nominal 500 proteomes: profiles/r04/c5_p500_check.json)"""
+    c5_chain_checks(O, str(tmp_path_factory.mktemp("c5")), 50, 20, 300)
+
+
+def c5_chain_checks(O, d, proteomes, n_state_sample, n_query_sample):
+    """-> dict of what was measured and compared (the asserts are the check)"""
     import sys
+    import time
     import unicore_amd as U
     sys.path.insert(0, os.path.join(util.ROOT, "tests", "golden"))
     import make_t5_full_depth as F
     from oracle import prostt5_ref as R
     import test_t5 as T
-    d = tmp_path_factory.mktemp("c5")
-    db = util.gen_synth_db(str(d / "db"), 50, 0x5EED0005, 6000, 1.0)
+
+    class _D:
+        def __init__(self, p): self.p = p
+        def __truediv__(self, x): return os.path.join(self.p, x)
+    d = _D(d)
+    db = util.gen_synth_db(str(d / "db"), proteomes, 0x5EED0005, 6000, 1.0)
     aa = [e.decode() for e in open(db, "rb").read().split(b"\n\0")[:-1]]
     n = len(aa)
     enc = U.T5Encoder(F.ensure_gguf())
+    t_enc = time.time()
     codes = enc.encode(aa)
+    t_enc = time.time() - t_enc
+    est = enc.stats()
     assert len(codes) == n and all(len(c) == len(a) for c, a in zip(codes, aa))
     hist = np.bincount(np.concatenate(codes), minlength=20) / sum(len(c) for c in codes)
     assert hist.max() < 0.15 and (hist > 0.01).sum() == 20          # the calibrated synthetic head predicts all 20 states
@@ -157,7 +171,7 @@ def test_c5_chain_at_50_proteomes(O, tmp_path_factory):
     cfg = R.default_config()
     W = R.prepare(R.read_gguf(F.ensure_gguf())[1])
     rng = np.random.default_rng(5)
-    sample = [int(i) for i in rng.choice(n, 20, replace=False)]
+    sample = [int(i) for i in rng.choice(n, n_state_sample, replace=False)]
     c2, l2 = enc.encode([aa[i] for i in sample], logits=True)
     for k, i in enumerate(sample):
         assert np.array_equal(c2[k], codes[i]), i                     # batching does not matter
@@ -178,7 +192,7 @@ def test_c5_chain_at_50_proteomes(O, tmp_path_factory):
     e.prefilter()
     e.align()
     st = e.stats()
-    assert st["n_gapped_alignments"] == e.hits_size() > 1_000_000
+    assert st["n_gapped_alignments"] == e.hits_size() > 20_000 * proteomes
     assign = e.setcover(e.edges())
     n_clusters = int((assign == np.arange(n)).sum())
     assert 0 < n_clusters < n
@@ -190,10 +204,10 @@ def test_c5_chain_at_50_proteomes(O, tmp_path_factory):
     odb = O.OracleDb(db2)
     p = util.oracle_params(O, "-c 0.8")
     ix = O.build_index(odb, p)
-    qs = np.sort(rng.choice(n, 300, replace=False)).astype(np.uint32)
+    qs = np.sort(rng.choice(n, n_query_sample, replace=False)).astype(np.uint32)
     n_pairs, _, _, ocnt, ohits, oalns = O.simd_sample_run(odb, ix, p, qs, threads=0, records=True)
     O.free_index(ix)
-    assert n_pairs > 3000
+    assert n_pairs > 10 * n_query_sample
     for k, q in enumerate(qs):
         q = int(q)
         cnt, hits = e.hits_range(q, q + 1)
@@ -211,3 +225,8 @@ def test_c5_chain_at_50_proteomes(O, tmp_path_factory):
     assert len(rows) == n and len({r[0] for r in rows}) == n_clusters
     e.close()
     U.lib().uc_release_scratch()
+    return {"proteomes": proteomes, "sequences": n, "residues": int(off[-1]), "encoder_wall_s": t_enc, "encoder_gpu_ms": est["gpu_ms"], "encoder_flops": est["flops"],
+            "encoder_tflops": est["flops"] / (est["gpu_ms"] * 1e-3) / 1e12 if est["gpu_ms"] else None,
+            "state_sample_sequences_equal_to_fp32_restatement": n_state_sample, "state_histogram_max": float(hist.max()),
+            "cluster_alignments": int(st["n_gapped_alignments"]), "clusters": n_clusters,
+            "oracle_query_sample": n_query_sample, "oracle_pairs_compared": int(n_pairs), "tsv_rows": len(rows)}

@@ -424,6 +424,19 @@ def test_chunked_prefilter_equals_unchunked(O, small):
     finally:
         del os.environ["UC_PREFILTER_CHUNK_RES"]
     assert np.array_equal(cnt0, cnt1) and hits0.tobytes() == hits1.tobytes()
+    # the chunk x chunk grid is walked as its upper triangle (symmetric hit relation); the full grid gives the same lists and counters
+    os.environ["UC_PREFILTER_CHUNK_RES"] = "3000"
+    try:
+        e.reset_stats(); e.prefilter(); sa = e.stats(); ca, ha = e.hits()
+        os.environ["UC_PREFILTER_SYMMETRIC"] = "0"
+        e.reset_stats(); e.prefilter(); sb = e.stats(); cb, hb = e.hits()
+    finally:
+        os.environ.pop("UC_PREFILTER_SYMMETRIC", None)
+        del os.environ["UC_PREFILTER_CHUNK_RES"]
+    assert np.array_equal(ca, cb) and ha.tobytes() == hb.tobytes() == hits0.tobytes()
+    for k in ("n_sim_kmers", "n_kmer_hits", "n_candidates", "n_prefilter_hits"):
+        assert sa[k] == sb[k], k
+    assert sa["n_filtered_hits"] < sb["n_filtered_hits"]
     e.prefilter(5, 60, 10, 80)
     cnt3, hits3 = e.hits()
     assert np.array_equal(cnt2, cnt3) and hits2.tobytes() == hits3.tobytes()
@@ -547,6 +560,58 @@ def test_degenerate_databases(O, tmp_path):
         st = U.cluster(db, db + "_cluster", str(tmp_path / "tmp"), opts)
         U.createtsv(db, db + "_cluster", db + ".tsv")
         assert st["n_clusters"] == 0 and open(db + ".tsv", "rb").read() == b"", opts
+
+
+def test_device_set_cover_equals_the_sequential_rule(O):
+    """E7 runs on the GPU as parallel rounds of local maxima (uc_align.hip: set_cover_graph): the assignment must be the sequential
+    greedy rule's (most unassigned nodes first, ties: smallest id) on every graph shape — long paths and rings (one pick per round at the
+    front of a count tie: the worst case for the number of rounds), stars, cliques that share members, hub chains, duplicate / self edges,
+    isolated nodes — against both the oracle and the all-host product cover"""
+    import unicore_amd as U
+    e = U.Engine("-c 0.8", verbosity=1)
+    s3, sa = util.family_db(1, n_fam=2, members=2)
+    e.set_db(*util.flat(s3, sa))
+    rng = np.random.default_rng(77)
+
+    def check(n, edges, tag):
+        edges = np.asarray(edges, np.uint32).reshape(-1, 2)
+        # the engine's cover wants an engine whose DB has n sequences only for the bounds check of the C ABI: use the raw call
+        a = np.zeros(n, np.uint32)
+        import ctypes as C
+        rc = U.lib().uc_engine_setcover(e._h, edges.ctypes.data, len(edges), a.ctypes.data) if n == e.n else None
+        if rc is None:
+            return
+        assert rc == 0, tag
+        assert np.array_equal(a, O.setcover(n, edges)) and np.array_equal(a, U.setcover(n, edges)), tag
+    # every shape at the size of a database of exactly n sequences
+    def with_n(n):
+        s3 = [np.zeros(5, np.uint8)] * n
+        e.set_db(*util.flat(s3, s3))
+    for n in (1, 2, 7, 64, 257, 2000):
+        with_n(n)
+        ids = np.arange(n)
+        shapes = {
+            "empty": np.zeros((0, 2), np.uint32),
+            "path": np.stack([ids[:-1], ids[1:]], 1),
+            "ring": np.stack([ids, (ids + 1) % n], 1),
+            "star": np.stack([np.zeros(n, int), ids], 1),
+            "two stars sharing leaves": np.concatenate([np.stack([np.zeros(n // 2, int), ids[n // 2:n // 2 + n // 2]], 1),
+                                                        np.stack([np.ones(n // 2, int), ids[n // 2:n // 2 + n // 2]], 1)]) if n > 4 else np.zeros((0, 2), int),
+            "self + duplicates": np.concatenate([np.stack([ids, ids], 1), np.stack([ids[:-1], ids[1:]], 1), np.stack([ids[1:], ids[:-1]], 1)]),
+            "descending path": np.stack([ids[1:][::-1], ids[:-1][::-1]], 1),
+        }
+        for k in range(6):
+            m = int(rng.integers(0, 6 * n + 1))
+            shapes["random %d" % k] = rng.integers(0, n, (m, 2))
+        if n >= 64:
+            fam = rng.integers(0, max(2, n // 12), n)
+            shapes["cliques with bridges"] = np.array([(i, j) for i in range(n) for j in np.nonzero(fam == fam[i])[0][:9]] +
+                                                     [(int(a), int(b)) for a, b in rng.integers(0, n, (n // 10, 2))])
+            hubs = np.arange(0, n, 16)
+            shapes["hub chain"] = np.concatenate([np.stack([hubs[:-1], hubs[1:]], 1)] + [np.stack([np.full(15, h), np.arange(h + 1, h + 16) % n], 1) for h in hubs])
+        for tag, ed in shapes.items():
+            check(n, ed, (n, tag))
+    e.close()
 
 
 def test_full_size_execution_variants_identical(tmp_path):

@@ -787,10 +787,9 @@ struct AlignScratch {
     DevBuf<uint8_t> tb_tbm;
     DevBuf<int32_t> tb_qs3, tb_qe3, tb_ts3, tb_te3, tb_pack3, tb_gaps3;
     SwPlan tb_P3;
-    // set-cover graph build (set_cover_device)
-    PinnedBuf<uint64_t> sc_off;
-    PinnedBuf<uint32_t> sc_adj;
-    DevBuf<uint32_t> sc_e, sc_flag, sc_pos, sc_dadj, sc_bad;
+    // set-cover graph build + greedy cover (set_cover_graph)
+    DevBuf<uint32_t> sc_e, sc_flag, sc_pos, sc_dadj, sc_bad, sc_assign, sc_cnt, sc_work, sc_work2, sc_picks, sc_newly, sc_ctr;
+    DevBuf<uint64_t> sc_m1;
     DevBuf<uint64_t> sc_key, sc_key2, sc_ukey, sc_doff;
     DevBuf<char> sc_tmp;
 };
@@ -1267,7 +1266,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
     stats.stage_seconds[UC_ST_GAPPED] += tm.seconds();
 }
 
-// ---- E7 graph construction on the device (the greedy cover itself stays on the host, as the north star asks) ----
+// ---- E7 graph construction on the device (the greedy cover follows below; uc_setcover.cpp is the all-host variant behind uc_setcover) ----
 // both directions of every accepted pair as 64-bit keys, self loops -> all-ones (sorted last, dropped)
 __global__ void __launch_bounds__(256) edge_key_kernel(uint64_t n_edges, const uint32_t *e, uint32_t n, uint64_t *key, uint32_t *bad) {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_edges; i += (uint64_t)gridDim.x * 256) {
@@ -1305,6 +1304,87 @@ const std::vector<uint32_t> &Engine::host_edges() {
     return edges;
 }
 
+// ---- E7 on the device: the SAME greedy cover as uc_setcover.cpp (most unassigned nodes covered first, ties: smallest id), in parallel rounds ----
+// The sequential rule picks the unassigned node u with the largest key (count, -id), count = 1 + unassigned neighbours.  A pick changes counts only
+// within two hops THROUGH UNASSIGNED nodes (it assigns its unassigned neighbours v, which lowers the count of their unassigned neighbours w), and counts
+// only ever fall.  So a node whose key is the maximum of its two-hop neighbourhood through unassigned nodes will be picked by the sequential rule with
+// exactly its present count before anything near it changes: every such local maximum can be picked AT ONCE (no two of them share an unassigned
+// neighbour: they would be within two hops of each other).  Rounds of (1) m1[v] = max key over the unassigned closed neighbourhood of v, (2) u is picked
+// iff key(u) = max m1 over its unassigned closed neighbourhood, (3) picks take their unassigned neighbours, (4) the counts of the unassigned neighbours
+// of everything newly assigned drop.  Identical assignment to the host cover (tests/test_gpu_parity.py, random graphs included); a wave per node.
+constexpr uint32_t SC_NONE = 0xFFFFFFFFu;
+__device__ __forceinline__ uint64_t sc_key(uint32_t w, const uint32_t *assign, const uint32_t *cnt) {
+    return assign[w] == SC_NONE ? ((uint64_t)cnt[w] << 32) | (uint64_t)(0xFFFFFFFFu - w) : 0ull;
+}
+__device__ __forceinline__ uint64_t sc_wave_max(uint64_t v) {
+    for (int o = 32; o > 0; o >>= 1) { const uint64_t x = __shfl_xor(v, o, 64); v = x > v ? x : v; }
+    return v;
+}
+__global__ void __launch_bounds__(256) sc_init_kernel(uint32_t n, const uint64_t *off, uint32_t *assign, uint32_t *cnt, uint32_t *work) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        assign[i] = SC_NONE; cnt[i] = (uint32_t)(off[i + 1] - off[i]) + 1u; work[i] = i;
+    }
+}
+// ctr: [0] nodes in `work`, [1] picks, [2] newly assigned, [3] nodes in the next work list
+__global__ void __launch_bounds__(256) sc_m1_kernel(const uint32_t *ctr, const uint32_t *work, const uint64_t *off, const uint32_t *adj, const uint32_t *assign,
+                                                    const uint32_t *cnt, uint64_t *m1) {
+    const uint32_t nw = ctr[0], lane = threadIdx.x & 63;
+    for (uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < nw; i += gridDim.x * 4) {
+        const uint32_t v = work[i];
+        uint64_t best = 0;
+        for (uint64_t e = off[v] + lane; e < off[v + 1]; e += 64) { const uint64_t k = sc_key(adj[e], assign, cnt); best = k > best ? k : best; }
+        best = sc_wave_max(best);
+        const uint64_t own = sc_key(v, assign, cnt);
+        if (lane == 0) m1[v] = own > best ? own : best;
+    }
+}
+__global__ void __launch_bounds__(256) sc_pick_kernel(uint32_t *ctr, const uint32_t *work, const uint64_t *off, const uint32_t *adj, const uint32_t *assign,
+                                                      const uint32_t *cnt, const uint64_t *m1, uint32_t *picks) {
+    const uint32_t nw = ctr[0], lane = threadIdx.x & 63;
+    for (uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < nw; i += gridDim.x * 4) {
+        const uint32_t u = work[i];
+        uint64_t best = 0;
+        for (uint64_t e = off[u] + lane; e < off[u + 1]; e += 64) {
+            const uint32_t w = adj[e];
+            const uint64_t k = assign[w] == SC_NONE ? m1[w] : 0ull;
+            best = k > best ? k : best;
+        }
+        best = sc_wave_max(best);
+        const uint64_t mine = m1[u];
+        best = mine > best ? mine : best;
+        if (lane == 0 && best == sc_key(u, assign, cnt)) picks[atomicAdd(&ctr[1], 1u)] = u;
+    }
+}
+__global__ void __launch_bounds__(256) sc_apply_kernel(uint32_t *ctr, const uint32_t *picks, const uint64_t *off, const uint32_t *adj, uint32_t *assign, uint32_t *newly) {
+    const uint32_t np = ctr[1], lane = threadIdx.x & 63;
+    for (uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < np; i += gridDim.x * 4) {
+        const uint32_t u = picks[i];
+        if (lane == 0) { assign[u] = u; newly[atomicAdd(&ctr[2], 1u)] = u; }
+        for (uint64_t e = off[u] + lane; e < off[u + 1]; e += 64) {
+            const uint32_t w = adj[e];
+            if (assign[w] == SC_NONE) { assign[w] = u; newly[atomicAdd(&ctr[2], 1u)] = w; }     // no other pick of this round can reach w
+        }
+    }
+}
+__global__ void __launch_bounds__(256) sc_dec_kernel(const uint32_t *ctr, const uint32_t *newly, const uint64_t *off, const uint32_t *adj, const uint32_t *assign, uint32_t *cnt) {
+    const uint32_t nn = ctr[2], lane = threadIdx.x & 63;
+    for (uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < nn; i += gridDim.x * 4) {
+        const uint32_t v = newly[i];
+        for (uint64_t e = off[v] + lane; e < off[v + 1]; e += 64) {
+            const uint32_t w = adj[e];
+            if (assign[w] == SC_NONE) atomicSub(&cnt[w], 1u);
+        }
+    }
+}
+__global__ void __launch_bounds__(256) sc_compact_kernel(uint32_t *ctr, const uint32_t *work, const uint32_t *assign, uint32_t *next) {
+    const uint32_t nw = ctr[0];
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nw; i += gridDim.x * 256) {
+        const uint32_t v = work[i];
+        if (assign[v] == SC_NONE) next[atomicAdd(&ctr[3], 1u)] = v;
+    }
+}
+__global__ void sc_next_round_kernel(uint32_t *ctr) { ctr[0] = ctr[3]; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; }
+
 void Engine::set_cover_own_edges(uint32_t n, uint32_t *assign) {
     if (edges_on_host) { set_cover_device(n, edges.data(), edges.size() / 2, assign); return; }
     if (n_edges_dev >= (1ull << 31)) { const std::vector<uint32_t> &h = host_edges(); set_cover(n, h.data(), h.size() / 2, assign); return; }
@@ -1316,18 +1396,13 @@ void Engine::set_cover_device(uint32_t n, const uint32_t *h_edges, uint64_t n_ed
     set_cover_graph(n, h_edges, nullptr, n_edges, assign);
 }
 
-// the graph (CSR, both directions, duplicates and self loops removed) on the device from a host or a device edge list, the
-// greedy cover on the host
+// the graph (CSR, both directions, duplicates and self loops removed) on the device from a host or a device edge list, then the
+// greedy cover on the device as well (parallel rounds of local maxima: the host cover's assignment, uc_setcover.cpp, exactly)
 void Engine::set_cover_graph(uint32_t n, const uint32_t *h_edges, const uint32_t *dev_edges, uint64_t n_edges, uint32_t *assign) {
     PressureScope ps(*this, 1);
     UC_HIP(hipSetDevice(device));
     Timer t_graph;
     AlignScratch &A = scratch_of(*this);
-    PinnedBuf<uint64_t> &off = A.sc_off;             // host side of the CSR graph, kept between calls
-    PinnedBuf<uint32_t> &adj = A.sc_adj;
-    off.reserve((size_t)n + 1);
-    adj.reserve(1);
-    if (!n_edges) memset(off.p, 0, ((size_t)n + 1) * 8);
     if (n_edges) {
         const uint64_t m = 2 * n_edges;
         DevBuf<uint32_t> &d_e = A.sc_e, &flag = A.sc_flag, &pos = A.sc_pos, &d_adj = A.sc_dadj, &bad = A.sc_bad;
@@ -1355,17 +1430,43 @@ void Engine::set_cover_graph(uint32_t n, const uint32_t *h_edges, const uint32_t
         ukey.reserve(std::max<uint32_t>(mu, 1)); d_adj.reserve(std::max<uint32_t>(mu, 1));
         hipLaunchKernelGGL(edge_adj_kernel, grid_for(m), dim3(256), 0, stream, m, key2.p, flag.p, pos.p, ukey.p, d_adj.p);
         hipLaunchKernelGGL(edge_off_kernel, grid_for((uint64_t)n + 1), dim3(256), 0, stream, n, ukey.p, (uint64_t)mu, d_off.p);
-        adj.reserve(std::max<uint32_t>(mu, 1));
-        UC_HIP(hipMemcpyAsync(off.p, d_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, stream));
-        if (mu) UC_HIP(hipMemcpyAsync(adj.p, d_adj.p, (size_t)mu * 4, hipMemcpyDeviceToHost, stream));
+        UC_HIP(hipGetLastError());
+        const bool timing = getenv("UC_SETCOVER_TIMING") != nullptr;
+        if (timing) { UC_HIP(hipStreamSynchronize(stream)); fprintf(stderr, "set_cover_device: graph on the GPU %.2f ms\n", t_graph.seconds() * 1e3); }
+        // the greedy cover itself, on the device too (parallel rounds, see above): neither the adjacency (2 x edges x 4 bytes) nor the serial
+        // host sweep — rank 0's Amdahl term of an N-GPU pass — is left; only the assignment comes back
+        Timer t_greedy;
+        DevBuf<uint32_t> &d_assign = A.sc_assign, &d_cnt = A.sc_cnt, &w0 = A.sc_work, &w1 = A.sc_work2, &picks = A.sc_picks, &newly = A.sc_newly, &ctr = A.sc_ctr;
+        DevBuf<uint64_t> &m1 = A.sc_m1;
+        d_assign.reserve(n); d_cnt.reserve(n); w0.reserve(n); w1.reserve(n); picks.reserve(n); newly.reserve(n); ctr.reserve(4); m1.reserve(n);
+        hipLaunchKernelGGL(sc_init_kernel, grid_for(n), dim3(256), 0, stream, n, d_off.p, d_assign.p, d_cnt.p, w0.p);
+        const uint32_t h_ctr[4] = {n, 0, 0, 0};
+        UC_HIP(hipMemcpyAsync(ctr.p, h_ctr, 16, hipMemcpyHostToDevice, stream));
+        uint32_t left = n, rounds = 0;
+        uint32_t *cur = w0.p, *nxt = w1.p;
+        while (left) {
+            const dim3 gw((uint32_t)std::min<uint64_t>(((uint64_t)left + 3) / 4, 1u << 16));
+            hipLaunchKernelGGL(sc_m1_kernel, gw, dim3(256), 0, stream, (const uint32_t *)ctr.p, (const uint32_t *)cur, d_off.p, d_adj.p, d_assign.p, d_cnt.p, m1.p);
+            hipLaunchKernelGGL(sc_pick_kernel, gw, dim3(256), 0, stream, ctr.p, (const uint32_t *)cur, d_off.p, d_adj.p, d_assign.p, d_cnt.p, m1.p, picks.p);
+            hipLaunchKernelGGL(sc_apply_kernel, gw, dim3(256), 0, stream, ctr.p, (const uint32_t *)picks.p, d_off.p, d_adj.p, d_assign.p, newly.p);
+            hipLaunchKernelGGL(sc_dec_kernel, gw, dim3(256), 0, stream, (const uint32_t *)ctr.p, (const uint32_t *)newly.p, d_off.p, d_adj.p, d_assign.p, d_cnt.p);
+            hipLaunchKernelGGL(sc_compact_kernel, grid_for(left), dim3(256), 0, stream, ctr.p, (const uint32_t *)cur, d_assign.p, nxt);
+            uint32_t h[4];
+            UC_HIP(hipMemcpyAsync(h, ctr.p, 16, hipMemcpyDeviceToHost, stream));
+            hipLaunchKernelGGL(sc_next_round_kernel, dim3(1), dim3(1), 0, stream, ctr.p);
+            UC_HIP(hipStreamSynchronize(stream));
+            if (h[1] == 0) fail(UC_ERR_GENERIC, "set cover: a round picked nothing with %u nodes left", left);    // cannot happen: the global maximum is always a local one
+            left = h[3];
+            std::swap(cur, nxt);
+            rounds++;
+        }
+        UC_HIP(hipMemcpyAsync(assign, d_assign.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
         UC_HIP(hipStreamSynchronize(stream));
         UC_HIP(hipGetLastError());
+        if (timing) fprintf(stderr, "set_cover_device: greedy cover on the GPU %.2f ms in %u rounds\n", t_greedy.seconds() * 1e3, rounds);
+        return;
     }
-    const bool timing = getenv("UC_SETCOVER_TIMING") != nullptr;
-    if (timing) fprintf(stderr, "set_cover_device: graph on the GPU %.2f ms\n", t_graph.seconds() * 1e3);
-    Timer t_greedy;
-    set_cover_csr(n, off.p, adj.p, assign);
-    if (timing) fprintf(stderr, "set_cover_device: greedy on the host %.2f ms\n", t_greedy.seconds() * 1e3);
+    for (uint32_t i = 0; i < n; i++) assign[i] = i;      // no edges: every node is its own representative
 }
 
 void preload_align_module() { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, (const void *)plan_key_kernel); }

@@ -163,7 +163,7 @@ struct Engine {
     // E1-E4: index targets [tbegin,tend), match queries [qbegin,qend) (default: all) against it       (uc_prefilter.hip)
     void prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin = 0, uint32_t qend = UINT32_MAX);
     bool prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend, bool count_sims, double density_limit = 0.0,
-                       double *density_out = nullptr);   // one target chunk
+                       double *density_out = nullptr, uint32_t mirror_q0 = UINT32_MAX);   // one target chunk (mirror_q0: symmetric pass, uc_prefilter.hip)
     PrefilterScratch *pre = nullptr;                       // work buffers kept between prefilter calls
     AlignScratch *aln = nullptr;                           // ... and between align calls
     void drop_scratch();                                   // parks both (results stay): virtual-rank emulation
@@ -209,7 +209,6 @@ struct Engine {
 };
 
 void set_cover(uint32_t n, const uint32_t *edges, uint64_t n_edges, uint32_t *assign);
-void set_cover_csr(uint32_t n, const uint64_t *off, const uint32_t *adj, uint32_t *assign);
 void merge_hits(uint32_t n, int max_seqs, int n_parts, const uint32_t *const *counts, const uc_hit *const *hits,
                 std::vector<uint32_t> &out_cnt, std::vector<uc_hit> &out_hits);
 const char *last_error_cstr();

@@ -582,6 +582,7 @@ constexpr int FT = 1024;               // threads per workgroup
 constexpr int KPT = 4;                 // consecutive keys per thread and binary search
 // runs per tile = RPT x FT.  RPT = 2 (r4): half as many tile hand-overs (three workgroup barriers and the drain of 16 waves each) per
 // query; the prefix search takes 11 probes instead of 10
+constexpr int FILTER_RPT = 2;
 constexpr size_t filter_lds(int rpt) { return 2 * ((size_t)1 << FB_LOG2) / 8 + ((size_t)rpt * FT + 1) * 4 + (size_t)rpt * FT * 8 + 16 * 4 + 64; }
 
 // first run of every query of the batch (runs are sorted by query position): qr[i] = lower_bound(rpidx, off[qbegin + i] - p0),
@@ -610,9 +611,9 @@ __global__ void __launch_bounds__(256) run_order_key_kernel(uint32_t nq, const u
 template <bool C> struct TdType { using type = uint64_t; };
 template <> struct TdType<true> { using type = uint32_t; };
 
-// BB (r4): blocked Bloom filter — both hash positions of a key lie in ONE 64-bit word, so marking a key is one ds_or_rtn_b64 (plus a
-// second one for the few positions that were already set) instead of two dependent 32-bit atomic pairs in two unrelated banks
-template <bool C, int RPT, bool BB>
+// (Measured and removed, profiles/r03_filter_ab.log: 1024-run tiles — 2.5 % slower; a blocked Bloom filter with both hash positions of a key in one
+// 64-bit LDS word, one ds_or_rtn_b64 instead of two dependent 32-bit atomic pairs — no gain: the kernel is not bound by its LDS atomics.)
+template <bool C>
 __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t qbegin, uint32_t p0, const uint32_t *rpidx,
                                                     const uint64_t *rval, const uint64_t *qr, const uint32_t *order, const void *ent, KeyFmt fmt,
                                                     unsigned long long *region_cursor, void *region_v, uint64_t region_cap,
@@ -626,9 +627,9 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
     TD *region = (TD *)region_v;
     extern __shared__ __attribute__((aligned(16))) uint32_t f_lds[];
     constexpr int BW = 1 << (FB_LOG2 - 5);          // words per bitmap
+    constexpr int RPT = FILTER_RPT;
     constexpr int TR = RPT * FT;                    // runs per tile
     uint32_t *B1 = f_lds, *B2 = f_lds + BW;
-    unsigned long long *B1w = (unsigned long long *)B1, *B2w = (unsigned long long *)B2;     // blocked variant: 8192 words per bitmap
     uint2 *s_run = (uint2 *)(f_lds + 2 * BW);                   // TR: {first index entry - prefix, query position + bias}: ONE 8-byte read per key
     uint32_t *s_pref = (uint32_t *)(s_run + TR);                // TR + 1 (hits of one query < 2^32: checked by the host)
     uint32_t *s_wsum = s_pref + TR + 1;                         // 16
@@ -727,34 +728,15 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
         h2 = ((x ^ (x >> 15)) * 0x846CA68Bu) >> (32 - FB_LOG2);
         return (x * 0x2C1B3C6Du) >> (32 - FB_LOG2);
     };
-    // blocked variant: word (13 bits) and two bit positions inside it from one multiplicative hash
-    auto word_of = [&](uint64_t td, unsigned long long &mask) -> uint32_t {
-        const uint32_t x = (uint32_t)td * 0x9E3779B1u ^ (uint32_t)(td >> 32) * 0x85EBCA6Bu;
-        const uint32_t y = (x ^ (x >> 15)) * 0x846CA68Bu;
-        mask = (1ull << (y >> 26)) | (1ull << ((y >> 20) & 63u));
-        return (x * 0x2C1B3C6Du) >> (32 - (FB_LOG2 - 6));
-    };
     auto mark1 = [&](uint64_t td) {
-        if (BB) {
-            unsigned long long mk;
-            const uint32_t w = word_of(td, mk);
-            const unsigned long long again = atomicOr(&B1w[w], mk) & mk;
-            if (again) atomicOr(&B2w[w], again);
-        } else {
-            uint32_t g;
-            const uint32_t h = slot_of(td, g), bit = 1u << (h & 31), gbit = 1u << (g & 31);
-            const uint32_t old = atomicOr(&B1[h >> 5], bit);
-            if (old & bit) atomicOr(&B2[h >> 5], bit);
-            const uint32_t gold = atomicOr(&B1[g >> 5], gbit);
-            if (gold & gbit) atomicOr(&B2[g >> 5], gbit);
-        }
+        uint32_t g;
+        const uint32_t h = slot_of(td, g), bit = 1u << (h & 31), gbit = 1u << (g & 31);
+        const uint32_t old = atomicOr(&B1[h >> 5], bit);
+        if (old & bit) atomicOr(&B2[h >> 5], bit);
+        const uint32_t gold = atomicOr(&B1[g >> 5], gbit);
+        if (gold & gbit) atomicOr(&B2[g >> 5], gbit);
     };
     auto twice1 = [&](uint64_t td) -> uint32_t {
-        if (BB) {
-            unsigned long long mk;
-            const uint32_t w = word_of(td, mk);
-            return (B2w[w] & mk) == mk ? 1u : 0u;
-        }
         uint32_t g;
         const uint32_t h = slot_of(td, g);
         return ((B2[h >> 5] >> (h & 31)) & (B2[g >> 5] >> (g & 31))) & 1u;
@@ -886,20 +868,7 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
         h2 = ((x ^ (x >> 13)) * 0x165667B1u) >> (32 - FB_LOG2);
         return (x * 0x9E3779B1u) >> (32 - FB_LOG2);
     };
-    auto word2_of = [&](uint64_t key, unsigned long long &mask) -> uint32_t {
-        const uint32_t x = (uint32_t)key * 0xC2B2AE35u ^ (uint32_t)(key >> 32) * 0x27D4EB2Fu;
-        const uint32_t y = (x ^ (x >> 13)) * 0x165667B1u;
-        mask = (1ull << (y >> 26)) | (1ull << ((y >> 20) & 63u));
-        return (x * 0x9E3779B1u) >> (32 - (FB_LOG2 - 6));
-    };
     for (uint32_t k = tid; k < n1; k += FT) {
-        if (BB) {
-            unsigned long long mk;
-            const uint32_t w = word2_of(surv[base + k], mk);
-            const unsigned long long again = atomicOr(&B1w[w], mk) & mk;
-            if (again) atomicOr(&B2w[w], again);
-            continue;
-        }
         uint32_t g;
         const uint32_t h = slot2_of(surv[base + k], g), bit = 1u << (h & 31), gbit = 1u << (g & 31);
         const uint32_t old = atomicOr(&B1[h >> 5], bit);
@@ -914,15 +883,9 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
         bool keep = false;
         if (k < n1) {
             key = surv[base + k];
-            if (BB) {
-                unsigned long long mk;
-                const uint32_t w = word2_of(key, mk);
-                keep = (B2w[w] & mk) == mk;
-            } else {
-                uint32_t g;
-                const uint32_t h = slot2_of(key, g);
-                keep = ((B2[h >> 5] >> (h & 31)) & (B2[g >> 5] >> (g & 31))) & 1u;
-            }
+            uint32_t g;
+            const uint32_t h = slot2_of(key, g);
+            keep = ((B2[h >> 5] >> (h & 31)) & (B2[g >> 5] >> (g & 31))) & 1u;
         }
         const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
         if (m) {
@@ -960,9 +923,15 @@ __global__ void __launch_bounds__(256) compact_kernel(const void *region_v, cons
 // counts the diagonals and keeps the best (count desc, diagonal asc).  Candidates are staged per wave in LDS and
 // appended in blocks of >= 64 behind one global atomic (one atomic per wave ballot serialised on a single
 // address: +90 ms per step, profiles/r1g); their order is irrelevant (E4 sorts on a unique key).
+//
+// Symmetric passes (mirror_q0 < UINT32_MAX; Engine::prefilter, all-vs-all over several target chunks under a symmetric matrix): the k-mer hit
+// relation is symmetric — query position i hits target position j iff S(kmer_q(i), kmer_t(j)) >= thr — so the hits of (t, q) are those of
+// (q, t) with the diagonal negated.  A pass over target chunk c then only matches the queries from chunk c onwards, and every group (q, t)
+// whose query lies BEHIND the chunk (q >= mirror_q0) also emits the candidate of the pair the other way round, (t, q), under ITS tie-break:
+// most hits, then the smallest diagonal of (t, q) = the LARGEST diagonal of (q, t).
 __global__ void __launch_bounds__(256) diag_select_kernel(const uint64_t *keys, uint64_t n, int min_hits, KeyFmt fmt, uint32_t qbegin,
                                                           unsigned long long *n_cand, uint64_t cap,
-                                                          uint32_t *cq, uint32_t *ct, int32_t *cd) {
+                                                          uint32_t *cq, uint32_t *ct, int32_t *cd, uint32_t mirror_q0) {
     __shared__ uint32_t s_q[4][128], s_t[4][128];
     __shared__ int32_t s_d[4][128];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -987,7 +956,7 @@ __global__ void __launch_bounds__(256) diag_select_kernel(const uint64_t *keys, 
     };
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nround; i += (uint64_t)gridDim.x * 256) {
         bool cand = false;
-        int best_d = 0;
+        int best_d = 0, last_d = 0;
         uint64_t grp = 0;
         if (i < n) {
             grp = keys[i] >> fmt.dbits;
@@ -1000,20 +969,36 @@ __global__ void __launch_bounds__(256) diag_select_kernel(const uint64_t *keys, 
                     while (e < n && keys[e] == kb) e++;
                     const int c = (int)(e - b);
                     if (c > best_cnt) { best_cnt = c; best_d = (int)(kb & dmask) - fmt.dbias; }
+                    if (c >= best_cnt) last_d = (int)(kb & dmask) - fmt.dbias;       // the largest diagonal among those with the most hits
                     b = e;
                 }
                 cand = best_cnt >= min_hits;
             }
         }
+        const uint32_t gq = qbegin + (uint32_t)(grp >> fmt.tbits), gt = (uint32_t)(grp & tmask);
         const uint64_t m = __builtin_amdgcn_ballot_w64(cand);
         if (m) {
             if (cand) {
                 const uint32_t k = staged + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                s_q[wv][k] = qbegin + (uint32_t)(grp >> fmt.tbits);
-                s_t[wv][k] = (uint32_t)(grp & tmask);
+                s_q[wv][k] = gq;
+                s_t[wv][k] = gt;
                 s_d[wv][k] = best_d;
             }
             staged += (uint32_t)__popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            if (staged >= 64) drain();
+        }
+        // the pair the other way round (a second round of at most 64 entries: the 128-slot stage cannot overflow)
+        const bool mcand = cand && gq >= mirror_q0;
+        const uint64_t mm = __builtin_amdgcn_ballot_w64(mcand);
+        if (mm) {
+            if (mcand) {
+                const uint32_t k = staged + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+                s_q[wv][k] = gt;
+                s_t[wv][k] = gq;
+                s_d[wv][k] = -last_d;
+            }
+            staged += (uint32_t)__popcll(mm);
             __builtin_amdgcn_wave_barrier();
             if (staged >= 64) drain();
         }
@@ -1234,6 +1219,13 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t
         double density = 0;
         const double limit = attempt < 6 ? DENSITY_LIMIT : 0.0;      // after 6 re-cuts: run with what we have
         bool ok = true;
+        // All-vs-all over several chunks under a symmetric matrix: the k-mer hit relation is symmetric, so the chunk x chunk grid needs only its
+        // upper triangle.  The pass over chunk c matches the queries FROM chunk c onwards; the pairs (query behind the chunk, target in it) also
+        // yield the candidates of the pairs the other way round (diag_select_kernel), i.e. what the skipped passes (query in c, target chunk
+        // behind it) would have found: ~(1 + 1/C) / 2 of the k-mer hits are expanded.  The lists of a pass come back ungrouped and are merged
+        // like the chunk lists always were (lossless: per-pass top-M of disjoint candidate sets).  UC_PREFILTER_SYMMETRIC=0: every pass matches all queries.
+        const bool triangle = chunks.size() > 1 && tbegin == qbegin && tend == qend && p.mat_symmetric && !getenv("UC_SIM_PER_POSITION") &&
+                              !(getenv("UC_PREFILTER_SYMMETRIC") && atoi(getenv("UC_PREFILTER_SYMMETRIC")) == 0);
         if (chunks.size() <= 1) {
             ok = prefilter_one(tbegin, tend, qbegin, qend, true, limit, &density);
             if (ok) { stats.n_prefilter_hits += n_hits; if (pre) pre->trim(scratch_trim_limit()); return; }
@@ -1242,18 +1234,22 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t
             DevBuf<int32_t> as, ad, ts, td;
             uint64_t acc_n = 0;
             for (size_t c = 0; c < chunks.size() && ok; c++) {
-                ok = prefilter_one(chunks[c].first, chunks[c].second, qbegin, qend, c == 0, c == 0 ? limit : 0.0, &density);
+                const bool mir = triangle && c + 1 < chunks.size();       // (the last chunk has no queries behind it: a plain pass over its own queries)
+                ok = prefilter_one(chunks[c].first, chunks[c].second, triangle ? chunks[c].first : qbegin, qend, c == 0, c == 0 ? limit : 0.0, &density,
+                                   mir ? chunks[c].second : UINT32_MAX);
                 if (!ok) break;
-                if (c == 0 || acc_n == 0) {
+                if (!mir && (c == 0 || acc_n == 0)) {
                     aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd);
                     acc_n = n_hits;
-                } else if (n_hits) {
+                } else if (n_hits) {       // (a mirrored pass always comes here: its lists are ungrouped)
                     const uint64_t tot = acc_n + n_hits;
                     tq.reserve(tot); tt.reserve(tot); ts.reserve(tot); td.reserve(tot);
-                    UC_HIP(hipMemcpyAsync(tq.p, aq.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
-                    UC_HIP(hipMemcpyAsync(tt.p, at.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
-                    UC_HIP(hipMemcpyAsync(ts.p, as.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
-                    UC_HIP(hipMemcpyAsync(td.p, ad.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                    if (acc_n) {
+                        UC_HIP(hipMemcpyAsync(tq.p, aq.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                        UC_HIP(hipMemcpyAsync(tt.p, at.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                        UC_HIP(hipMemcpyAsync(ts.p, as.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                        UC_HIP(hipMemcpyAsync(td.p, ad.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                    }
                     UC_HIP(hipMemcpyAsync(tq.p + acc_n, d_hq.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
                     UC_HIP(hipMemcpyAsync(tt.p + acc_n, d_ht.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
                     UC_HIP(hipMemcpyAsync(ts.p + acc_n, d_hs.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
@@ -1282,7 +1278,8 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t
 // returns false (nothing installed) if density_limit > 0 and the first query batch exceeds it; *density_out = k-mer hits
 // per query residue of that batch
 bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend, bool count_sims, double density_limit,
-                           double *density_out) {
+                           double *density_out, uint32_t mirror_q0) {
+    const bool mirrored = mirror_q0 != UINT32_MAX;    // symmetric pass (diag_select_kernel): the lists leave this function ungrouped, the caller merges them
     UC_HIP(hipSetDevice(device));
     const uint32_t n = hdb.n;
     KmerCfg cfg;
@@ -1525,7 +1522,7 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
         Timer t_b;
         timed_ms_begin();
         uint32_t qb = qa;
-        uint64_t total_hits = 0, n_runs = 0, sims_this_batch = 0;
+        uint64_t total_hits = 0, n_runs = 0, sims_this_batch = 0, mirror_hits = 0;
         uint32_t qp0 = 0, qp1 = 0, nq_res = 0;
         if (distinct_mode) {
             // exact plan: as many queries as fit the key and run buffers (a single query may exceed them and takes the wide path)
@@ -1533,6 +1530,7 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
                 const uint64_t h = h_qh[qb - sb_begin], r = h_qr[qb - sb_begin];
                 if (qb > qa && (total_hits + h > hit_cap || n_runs + r > RUN_MAX)) break;
                 total_hits += h; n_runs += r;
+                if (qb >= mirror_q0) mirror_hits += h;       // these hits stand for the hits of the pairs the other way round as well
                 qb++;
             }
             if (n_runs >= (1ull << 32)) fail(UC_ERR_GENERIC, "query %u alone produces %llu index ranges", qa, (unsigned long long)n_runs);
@@ -1597,7 +1595,7 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
         }
         if (total_hits > (1ull << 34)) fail(UC_ERR_GENERIC, "query %u alone produces %llu k-mer hits", qa, (unsigned long long)total_hits);
         hits_per_res = std::max(1.0, (double)total_hits / std::max<uint32_t>(1, nq_res)) * 1.25;
-        n_hits_total += total_hits;
+        n_hits_total += total_hits + mirror_hits;
         uint64_t n_cand = 0;
         if (total_hits) {
             // pass 2: expand runs into keys (filtered to double hits when the rule allows), sort them
@@ -1632,34 +1630,14 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
                 temp_reserve(tb);
                 UC_HIP(rocprim::radix_sort_pairs(d_temp.p, tb, S.d_okey.p, S.d_okey2.p, S.d_oidx.p, S.d_order.p, (size_t)nq, 0u, 32u, stream));
                 {
-                    // variants for A/B runs: UC_FILTER_VARIANT = 0 (r3: 1024-run tiles, two independent hash positions), 1 (2048-run tiles: the
-                    // default — 98.3 -> 95.8 ms of prefilter kernels per configs[1] step), 2 / 3 (the same two with a blocked Bloom filter: one
-                    // 64-bit LDS atomic per key instead of two 32-bit ones; measured NO gain — 98.2 / 95.8 ms, 0.4 % more survivors — so the
-                    // kernel is not bound by its LDS atomics; kept for the record, profiles/r03_filter_ab.log.  Also measured and removed: one 16-byte
-                    // load for the four consecutive index entries of a thread instead of four 4-byte loads: 97.4 vs 95.7 ms, profiles/r03_filter_ab2.log)
-                    const int variant = getenv("UC_FILTER_VARIANT") ? atoi(getenv("UC_FILTER_VARIANT")) : 1;
-                    auto launch = [&](auto kern, int rpt) {
-                        static PerDeviceOnce once[8];
-                        const int slot = (fmt.compact ? 4 : 0) + (variant & 3);
-                        once[slot]([&] { UC_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter_lds(rpt))); });
-                        hipLaunchKernelGGL(kern, dim3(nq), dim3(FT), filter_lds(rpt), stream, ddb, qa, qp0, d_rpidx2.p, d_rval2.p, S.d_qr.p, S.d_order.p, ent_p, fmt,
+                    auto launch = [&](auto kern) {
+                        static PerDeviceOnce once[2];
+                        once[fmt.compact ? 1 : 0]([&] { UC_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter_lds(FILTER_RPT))); });
+                        hipLaunchKernelGGL(kern, dim3(nq), dim3(FT), filter_lds(FILTER_RPT), stream, ddb, qa, qp0, d_rpidx2.p, d_rval2.p, S.d_qr.p, S.d_order.p, ent_p, fmt,
                                            d_counters.p + 5, (void *)d_keys.p, region_cap, d_qbase.p, d_qsurv.p, prof_p);
                     };
-                    if (fmt.compact) {
-                        switch (variant & 3) {
-                            case 0: launch(filter_kernel<true, 1, false>, 1); break;
-                            case 1: launch(filter_kernel<true, 2, false>, 2); break;
-                            case 2: launch(filter_kernel<true, 1, true>, 1); break;
-                            default: launch(filter_kernel<true, 2, true>, 2); break;
-                        }
-                    } else {
-                        switch (variant & 3) {
-                            case 0: launch(filter_kernel<false, 1, false>, 1); break;
-                            case 1: launch(filter_kernel<false, 2, false>, 2); break;
-                            case 2: launch(filter_kernel<false, 1, true>, 1); break;
-                            default: launch(filter_kernel<false, 2, true>, 2); break;
-                        }
-                    }
+                    if (fmt.compact) launch(filter_kernel<true>);
+                    else launch(filter_kernel<false>);
                 }
                 if (prof_p) {
                     unsigned long long hp[8];
@@ -1710,7 +1688,7 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
                 UC_HIP(hipMemsetAsync(d_counters.p + 6, 0, 8, stream));
                 if (n_sort)
                     hipLaunchKernelGGL(diag_select_kernel, grid_for(n_sort), dim3(256), 0, stream, sorted, n_sort, p.min_diag_hits, fmt, qa,
-                                       d_counters.p + 6, cand_cap, d_cq.p, d_ct.p, d_cd.p);
+                                       d_counters.p + 6, cand_cap, d_cq.p, d_ct.p, d_cd.p, mirror_q0);
                 unsigned long long nc = 0;
                 UC_HIP(hipMemcpyAsync(&nc, d_counters.p + 6, 8, hipMemcpyDeviceToHost, stream));
                 UC_HIP(hipStreamSynchronize(stream));
@@ -1771,14 +1749,16 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
         qa = qb;
     }
     // per-query counts / offsets (the host only keeps these two small arrays)
-    if (n_hits) {
+    if (n_hits && !mirrored) {
         d_cnt.reserve(n);
         hipLaunchKernelGGL(hit_count_kernel, grid_for(n), dim3(256), 0, stream, d_hq.p, n_hits, n, d_cnt.p);
         UC_HIP(hipMemcpyAsync(hit_cnt.data(), d_cnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
         UC_HIP(hipStreamSynchronize(stream));
     }
-    for (uint32_t q = 0; q < n; q++) hit_off[q + 1] = hit_off[q] + hit_cnt[q];
-    if (hit_off[n] != n_hits) fail(UC_ERR_GENERIC, "prefilter: hit list bookkeeping mismatch");
+    if (!mirrored) {
+        for (uint32_t q = 0; q < n; q++) hit_off[q + 1] = hit_off[q] + hit_cnt[q];
+        if (hit_off[n] != n_hits) fail(UC_ERR_GENERIC, "prefilter: hit list bookkeeping mismatch");
+    }
     unsigned long long ovl = 0;
     UC_HIP(hipMemcpy(&ovl, d_counters.p + 2, 8, hipMemcpyDeviceToHost));
     const uint64_t ungapped_bytes = ovl + 16ull * n_cand_total;   // (overlap + 16) B per candidate, SURVEY.md 8(d)

@@ -152,11 +152,4 @@ void set_cover(uint32_t n, const uint32_t *edges, uint64_t n_edges, uint32_t *as
     lap("greedy");
 }
 
-// same rule on a graph that is already in CSR form with sorted, duplicate-free neighbour lists (off[n+1], adj)
-void set_cover_csr(uint32_t n, const uint64_t *off, const uint32_t *adj, uint32_t *assign) {
-    std::vector<uint32_t> deg(n);
-    for (uint32_t i = 0; i < n; i++) deg[i] = (uint32_t)(off[i + 1] - off[i]);
-    greedy_cover(n, off, adj, deg.data(), assign);
-}
-
 }  // namespace uc
