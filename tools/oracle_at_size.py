@@ -76,7 +76,9 @@ def run_chunked(odb, p, threads, chunk, work, log=None):
     edges = np.concatenate(edge_parts) if edge_parts else np.zeros((0, 2), np.uint32)
     assign = O.setcover(n, edges)
     tot["n_clusters"] = int((assign == np.arange(n)).sum())
-    tot["edge_sha256"] = hashlib.sha256(np.ascontiguousarray(edges).tobytes()).hexdigest()
+    # the accepted pairs as a SET: sha256 over the sorted (query << 32 | target) keys (the engine appends its edges in plan order)
+    key = np.sort(edges[:, 0].astype(np.uint64) << np.uint64(32) | edges[:, 1].astype(np.uint64))
+    tot["edge_set_sha256"] = hashlib.sha256(key.tobytes()).hexdigest()
     return assign, tot, (t_pre, t_aln)
 
 
