@@ -12,8 +12,12 @@ also    : `value_disk_to_tsv` — SURVEY.md 8(d)'s definition: wall of uc_cluste
 workload: --config c2 (default) = BASELINE.json configs[1]: 50 synthetic proteomes (~150 k sequences), tools/gen_synth.c
           seed 0x5EED0002, "-c 0.8", the plain all-vs-all step (`--single-step-clustering` semantics);
           --config c3 = configs[2] (500 proteomes, seed 0x5EED0003); --config c4-lite = configs[3]'s options
-          ("-c 0.8 --min-seq-id 0.3 -s 7.5") on 50 proteomes (seed 0x5EED0004); --config c5 = configs[4]: the ProstT5 AA -> 3Di
+          ("-c 0.8 --min-seq-id 0.3 -s 7.5") on 50 proteomes (seed 0x5EED0004); --config c4 = configs[3] at its NOMINAL 2000
+          proteomes through the DEFAULT workflow; --config c5 = configs[4]: the ProstT5 AA -> 3Di
           encoder (MFMA) fused ahead of the cluster path on --proteomes 5 (its own metric line, see bench_c5).
+workflow: --workflow default (implied by c4; any config): one step = one uc_cluster call = what cluster.rs:45-49 triggers — the
+          linear-time pre-step + 3-step cascade — with per-round records from the workflow observer and a CPU baseline that re-does
+          the same rounds on the CPU (see bench_workflow / cpu_baseline_workflow).
 N > 1   : one process per GPU (torch.distributed.run).  The data path is inside the library: the target DB is range-
           partitioned across the ranks (Q x T grid, T = N by default = the north-star layout), the per-shard hit lists go to the
           query's home rank with RCCL over xGMI from C (uc_comm_*: ragged all-to-all), are merged there, the surviving pairs go to
@@ -21,6 +25,9 @@ N > 1   : one process per GPU (torch.distributed.run).  The data path is inside 
           barriers and the max-over-ranks of the timing.  Total work is fixed -> "strong".
 
           `python bench.py --gpus N` with WORLD_SIZE unset re-executes itself under torch.distributed.run with N ranks.
+          N > 1 keeps configs[1] as the headline (the N = 1 point of a scaling run then equals the single-GPU bench) and adds
+          `configs.c3`: ONE warm pass of configs[2] — the configuration BASELINE names for the 8-GPU node — over all N ranks, with
+          per-phase maxima over ranks, rccl_ranks and exchange bytes.
 also (N = 1, default config): `configs` — sub-records measured in the same run: c3 (BASELINE configs[2] = north_star's quoted
           1-GPU target size, 500 proteomes: ONE timed pass after one warm-up pass, with its own roofline block and CPU baseline sample) and c5-mini
           (the ProstT5 encoder's MFMA fraction on one synthetic proteome); `value_one_shot_processes` — what an unmodified

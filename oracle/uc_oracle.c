@@ -308,16 +308,35 @@ size_t uco_similar_kmers(const int8_t S3[UCO_A * UCO_A], const uint8_t c[UCO_K],
 /* ------------------------------------------------------------------ E3: ungapped diagonal score
  * MMseqs2 UngappedAlignment on the 3Di track: Kadane along the whole diagonal,
  * saturating at 255. */
-int32_t uco_ungapped(const uint8_t *q3, int lq, const uint8_t *t3, int lt, int diag, const int8_t S3[UCO_A * UCO_A]) {
+int32_t uco_ungapped_bias(const uint8_t *q3, int lq, const uint8_t *t3, int lt, int diag, const int8_t S3[UCO_A * UCO_A], const int8_t *qbias) {
     int i0 = diag > 0 ? diag : 0;
     int i1 = lq < lt + diag ? lq : lt + diag;
     int run = 0, best = 0;
     for (int i = i0; i < i1; i++) {
-        run += S3[q3[i] * UCO_A + t3[i - diag]];
+        run += S3[q3[i] * UCO_A + t3[i - diag]] + (qbias ? qbias[i] : 0);
         if (run < 0) run = 0;
         if (run > best) best = run;
     }
     return best > 255 ? 255 : best;
+}
+int32_t uco_ungapped(const uint8_t *q3, int lq, const uint8_t *t3, int lt, int diag, const int8_t S3[UCO_A * UCO_A]) {
+    return uco_ungapped_bias(q3, lq, t3, lt, diag, S3, NULL);
+}
+
+/* rule UC-1/B (MMseqs2 SubstitutionMatrix::calcLocalAaBiasCorrection restated on the 3Di track, uniform background): exact integers.
+   bias_i = round_half_away( scale/1000 * ( rowsum_i / 20 - sum_i / wl ) ) = round( scale * (rowsum_i * wl - 20 * sum_i) / (20000 * wl) ) */
+void uco_comp_bias(const uint8_t *q3, int lq, const int8_t S3[UCO_A * UCO_A], int scale_milli, int8_t *out) {
+    for (int i = 0; i < lq; i++) {
+        const int lo = i - 20 > 0 ? i - 20 : 0, hi = i + 20 < lq ? i + 20 : lq, wl = hi - lo;
+        const int8_t *row = S3 + q3[i] * UCO_A;
+        int sum = 0, rowsum = 0;
+        for (int j = lo; j < hi; j++) sum += row[q3[j]];
+        sum -= row[q3[i]];
+        for (int a = 0; a < UCO_KA; a++) rowsum += row[a];
+        const long long num = (long long)scale_milli * ((long long)rowsum * wl - 20LL * sum), den = 20000LL * wl;
+        long long b = num >= 0 ? (num + den / 2) / den : -((-num + den / 2) / den);
+        out[i] = (int8_t)(b > 127 ? 127 : b < -128 ? -128 : b);
+    }
 }
 
 /* ------------------------------------------------------------------ E2+E3+E4 for one query */
@@ -359,6 +378,8 @@ int uco_prefilter_query(const uco_db *db, const uco_index *ix, uint32_t q, const
     if (cnt) cnt->n_kmer_hits += nh;
     if (nh) qsort(hk, nh, sizeof(uint64_t), cmp_u64);   /* (qsort(NULL, 0, ..) is undefined: found by the UBSan job) */
     /* per target: diagonal with most hits (tie: smallest diagonal); double-hit rule */
+    int8_t *qbias = NULL;                                   /* rule UC-1/B (off by default) */
+    if (p->comp_bias_milli && lq > 0) { qbias = (int8_t *)malloc((size_t)lq); uco_comp_bias(q3, lq, p->S3, p->comp_bias_milli, qbias); }
     uco_hit *cand = NULL; size_t nc = 0, ccap = 0;
     size_t a = 0;
     while (a < nh) {
@@ -377,12 +398,13 @@ int uco_prefilter_query(const uco_db *db, const uco_index *ix, uint32_t q, const
             const uint8_t *t3 = db->s3 + db->off[t];
             int lt = (int)(db->off[t + 1] - db->off[t]);
             cand[nc].t = t; cand[nc].diag = best_d;
-            cand[nc].score = uco_ungapped(q3, lq, t3, lt, best_d, p->S3);
+            cand[nc].score = uco_ungapped_bias(q3, lq, t3, lt, best_d, p->S3, qbias);
             nc++;
         }
         a = b;
     }
     free(hk);
+    free(qbias);
     if (cnt) cnt->n_candidates += nc;
     size_t kept = 0;
     for (size_t k = 0; k < nc; k++) if (cand[k].score >= p->min_ungapped) cand[kept++] = cand[k];
@@ -439,6 +461,9 @@ void uco_sw(const uint8_t *q3, const uint8_t *qa, int lq, int rev_q,
     *score = best; *qend = bq; *tend = bt;
 }
 
+int32_t uco_min_score_q(const uco_params *p, uint32_t q, int lq, uint64_t db_residues) {
+    return p->min_score_table ? p->min_score_table[q] : uco_min_score(p, lq, db_residues);
+}
 int32_t uco_min_score(const uco_params *p, int lq, uint64_t db_residues) {
     double scale = p->K * (double)lq * (double)db_residues;
     int32_t s = 1;
@@ -637,7 +662,7 @@ int uco_cluster(const uco_db *db, const uco_params *p, int threads, uint32_t *as
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : c_f, c_r, c_s)
     for (int64_t q = 0; q < (int64_t)n; q++) {
         int lq = (int)(db->off[q + 1] - db->off[q]);
-        int32_t ms = uco_min_score(p, lq, dbres);
+        int32_t ms = uco_min_score_q(p, (uint32_t)q, lq, dbres);
         for (uint32_t k = 0; k < hcnt[q]; k++) {
             uco_aln a;
             uint32_t t = hits[(size_t)q * M + k].t;
@@ -1031,7 +1056,7 @@ uint64_t uco_sample_run(const uco_db *db, const uco_index *ix, const uco_params 
     int32_t *pms = (int32_t *)malloc((pairs + 1) * sizeof(int32_t));
     for (uint32_t k = 0; k < n_queries; k++) {
         const uint32_t q = queries[k];
-        const int32_t ms = uco_min_score(p, (int)(db->off[q + 1] - db->off[q]), dbres);
+        const int32_t ms = uco_min_score_q(p, q, (int)(db->off[q + 1] - db->off[q]), dbres);
         for (uint32_t h = 0; h < hcnt[k]; h++) { pq[poff[k] + h] = q; pt[poff[k] + h] = hits[(size_t)k * M + h].t; pms[poff[k] + h] = ms; }
     }
 #pragma omp parallel for schedule(dynamic, 8) reduction(+ : acc)

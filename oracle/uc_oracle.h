@@ -91,6 +91,15 @@ typedef struct uco_params {
     int cov_mode;
     float min_seq_id;
     int want_tb;                  /* 1: traceback statistics for every accepted pair (search / convertalis) */
+    /* ---- optional rules, default off (walking towards Foldseek once a binary can be diffed: INTEGRATION.md section D) ----
+     * UC-1/B  compositional bias on the ungapped score (restates MMseqs2 SubstitutionMatrix::calcLocalAaBiasCorrection on the 3Di
+     *         track): query position i gets bias_i = round(scale * (rowsum(q_i) / 20 - sum_{j in window(i), j != i} S3[q_i][q_j] / |window|)),
+     *         window = [max(0, i - 20), min(L, i + 20)), uniform background over the 20 letters, scale = comp_bias_milli / 1000, computed
+     *         in exact integer arithmetic (round half away from zero); E3 scores S3[q_i][t_j] + bias_i.  The k-mer stage is untouched.
+     * UC-1/E  per-query gate: min_score_table[q] (one integer per sequence of the database) replaces the Karlin-Altschul threshold on the
+     *         corrected score — the hook for a fitted per-query E-value model (Foldseek predicts mu / lambda per query); plain step only. */
+    int comp_bias_milli;          /* 0 = off */
+    const int32_t *min_score_table;
 } uco_params;
 
 typedef struct uco_db {           /* sequences as codes 0..20, concatenated, no padding */
@@ -140,6 +149,9 @@ void uco_index_free(uco_index *ix);
 size_t uco_similar_kmers(const int8_t S3[UCO_A * UCO_A], const uint8_t c[UCO_K], int thr, uint32_t *out, size_t cap);
 
 int32_t uco_ungapped(const uint8_t *q3, int lq, const uint8_t *t3, int lt, int diag, const int8_t S3[UCO_A * UCO_A]);
+/* rule UC-1/B: per-position bias of a query (out[lq]); uco_ungapped with it added per query position (qbias may be NULL) */
+void uco_comp_bias(const uint8_t *q3, int lq, const int8_t S3[UCO_A * UCO_A], int scale_milli, int8_t *out);
+int32_t uco_ungapped_bias(const uint8_t *q3, int lq, const uint8_t *t3, int lt, int diag, const int8_t S3[UCO_A * UCO_A], const int8_t *qbias);
 
 /* E2+E3+E4 for one query; hits must hold max_seqs; cand (optional, cap ncand_cap) receives the
    pre-selection candidates (t, ungapped score, diag) in (t asc) order */
@@ -152,6 +164,7 @@ void uco_sw(const uint8_t *q3, const uint8_t *qa, int lq, int rev_q,
             const uco_params *p, int32_t *score, int32_t *qend, int32_t *tend);
 
 int32_t uco_min_score(const uco_params *p, int lq, uint64_t db_residues);
+int32_t uco_min_score_q(const uco_params *p, uint32_t q, int lq, uint64_t db_residues);   /* rule UC-1/E: the table entry of q if a table is set */
 void uco_align_pair(const uco_db *db, uint32_t q, uint32_t t, const uco_params *p, int32_t min_score, uco_aln *out);
 
 /* greedy set cover; edges are (a,b) pairs, any direction, duplicates allowed; assign[i] = representative id */

@@ -249,7 +249,7 @@ uint64_t uco_simd_sample_run_counts(const uco_db *db, const uco_index *ix, const
         for (int64_t kk = 0; kk < (int64_t)n_queries; kk++) {
             const uint32_t k = qo[kk].idx, q = queries[k];
             for (uint32_t h = 0; h < hcnt[k]; h++) tg[h] = hits[(size_t)k * M + h].t;
-            const int32_t ms = uco_min_score(p, (int)(db->off[q + 1] - db->off[q]), dbres);
+            const int32_t ms = uco_min_score_q(p, q, (int)(db->off[q + 1] - db->off[q]), dbres);
             uco_simd_align_query(db, q, tg, hcnt[k], p, ms, aln_out ? aln_out + (size_t)k * M : buf);
         }
         free(buf); free(tg);

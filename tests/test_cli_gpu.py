@@ -209,6 +209,17 @@ def test_cluster_step_and_one_rank_rccl_communicator(synth_db):
     st = e.stats()
     assert st["exchange_seconds"] > 0 and st["exchange_bytes"] == 0          # bytes received from PEERS: none with one rank
     assert comm.info()[:2] == (1, 0)
+    # a failure BETWEEN ncclGroupStart and ncclGroupEnd must close the group on its way out (scope guard) — the same communicator
+    # and thread then still work.  UC_FAIL_RANK=<rank>:2 throws inside the grouped exchange.
+    os.environ["UC_FAIL_RANK"] = "0:2"
+    try:
+        with pytest.raises(U.UcError) as ei:
+            e.cluster_step(comm, target_shards=0)
+        assert "inside the grouped exchange" in str(ei.value)
+    finally:
+        del os.environ["UC_FAIL_RANK"]
+    a2, k2 = e.cluster_step(comm, target_shards=0)
+    assert np.array_equal(a2, ref) and k2 == n_ref
     comm.close()
     e.close()
     U.lib().uc_release_scratch()

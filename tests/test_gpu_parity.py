@@ -114,7 +114,9 @@ def test_sw_long_query_fallback(O):
                                   "-c 0.8 --min-diag-hits 1 --k-score 40", "-c 0.7 --min-diag-hits 3 -s 5",
                                   "-c 0.8 --sym-dedup 0", "-c 0.5 -e 1e-6 --sym-dedup 0 --rev-correction 0",
                                   # optional rule UC-1/M (default off): matrices rescaled by MMseqs2-style bit factors, both sides
-                                  "-c 0.8 --mat-bit-factor-3di 2.1 --mat-bit-factor-aa 1.4", "-c 0.5 --mat-bit-factor-3di 2.1 --min-seq-id 0.3 -s 6"])
+                                  "-c 0.8 --mat-bit-factor-3di 2.1 --mat-bit-factor-aa 1.4", "-c 0.5 --mat-bit-factor-3di 2.1 --min-seq-id 0.3 -s 6",
+                                  # optional rule UC-1/B (default off): compositional bias on the ungapped score, both sides
+                                  "-c 0.8 --comp-bias-corr 1", "-c 0.5 --comp-bias-corr 1 --comp-bias-corr-scale 0.5 --min-seq-id 0.3 --max-seqs 8"])
 def test_pipeline_stage_parity(O, small, opts):
     """prefilter hit lists, per-pair alignment records, edges and the set cover all equal the oracle's"""
     import unicore_amd as U
@@ -560,6 +562,46 @@ def test_degenerate_databases(O, tmp_path):
         st = U.cluster(db, db + "_cluster", str(tmp_path / "tmp"), opts)
         U.createtsv(db, db + "_cluster", db + ".tsv")
         assert st["n_clusters"] == 0 and open(db + ".tsv", "rb").read() == b"", opts
+
+
+def test_per_query_threshold_table_rule(O, small, tmp_path):
+    """optional rule UC-1/E (default off): `--min-score-table FILE` — one integer per database sequence replaces the Karlin-Altschul
+    threshold on the corrected score (the hook for a fitted per-query E-value model) — honoured alike by oracle and engine; plain step only"""
+    import ctypes as C
+    import unicore_amd as U
+    n = len(small["s3"])
+    rng = np.random.default_rng(8)
+    base = util.oracle_params(O, "-c 0.5")
+    table = np.array([max(1, O.min_score(small["odb"], base, q) + int(rng.integers(-25, 40))) for q in range(n)], np.int32)
+    path = str(tmp_path / "thr.txt")
+    np.savetxt(path, table, fmt="%d")
+    opts = "-c 0.5 --single-step-clustering --min-score-table " + path
+    e = U.Engine(opts, verbosity=1)
+    e.set_db(small["off"], *util.flat(small["s3"], small["sa"])[1:])
+    e.prefilter(); e.align()
+    p = util.oracle_params(O, "-c 0.5")
+    p.min_score_table = table.ctypes.data
+    ref = O.cluster(small["odb"], p, threads=8)
+    ref0 = O.cluster(small["odb"], base, threads=8)
+    cnt, _ = e.hits()
+    al = e.alns()
+    ra = np.concatenate([ref["aln"][i, : cnt[i]] for i in range(len(cnt))])
+    for f in ("score", "score_rev", "corrected", "pass_evalue", "accepted"):
+        assert np.array_equal(al[f], ra[f]), f
+    assert np.array_equal(U.setcover(e.n, e.edges()), ref["assign"])
+    assert (ref["aln"]["pass_evalue"] != ref0["aln"]["pass_evalue"]).sum() > 0          # the table does change the gate
+    e.close()
+    # wrong length, cascade: errors, not silence
+    np.savetxt(path, table[:-1], fmt="%d")
+    e = U.Engine(opts, verbosity=1)
+    e.set_db(small["off"], *util.flat(small["s3"], small["sa"])[1:])
+    e.prefilter()
+    with pytest.raises(U.UcError):
+        e.align()
+    e.close()
+    assert U.check_options("-c 0.8 --min-score-table " + path) == 0          # syntax only: the workflow check happens when the parameters are finalised
+    with pytest.raises(U.UcError):
+        U.Engine("-c 0.8 --cluster-steps 3 --min-score-table " + path)
 
 
 def test_device_set_cover_equals_the_sequential_rule(O):

@@ -67,7 +67,7 @@ def test_real_rccl_ranks_give_the_one_gpu_tsv(db, workflow, tmp_path):
 
 @needs2
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("stage", [0, 1])
+@pytest.mark.parametrize("stage", [0, 1, 2])      # 2 = INSIDE the grouped point-to-point exchange (abort must not wait for the enqueue)
 def test_a_rank_that_dies_gives_an_error_not_a_hang_real_rccl(db, stage, tmp_path):
     import unicore_amd as U
     with pytest.raises(U.UcError) as ei:

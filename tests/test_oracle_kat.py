@@ -450,3 +450,42 @@ def test_matrix_bit_factor_rule_is_the_same_on_both_sides():
     assert abs(L.uco_matrix_header_lambda(f.name.encode()) - 0.351568) < 1e-9
     assert L.uco_matrix_header_lambda(O.data_path("blosum62.out").encode()) == 0.0
     os.unlink(f.name)
+
+
+def test_compositional_bias_rule_known_answers():
+    """optional rule UC-1/B: bias_i = round_half_away(scale * (rowsum(q_i) / 20 - sum_{j in window, j != i} S[q_i][q_j] / |window|)), window =
+    [max(0, i - 20), min(L, i + 20)) — checked against a direct float64 restatement (ties excluded by construction: exact integer arithmetic in C)
+    and against a hand-computed case; the biased ungapped score adds bias_i per QUERY position"""
+    import ctypes as C
+    L = O.lib()
+    p = O.default_params()
+    S = np.array(p.S3[:], np.int32).reshape(21, 21)
+    rng = np.random.default_rng(3)
+    L.uco_comp_bias.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    L.uco_ungapped_bias.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.uco_ungapped_bias.restype = C.c_int32
+    for n, scale in ((1, 1000), (7, 1000), (45, 500), (130, 1000), (130, 2500)):
+        q = rng.integers(0, 21, n).astype(np.uint8)
+        out = np.zeros(n, np.int8)
+        L.uco_comp_bias(q.ctypes.data, n, C.addressof(p.S3), scale, out.ctypes.data)
+        for i in range(n):
+            lo, hi = max(0, i - 20), min(n, i + 20)
+            sm = int(S[q[i], q[lo:hi]].sum() - S[q[i], q[i]])
+            from fractions import Fraction
+            v = Fraction(scale, 1000) * (Fraction(int(S[q[i], :20].sum()), 20) - Fraction(sm, hi - lo))
+            exp = int(v + Fraction(1, 2)) if v >= 0 else -int(-v + Fraction(1, 2))
+            assert out[i] == max(-128, min(127, exp)), (n, scale, i)
+    # a sequence of one repeated letter: every neighbour scores the diagonal entry -> strongly negative bias (low complexity is penalised)
+    q = np.full(50, 3, np.uint8)
+    out = np.zeros(50, np.int8)
+    L.uco_comp_bias(q.ctypes.data, 50, C.addressof(p.S3), 1000, out.ctypes.data)
+    assert (out < 0).all() and out[25] == round(float(S[3, :20].sum()) / 20 - float(S[3, 3]) * 39 / 40)
+    # ungapped with bias = Kadane over S[q_i][t_j] + bias_i
+    t = rng.integers(0, 20, 60).astype(np.uint8)
+    qq = rng.integers(0, 20, 50).astype(np.uint8)
+    L.uco_comp_bias(qq.ctypes.data, 50, C.addressof(p.S3), 1000, out.ctypes.data)
+    for d in (-7, 0, 5):
+        run = best = 0
+        for i in range(max(d, 0), min(50, 60 + d)):
+            run = max(0, run + int(S[qq[i], t[i - d]]) + int(out[i])); best = max(best, run)
+        assert L.uco_ungapped_bias(qq.ctypes.data, 50, t.ctypes.data, 60, d, C.addressof(p.S3), out.ctypes.data) == min(best, 255)

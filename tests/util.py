@@ -111,9 +111,14 @@ def oracle_params(O, opts=""):
         elif f == "--gap-extend": kw["gap_ext"] = int(v)
         elif f == "--mat-bit-factor-3di": kw["bit_factor_3di"] = float(v)
         elif f == "--mat-bit-factor-aa": kw["bit_factor_aa"] = float(v)
+        elif f == "--comp-bias-corr": kw["_cb"] = int(v)
+        elif f == "--comp-bias-corr-scale": kw["_cbs"] = float(v)
         elif f in ("--sw-kernel", "--sym-dedup"): pass      # engine-side execution choices, no effect on results
         else: raise ValueError(f)
         i += 2
+    cb, cbs = kw.pop("_cb", 0), kw.pop("_cbs", 1.0)
+    if cb:
+        kw["comp_bias_milli"] = int(round(cbs * 1000))       # rule UC-1/B: scale in thousandths
     p = O.default_params(**kw)
     if kscore is None:
         diag = sum(p.S3[a * 21 + a] for a in range(20))

@@ -956,7 +956,10 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
     if (!alns_valid && n_hits) UC_HIP(hipMemsetAsync(d_alns.p, 0, n_hits * sizeof(uc_aln), s));
     // E-value gate as an integer threshold per query length (host; exp() evaluated once per distinct length)
     std::vector<int32_t> ms_by_len(65536, -1), h_ms(qend - qbegin);
+    if (!p.min_score_table.empty() && p.min_score_table.size() != hdb.n)
+        fail(UC_ERR_ARGS, "--min-score-table holds %zu thresholds, the database has %u sequences", p.min_score_table.size(), hdb.n);
     for (uint32_t q = qbegin; q < qend; q++) {
+        if (!p.min_score_table.empty()) { h_ms[q - qbegin] = p.min_score_table[q]; continue; }     // rule UC-1/E (optional): thresholds of a fitted per-query model
         int32_t &m = ms_by_len[h_len[q]];
         if (m < 0) m = min_score_for(p, (int)h_len[q], dbres);
         h_ms[q - qbegin] = m;

@@ -32,6 +32,7 @@ struct DeviceDb {
     const uint32_t *off = nullptr;   // n+1
     const uint32_t *len = nullptr;   // n
     const int8_t *S3 = nullptr, *SA = nullptr;   // 21x21 each
+    const int8_t *bias = nullptr;    // rule UC-1/B (off: null): per-residue compositional bias of the 3Di track, same offsets as s3
 };
 
 // one workgroup of the gapped kernel = one query + a contiguous run of its pairs
@@ -72,6 +73,7 @@ void launch_ungapped(const DeviceDb &db, uint64_t n, const uint32_t *q, const ui
 bool sw_class_for(int lq, int *G, int *R);
 // padded device layout of the sequence tracks from the raw (unpadded) ones: s3 / sa[total] with pad letter 20, lt[total + 16]
 // (16 PAD pairs in front) with the PAD pair in all padding; off = padded offsets (n + 1), roff = raw offsets (n + 1)
+void launch_comp_bias(const DeviceDb &db, int scale_milli, int8_t *out, hipStream_t s);   // rule UC-1/B
 void launch_db_pad(uint32_t n, const uint32_t *off, const uint32_t *len, const uint32_t *cur /* nullable: raw sequence id of sequence i */,
                    const uint64_t *roff, const uint8_t *r3, const uint8_t *ra,
                    uint64_t total, uint8_t *s3, uint8_t *sa, uint16_t *lt, hipStream_t s);

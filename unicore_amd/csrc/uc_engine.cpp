@@ -99,6 +99,15 @@ void Engine::finish_db_install(Timer &tm) {
     ddb.n = n;
     ddb.s3 = d_s3.p; ddb.sa = d_sa.p; ddb.lt = d_lt.p + 16; ddb.off = d_off.p; ddb.len = d_len.p;
     ddb.S3 = d_S3.p; ddb.SA = d_SA.p;
+    ddb.bias = nullptr;
+    if (p.comp_bias && n) {      // rule UC-1/B (optional): per-residue bias of the resident database, computed where the letters are
+        d_bias.reserve((size_t)h_poff[n] + 64);
+        UC_HIP(hipMemsetAsync(d_bias.p, 0, (size_t)h_poff[n] + 64, stream));
+        launch_comp_bias(ddb, p.comp_bias_milli, d_bias.p, stream);
+        UC_HIP(hipStreamSynchronize(stream));
+        UC_HIP(hipGetLastError());
+        ddb.bias = d_bias.p;
+    }
     have_db = true;
     hit_cnt.assign(n, 0);
     hit_off.assign((size_t)n + 1, 0);

@@ -129,6 +129,7 @@ struct Engine {
     bool raw_resident = false;   // an EMPTY database can be resident too (raw_n == 0): the cascade of a bare "-c 0.8" on it must not fail
     DevBuf<uint32_t> d_off, d_len;
     DevBuf<int8_t> d_S3, d_SA;
+    DevBuf<int8_t> d_bias;             // rule UC-1/B only
     DeviceDb ddb;
 
     uint32_t max_len = 1;

@@ -118,7 +118,7 @@ int option_arity(const std::string &f) {
         "--gap-open", "--gap-extend", "--spaced-kmer-pattern", "--rev-correction", "--linclust", "--kmer-per-seq", "--sym-dedup",
         "--sw-kernel", "--evalue-lambda", "--evalue-k", "--mat3di", "--mat-aa", "--cluster-mode", "--cluster-steps",
         "--alignment-type", "--alignment-mode", "--threads", "-v", "--remove-tmp-files", "--db-load-mode", "--compressed",
-        "--gpus", "--target-shards", "--mat-bit-factor-3di", "--mat-bit-factor-aa"};
+        "--gpus", "--target-shards", "--mat-bit-factor-3di", "--mat-bit-factor-aa", "--comp-bias-corr", "--comp-bias-corr-scale", "--min-score-table"};
     for (const char *v : valued) if (f == v) return 1;
     if (f == "--single-step-clustering") return 2;
     return -1;
@@ -161,6 +161,9 @@ void parse_cluster_options(const std::string &opts, Params &p) {
         else if (f == "--mat-aa") { p.mataa_path = value(); }
         else if (f == "--mat-bit-factor-3di") { p.bit_factor_3di = to_double(f, value()); if (p.bit_factor_3di < 0 || p.bit_factor_3di > 16) fail(UC_ERR_ARGS, "--mat-bit-factor-3di must be in [0,16]"); }
         else if (f == "--mat-bit-factor-aa") { p.bit_factor_aa = to_double(f, value()); if (p.bit_factor_aa < 0 || p.bit_factor_aa > 16) fail(UC_ERR_ARGS, "--mat-bit-factor-aa must be in [0,16]"); }
+        else if (f == "--comp-bias-corr") { p.comp_bias = to_int(f, value()) != 0; }
+        else if (f == "--comp-bias-corr-scale") { const double v = to_double(f, value()); if (v < 0 || v > 8) fail(UC_ERR_ARGS, "--comp-bias-corr-scale must be in [0,8]"); p.comp_bias_milli = (int)std::lround(v * 1000.0); }
+        else if (f == "--min-score-table") { p.min_score_table_path = value(); }
         else if (f == "--cluster-mode") { p.cluster_mode = to_int(f, value()); if (p.cluster_mode != 0) fail(UC_ERR_ARGS, "--cluster-mode %d unsupported (only 0 = greedy set cover)", p.cluster_mode); }
         else if (f == "--single-step-clustering") { p.single_step = opt_bool(); p.single_step_given = true; }
         else if (f == "--cluster-steps") { p.cluster_steps = to_int(f, value()); p.cluster_steps_given = true; }
@@ -236,6 +239,21 @@ void finalize_params(Params &p, const std::string &data_dir_in) {
     if (p.cluster_steps < 1 || p.cluster_steps > 16) fail(UC_ERR_ARGS, "--cluster-steps must be in [1,16]");
     p.single_step = p.cluster_steps == 1 && !p.linclust;
     if (p.threads < 1) p.threads = 1;
+    if (!p.min_score_table_path.empty()) {      // rule UC-1/E: per-query thresholds from a fitted model, whitespace-separated integers in database order
+        if (!p.single_step) fail(UC_ERR_ARGS, "--min-score-table is indexed by database sequence: it needs --single-step-clustering (the rounds of the default workflow run on sub-databases)");
+        FILE *f = fopen(p.min_score_table_path.c_str(), "r");
+        if (!f) fail(UC_ERR_IO, "cannot open --min-score-table %s", p.min_score_table_path.c_str());
+        p.min_score_table.clear();
+        long v;
+        int rc;
+        while ((rc = fscanf(f, "%ld", &v)) == 1) {
+            if (v < 1 || v > 30000) { fclose(f); fail(UC_ERR_ARGS, "--min-score-table: threshold %ld out of [1,30000]", v); }
+            p.min_score_table.push_back((int32_t)v);
+        }
+        const bool junk = rc != EOF;
+        fclose(f);
+        if (junk) fail(UC_ERR_ARGS, "--min-score-table %s: not a list of integers", p.min_score_table_path.c_str());
+    }
 }
 
 // sensitivity -> k-mer threshold: mean self score of a k-mer + 3 - 2*s  (data-driven stand-in for Foldseek's

@@ -74,6 +74,35 @@ void launch_db_pad(uint32_t n, const uint32_t *off, const uint32_t *len, const u
     hipLaunchKernelGGL(db_pad_kernel, dim3(blocks), dim3(256), 0, s, n, off, len, cur, roff, r3, ra, total, s3, sa, lt);
 }
 
+// ---- rule UC-1/B (optional, default off): compositional bias per residue of the 3Di track (oracle/uc_oracle.c:uco_comp_bias; exact integers) ----
+__global__ void __launch_bounds__(256) comp_bias_kernel(const DeviceDb db, int scale_milli, int8_t *out) {
+    __shared__ int8_t S[21 * 21 + 3];
+    __shared__ int rowsum[21];
+    for (int i = threadIdx.x; i < 441; i += 256) S[i] = db.S3[i];
+    __syncthreads();
+    if (threadIdx.x < 21) { int r = 0; for (int a = 0; a < 20; a++) r += S[threadIdx.x * 21 + a]; rowsum[threadIdx.x] = r; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (uint32_t s = blockIdx.x * 4 + (threadIdx.x >> 6); s < db.n; s += gridDim.x * 4) {      // a wave per sequence
+        const uint8_t *q3 = db.s3 + db.off[s];
+        const int lq = (int)db.len[s];
+        for (int i = lane; i < lq; i += 64) {
+            const int lo = i - 20 > 0 ? i - 20 : 0, hi = i + 20 < lq ? i + 20 : lq, wl = hi - lo;
+            const int8_t *row = S + q3[i] * 21;
+            int sum = 0;
+            for (int j = lo; j < hi; j++) sum += row[q3[j]];
+            sum -= row[q3[i]];
+            const long long num = (long long)scale_milli * ((long long)rowsum[q3[i]] * wl - 20LL * sum), den = 20000LL * wl;
+            const long long b = num >= 0 ? (num + den / 2) / den : -((-num + den / 2) / den);
+            out[db.off[s] + i] = (int8_t)(b > 127 ? 127 : b < -128 ? -128 : b);
+        }
+    }
+}
+void launch_comp_bias(const DeviceDb &db, int scale_milli, int8_t *out, hipStream_t s) {
+    if (db.n == 0) return;
+    hipLaunchKernelGGL(comp_bias_kernel, dim3(std::min<uint32_t>((db.n + 3) / 4, 16384u)), dim3(256), 0, s, db, scale_milli, out);
+}
+
 // ---- stage E3: ungapped diagonal score (MMseqs2 UngappedAlignment on the 3Di track) ----
 // One lane per candidate (q, t, diag): Kadane along the whole diagonal, saturating at 255.  The 21x21
 // 3Di matrix sits in LDS; candidates arrive sorted by (q, t) so neighbouring lanes share the query.
@@ -93,6 +122,13 @@ __global__ void __launch_bounds__(256) ungapped_kernel(const DeviceDb db, uint64
         int run = 0, best = 0;
         int i = i0;
         // four residues per pair of (possibly unaligned) dword loads; every sequence is followed by >= 16 pad bytes
+        if (db.bias) {      // rule UC-1/B: the query position's compositional bias joins every score of its row (wave-uniform branch)
+            const int8_t *qb = db.bias + db.off[qq];
+            for (; i < i1; i++) {
+                run = max(run + S[q3[i] * 21 + t3[i - d]] + qb[i], 0);
+                best = max(best, run);
+            }
+        }
         for (; i + 4 <= i1; i += 4) {
             uint32_t wq, wt;
             __builtin_memcpy(&wq, q3 + i, 4);
