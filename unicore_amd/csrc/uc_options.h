@@ -43,7 +43,7 @@ struct Params {
     float cov = 0.8f;
     int cov_mode = 0;
     float min_seq_id = 0.0f;
-    // optional rules, default off (spec UC-1/B, UC-1/E in oracle/uc_oracle.h)
+    // optional rules, default off (spec UC-1/B, UC-1/E)
     int comp_bias = 0;                      // --comp-bias-corr 1: compositional bias on the ungapped score
     int comp_bias_milli = 1000;             // --comp-bias-corr-scale F, in thousandths (exact integer arithmetic on both sides)
     std::string min_score_table_path;       // --min-score-table FILE: one integer per sequence replaces the Karlin-Altschul threshold (plain step only)

@@ -74,7 +74,8 @@ void launch_db_pad(uint32_t n, const uint32_t *off, const uint32_t *len, const u
     hipLaunchKernelGGL(db_pad_kernel, dim3(blocks), dim3(256), 0, s, n, off, len, cur, roff, r3, ra, total, s3, sa, lt);
 }
 
-// ---- rule UC-1/B (optional, default off): compositional bias per residue of the 3Di track (oracle/uc_oracle.c:uco_comp_bias; exact integers) ----
+// ---- rule UC-1/B (optional, default off): compositional bias per residue of the 3Di track: bias_i = round_half_away(scale * (rowsum(q_i) / 20 -
+// sum over the +-20 window without i of S3[q_i][q_j] / window length)), uniform background, exact integer arithmetic ----
 __global__ void __launch_bounds__(256) comp_bias_kernel(const DeviceDb db, int scale_milli, int8_t *out) {
     __shared__ int8_t S[21 * 21 + 3];
     __shared__ int rowsum[21];
