@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """tools/property_campaign.py <first_seed> <n_seeds> — the property test of tests/test_gpu_parity.py (random small databases x
 random option strings against the oracle: hit lists, every alignment field, set cover) for seeds beyond the 16 of the suite;
-every third seed also forces the prefilter's super-batch cut (UC_DRUN_MAX) or the per-position path.  Run on the GPU box after
+every third seed also forces the prefilter's super-batch cut (UC_DRUN_MAX) or the per-position path, every fourth tiny index chunks
+(the upper-triangle walk of the chunk grid).  Run on the GPU box after
 kernel changes; the result line goes into DESIGN.md 2."""
 import os, sys, time, traceback
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,6 +19,7 @@ for seed in range(first, first + n):
     env = {}
     if seed % 3 == 1: env = {"UC_DRUN_MAX": str(500 + 37 * (seed % 50))}
     if seed % 3 == 2 and seed % 2 == 0: env = {"UC_SIM_PER_POSITION": "1"}
+    if seed % 4 == 3: env = dict(env, UC_PREFILTER_CHUNK_RES=str(1500 + 113 * (seed % 40)))      # r04: several index chunks -> the symmetric (upper-triangle) walk + the single merge
     os.environ.update(env)
     try:
         fn(O, seed)

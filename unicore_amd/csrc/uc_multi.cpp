@@ -189,7 +189,6 @@ void Comm::broadcast_dev(Engine &E, void *buf, size_t bytes, int root) {
 }
 
 uint64_t Comm::gather_edges_dev(Engine &E, const uint32_t **dev_out) {
-    Timer tg;
     CommScratch &S = *scratch;
     if (dev_out) *dev_out = nullptr;
     // this rank's list as a device array (align() leaves it on the device; a list that only exists on the host is staged once)
@@ -207,6 +206,7 @@ uint64_t Comm::gather_edges_dev(Engine &E, const uint32_t **dev_out) {
     }
     std::vector<uint64_t> sz((size_t)world);
     all_gather_u64(E, mine, sz.data());
+    Timer tg;   // phase 6 = the gather itself: the size exchange above is also where a rank waits for the slowest rank's gapped stage (that rank's phase 5)
     uint64_t tot = 0;
     for (uint64_t c : sz) tot += c;
     if (rank == 0) S.e_recv.reserve(std::max<uint64_t>(2 * tot, 1));
