@@ -1230,47 +1230,43 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t
             ok = prefilter_one(tbegin, tend, qbegin, qend, true, limit, &density);
             if (ok) { stats.n_prefilter_hits += n_hits; if (pre) pre->trim(scratch_trim_limit()); return; }
         } else {
-            // the lists of the passes are concatenated and merged ONCE at the end (per-pass top-M of disjoint candidate sets: the merge of their union
-            // is the global top-M whenever it happens); progressive merging sorted the growing accumulator again after every chunk — 3.5 G records
-            // over the five chunks of configs[2] against 1.5 G for the single merge.  Beyond MERGE_LIMIT records the accumulator is merged early.
-            const uint64_t MERGE_LIMIT = 3ull << 29;      // 1.6 G records: the merge needs ~64 B per record
-            DevBuf<uint32_t> cq, ct;
-            DevBuf<int32_t> cs, cd;
-            uint64_t cat_n = 0;
-            auto merge_cat = [&]() {       // install the merge of the accumulator and take the result back as the new accumulator
-                const uint64_t k = import_hits_dev(cat_n, cq.p, ct.p, cs.p, cd.p, 0, 1);
-                cq.reserve(std::max<uint64_t>(k, 1)); ct.reserve(std::max<uint64_t>(k, 1)); cs.reserve(std::max<uint64_t>(k, 1)); cd.reserve(std::max<uint64_t>(k, 1));
-                if (k) export_hits_dev(cq.p, ct.p, cs.p, cd.p);
-                cat_n = k;
-            };
+            // (Measured and reverted in r04: concatenating the per-pass lists and merging ONCE at the end — 1.5-2 G records in one sort instead of a
+            // running top-M accumulator of <= max_seqs x queries — made configs[2] SLOWER, 35.7 -> 39.3 s per pass: the single merge needs ~64 B per
+            // record of work buffers at the moment the key regions are largest.  The accumulator is merged after every pass.)
+            DevBuf<uint32_t> aq, at, tq, tt;
+            DevBuf<int32_t> as, ad, ts, td;
+            uint64_t acc_n = 0;
+            bool installed = false;       // the last pass's merge leaves its result installed in the engine: no second merge of the accumulator
             for (size_t c = 0; c < chunks.size() && ok; c++) {
                 const bool mir = triangle && c + 1 < chunks.size();       // (the last chunk has no queries behind it: a plain pass over its own queries)
                 ok = prefilter_one(chunks[c].first, chunks[c].second, triangle ? chunks[c].first : qbegin, qend, c == 0, c == 0 ? limit : 0.0, &density,
                                    mir ? chunks[c].second : UINT32_MAX);
                 if (!ok) break;
-                if (n_hits) {
-                    if (cat_n && cat_n + n_hits > MERGE_LIMIT) {
-                        // park this pass's lists while the accumulator is merged (the merge installs its result in the engine's own arrays)
-                        DevBuf<uint32_t> pq, pt; DevBuf<int32_t> ps, pd;
-                        const uint64_t pn = n_hits;
-                        pq.swap(d_hq); pt.swap(d_ht); ps.swap(d_hs); pd.swap(d_hd);
-                        merge_cat();
-                        d_hq.swap(pq); d_ht.swap(pt); d_hs.swap(ps); d_hd.swap(pd);
-                        n_hits = pn;
+                if (!mir && (c == 0 || acc_n == 0)) {
+                    aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd);
+                    acc_n = n_hits;
+                } else if (n_hits) {       // (a mirrored pass always comes here: its lists are ungrouped)
+                    const uint64_t tot = acc_n + n_hits;
+                    tq.reserve(tot); tt.reserve(tot); ts.reserve(tot); td.reserve(tot);
+                    if (acc_n) {
+                        UC_HIP(hipMemcpyAsync(tq.p, aq.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                        UC_HIP(hipMemcpyAsync(tt.p, at.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                        UC_HIP(hipMemcpyAsync(ts.p, as.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
+                        UC_HIP(hipMemcpyAsync(td.p, ad.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
                     }
-                    const uint64_t tot = cat_n + n_hits;
-                    cq.grow_preserve(tot, cat_n, stream); ct.grow_preserve(tot, cat_n, stream); cs.grow_preserve(tot, cat_n, stream); cd.grow_preserve(tot, cat_n, stream);
-                    UC_HIP(hipMemcpyAsync(cq.p + cat_n, d_hq.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-                    UC_HIP(hipMemcpyAsync(ct.p + cat_n, d_ht.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-                    UC_HIP(hipMemcpyAsync(cs.p + cat_n, d_hs.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-                    UC_HIP(hipMemcpyAsync(cd.p + cat_n, d_hd.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipMemcpyAsync(tq.p + acc_n, d_hq.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipMemcpyAsync(tt.p + acc_n, d_ht.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipMemcpyAsync(ts.p + acc_n, d_hs.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+                    UC_HIP(hipMemcpyAsync(td.p + acc_n, d_hd.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
                     UC_HIP(hipStreamSynchronize(stream));
-                    cat_n = tot;
+                    acc_n = import_hits_dev(tot, tq.p, tt.p, ts.p, td.p, 0, 1);      // merge + truncate to max_seqs
+                    if (c + 1 == chunks.size()) installed = true;
+                    else { aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd); }
                 }
             }
             if (ok) {
-                // install the merged lists (also rebuilds the per-query counts)
-                import_hits_dev(cat_n, cq.p, ct.p, cs.p, cd.p, 0, 1);
+                // install the accumulated lists (also rebuilds the per-query counts) unless the last merge already did
+                if (!installed) import_hits_dev(acc_n, aq.p, at.p, as.p, ad.p, 0, 1);
                 stats.n_prefilter_hits += n_hits;
                 if (pre) pre->trim(scratch_trim_limit());
                 return;
