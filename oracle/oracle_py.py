@@ -393,6 +393,17 @@ def simd_run_counts(odb, ix, p, queries, threads=0):
     return int(n), sec[0], sec[1], cnt, hits, alns, {f: int(getattr(pc, f)) for f, _ in Counts._fields_}
 
 
+def simd_align_pairs(odb, p, pairs, threads=0):
+    """E5/E6 records of a (query, target) pair list sorted by query, through the SIMD leg (one query group at a time, groups in parallel)"""
+    pr = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+    out = np.zeros(max(len(pr), 1), ALN_DTYPE)
+    L = lib()
+    L.uco_simd_align_pairs.argtypes = [C.POINTER(Db), C.c_void_p, C.c_uint64, C.POINTER(Params), C.c_int, C.c_void_p]
+    L.uco_simd_align_pairs.restype = None
+    L.uco_simd_align_pairs(C.byref(odb.db), pr.ctypes.data, len(pr), C.byref(p), threads, out.ctypes.data)
+    return out[: len(pr)]
+
+
 def simd_cells():
     """(useful, swept) DP cells of the SIMD gapped stage since the last call (resets the counters)"""
     out = (C.c_uint64 * 2)()

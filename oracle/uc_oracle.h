@@ -233,6 +233,8 @@ uint64_t uco_simd_sample_run(const uco_db *db, const uco_index *ix, const uco_pa
 uint64_t uco_simd_sample_run_counts(const uco_db *db, const uco_index *ix, const uco_params *p, int threads,
                                     const uint32_t *queries, uint32_t n_queries, double seconds[2],
                                     uco_hit *hit_out, uint32_t *cnt_out, uco_aln *aln_out, uco_counts *pc);
+/* E5/E6 of a pair list sorted by query (pre-step pairs), one SIMD query group at a time, groups in parallel; out[np] in list order */
+void uco_simd_align_pairs(const uco_db *db, const uint32_t *pairs, uint64_t np, const uco_params *p, int threads, uco_aln *out);
 /* DP cells since the last call: out[0] = rows x columns of the problems handed to the SIMD kernel (forward, reversed and start
  * passes), out[1] = cells the 16-lane batches swept including lane padding; resets both */
 void uco_simd_cells(uint64_t out[2]);

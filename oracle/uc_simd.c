@@ -261,3 +261,34 @@ uint64_t uco_simd_sample_run_counts(const uco_db *db, const uco_index *ix, const
     if (!cnt_out) free(hcnt);
     return pairs;
 }
+
+/* E5/E6 of a (query, target) pair list sorted by query (the pre-step's (centre, member) pairs): one uco_simd_align_query per query group, groups in
+ * parallel.  out[np] receives the records in list order.  tools/oracle_at_size.py --workflow uses it for the linear-time pre-step at full size. */
+void uco_simd_align_pairs(const uco_db *db, const uint32_t *pairs, uint64_t np, const uco_params *p, int threads, uco_aln *out) {
+    if (!np) return;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+    uint64_t ng = 0;
+    uint64_t *gb = (uint64_t *)malloc((np + 1) * sizeof(uint64_t));
+    for (uint64_t k = 0; k < np; k++) if (k == 0 || pairs[2 * k] != pairs[2 * (k - 1)]) gb[ng++] = k;
+    gb[ng] = np;
+    const uint64_t dbres = db->off[db->n];
+#pragma omp parallel
+    {
+        uint32_t *tg = NULL; size_t cap = 0;
+#pragma omp for schedule(dynamic, 8)
+        for (int64_t g = 0; g < (int64_t)ng; g++) {
+            const uint64_t b = gb[g], e = gb[g + 1];
+            const uint32_t q = pairs[2 * b];
+            if (e - b > cap) { cap = (size_t)(e - b) * 2; tg = (uint32_t *)realloc(tg, cap * sizeof(uint32_t)); }
+            for (uint64_t k = b; k < e; k++) tg[k - b] = pairs[2 * k + 1];
+            const int32_t ms = uco_min_score(p, (int)(db->off[q + 1] - db->off[q]), dbres);
+            uco_simd_align_query(db, q, tg, (uint32_t)(e - b), p, ms, out + b);
+        }
+        free(tg);
+    }
+    free(gb);
+}

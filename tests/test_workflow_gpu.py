@@ -176,6 +176,19 @@ def test_default_workflow_at_size(name, O, tmp_path_factory):
     rows = util.tsv_invariants(out + ".tsv", names)
     assert len(rows) == n and len({r[0] for r in rows}) == st["n_clusters"]
     del rows, names
+    # the WHOLE clust.tsv, the round sizes and the summed stage counters against the CPU oracle's workflow run end to end at this size in the build
+    # container (tools/oracle_at_size.py --workflow -> tests/golden/<name>_workflow_sha.json), where that run exists
+    gold = os.path.join(util.ROOT, "tests", "golden", "%s_workflow_sha.json" % name)
+    if os.path.exists(gold):
+        import hashlib
+        import json
+        g = json.load(open(gold))
+        data = open(out + ".tsv", "rb").read()
+        assert g["sequences"] == n and g["round_sizes"] == sizes
+        assert len(data) == g["tsv_bytes"] and hashlib.sha256(data).hexdigest() == g["tsv_sha256"], "workflow clust.tsv differs from the CPU oracle's at full size"
+        for a, b in (("n_sim_kmers", "n_sim_kmers"), ("n_kmer_hits", "n_kmer_hits"), ("n_candidates", "n_candidates"), ("n_gapped_alignments", "n_alignments"),
+                     ("cells_fwd", "cells_fwd"), ("cells_rev", "cells_rev"), ("cells_start", "cells_start"), ("n_clusters", "n_clusters")):
+            assert st[a] == g["counts"][b], (a, st[a], g["counts"][b])
     odb = O.OracleDb(db)
     assert odb.n == n
     compared = check_rounds(O, odb, cfg["opts"], recs, target_s=cfg["s"])

@@ -82,6 +82,49 @@ def run_chunked(odb, p, threads, chunk, work, log=None):
     return assign, tot, (t_pre, t_aln)
 
 
+def run_workflow(odb, p, target_s, steps, m, threads, chunk, work, log=None):
+    """the DEFAULT workflow (uco_cluster_workflow: linear-time pre-step + `steps` cascade rounds on the representatives, sensitivity 1 -> target_s)
+    with the gapped stages through the SIMD leg and the cascade rounds chunked / checkpointed -> (assign, counts summed over the rounds, round sizes)"""
+    n = odb.n
+    thr = O.cascade_thresholds(p, target_s, steps)
+    cur = np.arange(n, dtype=np.int64)
+    assign = np.arange(n, dtype=np.int64)
+    total = dict(n_sim_kmers=0, n_kmer_hits=0, n_candidates=0, n_prefilter_hits=0, n_alignments=0, n_edges=0, cells_fwd=0, cells_rev=0, cells_start=0)
+    sizes = []
+    for r in range(steps + 1):
+        sizes.append(int(len(cur)))
+        sub = odb if len(cur) == n else odb.subset(cur)
+        if r == 0:                                   # E8a: (centre, member) pairs, every pair through E5/E6, set cover
+            pairs = O.linclust_pairs(sub, p, m)
+            al = O.simd_align_pairs(sub, p, pairs, threads=threads)
+            off = sub.offsets().astype(np.int64); lens = off[1:] - off[:-1]
+            lq, lt = lens[pairs[:, 0]], lens[pairs[:, 1]]
+            ms = np.array([O.lib().uco_min_score(p, int(l), int(off[-1])) for l in np.unique(lq)], np.int64)
+            msq = ms[np.searchsorted(np.unique(lq), lq)]
+            c = dict(n_prefilter_hits=len(pairs), n_alignments=len(pairs), n_edges=int((al["accepted"] == 1).sum()),
+                     cells_fwd=int((lq * lt).sum()), cells_rev=int((lq * lt * (al["score"] >= msq)).sum()) if p.rev_correction else 0,
+                     cells_start=int(((al["qend"].astype(np.int64) + 1) * (al["tend"].astype(np.int64) + 1) * (al["pass_evalue"] == 1)).sum()))
+            sa_ = O.setcover(sub.n, pairs[al["accepted"] == 1]).astype(np.int64)
+            if log: log("pre-step: %d sequences, %d pairs, %d accepted" % (sub.n, len(pairs), c["n_edges"]))
+        else:
+            keep = p.kmer_thr
+            p.kmer_thr = thr[r - 1]
+            w = os.path.join(work, "round%d" % r) if work else None
+            if w: os.makedirs(w, exist_ok=True)
+            sa_, c, _ = run_chunked(sub, p, threads, chunk, w, log)
+            p.kmer_thr = keep
+            sa_ = sa_.astype(np.int64)
+            if log: log("round %d: %d sequences, k-score %d, %d alignments, %d accepted" % (r, sub.n, thr[r - 1], c["n_alignments"], c["n_edges"]))
+        for k in total:
+            total[k] += int(c.get(k, 0))
+        posmap = np.zeros(n, np.int64); posmap[cur] = np.arange(len(cur))
+        assign = cur[sa_[posmap[assign]]]              # mergeclusters: the representative of a sequence is the representative of its representative
+        cur = cur[sa_ == np.arange(len(cur))]
+        del sub
+    total["n_clusters"] = int(len(cur))
+    return assign.astype(np.uint32), total, sizes
+
+
 def selfcheck():
     """the chunked driver == uco_cluster (assignment and all counters) on a family database"""
     s3, sa = util.family_db(11, n_fam=40, members=6, extra=(700, 900))
@@ -92,6 +135,18 @@ def selfcheck():
     assert np.array_equal(assign, ref["assign"])
     for k, v in ref["counts"].items():
         assert int(v) == tot[k], (k, int(v), tot[k])
+    # ... and the workflow driver == uco_cluster_workflow on a synthetic proteome set
+    import tempfile
+    d = tempfile.mkdtemp(prefix="uc_oas_")
+    db = util.gen_synth_db(os.path.join(d, "db"), 6, 0x5EED0004, 40, 0.6)
+    odb = O.OracleDb(db)
+    for opts, s_ in (("-c 0.8", 4.0), ("-c 0.8 --min-seq-id 0.3 -s 7.5", 7.5)):
+        p = util.oracle_params(O, opts)
+        ref = O.cluster_workflow(odb, p, O.cascade_thresholds(p, s_, 3), linclust_m=20, threads=4)
+        assign, tot, sizes = run_workflow(odb, p, s_, 3, 20, 4, 50, None)
+        assert np.array_equal(assign, ref["assign"]) and sizes == [int(x) for x in ref["round_sizes"]]
+        for k in ("n_alignments", "n_edges", "n_clusters", "n_prefilter_hits", "cells_fwd", "cells_rev", "cells_start", "n_kmer_hits", "n_candidates", "n_sim_kmers"):
+            assert int(ref["counts"][k]) == tot[k], (opts, k, int(ref["counts"][k]), tot[k])
     return True
 
 
@@ -103,6 +158,7 @@ def main():
     ap.add_argument("--work", default=None)
     ap.add_argument("--out", default=None)
     ap.add_argument("--selfcheck", action="store_true")
+    ap.add_argument("--workflow", action="store_true", help="the DEFAULT workflow (pre-step + 3-step cascade) instead of the plain step -> <config>_workflow_sha.json")
     a = ap.parse_args()
     if a.selfcheck:
         print("selfcheck", selfcheck()); return
@@ -117,15 +173,21 @@ def main():
     odb = O.OracleDb(db)
     p = util.oracle_params(O, opts)
     log("%d sequences, %d residues, options %r, %d threads" % (odb.n, int(odb.offsets()[-1]), opts, a.threads))
-    assign, tot, (tp, ta) = run_chunked(odb, p, a.threads, a.chunk, work, log)
-    tsv = os.path.join(work, "clust.tsv")
+    sizes = None
+    if a.workflow:
+        assign, tot, sizes = run_workflow(odb, p, 4.0, 3, 20, a.threads, a.chunk, os.path.join(work, "workflow"), log)
+        tp = ta = 0.0
+    else:
+        assign, tot, (tp, ta) = run_chunked(odb, p, a.threads, a.chunk, work, log)
+    tsv = os.path.join(work, "clust_workflow.tsv" if a.workflow else "clust.tsv")
     O.write_tsv(tsv, odb, assign)
     data = open(tsv, "rb").read()
-    res = {"config": a.config, "proteomes": prot, "seed": hex(seed), "options": opts + " --single-step-clustering",
+    res = {"config": a.config, "proteomes": prot, "seed": hex(seed), "options": opts + ("" if a.workflow else " --single-step-clustering"),
+           "workflow": "default (pre-step + 3-step cascade)" if a.workflow else "plain step", "round_sizes": sizes,
            "sequences": int(odb.n), "residues": int(odb.offsets()[-1]),
            "tsv_sha256": hashlib.sha256(data).hexdigest(), "tsv_bytes": len(data), "counts": tot,
            "made_by": "tools/oracle_at_size.py (build container, %d threads; prefilter %.0f s + gapped %.0f s of this process, checkpointed chunks not included)" % (a.threads, tp, ta)}
-    out = a.out or os.path.join(ROOT, "tests", "golden", "%s_sha.json" % a.config)
+    out = a.out or os.path.join(ROOT, "tests", "golden", "%s%s_sha.json" % (a.config, "_workflow" if a.workflow else ""))
     json.dump(res, open(out, "w"), indent=1)
     log("wrote " + out)
     print(json.dumps(res))
