@@ -919,8 +919,8 @@ __global__ void __launch_bounds__(256) compact_kernel(const void *region_v, cons
     }
 }
 
-// one pass over the sorted hit keys: the first key of every (query,target) group walks its group, run-length-
-// counts the diagonals and keeps the best (count desc, diagonal asc).  Candidates are staged per wave in LDS and
+// one pass over the sorted hit keys: per (query,target) group the diagonals are run-length-counted and the best one
+// (count desc, diagonal asc) is kept.  Candidates are staged per wave in LDS and
 // appended in blocks of >= 64 behind one global atomic (one atomic per wave ballot serialised on a single
 // address: +90 ms per step, profiles/r1g); their order is irrelevant (E4 sorts on a unique key).
 //
@@ -929,11 +929,18 @@ __global__ void __launch_bounds__(256) compact_kernel(const void *region_v, cons
 // (q, t) with the diagonal negated.  A pass over target chunk c then only matches the queries from chunk c onwards, and every group (q, t)
 // whose query lies BEHIND the chunk (q >= mirror_q0) also emits the candidate of the pair the other way round, (t, q), under ITS tie-break:
 // most hits, then the smallest diagonal of (t, q) = the LARGEST diagonal of (q, t).
+// Long groups: a sequence against itself (and close homologs) gives groups of hundreds to thousands of keys with one run — diagonal 0 — as long as
+// the sequence; a lane walking such a group or run key by key (dependent loads) was the kernel's whole duration (~2.5 ms per launch at configs[1]
+// whatever the other 99 % of the keys cost).  A group that covers the whole NEXT window is therefore only flagged here (wflag[window] = lane + 1)
+// and evaluated by diag_long_kernel, a wave per long group; every serial walk left in this kernel is bounded by 64 keys.
 __global__ void __launch_bounds__(256) diag_select_kernel(const uint64_t *keys, uint64_t n, int min_hits, KeyFmt fmt, uint32_t qbegin,
                                                           unsigned long long *n_cand, uint64_t cap,
-                                                          uint32_t *cq, uint32_t *ct, int32_t *cd, uint32_t mirror_q0) {
-    __shared__ uint32_t s_q[4][128], s_t[4][128];
-    __shared__ int32_t s_d[4][128];
+                                                          uint32_t *cq, uint32_t *ct, int32_t *cd, uint32_t mirror_q0, uint8_t *wflag) {
+    // candidates are staged per wave and appended behind ONE global cursor in blocks of >= 64 (a 512-entry stage was measured SLOWER, 16 vs 11 ms:
+    // the appends are not what bounds the kernel — the serial walks of the long groups were, see below)
+    constexpr int DS_SLOTS = 128, DS_DRAIN = 64;
+    __shared__ uint32_t s_q[4][DS_SLOTS], s_t[4][DS_SLOTS];
+    __shared__ int32_t s_d[4][DS_SLOTS];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint64_t dmask = (1ull << fmt.dbits) - 1, tmask = (1ull << fmt.tbits) - 1;
     const uint64_t nround = (n + 255) / 256 * 256;   // whole waves stay in the loop (ballot below)
@@ -954,26 +961,84 @@ __global__ void __launch_bounds__(256) diag_select_kernel(const uint64_t *keys, 
         staged = 0;
         __builtin_amdgcn_wave_barrier();
     };
+    // A wave looks at 64 consecutive keys at a time (one coalesced load; r04 — until then the first key of every group walked its group alone with
+    // dependent loads while the other lanes of the wave idled: 9.4 ms for 0.22 G keys at configs[1], ~0.2 TB/s).  Run starts (key differs from its
+    // predecessor) and group starts come from two ballots; a run's length is the distance to the next run start; the group's first lane folds the
+    // (length, diagonal) pairs of its runs out of LDS.  Only the ONE run and the ONE group that reach past the wave's 64 keys are finished serially.
+    __shared__ uint64_t s_v1[4][64], s_v2[4][64];
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nround; i += (uint64_t)gridDim.x * 256) {
-        bool cand = false;
+        bool cand = false, deferred = false;
         int best_d = 0, last_d = 0;
         uint64_t grp = 0;
-        if (i < n) {
-            grp = keys[i] >> fmt.dbits;
-            if (i == 0 || (keys[i - 1] >> fmt.dbits) != grp) {
-                int best_cnt = 0;
-                uint64_t b = i;
-                while (b < n && (keys[b] >> fmt.dbits) == grp) {
-                    const uint64_t kb = keys[b];
-                    uint64_t e = b + 1;
-                    while (e < n && keys[e] == kb) e++;
-                    const int c = (int)(e - b);
-                    if (c > best_cnt) { best_cnt = c; best_d = (int)(kb & dmask) - fmt.dbias; }
-                    if (c >= best_cnt) last_d = (int)(kb & dmask) - fmt.dbias;       // the largest diagonal among those with the most hits
-                    b = e;
-                }
-                cand = best_cnt >= min_hits;
+        const uint64_t wbase = i - (uint64_t)lane;                    // first key of this wave's window
+        const bool valid = i < n;
+        const uint64_t k = valid ? keys[i] : ~0ull;
+        uint64_t kp = (uint64_t)__shfl_up((unsigned long long)k, 1, 64);
+        if (lane == 0) kp = (valid && i > 0) ? keys[i - 1] : ~k;
+        const bool run_start = valid && kp != k;
+        const bool grp_start = valid && (i == 0 || (kp >> fmt.dbits) != (k >> fmt.dbits));
+        const uint64_t starts = __builtin_amdgcn_ballot_w64(run_start), gstarts = __builtin_amdgcn_ballot_w64(grp_start);
+        const uint64_t above = lane == 63 ? 0ull : (~0ull << (lane + 1));
+        const uint64_t wend = wbase + 64 < n ? wbase + 64 : n;        // first key behind the window (or the end of the list)
+        // the window's last group — the only one that can reach behind it — is LONG if it covers the whole next window: decided first (one load by its
+        // first lane), so that the window's last run, which belongs to that group, is not walked for nothing
+        if (grp_start && !(gstarts & above) && wend < n) {
+            const uint64_t far = wend + 63 < n ? wend + 63 : n - 1;
+            deferred = (keys[far] >> fmt.dbits) == (k >> fmt.dbits);
+        }
+        const bool long_tail = __builtin_amdgcn_ballot_w64(deferred) != 0;
+        uint64_t v1 = 0, v2 = 0;
+        if (run_start) {
+            const uint64_t nx = starts & above;
+            uint64_t cnt;
+            if (nx) cnt = (uint64_t)(__builtin_ctzll(nx) - lane);
+            else {                                                     // the window's last run: it may go on behind the window, for < 64 keys
+                uint64_t e = wend;                                     // (otherwise its group is long and nothing here is used)
+                const uint64_t lim = wend + 64 < n ? wend + 64 : n;
+                if (!long_tail) while (e < lim && keys[e] == k) e++;
+                cnt = e - i;
             }
+            const uint64_t d = k & dmask;                              // diagonal + bias
+            v1 = (cnt << 32) | (0xFFFFFFFFull - d);                    // max: most hits, then the SMALLEST diagonal
+            v2 = (cnt << 32) | d;                                      // max: most hits, then the LARGEST diagonal (the pair the other way round)
+        }
+        s_v1[wv][lane] = v1; s_v2[wv][lane] = v2;
+        __builtin_amdgcn_wave_barrier();
+        if (grp_start) {
+            grp = k >> fmt.dbits;
+            const uint64_t ng = gstarts & above;
+            const int gend = ng ? __builtin_ctzll(ng) : 64;            // this group's lanes inside the window: [lane, gend)
+            uint64_t b1 = 0, b2 = 0;
+            uint64_t runs = starts & (~0ull << lane) & (gend == 64 ? ~0ull : ((1ull << gend) - 1ull));
+            while (runs) {
+                const int r = __builtin_ctzll(runs);
+                runs &= runs - 1;
+                const uint64_t a = s_v1[wv][r], c2 = s_v2[wv][r];
+                b1 = a > b1 ? a : b1; b2 = c2 > b2 ? c2 : b2;
+            }
+            if (gend == 64 && wend < n && !deferred) {                 // the group ends inside the next window: the rest of it, run by run
+                uint64_t e = wend;
+                // skip what is left of the window's last run (already counted by its own lane), then walk the following runs of the group
+                const uint64_t kw = keys[wend - 1];
+                while (e < n && keys[e] == kw) e++;
+                while (e < n && (keys[e] >> fmt.dbits) == grp) {
+                    const uint64_t kb = keys[e];
+                    uint64_t f = e + 1;
+                    while (f < n && keys[f] == kb) f++;
+                    const uint64_t cnt = f - e, d = kb & dmask;
+                    const uint64_t a = (cnt << 32) | (0xFFFFFFFFull - d), c2 = (cnt << 32) | d;
+                    b1 = a > b1 ? a : b1; b2 = c2 > b2 ? c2 : b2;
+                    e = f;
+                }
+            }
+            cand = !deferred && (int)(b1 >> 32) >= min_hits;
+            best_d = (int)(0xFFFFFFFFull - (b1 & 0xFFFFFFFFull)) - fmt.dbias;
+            last_d = (int)(b2 & 0xFFFFFFFFull) - fmt.dbias;
+        }
+        __builtin_amdgcn_wave_barrier();                               // the LDS rows are rewritten in the next round
+        {   // at most one group of a window can be long (it reaches the window's end): one flag byte per window
+            const uint64_t dm = __builtin_amdgcn_ballot_w64(deferred);
+            if (lane == 0 && wbase < n) wflag[wbase >> 6] = dm ? (uint8_t)(__builtin_ctzll(dm) + 1) : (uint8_t)0;
         }
         const uint32_t gq = qbegin + (uint32_t)(grp >> fmt.tbits), gt = (uint32_t)(grp & tmask);
         const uint64_t m = __builtin_amdgcn_ballot_w64(cand);
@@ -986,9 +1051,9 @@ __global__ void __launch_bounds__(256) diag_select_kernel(const uint64_t *keys, 
             }
             staged += (uint32_t)__popcll(m);
             __builtin_amdgcn_wave_barrier();
-            if (staged >= 64) drain();
+            if (staged >= DS_DRAIN) drain();
         }
-        // the pair the other way round (a second round of at most 64 entries: the 128-slot stage cannot overflow)
+        // the pair the other way round (a second round of at most 64 entries: a stage that was below DS_DRAIN cannot overflow)
         const bool mcand = cand && gq >= mirror_q0;
         const uint64_t mm = __builtin_amdgcn_ballot_w64(mcand);
         if (mm) {
@@ -1000,7 +1065,112 @@ __global__ void __launch_bounds__(256) diag_select_kernel(const uint64_t *keys, 
             }
             staged += (uint32_t)__popcll(mm);
             __builtin_amdgcn_wave_barrier();
-            if (staged >= 64) drain();
+            if (staged >= DS_DRAIN) drain();
+        }
+    }
+    if (staged) drain();
+}
+
+// the long groups flagged by diag_select_kernel: a wave per group scans it 64 keys at a time; a run that reaches the end of a window is carried
+// (key, length so far) into the next one, so nothing is walked key by key.  Same result rule, same staging of the candidates.
+__global__ void __launch_bounds__(256) diag_long_kernel(const uint64_t *keys, uint64_t n, int min_hits, KeyFmt fmt, uint32_t qbegin,
+                                                        unsigned long long *n_cand, uint64_t cap,
+                                                        uint32_t *cq, uint32_t *ct, int32_t *cd, uint32_t mirror_q0, const uint8_t *wflag) {
+    __shared__ uint32_t s_q[4][128], s_t[4][128];
+    __shared__ int32_t s_d[4][128];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t dmask = (1ull << fmt.dbits) - 1, tmask = (1ull << fmt.tbits) - 1;
+    const uint64_t nwin = (n + 63) >> 6;
+    uint32_t staged = 0;
+    auto drain = [&]() {
+        uint32_t blo = 0, bhi = 0;
+        if (lane == 0) {
+            const unsigned long long b = atomicAdd(n_cand, (unsigned long long)staged);
+            blo = (uint32_t)b; bhi = (uint32_t)(b >> 32);
+        }
+        blo = (uint32_t)__shfl((int)blo, 0, 64);
+        bhi = (uint32_t)__shfl((int)bhi, 0, 64);
+        const uint64_t base = ((uint64_t)bhi << 32) | blo;
+        for (uint32_t k = lane; k < staged; k += 64) {
+            const uint64_t w = base + k;
+            if (w < cap) { cq[w] = s_q[wv][k]; ct[w] = s_t[wv][k]; cd[w] = s_d[wv][k]; }
+        }
+        staged = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto wmax = [&](uint64_t v) -> uint64_t {
+        for (int o = 32; o > 0; o >>= 1) { const uint64_t x = (uint64_t)__shfl_xor((unsigned long long)v, o, 64); v = x > v ? x : v; }
+        return v;
+    };
+    const uint64_t nw64 = (nwin + 63) >> 6;                            // a wave looks at the flags of 64 windows at a time
+    for (uint64_t wb = (uint64_t)blockIdx.x * 4 + wv; wb < nw64; wb += (uint64_t)gridDim.x * 4) {
+        const uint64_t w = wb * 64 + lane;
+        const uint32_t fl = w < nwin ? wflag[w] : 0u;
+        uint64_t pending = __builtin_amdgcn_ballot_w64(fl != 0);
+        while (pending) {                                              // wave-uniform loop over the flagged windows
+            const int src = __builtin_ctzll(pending);
+            pending &= pending - 1;
+            const uint32_t f = (uint32_t)__shfl((int)fl, src, 64);
+            const uint64_t i0 = ((wb * 64 + (uint64_t)src) << 6) + (f - 1);      // first key of the long group
+            const uint64_t grp = keys[i0] >> fmt.dbits;
+            uint64_t b1 = 0, b2 = 0, carry_key = 0, carry_cnt = 0;
+            bool carry = false;
+            for (uint64_t pos = i0;; pos += 64) {
+                const uint64_t idx = pos + lane;
+                const uint64_t k = idx < n ? keys[idx] : ~0ull;
+                const bool in = idx < n && (k >> fmt.dbits) == grp;
+                const uint64_t inmask = __builtin_amdgcn_ballot_w64(in);
+                const int nin = inmask == ~0ull ? 64 : __builtin_ctzll(~inmask);          // the group's keys are contiguous: leading lanes
+                if (nin == 0) break;
+                uint64_t kp = (uint64_t)__shfl_up((unsigned long long)k, 1, 64);
+                if (lane == 0) kp = carry ? carry_key : ~k;
+                const bool rs = lane < nin && kp != k;
+                const uint64_t starts = __builtin_amdgcn_ballot_w64(rs);
+                const int lead = starts ? __builtin_ctzll(starts) : nin;                  // keys that continue the carried run
+                if (carry) {
+                    carry_cnt += (uint64_t)lead;
+                    if (lead < nin || nin < 64) {                                          // the carried run ends in this window
+                        const uint64_t d = carry_key & dmask, a = (carry_cnt << 32) | (0xFFFFFFFFull - d), c2 = (carry_cnt << 32) | d;
+                        b1 = a > b1 ? a : b1; b2 = c2 > b2 ? c2 : b2;
+                        carry = false;
+                    }
+                }
+                const uint64_t above = lane == 63 ? 0ull : (~0ull << (lane + 1));
+                uint64_t v1 = 0, v2 = 0;
+                bool open = false;                                                         // this lane's run reaches the window's end inside the group
+                if (rs) {
+                    const uint64_t nx = starts & above;
+                    const int end = nx ? __builtin_ctzll(nx) : nin;
+                    const uint64_t cnt = (uint64_t)(end - lane), d = k & dmask;
+                    open = !nx && nin == 64;
+                    if (!open) { v1 = (cnt << 32) | (0xFFFFFFFFull - d); v2 = (cnt << 32) | d; }
+                }
+                v1 = wmax(v1); v2 = wmax(v2);
+                b1 = v1 > b1 ? v1 : b1; b2 = v2 > b2 ? v2 : b2;
+                const uint64_t om = __builtin_amdgcn_ballot_w64(open);
+                if (om) {                                                                  // the new carried run (at most one)
+                    const int ol = __builtin_ctzll(om);
+                    carry_key = (uint64_t)__shfl((unsigned long long)k, ol, 64);
+                    carry_cnt = (uint64_t)(64 - ol);
+                    carry = true;
+                }
+                if (nin < 64) break;
+            }
+            if (carry) {                                                                   // the group ended exactly at a window boundary
+                const uint64_t d = carry_key & dmask, a = (carry_cnt << 32) | (0xFFFFFFFFull - d), c2 = (carry_cnt << 32) | d;
+                b1 = a > b1 ? a : b1; b2 = c2 > b2 ? c2 : b2;
+            }
+            if ((int)(b1 >> 32) >= min_hits) {                                             // wave-uniform
+                const uint32_t gq = qbegin + (uint32_t)(grp >> fmt.tbits), gt = (uint32_t)(grp & tmask);
+                const bool mir = gq >= mirror_q0;
+                if (lane == 0) {
+                    s_q[wv][staged] = gq; s_t[wv][staged] = gt; s_d[wv][staged] = (int)(0xFFFFFFFFull - (b1 & 0xFFFFFFFFull)) - fmt.dbias;
+                    if (mir) { s_q[wv][staged + 1] = gt; s_t[wv][staged + 1] = gq; s_d[wv][staged + 1] = -((int)(b2 & 0xFFFFFFFFull) - fmt.dbias); }
+                }
+                staged += mir ? 2u : 1u;
+                __builtin_amdgcn_wave_barrier();
+                if (staged >= 64) drain();
+            }
         }
     }
     if (staged) drain();
@@ -1122,7 +1292,7 @@ struct PrefilterScratch {
     DevBuf<uint64_t> d_keys, d_keys2, d_pos, d_skey, d_skey2, d_rval, d_rval2, d_qbase, d_soff, d_qr;
     DevBuf<int32_t> d_cd, d_cd2, d_score;
     // distinct-k-mer enumeration (E2)
-    DevBuf<uint8_t> d_kflag;
+    DevBuf<uint8_t> d_kflag, d_wflag;
     DevBuf<uint32_t> d_qk, d_kid, d_dk, d_nsimk, d_drk, d_drk2, d_roff, d_nr, d_src, d_ph;
     DevBuf<uint64_t> d_drv, d_drv2, d_cumh, d_cumr, d_qh, d_qrn;
     DevBuf<RankRec> d_rec;
@@ -1131,7 +1301,7 @@ struct PrefilterScratch {
     template <class F> void each(F f) {
         f(d_counters); f(d_prof); f(d_temp); f(d_koff); f(k_in); f(k_out); f(d_ent32); f(v_in32); f(d_okey); f(d_okey2); f(d_oidx); f(d_order);
         f(d_ent); f(v_in); f(d_cnt); f(d_flag); f(d_cq); f(d_ct); f(d_rpidx); f(d_rpidx2); f(d_qsurv); f(d_keys); f(d_keys2); f(d_pos); f(d_skey);
-        f(d_skey2); f(d_rval); f(d_rval2); f(d_qbase); f(d_soff); f(d_qr); f(d_cd); f(d_cd2); f(d_score); f(d_kflag); f(d_qk); f(d_kid); f(d_dk);
+        f(d_skey2); f(d_rval); f(d_rval2); f(d_qbase); f(d_soff); f(d_qr); f(d_cd); f(d_cd2); f(d_score); f(d_kflag); f(d_wflag); f(d_qk); f(d_kid); f(d_dk);
         f(d_nsimk); f(d_drk); f(d_drk2); f(d_roff); f(d_nr); f(d_src); f(d_ph); f(d_drv); f(d_drv2); f(d_cumh); f(d_cumr); f(d_qh); f(d_qrn); f(d_rec); f(d_kbits);
     }
     size_t bytes() {
@@ -1691,9 +1861,13 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
             for (;;) {
                 d_cq.reserve(cand_cap); d_ct.reserve(cand_cap); d_cd.reserve(cand_cap);
                 UC_HIP(hipMemsetAsync(d_counters.p + 6, 0, 8, stream));
-                if (n_sort)
+                if (n_sort) {
+                    S.d_wflag.reserve((n_sort + 63) / 64 + 64);
                     hipLaunchKernelGGL(diag_select_kernel, grid_for(n_sort), dim3(256), 0, stream, sorted, n_sort, p.min_diag_hits, fmt, qa,
-                                       d_counters.p + 6, cand_cap, d_cq.p, d_ct.p, d_cd.p, mirror_q0);
+                                       d_counters.p + 6, cand_cap, d_cq.p, d_ct.p, d_cd.p, mirror_q0, S.d_wflag.p);
+                    hipLaunchKernelGGL(diag_long_kernel, grid_for((n_sort + 63) / 64), dim3(256), 0, stream, sorted, n_sort, p.min_diag_hits, fmt, qa,
+                                       d_counters.p + 6, cand_cap, d_cq.p, d_ct.p, d_cd.p, mirror_q0, (const uint8_t *)S.d_wflag.p);
+                }
                 unsigned long long nc = 0;
                 UC_HIP(hipMemcpyAsync(&nc, d_counters.p + 6, 8, hipMemcpyDeviceToHost, stream));
                 UC_HIP(hipStreamSynchronize(stream));
