@@ -19,9 +19,11 @@ import numpy as np
 import util
 from oracle import oracle_py as O
 
-CONFIGS = {  # == bench.py CONFIGS / tests/test_configs_gpu.py
-    "c2": (50, 6000, 1.0, 0x5EED0002, "-c 0.8"),
-    "c3": (500, 6000, 1.0, 0x5EED0003, "-c 0.8"),
+CONFIGS = {  # == bench.py CONFIGS / tests/test_configs_gpu.py / tests/test_workflow_gpu.py (name: proteomes, families, scale, seed, options, target sensitivity)
+    "c2": (50, 6000, 1.0, 0x5EED0002, "-c 0.8", 4.0),
+    "c3": (500, 6000, 1.0, 0x5EED0003, "-c 0.8", 4.0),
+    "c4-200": (200, 6000, 1.0, 0x5EED0004, "-c 0.8 --min-seq-id 0.3 -s 7.5", 7.5),
+    "c4-500": (500, 6000, 1.0, 0x5EED0004, "-c 0.8 --min-seq-id 0.3 -s 7.5", 7.5),
 }
 
 
@@ -162,7 +164,7 @@ def main():
     a = ap.parse_args()
     if a.selfcheck:
         print("selfcheck", selfcheck()); return
-    prot, fam, scale, seed, opts = CONFIGS[a.config]
+    prot, fam, scale, seed, opts, target_s = CONFIGS[a.config]
     work = a.work or "/tmp/uc_oracle_%s" % a.config
     os.makedirs(work, exist_ok=True)
     t0 = time.perf_counter()
@@ -175,7 +177,7 @@ def main():
     log("%d sequences, %d residues, options %r, %d threads" % (odb.n, int(odb.offsets()[-1]), opts, a.threads))
     sizes = None
     if a.workflow:
-        assign, tot, sizes = run_workflow(odb, p, 4.0, 3, 20, a.threads, a.chunk, os.path.join(work, "workflow"), log)
+        assign, tot, sizes = run_workflow(odb, p, target_s, 3, 20, a.threads, a.chunk, os.path.join(work, "workflow"), log)
         tp = ta = 0.0
     else:
         assign, tot, (tp, ta) = run_chunked(odb, p, a.threads, a.chunk, work, log)
