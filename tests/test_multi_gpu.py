@@ -90,6 +90,23 @@ def test_a_rank_that_dies_gives_an_error_not_a_hang_virtual_ranks(db, stage, tmp
         assert ei.value.code == U.UC_ERR_DEVICE and "GPU rank 1" in str(ei.value) and "injected" in str(ei.value)
 
 
+@pytest.mark.parametrize("opts", ["-c 0.8 --single-step-clustering", "-c 0.8 --single-step-clustering --min-seq-id 0.3 -s 6", "-c 0.8"])
+def test_symmetric_rank_layout_equals_the_full_grid(db, opts, tmp_path):
+    """T = N under a symmetric matrix (r04): a rank matches its target shard against its own sequences and the queries of the next N/2 shards only,
+    the pairs the other way round are mirrored and travel with exchange 1 — same clust.tsv, same alignments, and the SAME algorithmic counters as
+    the full shard x all-queries grid (UC_PREFILTER_SYMMETRIC=0) and as one GPU, for even and odd N, with the shards cut into index chunks too"""
+    ref, st1 = _run(db, str(tmp_path / "g1"), opts, 1)
+    for n in (2, 3, 4, 5, 8):
+        for extra in ({}, {"UC_PREFILTER_CHUNK_RES": "9000"}):
+            got, st = _run(db, str(tmp_path / ("s%d" % n)), opts, n, env=dict(extra, UC_VIRTUAL_GPUS="1"))
+            full, stf = _run(db, str(tmp_path / ("f%d" % n)), opts, n, env=dict(extra, UC_VIRTUAL_GPUS="1", UC_PREFILTER_SYMMETRIC="0"))
+            assert got == ref and full == ref, (n, extra)
+            for k in ("n_gapped_alignments", "n_clusters", "n_kmer_hits", "n_candidates"):
+                assert st[k] == st1[k] == stf[k], (n, extra, k, st[k], st1[k], stf[k])
+            if "single-step" in opts and not extra:
+                assert st["n_filtered_hits"] < stf["n_filtered_hits"], n        # fewer keys expanded and sorted
+
+
 def test_phase_times_and_serialized_virtual_ranks(db, tmp_path):
     """the per-phase clock of the sharded pass (uc_stats.phase_seconds) and the emulation mode behind tools/critical_path.py:
     with UC_VIRTUAL_SERIAL=1 the compute phases of the virtual ranks take turns on the GPU; results are unchanged"""

@@ -565,11 +565,10 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
                     if (r == 0)
                         logf(3, "unicore-cluster: pre-step: %u sequences, %zu candidate pairs (%d k-mers per sequence)\n", m, pre_pairs.size() / 2, p.kmer_per_seq);
                 } else {
-                    const GridCell g = grid_cell(E.h_len, W, p.target_shards, r);
                     {
                         Turn turn(C, &E);
                         Timer tp;
-                        E.prefilter(g.tb, g.te, g.qb, g.qe);
+                        prefilter_cell(E, W, p.target_shards, r);
                         E.stats.phase_seconds[0] += tp.seconds();
                     }
                     if (fail_rank == r && fail_stage == 1) fail(UC_ERR_DEVICE, "injected failure of rank %d (UC_FAIL_RANK)", r);

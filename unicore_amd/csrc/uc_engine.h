@@ -163,6 +163,11 @@ struct Engine {
     void finish_db_install(struct Timer &tm);
     // E1-E4: index targets [tbegin,tend), match queries [qbegin,qend) (default: all) against it       (uc_prefilter.hip)
     void prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin = 0, uint32_t qend = UINT32_MAX);
+    // the same for a rank's share of a symmetric multi-rank pass (uc_multi.cpp:prefilter_cell): target shard [tbegin,tend) against its own sequences
+    // and against the queries of `others` (disjoint from the shard), every pair of the latter also mirrored (the candidate of the pair the other
+    // way round, diag_select_kernel); installs the merged lists of all queries touched
+    void prefilter_cells(uint32_t tbegin, uint32_t tend, const std::vector<std::pair<uint32_t, uint32_t>> &others);
+    void prefilter_impl(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend, bool mirror_all);
     bool prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend, bool count_sims, double density_limit = 0.0,
                        double *density_out = nullptr, uint32_t mirror_q0 = UINT32_MAX);   // one target chunk (mirror_q0: symmetric pass, uc_prefilter.hip)
     PrefilterScratch *pre = nullptr;                       // work buffers kept between prefilter calls

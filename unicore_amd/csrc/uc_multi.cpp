@@ -284,6 +284,22 @@ GridCell grid_cell(const std::vector<uint32_t> &len, int world, int target_shard
     return {tr[(size_t)(rank % T)].first, tr[(size_t)(rank % T)].second, qr[(size_t)(rank / T)].first, qr[(size_t)(rank / T)].second};
 }
 
+void prefilter_cell(Engine &E, int world, int target_shards, int rank) {
+    int Q, T;
+    grid_shape(world, target_shards, &Q, &T);
+    const GridCell g = grid_cell(E.h_len, world, target_shards, rank);
+    const char *off = getenv("UC_PREFILTER_SYMMETRIC");
+    const bool sym = T == world && world > 1 && E.p.mat_symmetric && !(off && atoi(off) == 0) && !getenv("UC_SIM_PER_POSITION");
+    if (!sym) { E.prefilter(g.tb, g.te, g.qb, g.qe); return; }
+    const auto shards = shard_ranges(E.h_len, world);
+    std::vector<std::pair<uint32_t, uint32_t>> others;
+    for (int d = 1; d <= world / 2; d++) {
+        if (2 * d == world && rank >= world / 2) continue;      // the block at distance N/2 is reachable from both sides: the lower rank takes it
+        others.push_back(shards[(size_t)((rank + d) % world)]);
+    }
+    E.prefilter_cells(g.tb, g.te, others);
+}
+
 // ---------------------------------------------------------------------------------------------- the exchange
 namespace {
 uint64_t round_limit() {   // records a rank receives per round of exchange 1 (beyond it the home range is worked off in several rounds)
@@ -488,11 +504,10 @@ uint64_t cluster_step(Engine &E, Comm &C, int target_shards, uint32_t *assign) {
     if (!E.have_db) fail(UC_ERR_ARGS, "no database loaded");
     UC_HIP(hipSetDevice(E.device));
     const uint32_t n = E.hdb.n;
-    const GridCell g = grid_cell(E.h_len, C.world, target_shards, C.rank);
     {
         Turn turn(C, &E);
         Timer tp;
-        E.prefilter(g.tb, g.te, g.qb, g.qe);
+        prefilter_cell(E, C.world, target_shards, C.rank);
         E.stats.phase_seconds[0] += tp.seconds();
     }
     uint64_t n_aln = E.n_hits;

@@ -98,6 +98,14 @@ std::vector<std::pair<uint32_t, uint32_t>> shard_ranges(const std::vector<uint32
 void grid_shape(int world, int target_shards, int *Q, int *T);
 GridCell grid_cell(const std::vector<uint32_t> &len, int world, int target_shards, int rank);
 
+// E1-E4 of this rank's share of the pass.  T = N under a symmetric matrix (the north-star layout): the shard x shard grid needs only half of its
+// off-diagonal blocks, because the hits of (t, q) are those of (q, t) with the diagonal negated — rank r matches its target shard against its own
+// sequences and against the queries of the next N/2 shards in cyclic order (the shard at distance exactly N/2 only from the lower half of the
+// ranks), and every pair of those blocks also yields the candidate of the pair the other way round, which travels to its query's home rank with
+// exchange 1 like any other record: 5 (ranks 0-3) or 4 blocks per rank instead of 8 at N = 8.  Q x T grids with Q > 1, non-symmetric matrices and
+// UC_PREFILTER_SYMMETRIC=0 match the rank's whole cell as before.
+void prefilter_cell(Engine &E, int world, int target_shards, int rank);
+
 // all-gather + merge + ownership filter of the engine's hit lists; returns the pairs this rank now owns
 uint64_t exchange_hits(Engine &E, Comm &C);
 // one pass of the sharded path on this rank (prefilter of the rank's cell -> exchange -> E5/E6 -> edges to rank 0 -> set

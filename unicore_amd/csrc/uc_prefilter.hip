@@ -1364,7 +1364,41 @@ static size_t scratch_trim_limit() {
 // (target, diagonal) hashes in 2 x 2^19 LDS bits, which only works while a query has well under ~500 k k-mer hits,
 // i.e. up to ~100 M target residues per chunk at default sensitivity (at 760 M residues in one chunk 75 % of the
 // hits survived the filter and the key sort took 2/3 of the run).
-void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend) {
+void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend) { prefilter_impl(tbegin, tend, qbegin, qend, false); }
+
+// A rank of a symmetric N-rank pass: the shard's own block (with its inner triangle if it spans several chunks) and one mirrored block per other
+// query range; the lists of the blocks (disjoint candidate sets, each truncated to its own top-M) are concatenated and merged once.
+void Engine::prefilter_cells(uint32_t tbegin, uint32_t tend, const std::vector<std::pair<uint32_t, uint32_t>> &others) {
+    PressureScope ps(*this, 0);
+    DevBuf<uint32_t> cq, ct;
+    DevBuf<int32_t> cs, cd;
+    uint64_t cat_n = 0;
+    auto take = [&]() {       // append the engine's current lists (grouped or not) to the accumulator
+        if (!n_hits) return;
+        const uint64_t tot = cat_n + n_hits;
+        cq.grow_preserve(tot, cat_n, stream); ct.grow_preserve(tot, cat_n, stream); cs.grow_preserve(tot, cat_n, stream); cd.grow_preserve(tot, cat_n, stream);
+        UC_HIP(hipMemcpyAsync(cq.p + cat_n, d_hq.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+        UC_HIP(hipMemcpyAsync(ct.p + cat_n, d_ht.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+        UC_HIP(hipMemcpyAsync(cs.p + cat_n, d_hs.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+        UC_HIP(hipMemcpyAsync(cd.p + cat_n, d_hd.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
+        UC_HIP(hipStreamSynchronize(stream));
+        cat_n = tot;
+    };
+    const uint64_t before = stats.n_prefilter_hits;
+    prefilter_impl(tbegin, tend, tbegin, tend, false);
+    take();
+    for (const auto &r : others) {
+        if (r.first >= r.second) continue;
+        if (r.first < tend && r.second > tbegin) fail(UC_ERR_GENERIC, "prefilter_cells: a mirrored query range overlaps the target shard");
+        prefilter_impl(tbegin, tend, r.first, r.second, true);
+        take();
+    }
+    const uint64_t kept = import_hits_dev(cat_n, cq.p, ct.p, cs.p, cd.p, 0, 1);
+    stats.n_prefilter_hits = before + kept;
+    if (pre) pre->trim(scratch_trim_limit());
+}
+
+void Engine::prefilter_impl(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend, bool mirror_all) {
     PressureScope ps(*this, 0);
     if (!have_db) fail(UC_ERR_ARGS, "no database loaded");
     if (tbegin > tend || tend > hdb.n) fail(UC_ERR_ARGS, "prefilter: bad target range");
@@ -1397,8 +1431,10 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t
         const bool triangle = chunks.size() > 1 && tbegin == qbegin && tend == qend && p.mat_symmetric && !getenv("UC_SIM_PER_POSITION") &&
                               !(getenv("UC_PREFILTER_SYMMETRIC") && atoi(getenv("UC_PREFILTER_SYMMETRIC")) == 0);
         if (chunks.size() <= 1) {
-            ok = prefilter_one(tbegin, tend, qbegin, qend, true, limit, &density);
-            if (ok) { stats.n_prefilter_hits += n_hits; if (pre) pre->trim(scratch_trim_limit()); return; }
+            // (mirror_all — prefilter_cells only: every query lies outside the shard and yields the pair the other way round as well; the lists come
+            // back ungrouped and are merged by the caller)
+            ok = prefilter_one(tbegin, tend, qbegin, qend, true, limit, &density, mirror_all ? qbegin : UINT32_MAX);
+            if (ok) { stats.n_prefilter_hits += n_hits; if (pre && !mirror_all) pre->trim(scratch_trim_limit()); return; }
         } else {
             // (Measured and reverted in r04: concatenating the per-pass lists and merging ONCE at the end — 1.5-2 G records in one sort instead of a
             // running top-M accumulator of <= max_seqs x queries — made configs[2] SLOWER, 35.7 -> 39.3 s per pass: the single merge needs ~64 B per
@@ -1408,9 +1444,9 @@ void Engine::prefilter(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t
             uint64_t acc_n = 0;
             bool installed = false;       // the last pass's merge leaves its result installed in the engine: no second merge of the accumulator
             for (size_t c = 0; c < chunks.size() && ok; c++) {
-                const bool mir = triangle && c + 1 < chunks.size();       // (the last chunk has no queries behind it: a plain pass over its own queries)
+                const bool mir = mirror_all || (triangle && c + 1 < chunks.size());       // (the last chunk has no queries behind it: a plain pass over its own queries)
                 ok = prefilter_one(chunks[c].first, chunks[c].second, triangle ? chunks[c].first : qbegin, qend, c == 0, c == 0 ? limit : 0.0, &density,
-                                   mir ? chunks[c].second : UINT32_MAX);
+                                   mirror_all ? qbegin : mir ? chunks[c].second : UINT32_MAX);
                 if (!ok) break;
                 if (!mir && (c == 0 || acc_n == 0)) {
                     aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd);
