@@ -676,6 +676,20 @@ def test_full_size_execution_variants_identical(tmp_path):
         del e
     assert res[0][3] > 10_000_000
     assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    # ... and both equal the CPU oracle run END TO END at this size in the build container (tools/oracle_at_size.py --config c2 ->
+    # tests/golden/c2_sha.json): the whole clust.tsv, the set of accepted pairs, the alignment and cluster counts
+    gold = os.path.join(util.ROOT, "tests", "golden", "c2_sha.json")
+    if os.path.exists(gold):
+        import hashlib
+        import json
+        g = json.load(open(gold))
+        assert hashlib.sha256(res[0][1]).hexdigest() == g["counts"]["edge_set_sha256"] and res[0][3] == g["counts"]["n_alignments"]
+        out = str(tmp_path / "clust")
+        assign = np.frombuffer(res[0][2], np.uint32)
+        assert int((assign == np.arange(len(assign))).sum()) == g["counts"]["n_clusters"]
+        assert U.lib().uc_write_cluster_db((out + "_cluster").encode(), len(assign), assign.ctypes.data) == 0
+        U.createtsv(db, out + "_cluster", out + ".tsv")
+        assert hashlib.sha256(open(out + ".tsv", "rb").read()).hexdigest() == g["tsv_sha256"]
 
 
 def test_bench_line_contract(tmp_path):

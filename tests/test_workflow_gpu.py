@@ -7,6 +7,7 @@ workflow observer of the C ABI (uc_set_round_hook) to look INTO every round: the
 and alignment records of a random query sample, which are then recomputed by the CPU oracle on that round's sub-database.
 
   small   every query of every round against the oracle + clust.tsv bytes against uco_cluster_workflow
+  c2      BASELINE configs[1]: 50 proteomes, "-c 0.8"
   c3      BASELINE configs[2]: 500 proteomes, "-c 0.8"
   c4-200  BASELINE configs[3]'s options "-c 0.8 --min-seq-id 0.3 -s 7.5" on 200 proteomes
   c4-500  ... on 500 proteomes (1.59 M sequences)
@@ -142,6 +143,7 @@ def test_round_hook_every_round_equals_the_oracle(O, tmp_path):
 
 
 AT_SIZE = {
+    "c2": dict(proteomes=50, seed=0x5EED0002, opts="-c 0.8", s=4.0, per_round=300, min_aln=2_000_000),
     "c3": dict(proteomes=500, seed=0x5EED0003, opts="-c 0.8", s=4.0, per_round=500, min_aln=50_000_000),
     "c4-200": dict(proteomes=200, seed=0x5EED0004, opts="-c 0.8 --min-seq-id 0.3 -s 7.5", s=7.5, per_round=500, min_aln=20_000_000),
     "c4-500": dict(proteomes=500, seed=0x5EED0004, opts="-c 0.8 --min-seq-id 0.3 -s 7.5", s=7.5, per_round=500, min_aln=100_000_000),
