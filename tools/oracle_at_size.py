@@ -37,7 +37,6 @@ def run_chunked(odb, p, threads, chunk, work, log=None):
     tot = dict(n_sim_kmers=0, n_kmer_hits=0, n_candidates=0, n_prefilter_hits=0, n_alignments=0, n_edges=0,
                cells_fwd=0, cells_rev=0, cells_start=0)
     edge_parts, t_pre, t_aln = [], 0.0, 0.0
-    ms_all = None
     for c0 in range(0, n, chunk):
         c1 = min(n, c0 + chunk)
         ck = os.path.join(work, "chunk_%09d_%09d.npz" % (c0, c1)) if work else None
