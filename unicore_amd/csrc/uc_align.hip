@@ -375,13 +375,14 @@ __global__ void __launch_bounds__(256) finalize_kernel(uint32_t n2, const uint32
 __global__ void __launch_bounds__(256) tb_gather_kernel(uint32_t n2, const uint32_t *eflag, const uint32_t *epos, const uint32_t *idx2,
                                                         const uint32_t *link, const uint32_t *idx0, const uint32_t *sq2, const uint32_t *st2,
                                                         const uc_aln *alns, uint32_t *q3, uint32_t *t3, int32_t *qs3, int32_t *qe3,
-                                                        int32_t *ts3, int32_t *te3, uint32_t *src3) {
+                                                        int32_t *ts3, int32_t *te3, uint32_t *src3, int32_t *sc3) {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
         if (!eflag[i]) continue;
         const uint32_t w = epos[i], o = idx0[link[idx2[i]]];
         const uc_aln a = alns[o];
         q3[w] = sq2[i]; t3[w] = st2[i]; qs3[w] = a.qstart; qe3[w] = a.qend; ts3[w] = a.tstart; te3[w] = a.tend;
         src3[w] = i;
+        sc3[w] = a.score;                                   // H of the box's end cell: where the walk over the H bytes starts
     }
 }
 __global__ void __launch_bounds__(256) tb_apply_kernel(uint32_t n3, const uint32_t *idx3, const uint32_t *src3, const int32_t *pack,
@@ -420,39 +421,81 @@ __global__ void __launch_bounds__(256) tb_size_kernel(uint32_t n_pk, const uint6
         size[p] = (unsigned long long)(tl + G + 2) * (unsigned long long)(G * RB);
     }
 }
-// one thread per pair follows the decision bytes from the end cell (oracle: traceback(), diag > F > E, a gap is left as soon
-// as it can be): (alignment length << 16 | identities | tie << 31) and the number of gaps
+// one thread per pair walks its matrix of H bytes (packed MODE 7) from the end cell (oracle: traceback(), diag > F > E, a gap is left
+// as soon as it can be): (alignment length << 16 | identities | tie << 31) and the number of gaps.
+// The end cell's H is the pair's score; a cell next to one whose H is known differs from it by less than 128 (vertical / horizontal
+// neighbours: -open .. M + open, diagonal: min score .. M, M = the largest substitution score; the host checks M + open <= 127 and
+// sends everything else through the int32 pass), so its byte gives its H exactly.  Every decision the traceback takes is a comparison
+// of such values:  diagonal iff H(i,j) == H(i-1,j-1) + s(i,j);  H(i,j) == F(i,j) iff some k has H(i-k,j) - open - (k-1) ext == H(i,j),
+// and the search up the column ends at the first k with H(i-k,j) < H(i,j) + k ext (F <= H in every cell, so no gap that long or longer
+// can reach H(i,j));  inside a gap of value f the gap was opened from the neighbour iff H(neighbour) - open == f.  E likewise along the row.
 __global__ void __launch_bounds__(256) tb_walk_kernel(uint32_t n_pk, const DeviceDb db, const uint64_t *key, const uint32_t *st,
                                                       const int32_t *sqs, const int32_t *sqe, const int32_t *sts, const int32_t *ste,
+                                                      const int32_t *score, int open, int ext,
                                                       int tab, const uint8_t *tbm, const unsigned long long *tboff, int32_t *pack,
                                                       int32_t *gaps_out) {
+    __shared__ int8_t s_S3[21 * 21], s_SA[21 * 21];
+    for (int k = threadIdx.x; k < 21 * 21; k += 256) { s_S3[k] = db.S3[k]; s_SA[k] = db.SA[k]; }
+    __syncthreads();
     for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < n_pk; p += gridDim.x * 256) {
         const int cls = (int)(key[p] >> 40);
         const uint32_t q = (uint32_t)(key[p] >> 16) & 0xFFFFFFu, t = st[p];
         const int G = c_tab[tab].G[cls], R = c_tab[tab].R[cls], RB = 4 * ((R + 3) / 4);
         const int qs = sqs[p], ts = sts[p];
         const uint8_t *m = tbm + tboff[p];
-        const uint8_t *qa = db.sa + db.off[q], *ta = db.sa + db.off[t];
-        auto cell = [&](int i, int j) -> uint32_t {   // byte of cell (query row i, target column j)
-            const int lane = i / R;
-            return m[(unsigned long long)(j - ts + lane) * (unsigned long long)(G * RB) + (unsigned long long)lane * RB + (i - lane * R)];
+        const uint16_t *ql = db.lt + db.off[q], *tl = db.lt + db.off[t];   // 3Di | AA << 8 per residue
+        // full H of cell (ii, jj), a neighbour of a cell (or gap state) whose value is within 127 of it: ref
+        auto H_at = [&](int ii, int jj, int ref) -> int {
+            if (ii < qs || jj < ts) return 0;
+            const int lane = ii / R;
+            const uint32_t b = m[(unsigned long long)(jj - ts + lane) * (unsigned long long)(G * RB) + (unsigned long long)lane * RB + (ii - lane * R)];
+            return ref + (int)(int8_t)(uint8_t)(b - (uint32_t)ref);
         };
         int i = sqe[p], j = ste[p], state = 0;
+        int h = score[p];            // state 0: H(i,j);  states 1 / 2: the value of the gap state the walk is in
         uint32_t len = 0, id = 0, gaps = 0, tie = 0;
         while (i >= qs && j >= ts) {
             if (state == 0) {
-                const uint32_t c = cell(i, j);
-                if (!(c & 8u)) break;                                   // H == 0
-                if (!(c & 1u)) { len++; id += qa[i] == ta[j]; i--; j--; }
-                else if (!(c & 2u)) { tie |= (c & 4u) ? 0u : 1u; state = 1; gaps++; }
-                else { state = 2; gaps++; }
-            } else if (state == 1) {                                    // gap consuming query residue i
+                if (h <= 0) break;                                      // H == 0
+                const uint32_t lq = ql[i], lt = tl[j];
+                const int hd = H_at(i - 1, j - 1, h);
+                const int sc = (int)s_S3[(lq & 0xffu) * 21 + (lt & 0xffu)] + (int)s_SA[(lq >> 8) * 21 + (lt >> 8)];
+                if (h == hd + sc) { len++; id += (lq >> 8) == (lt >> 8); i--; j--; h = hd; continue; }
+                bool fv = false, ev = false;
+                {
+                    int hu = h;
+                    for (int k = 1; i - k >= qs; k++) {
+                        hu = H_at(i - k, j, hu);
+                        if (hu == h + open + (k - 1) * ext) { fv = true; break; }
+                        if (hu < h + k * ext) break;
+                    }
+                }
+                if (fv) {   // the tie mark: H == E as well (the transposed path of a mutual hit would take the other gap first)
+                    int hl = h;
+                    for (int k = 1; j - k >= ts; k++) {
+                        hl = H_at(i, j - k, hl);
+                        if (hl == h + open + (k - 1) * ext) { ev = true; break; }
+                        if (hl < h + k * ext) break;
+                    }
+                    tie |= ev ? 1u : 0u;
+                    state = 1;
+                } else state = 2;
+                gaps++;
+            } else if (state == 1) {                                    // gap consuming query residue i, value h = F(i,j)
                 len++;
-                if (i - 1 < qs || !(cell(i - 1, j) & 16u)) state = 0;   // F(i,j) was opened from H(i-1,j)
+                if (i - 1 < qs) state = 0;
+                else {
+                    const int hu = H_at(i - 1, j, h);                   // F(i,j) = max(F(i-1,j) - ext, H(i-1,j) - open): ext .. open above h
+                    if (hu - open == h) { state = 0; h = hu; } else h += ext;
+                }
                 i--;
-            } else {                                                    // gap consuming target residue j
+            } else {                                                    // gap consuming target residue j, value h = E(i,j)
                 len++;
-                if (j - 1 < ts || !(cell(i, j - 1) & 32u)) state = 0;
+                if (j - 1 < ts) state = 0;
+                else {
+                    const int hl = H_at(i, j - 1, h);
+                    if (hl - open == h) { state = 0; h = hl; } else h += ext;
+                }
                 j--;
             }
         }
@@ -785,7 +828,7 @@ struct AlignScratch {
     DevBuf<uint32_t> tb_q3, tb_t3, tb_src3, tb_trun, tb_tpos, tb_tpart, tb_ttie, tb_tlo, tb_thi, tb_tchunk, tb_tcpos;
     DevBuf<unsigned long long> tb_tbsize, tb_tboff;
     DevBuf<uint8_t> tb_tbm;
-    DevBuf<int32_t> tb_qs3, tb_qe3, tb_ts3, tb_te3, tb_pack3, tb_gaps3;
+    DevBuf<int32_t> tb_qs3, tb_qe3, tb_ts3, tb_te3, tb_pack3, tb_gaps3, tb_sc3;
     SwPlan tb_P3;
     // set-cover graph build + greedy cover (set_cover_graph)
     DevBuf<uint32_t> sc_e, sc_flag, sc_pos, sc_dadj, sc_bad, sc_assign, sc_cnt, sc_work, sc_work2, sc_picks, sc_newly, sc_ctr;
@@ -1140,7 +1183,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                                      &ttie = A.tb_ttie, &tlo = A.tb_tlo, &thi = A.tb_thi, &tchunk = A.tb_tchunk, &tcpos = A.tb_tcpos;
                     DevBuf<unsigned long long> &tbsize = A.tb_tbsize, &tboff = A.tb_tboff;
                     DevBuf<uint8_t> &tbm = A.tb_tbm;
-                    DevBuf<int32_t> &qs3 = A.tb_qs3, &qe3 = A.tb_qe3, &ts3 = A.tb_ts3, &te3 = A.tb_te3, &pack3 = A.tb_pack3, &gaps3 = A.tb_gaps3;
+                    DevBuf<int32_t> &qs3 = A.tb_qs3, &qe3 = A.tb_qe3, &ts3 = A.tb_ts3, &te3 = A.tb_te3, &pack3 = A.tb_pack3, &gaps3 = A.tb_gaps3, &sc3 = A.tb_sc3;
                     SwPlan &P3 = A.tb_P3;
                     trun.reserve(n2); tpos.reserve(n2); tpart.reserve(n2); ttie.reserve(n2);
                     UC_HIP(hipMemsetAsync(ttie.p, 0, (size_t)n2 * 4, s));
@@ -1151,9 +1194,9 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                         const uint32_t nt = scan_total(*this, flag, tpos.p, n2);
                         if (!nt) return;
                         q3.reserve(nt); t3.reserve(nt); src3.reserve(nt); qs3.reserve(nt); qe3.reserve(nt); ts3.reserve(nt); te3.reserve(nt);
-                        pack3.reserve(nt); gaps3.reserve(nt);
+                        pack3.reserve(nt); gaps3.reserve(nt); sc3.reserve(nt);
                         hipLaunchKernelGGL(tb_gather_kernel, grid_for(n2), dim3(256), 0, s, n2, flag, tpos.p, iota2.p, link.p, Lidx, q2.p,
-                                           t2.p, d_alns.p + b, q3.p, t3.p, qs3.p, qe3.p, ts3.p, te3.p, src3.p);
+                                           t2.p, d_alns.p + b, q3.p, t3.p, qs3.p, qe3.p, ts3.p, te3.p, src3.p, sc3.p);
                         static const uint32_t tb_gaps[4] = {0u, 0u, 1u, 0u};
                         uint64_t launches = 0;
                         int passes = 1;
@@ -1167,7 +1210,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                             }
                             stats.sw_kernel_ms += timed_ms_end();
                         } else {
-                            build_plan(*this, P3, tmp, nt, q3.p, t3.p, qe3.p, te3.p, 1, qs3.p, ts3.p);
+                            build_plan(*this, P3, tmp, nt, q3.p, t3.p, qe3.p, te3.p, 1, qs3.p, ts3.p, sc3.p);
                             const uint32_t n_pk3 = P3.pair_base[h_tab[1].n];      // every systolic class of table 1 is packed
                             tbsize.reserve((size_t)n_pk3 + 1); tboff.reserve((size_t)n_pk3 + 1);
                             unsigned long long total = 0;
@@ -1192,7 +1235,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                                 launches += launch_plan(*this, P3, 3, gaps3.p, nullptr, nullptr, work, tb_gaps, /*only_long=*/true);
                             if (n_pk3)
                                 hipLaunchKernelGGL(tb_walk_kernel, grid_for(n_pk3), dim3(256), 0, s, n_pk3, ddb, P3.key2.p, P3.st.p, P3.sqs.p, P3.sqe.p,
-                                                   P3.sts.p, P3.ste.p, 1, tbm.p, tboff.p, pack3.p, gaps3.p);
+                                                   P3.sts.p, P3.ste.p, P3.saux.p, p.gap_open, p.gap_ext, 1, tbm.p, tboff.p, pack3.p, gaps3.p);
                             stats.sw_kernel_ms += timed_ms_end();
                             P3.tbm = nullptr; P3.tboff = nullptr;
                         }
@@ -1204,8 +1247,19 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                                            p.want_tb ? gaps3.p : (const int32_t *)nullptr, iota2.p, link.p, Lidx, p.min_seq_id, d_alns.p + b,
                                            eflag.p, ttie.p);
                     };
+                    // the walk over H bytes needs neighbouring cells within 127 of each other: largest substitution score + gap open
+                    // (uc_align.hip tb_walk_kernel); anything else takes the int32 pass
+                    bool tb_bytes_ok = p.gap_open >= p.gap_ext && p.gap_ext >= 0;
+                    {
+                        int m3 = -128, ma = -128, n3 = 127, na = 127;
+                        for (int k = 0; k < 21 * 21; k++) {
+                            m3 = std::max<int>(m3, p.S3[k]); ma = std::max<int>(ma, p.SA[k]);
+                            n3 = std::min<int>(n3, p.S3[k]); na = std::min<int>(na, p.SA[k]);
+                        }
+                        tb_bytes_ok = tb_bytes_ok && m3 + ma + p.gap_open <= 127 && n3 + na >= -127;
+                    }
                     auto run_tb = [&](const uint32_t *flag) {
-                        if (!p.sw_pk) { tb_batch(flag, false); return; }
+                        if (!p.sw_pk || !tb_bytes_ok) { tb_batch(flag, false); return; }
                         tlo.reserve(n2); thi.reserve(n2); tchunk.reserve(n2); tcpos.reserve(n2);
                         hipLaunchKernelGGL(tb_split_kernel, grid_for(n2), dim3(256), 0, s, n2, flag, link.p, Lidx, d_alns.p + b, SW_PK_OVF_HOST, tlo.p, thi.p);
                         tb_batch(thi.p, false);                               // scores beyond the packed range: int32 MODE 3

@@ -62,10 +62,12 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
     // column, and only at such steps (a rare, wave-level branch) the lane looks at its rows: first optimal row, and
     // whether a single row holds all optimal cells (the condition under which a mutual hit may share the result).
     // MODE 7 = traceback bytes: the forward DP on the box [qs..qe] x [ts..te] of an accepted pair; instead of tracking an
-    // end position every cell stores one byte of decisions (bit 0 H != diagonal candidate, 1 H != F, 2 H != E, 3 H != 0,
-    // 4 F of the next row extends (not opened from this H), 5 E of the next column extends) into a per-pair matrix in
-    // HBM, laid out by anti-diagonal step so that a lane group stores G*RB contiguous bytes per step.  A second kernel
-    // (tb_walk_kernel, uc_align.hip) walks every pair's matrix from the end cell: alignment length, identities, gaps.
+    // end position every cell stores ONE byte, H mod 256, into a per-pair matrix in HBM, laid out by anti-diagonal step so
+    // that a lane group stores G*RB contiguous bytes per step.  No decision is computed here (r04: six compare bits per
+    // cell had cost 16 of the pass's 27 VALU instructions per row and step; a byte of H costs the byte shuffle only).  A
+    // second kernel (tb_walk_kernel, uc_align.hip) walks every pair's matrix from the end cell, whose H it knows (the
+    // score): neighbouring cells differ by less than 128, so every H it needs is exact again, and every decision of the
+    // traceback (diagonal / F / E, gap opened or extended) is a comparison of H values: alignment length, identities, gaps.
     constexpr bool TBB = MODE == 7;
     constexpr bool KNOWN = MODE == 4 || MODE == 6;
     constexpr int BASE = KNOWN ? MODE - 4 : (TBB ? 0 : MODE);
@@ -279,16 +281,7 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
             H[r] = h;
             const uint32_t t = pk_sub_sat(h, open2);
             const uint32_t esub = pk_sub_sat(e, ext2), fsub = pk_sub_sat(f, ext2);
-            if constexpr (TBB) {   // one decision byte per cell and half (0/1 per half by min(.,1): no packed compare exists)
-                const uint32_t one2 = 0x00010001u;
-                uint32_t c = pk_min(x ^ h, one2);
-                c |= pk_min(f ^ h, one2) << 1;
-                c |= pk_min(e ^ h, one2) << 2;
-                c |= pk_min(h, one2) << 3;
-                c |= pk_min(pk_sub_sat(fsub, t), one2) << 4;
-                c |= pk_min(pk_sub_sat(esub, t), one2) << 5;
-                code[r] = c;
-            }
+            if constexpr (TBB) code[r] = h;   // the cell's byte = H mod 256 of either half (packed into byte streams below)
             E[r] = pk_max(esub, t);
             f = pk_max(fsub, t);
             if constexpr (TRACK && !KNOWN) { if (ODD) rowbest[r] = pk_max3(rowbest[r], hprev, h); }
