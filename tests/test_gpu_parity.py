@@ -116,7 +116,13 @@ def test_sw_long_query_fallback(O):
                                   # optional rule UC-1/M (default off): matrices rescaled by MMseqs2-style bit factors, both sides
                                   "-c 0.8 --mat-bit-factor-3di 2.1 --mat-bit-factor-aa 1.4", "-c 0.5 --mat-bit-factor-3di 2.1 --min-seq-id 0.3 -s 6",
                                   # optional rule UC-1/B (default off): compositional bias on the ungapped score, both sides
-                                  "-c 0.8 --comp-bias-corr 1", "-c 0.5 --comp-bias-corr 1 --comp-bias-corr-scale 0.5 --min-seq-id 0.3 --max-seqs 8"])
+                                  "-c 0.8 --comp-bias-corr 1", "-c 0.5 --comp-bias-corr 1 --comp-bias-corr-scale 0.5 --min-seq-id 0.3 --max-seqs 8",
+                                  # the traceback walk rebuilds every H from a neighbour's and its own byte: neighbours must stay within 127 of each
+                                  # other, i.e. largest substitution score + gap open <= 127.  Matrices scaled close to the +-48 limit of either track
+                                  # (3Di -48..38, AA -17..48) with the largest gap open: 86 + 31 = 117 (long sequences leave the packed score range and
+                                  # take the int32 pass, the others the byte walk)
+                                  "-c 0.5 --mat-bit-factor-3di 9.5 --mat-bit-factor-aa 8.7 --gap-open 31 --gap-extend 3 --min-seq-id 0.3",
+                                  "-c 0.5 --mat-bit-factor-aa 8.7 --gap-open 31 --gap-extend 31 --min-seq-id 0.2 --max-seqs 50"])
 def test_pipeline_stage_parity(O, small, opts):
     """prefilter hit lists, per-pair alignment records, edges and the set cover all equal the oracle's"""
     import unicore_amd as U

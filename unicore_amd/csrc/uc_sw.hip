@@ -130,6 +130,20 @@ __global__ void __launch_bounds__(256) ungapped_kernel(const DeviceDb db, uint64
                 best = max(best, run);
             }
         }
+        // sixteen residues per pair of (unaligned) 16-byte loads: every lane follows its own diagonal, so a wave's load touches 64 lines
+        // whatever its width — the kernel is bound by those line accesses, and a quarter as many loads cover the same residues (r04)
+        for (; i + 16 <= i1; i += 16) {
+            uint32_t wq[4], wt[4];
+            __builtin_memcpy(wq, q3 + i, 16);
+            __builtin_memcpy(wt, t3 + (i - d), 16);
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    run = max(run + S[((wq[w] >> (8 * b)) & 0xffu) * 21 + ((wt[w] >> (8 * b)) & 0xffu)], 0);
+                    best = max(best, run);
+                }
+        }
         for (; i + 4 <= i1; i += 4) {
             uint32_t wq, wt;
             __builtin_memcpy(&wq, q3 + i, 4);
