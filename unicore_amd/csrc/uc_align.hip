@@ -10,6 +10,8 @@
 #include <mutex>
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -1269,8 +1271,19 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                         const uint32_t nlo = scan_total(*this, tlo.p, tcpos.p, n2);
                         unsigned long long est = 0;
                         UC_HIP(hipMemcpy(&est, d_cells.p, 8, hipMemcpyDeviceToHost));
-                        const unsigned long long budget = tb_budget_bytes(tbm.cap);
+                        unsigned long long budget = tb_budget_bytes(tbm.cap);
                         est += est / 8;                                       // slot partners can be longer than the pair itself
+                        // Fresh device memory is not free: 25-60 ms per GiB on a box whose memory has been used before (tools/ubench/alloc_cost.hip,
+                        // profiles/r04/alloc_*.log; UC_ALLOC_LOG=1 prints what every allocation costs).  The pre-step of configs[3]'s options at 500
+                        // proteomes took ONE 126 GiB buffer for its 26 M boxes: 2.9 s of a 5.1 s stage.  Small batches cost more than the allocation
+                        // saves, though (36 GiB batches for 2.6 TB of matrices: SW kernels 9.3 -> 11.0 s, the tails of 28 class kernels per batch), so
+                        // only a call whose matrices would fit a few times over is cut down: an eighth of the (conservative: ~3x) estimate, at least
+                        // 16 GiB — three or four batches for the pre-step above, the free-memory budget as before for every cascade round of that
+                        // database.  What the buffer already holds is free to use.
+                        if (!getenv("UC_TB_BUDGET_MB")) {
+                            const unsigned long long want = std::max<unsigned long long>(16ull << 30, est / 8);
+                            budget = std::min(budget, std::max<unsigned long long>(want, (unsigned long long)tbm.cap));
+                        }
                         const uint32_t nchunk = (uint32_t)std::max<unsigned long long>(1, (est + budget - 1) / budget);
                         const uint32_t per = (nlo + nchunk - 1) / std::max<uint32_t>(nchunk, 1);
                         for (uint32_t c = 0; c < nchunk && nlo; c++) {

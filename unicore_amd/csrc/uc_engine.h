@@ -3,7 +3,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <utility>
 #include <vector>
@@ -25,15 +30,28 @@ namespace uc {
 struct OomRelief { bool (*fn)(void *) = nullptr; void *ctx = nullptr; };
 inline OomRelief &oom_relief_slot() { static thread_local OomRelief r; return r; }
 inline hipError_t malloc_with_relief(void **p, size_t bytes) {
+    static const bool log = getenv("UC_ALLOC_LOG") != nullptr;   // what every allocation of 64 MiB and more costs (fresh device memory: ~60 ms per GiB on this box)
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(p, bytes);
     if (e == hipErrorOutOfMemory) {
         const OomRelief r = oom_relief_slot();
         (void)hipGetLastError();
         if (r.fn && r.fn(r.ctx)) e = hipMalloc(p, bytes);
     }
+    if (log && bytes >= (64u << 20)) {
+        static std::atomic<uint64_t> tot_us{0}, tot_mib{0};
+        const uint64_t us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+        tot_us += us; tot_mib += bytes >> 20;
+        fprintf(stderr, "unicore-cluster[alloc]: %8.1f MiB in %8.2f ms (running total %.1f GiB, %.1f ms)\n", (double)bytes / (1 << 20), us / 1e3, tot_mib.load() / 1024.0,
+                tot_us.load() / 1e3);
+    }
     return e;
 }
 
+// (Measured and not kept, r04: the same buffers on HIP's virtual-memory API — address space reserved once, 1 GiB physical chunks mapped behind what
+// is there as a buffer grows.  In isolation 64 x hipMemCreate(1 GiB) + hipMemMap took 1.2 ms (tools/ubench/alloc_vmm.hip), but inside the workflow the
+// first 126 GiB took 3.6 s — the same ~29 ms per GiB as hipMalloc: what costs is acquiring physical memory that was used before, whatever the API —
+// and address reservations of this size ran into hipErrorInvalidValue.  profiles/r04/alloc_*.log.)
 template <typename T>
 struct DevBuf {   // plain owning device allocation (hipMalloc), grows geometrically
     T *p = nullptr;
@@ -48,12 +66,6 @@ struct DevBuf {   // plain owning device allocation (hipMalloc), grows geometric
         if (n <= cap) return;
         release();
         size_t want = n + n / 8 + 64;
-        if (want * sizeof(T) >= (1ull << 30) && getenv("UC_ALLOC_LOG")) {
-            size_t fr = 0, tot = 0;
-            (void)hipMemGetInfo(&fr, &tot);
-            fprintf(stderr, "unicore-cluster[alloc]: %.2f GiB (%zu x %zu B), %.1f GiB free before\n", (double)(want * sizeof(T)) / (1ull << 30), want, sizeof(T),
-                    (double)fr / (1ull << 30));
-        }
         UC_HIP(malloc_with_relief((void **)&p, want * sizeof(T)));
         cap = want;
     }
