@@ -24,6 +24,7 @@ class Params(C.Structure):
         ("evalue", C.c_double), ("lambda_", C.c_double), ("K", C.c_double),
         ("cov", C.c_float), ("cov_mode", C.c_int), ("min_seq_id", C.c_float), ("want_tb", C.c_int),
         ("comp_bias_milli", C.c_int), ("min_score_table", C.c_void_p),       # optional rules UC-1/B, UC-1/E (default off)
+        ("len_gate", C.c_int),                                               # optional rule UC-1/L (default off)
     ]
 
 

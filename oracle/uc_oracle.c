@@ -461,6 +461,13 @@ void uco_sw(const uint8_t *q3, const uint8_t *qa, int lq, int rev_q,
     *score = best; *qend = bq; *tend = bt;
 }
 
+int uco_can_be_covered(const uco_params *p, int lq, int lt) {
+    if (!p->len_gate || !(p->cov > 0.0f)) return 1;
+    if (lq <= 0 || lt <= 0) return 0;
+    const float ql = (float)lq, tl = (float)lt;
+    return p->cov_mode == 0 ? (ql / tl >= p->cov && tl / ql >= p->cov) : p->cov_mode == 1 ? (ql / tl >= p->cov) : (tl / ql >= p->cov);
+}
+
 int32_t uco_min_score_q(const uco_params *p, uint32_t q, int lq, uint64_t db_residues) {
     return p->min_score_table ? p->min_score_table[q] : uco_min_score(p, lq, db_residues);
 }
@@ -530,6 +537,7 @@ void uco_align_pair(const uco_db *db, uint32_t q, uint32_t t, const uco_params *
     const uint8_t *t3 = db->s3 + db->off[t], *ta = db->sa + db->off[t];
     int lq = (int)(db->off[q + 1] - db->off[q]), lt = (int)(db->off[t + 1] - db->off[t]);
     int32_t qe, te, dq, dt;
+    if (!uco_can_be_covered(p, lq, lt)) return;      /* rule UC-1/L (optional): not aligned, all-zero record */
     uco_sw(q3, qa, lq, 0, t3, ta, lt, 0, p, &o->score, &qe, &te);
     /* UC-1.1: corrected <= score, so a pair whose forward score is below the threshold cannot pass and the
        reversed-query pass is not run for it (score_rev stays 0) */
@@ -658,8 +666,8 @@ int uco_cluster(const uco_db *db, const uco_params *p, int threads, uint32_t *as
     uint32_t *edges = (uint32_t *)malloc((2 * npairs + 2) * sizeof(uint32_t));
     uint8_t *acc = (uint8_t *)calloc(npairs + 1, 1);
     const uint64_t dbres = db->off[n];
-    uint64_t c_f = 0, c_r = 0, c_s = 0;
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : c_f, c_r, c_s)
+    uint64_t c_f = 0, c_r = 0, c_s = 0, n_gated = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : c_f, c_r, c_s, n_gated)
     for (int64_t q = 0; q < (int64_t)n; q++) {
         int lq = (int)(db->off[q + 1] - db->off[q]);
         int32_t ms = uco_min_score_q(p, (uint32_t)q, lq, dbres);
@@ -668,6 +676,7 @@ int uco_cluster(const uco_db *db, const uco_params *p, int threads, uint32_t *as
             uint32_t t = hits[(size_t)q * M + k].t;
             uco_align_pair(db, (uint32_t)q, t, p, ms, &a);
             int lt = (int)(db->off[t + 1] - db->off[t]);
+            if (!uco_can_be_covered(p, lq, lt)) { n_gated++; if (aln_out) aln_out[(size_t)q * M + k] = a; continue; }
             c_f += (uint64_t)lq * lt; if (p->rev_correction && a.score >= ms) c_r += (uint64_t)lq * lt;
             if (a.pass_evalue) c_s += (uint64_t)(a.qend + 1) * (a.tend + 1);
             acc[poff[q] + k] = (uint8_t)a.accepted;
@@ -681,7 +690,7 @@ int uco_cluster(const uco_db *db, const uco_params *p, int threads, uint32_t *as
     uco_setcover(n, edges, ne, assign);
     uint64_t ncl = 0;
     for (uint32_t i = 0; i < n; i++) ncl += (assign[i] == i);
-    total.n_alignments = npairs; total.n_edges = ne; total.n_clusters = ncl;
+    total.n_alignments = npairs - n_gated; total.n_edges = ne; total.n_clusters = ncl;
     total.cells_fwd = c_f; total.cells_rev = c_r; total.cells_start = c_s;
     if (cnt) *cnt = total;
     free(edges); free(acc); free(poff);
@@ -738,6 +747,7 @@ int uco_search(const uco_db *qdb, const uco_db *tdb, const uco_params *p_in, int
             const uint32_t t = hits_out[(size_t)q * M + k].t;
             uco_align_pair(&db, nt + (uint32_t)q, t, p, ms, &a);
             const int lt = (int)(tdb->off[t + 1] - tdb->off[t]);
+            if (!uco_can_be_covered(p, lq, lt)) { aln_out[(size_t)q * M + k] = a; continue; }
             c_f += (uint64_t)lq * lt; if (p->rev_correction && a.score >= ms) c_r += (uint64_t)lq * lt;
             if (a.pass_evalue) c_s += (uint64_t)(a.qend + 1) * (a.tend + 1);
             npairs++; ne += a.accepted;
@@ -868,18 +878,19 @@ int uco_cluster_linclust(const uco_db *db, const uco_params *p, int m, int threa
     const uint32_t n = db->n;
     const uint64_t dbres = db->off[n];
     uint8_t *acc = (uint8_t *)calloc(np + 1, 1);
-    uint64_t c_f = 0, c_r = 0, c_s = 0;
+    uint64_t c_f = 0, c_r = 0, c_s = 0, n_gated = 0;
     (void)threads;
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
 #endif
-#pragma omp parallel for schedule(dynamic, 16) reduction(+ : c_f, c_r, c_s)
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : c_f, c_r, c_s, n_gated)
     for (int64_t k = 0; k < (int64_t)np; k++) {
         const uint32_t q = pairs[2 * k], t = pairs[2 * k + 1];
         const int lq = (int)(db->off[q + 1] - db->off[q]), lt = (int)(db->off[t + 1] - db->off[t]);
         const int32_t ms = uco_min_score(p, lq, dbres);
         uco_aln a;
         uco_align_pair(db, q, t, p, ms, &a);
+        if (!uco_can_be_covered(p, lq, lt)) { n_gated++; continue; }
         c_f += (uint64_t)lq * lt; if (p->rev_correction && a.score >= ms) c_r += (uint64_t)lq * lt;
         if (a.pass_evalue) c_s += (uint64_t)(a.qend + 1) * (a.tend + 1);
         acc[k] = (uint8_t)a.accepted;
@@ -893,7 +904,7 @@ int uco_cluster_linclust(const uco_db *db, const uco_params *p, int m, int threa
         memset(cnt, 0, sizeof *cnt);
         uint64_t ncl = 0;
         for (uint32_t i = 0; i < n; i++) ncl += assign[i] == i;
-        cnt->n_prefilter_hits = np; cnt->n_alignments = np; cnt->n_edges = ne; cnt->n_clusters = ncl;
+        cnt->n_prefilter_hits = np; cnt->n_alignments = np - n_gated; cnt->n_edges = ne; cnt->n_clusters = ncl;
         cnt->cells_fwd = c_f; cnt->cells_rev = c_r; cnt->cells_start = c_s;
     }
     free(edges); free(acc); free(pairs);
@@ -1059,6 +1070,9 @@ uint64_t uco_sample_run(const uco_db *db, const uco_index *ix, const uco_params 
         const int32_t ms = uco_min_score_q(p, q, (int)(db->off[q + 1] - db->off[q]), dbres);
         for (uint32_t h = 0; h < hcnt[k]; h++) { pq[poff[k] + h] = q; pt[poff[k] + h] = hits[(size_t)k * M + h].t; pms[poff[k] + h] = ms; }
     }
+    uint64_t gated = 0;   /* rule UC-1/L (optional): pairs the length gate rules out are not alignments */
+    for (uint64_t i = 0; i < pairs; i++)
+        gated += !uco_can_be_covered(p, (int)(db->off[pq[i] + 1] - db->off[pq[i]]), (int)(db->off[pt[i] + 1] - db->off[pt[i]]));
 #pragma omp parallel for schedule(dynamic, 8) reduction(+ : acc)
     for (int64_t i = 0; i < (int64_t)pairs; i++) {
         uco_aln a;
@@ -1069,5 +1083,5 @@ uint64_t uco_sample_run(const uco_db *db, const uco_index *ix, const uco_params 
     double t2 = now_s();
     seconds[0] = t1 - t0; seconds[1] = t2 - t1;
     free(hits); free(hcnt);
-    return pairs + 0 * acc;
+    return pairs - gated + 0 * acc;
 }

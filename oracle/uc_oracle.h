@@ -100,6 +100,12 @@ typedef struct uco_params {
      *         corrected score — the hook for a fitted per-query E-value model (Foldseek predicts mu / lambda per query); plain step only. */
     int comp_bias_milli;          /* 0 = off */
     const int32_t *min_score_table;
+    /* UC-1/L  length gate before E5 (restates MMseqs2 Util::canBeCovered as its alignment modules call it before aligning a pair; that
+     *         Foldseek's structurealign does the same is EXT-UNVERIFIED): a pair whose LENGTHS alone rule the coverage threshold out is not
+     *         aligned at all - cov_mode 0: Lq / Lt >= cov and Lt / Lq >= cov; 1 (target coverage): Lq / Lt >= cov; 2 (query coverage):
+     *         Lt / Lq >= cov, float division.  Its record stays all-zero (never accepted), it counts neither as an alignment nor in the cell
+     *         counters.  A heuristic, not a bound: gaps can stretch a short sequence over 80 % of a longer one. */
+    int len_gate;                 /* 0 = off */
 } uco_params;
 
 typedef struct uco_db {           /* sequences as codes 0..20, concatenated, no padding */
@@ -131,6 +137,8 @@ typedef struct uco_counts {
     uint64_t cells_fwd, cells_rev, cells_start;
 } uco_counts;
 
+/* rule UC-1/L; 1 when the rule is off */
+int  uco_can_be_covered(const uco_params *p, int lq, int lt);
 int  uco_letter_code(char c);
 void uco_params_default(uco_params *p);
 int  uco_load_matrix(const char *path, int8_t out[UCO_A * UCO_A]);

@@ -126,11 +126,17 @@ void uco_simd_align_query(const uco_db *db, uint32_t q, const uint32_t *targets,
     uint8_t *redo = (uint8_t *)calloc(nh, 1);
     lane_t ln[L];
     res_t rs[L];
-    /* pass 1: forward, targets grouped by length */
-    for (uint32_t h = 0; h < nh; h++) { ord[h].idx = h; ord[h].key = (int)(db->off[targets[h] + 1] - db->off[targets[h]]); }
-    if (nh) qsort(ord, nh, sizeof(ord_t), ord_cmp);
-    for (uint32_t b = 0; b < nh; b += L) {
-        const int nl = (int)(nh - b < L ? nh - b : L);
+    /* pass 1: forward, targets grouped by length; rule UC-1/L (optional): pairs the length gate rules out keep their all-zero record */
+    uint8_t *gated = (uint8_t *)calloc(nh, 1);
+    uint32_t n1 = 0;
+    for (uint32_t h = 0; h < nh; h++) {
+        const int lt = (int)(db->off[targets[h] + 1] - db->off[targets[h]]);
+        if (!uco_can_be_covered(p, lq, lt)) { gated[h] = 1; continue; }
+        ord[n1].idx = h; ord[n1].key = lt; n1++;
+    }
+    if (n1) qsort(ord, n1, sizeof(ord_t), ord_cmp);
+    for (uint32_t b = 0; b < n1; b += L) {
+        const int nl = (int)(n1 - b < L ? n1 - b : L);
         for (int l = 0; l < nl; l++) {
             const uint32_t t = targets[ord[b + l].idx];
             ln[l].t3 = db->s3 + db->off[t]; ln[l].ta = db->sa + db->off[t]; ln[l].lt = ord[b + l].key; ln[l].rev_t = 0; ln[l].skip = 0;
@@ -145,7 +151,7 @@ void uco_simd_align_query(const uco_db *db, uint32_t q, const uint32_t *targets,
     /* pass 2: reversed query for the pairs whose forward score reaches the threshold (UC-1.1) */
     uint32_t n2 = 0;
     for (uint32_t h = 0; h < nh; h++)
-        if (!redo[h] && p->rev_correction && out[h].score >= min_score) { ord[n2].idx = h; ord[n2].key = (int)(db->off[targets[h] + 1] - db->off[targets[h]]); n2++; }
+        if (!gated[h] && !redo[h] && p->rev_correction && out[h].score >= min_score) { ord[n2].idx = h; ord[n2].key = (int)(db->off[targets[h] + 1] - db->off[targets[h]]); n2++; }
     if (n2) qsort(ord, n2, sizeof(ord_t), ord_cmp);
     for (uint32_t b = 0; b < n2; b += L) {
         const int nl = (int)(n2 - b < L ? n2 - b : L);
@@ -157,6 +163,7 @@ void uco_simd_align_query(const uco_db *db, uint32_t q, const uint32_t *targets,
         for (int l = 0; l < nl; l++) { out[ord[b + l].idx].score_rev = rs[l].score; if (rs[l].score >= OVF) redo[ord[b + l].idx] = 1; }
     }
     for (uint32_t h = 0; h < nh; h++) {
+        if (gated[h]) continue;
         out[h].corrected = out[h].score - out[h].score_rev;
         out[h].pass_evalue = out[h].score > 0 && out[h].corrected >= min_score;
     }
@@ -181,6 +188,7 @@ void uco_simd_align_query(const uco_db *db, uint32_t q, const uint32_t *targets,
     /* gates; the seq-id traceback (few pairs) and anything near the int16 range go through the scalar oracle */
     for (uint32_t h = 0; h < nh; h++) {
         uco_aln *o = &out[h];
+        if (gated[h]) continue;
         if (redo[h]) { uco_align_pair(db, q, targets[h], p, min_score, o); continue; }
         if (!o->pass_evalue) continue;
         const int lt = (int)(db->off[targets[h] + 1] - db->off[targets[h]]);
@@ -193,7 +201,7 @@ void uco_simd_align_query(const uco_db *db, uint32_t q, const uint32_t *targets,
         }
         o->accepted = ok;
     }
-    free(Hbuf); free(Ebuf); free(ord); free(redo);
+    free(Hbuf); free(Ebuf); free(ord); free(redo); free(gated);
 }
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
@@ -237,6 +245,12 @@ uint64_t uco_simd_sample_run_counts(const uco_db *db, const uco_index *ix, const
     const uint64_t dbres = db->off[db->n];
     uint64_t pairs = 0;
     for (uint32_t k = 0; k < n_queries; k++) pairs += hcnt[k];
+    if (p->len_gate)      /* rule UC-1/L (optional): pairs the length gate rules out are not alignments */
+        for (uint32_t k = 0; k < n_queries; k++)
+            for (uint32_t h = 0; h < hcnt[k]; h++) {
+                const uint32_t q = queries[k], t = hits[(size_t)k * M + h].t;
+                pairs -= !uco_can_be_covered(p, (int)(db->off[q + 1] - db->off[q]), (int)(db->off[t + 1] - db->off[t]));
+            }
     /* one task = one query with its whole hit list (its targets share the query profile); heavy queries first */
     ord_t *qo = (ord_t *)malloc(((size_t)n_queries + 1) * sizeof(ord_t));
     for (uint32_t k = 0; k < n_queries; k++) { qo[k].idx = k; qo[k].key = (int)((db->off[queries[k] + 1] - db->off[queries[k]]) * (uint64_t)hcnt[k] >> 6); }

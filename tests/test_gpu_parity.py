@@ -117,6 +117,10 @@ def test_sw_long_query_fallback(O):
                                   "-c 0.8 --mat-bit-factor-3di 2.1 --mat-bit-factor-aa 1.4", "-c 0.5 --mat-bit-factor-3di 2.1 --min-seq-id 0.3 -s 6",
                                   # optional rule UC-1/B (default off): compositional bias on the ungapped score, both sides
                                   "-c 0.8 --comp-bias-corr 1", "-c 0.5 --comp-bias-corr 1 --comp-bias-corr-scale 0.5 --min-seq-id 0.3 --max-seqs 8",
+                                  # optional rule UC-1/L (default off): pairs whose lengths alone rule the coverage threshold out are not aligned
+                                  # (all-zero record, counted neither as alignment nor in the cells), both sides, every coverage mode
+                                  "-c 0.8 --length-gate 1", "-c 0.7 --cov-mode 1 --length-gate 1 --min-seq-id 0.3",
+                                  "-c 0.8 --cov-mode 2 --length-gate 1 --sym-dedup 0 -s 6",
                                   # the traceback walk rebuilds every H from a neighbour's and its own byte: neighbours must stay within 127 of each
                                   # other, i.e. largest substitution score + gap open <= 127.  Matrices scaled close to the +-48 limit of either track
                                   # (3Di -48..38, AA -17..48) with the largest gap open: 86 + 31 = 117 (long sequences leave the packed score range and
@@ -151,6 +155,16 @@ def test_pipeline_stage_parity(O, small, opts):
             assert 0 < ra["accepted"][ra["aln_len"] > 0].mean() < 1   # the identity gate bites both ways
     st = e.stats()
     c = ref["counts"]
+    if "--length-gate 1" in opts:             # the gate bites, and not on everything; what it lets through has the records of the rule-off run
+        assert 0 < c["n_alignments"] < int(cnt.sum()) and c["n_edges"] > 0
+        off_ref = O.cluster(small["odb"], util.oracle_params(O, opts.replace("--length-gate 1", "--length-gate 0")), threads=8)
+        oa = np.concatenate([off_ref["aln"][i, : cnt[i]] for i in range(len(cnt))])
+        lens = np.diff(small["off"]).astype(np.float32)
+        ql, tl = lens[np.repeat(np.arange(len(cnt)), cnt)], lens[hits["target"]]
+        cov = np.float32(p.cov)
+        keep = ((ql / tl >= cov) & (tl / ql >= cov)) if p.cov_mode == 0 else (ql / tl >= cov) if p.cov_mode == 1 else (tl / ql >= cov)
+        assert int(keep.sum()) == c["n_alignments"]
+        assert ra[keep].tobytes() == oa[keep].tobytes() and not ra[~keep].view(np.uint8).any()
     for a, b in (("n_sim_kmers", "n_sim_kmers"), ("n_kmer_hits", "n_kmer_hits"), ("n_candidates", "n_candidates"),
                  ("n_prefilter_hits", "n_prefilter_hits"), ("n_gapped_alignments", "n_alignments"), ("n_edges", "n_edges"),
                  ("cells_fwd", "cells_fwd"), ("cells_start", "cells_start")):
@@ -787,7 +801,8 @@ def test_traceback_bytes_in_several_batches(O, small):
 
 
 @pytest.mark.parametrize("opts,steps,m", [("-c 0.8 --linclust 1 --cluster-steps 1", 1, 20), ("-c 0.8 --linclust 1 --cluster-steps 3", 3, 20),
-                                          ("-c 0.5 --linclust 1 --kmer-per-seq 5 --cluster-steps 2", 2, 5)])
+                                          ("-c 0.5 --linclust 1 --kmer-per-seq 5 --cluster-steps 2", 2, 5),
+                                          ("-c 0.8 --length-gate 1 --linclust 1 --cluster-steps 3", 3, 20)])      # rule UC-1/L through every round
 def test_linclust_workflow_tsv_bytes(O, tmp_path, opts, steps, m):
     """E8a: linear-time pre-step (minimum-hash k-mer groups, centre = longest member, candidate pairs
     through E5/E6, set cover) in front of the cascade rounds == the oracle's workflow, byte for byte"""

@@ -303,7 +303,42 @@ def test_cascade_oracle_invariants():
     assert all(a[r1[i]] == a[i] for i in range(odb.n))
 
 
-@pytest.mark.parametrize("opts", ["-c 0.8", "-c 0.5 -e 1e-2 --min-seq-id 0.3 --gap-open 7 --gap-extend 2 --cov-mode 1", "-c 0.8 --rev-correction 0 --max-seqs 9"])
+def test_length_gate_rule(tmp_path):
+    """optional rule UC-1/L (default off): MMseqs2's canBeCovered on the two lengths.  Known answers for the three coverage modes, off by
+    default, and through the pipeline: gated pairs keep all-zero records and count neither as alignments nor in the cell counters, every
+    other record and every prefilter list is the rule-off run's."""
+    import util
+    L = O.lib()
+    L.uco_can_be_covered.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    p = util.oracle_params(O, "-c 0.8")
+    assert p.len_gate == 0 and L.uco_can_be_covered(C.byref(p), 10, 1000) == 1            # off: everything passes
+    for mode, cases in ((0, ((100, 100, 1), (80, 100, 1), (100, 80, 1), (79, 100, 0), (100, 79, 0), (4, 5, 1), (3, 5, 0))),
+                        (1, ((80, 100, 1), (79, 100, 0), (500, 100, 1))),                 # target coverage: the query must be long enough
+                        (2, ((100, 80, 1), (100, 79, 0), (100, 500, 1)))):                # query coverage: the target must be long enough
+        p = util.oracle_params(O, "-c 0.8 --cov-mode %d --length-gate 1" % mode)
+        for lq, lt, exp in cases:
+            assert L.uco_can_be_covered(C.byref(p), lq, lt) == exp, (mode, lq, lt)
+    assert L.uco_can_be_covered(C.byref(util.oracle_params(O, "-c 0 --length-gate 1")), 1, 1000) == 1   # no coverage threshold, no gate
+    s3, sa = util.family_db(23, n_fam=10, members=6, lmin=30, lmax=300, indel=0.08, extra=(500,))
+    odb = O.OracleDb(s3=s3, sa=sa)
+    on = O.cluster(odb, util.oracle_params(O, "-c 0.8 --length-gate 1"), threads=4)
+    off = O.cluster(odb, util.oracle_params(O, "-c 0.8"), threads=4)
+    assert np.array_equal(on["hit_cnt"], off["hit_cnt"]) and on["hits"].tobytes() == off["hits"].tobytes()      # E1-E4 untouched
+    lens = np.array([len(x) for x in s3], np.float32)
+    gated = kept = 0
+    for q in range(odb.n):
+        for k in range(on["hit_cnt"][q]):
+            t = int(on["hits"][q, k]["t"])
+            if min(lens[q] / lens[t], lens[t] / lens[q]) >= np.float32(0.8):
+                assert on["aln"][q, k].tobytes() == off["aln"][q, k].tobytes(); kept += 1
+            else:
+                assert not np.frombuffer(on["aln"][q, k].tobytes(), np.uint8).any(); gated += 1
+    assert gated > 20 and kept > 20 and on["counts"]["n_alignments"] == kept and off["counts"]["n_alignments"] == kept + gated
+    assert on["counts"]["cells_fwd"] < off["counts"]["cells_fwd"] and on["counts"]["n_edges"] <= off["counts"]["n_edges"]
+
+
+@pytest.mark.parametrize("opts", ["-c 0.8", "-c 0.5 -e 1e-2 --min-seq-id 0.3 --gap-open 7 --gap-extend 2 --cov-mode 1", "-c 0.8 --rev-correction 0 --max-seqs 9",
+                                  "-c 0.8 --length-gate 1", "-c 0.7 --cov-mode 2 --length-gate 1 --min-seq-id 0.3"])
 def test_simd_cpu_leg_equals_the_scalar_oracle(opts, tmp_path):
     """oracle/uc_simd.c (bench.py's cpu_baseline "simd": AVX2 inter-sequence Smith-Waterman, 16 targets per register)
     must give the scalar oracle's record for every pair - score, reversed-query score, ends, starts, gates, traceback
@@ -319,7 +354,7 @@ def test_simd_cpu_leg_equals_the_scalar_oracle(opts, tmp_path):
     n, _, _, cnt, hits, alns = O.simd_sample_run(odb, ix, p, queries, threads=4, records=True)
     n_ref, _, _ = O.sample_run(odb, ix, p, queries, threads=4)
     O.free_index(ix)
-    assert n == n_ref == int(cnt.sum()) and n > 200
+    assert n == n_ref and n > 200 and (n < int(cnt.sum()) if "--length-gate 1" in opts else n == int(cnt.sum()))   # gated pairs are no alignments
     checked = 0
     for k, q in enumerate(queries):
         ms = O.min_score(odb, p, int(q))
@@ -332,7 +367,7 @@ def test_simd_cpu_leg_equals_the_scalar_oracle(opts, tmp_path):
                 for f in ("qstart", "qend", "tstart", "tend"):
                     assert got[f] == ref[f], (opts, int(q), int(hits[k, h]["t"]), f, got, ref)
             checked += 1
-    assert checked == n
+    assert checked == int(cnt.sum())
 
 
 # ------------------------------------------------------------------ published constants / textbook properties

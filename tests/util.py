@@ -113,6 +113,7 @@ def oracle_params(O, opts=""):
         elif f == "--mat-bit-factor-aa": kw["bit_factor_aa"] = float(v)
         elif f == "--comp-bias-corr": kw["_cb"] = int(v)
         elif f == "--comp-bias-corr-scale": kw["_cbs"] = float(v)
+        elif f == "--length-gate": kw["len_gate"] = int(v)     # rule UC-1/L
         elif f in ("--sw-kernel", "--sym-dedup"): pass      # engine-side execution choices, no effect on results
         else: raise ValueError(f)
         i += 2

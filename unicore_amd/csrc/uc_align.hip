@@ -325,6 +325,28 @@ __global__ void __launch_bounds__(256) sm_score_kernel(uint32_t nb, const uint32
 __global__ void __launch_bounds__(256) iota_kernel(uint32_t n, uint32_t *out) {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[i] = i;
 }
+// rule UC-1/L (optional): flag = the lengths of the pair leave the coverage threshold reachable (float division, as the checker's)
+__global__ void __launch_bounds__(256) len_gate_kernel(uint32_t n, const uint32_t *q, const uint32_t *t, const uint32_t *len, float cov, int cov_mode,
+                                                       uint32_t *flag) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float ql = (float)len[q[i]], tl = (float)len[t[i]];
+        const bool ok = len[q[i]] && len[t[i]] &&
+                        (cov_mode == 0 ? (ql / tl >= cov && tl / ql >= cov) : cov_mode == 1 ? (ql / tl >= cov) : (tl / ql >= cov));
+        flag[i] = ok ? 1u : 0u;
+    }
+}
+__global__ void __launch_bounds__(256) len_gate_gather_kernel(uint32_t n, const uint32_t *flag, const uint32_t *pos, const uint32_t *q, const uint32_t *t,
+                                                              uint32_t *qc, uint32_t *tc, uint32_t *map) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        if (!flag[i]) continue;
+        const uint32_t w = pos[i];
+        qc[w] = q[i]; tc[w] = t[i]; map[w] = i;
+    }
+}
+// records of the compacted pair list -> their places in the hit-list order (the gated pairs keep the all-zero record)
+__global__ void __launch_bounds__(256) len_gate_putback_kernel(uint32_t nc, const uint32_t *map, const uc_aln *src, uc_aln *dst) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nc; i += gridDim.x * 256) dst[map[i]] = src[i];
+}
 // algorithmic cells of the start pass: (qEnd+1) x (tEnd+1) per gate passer
 __global__ void __launch_bounds__(256) cells_box_kernel(uint32_t n, const int32_t *qe, const int32_t *te, unsigned long long *out) {
     unsigned long long c = 0;
@@ -820,6 +842,8 @@ struct AlignScratch {
     DevBuf<uint32_t> uidx_in, uidx, fq, ft, mirror, rep, rpos, qr, tr, jrep, rcopy;
     DevBuf<int32_t> su, qeu, teu, s2s, q2os, t2os, qe2a, te2a, sknown;
     DevBuf<uint32_t> iota2, smkeep, smpos, partner, uniq, q2a, t2a, mapa;
+    DevBuf<uint32_t> lg_q, lg_t, lg_map, lg_flag, lg_pos;   // rule UC-1/L: the compacted pair list of a batch and its records
+    DevBuf<uc_aln> lg_alns;
     DevBuf<unsigned long long> d_cells;
     DevBuf<char> tmp;
     SwPlan P0, P1, P2, P2b;
@@ -1036,10 +1060,27 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
         uint32_t qb = qa;
         while (qb < qend && (qb == qa || hit_off[qb + 1] - hit_off[qa] <= CHUNK)) qb++;
         const uint64_t b = hit_off[qa];
-        const uint32_t n = (uint32_t)(hit_off[qb] - b);
+        const uint32_t n_listed = (uint32_t)(hit_off[qb] - b);
+        uint32_t n = n_listed;
+        const uint32_t *dq = d_hq.p + b, *dt = d_ht.p + b;
+        uc_aln *alns_b = d_alns.p + b;                 // where record i of the batch's pair list goes
+        if (p.len_gate && p.cov > 0.0f && n) {
+            // rule UC-1/L (optional): the stage works on the pairs the length gate lets through - a compacted copy of the batch's pair list with its own
+            // record array; the records return to their places in the hit-list order at the end of the batch, the gated pairs keep all-zero records
+            DevBuf<uint32_t> &lgq = A.lg_q, &lgt = A.lg_t, &lgmap = A.lg_map, &lgflag = A.lg_flag, &lgpos = A.lg_pos;
+            lgflag.reserve(n); lgpos.reserve(n);
+            hipLaunchKernelGGL(len_gate_kernel, grid_for(n), dim3(256), 0, s, n, dq, dt, ddb.len, p.cov, p.cov_mode, lgflag.p);
+            scan_u32(*this, tmp, lgflag.p, lgpos.p, n, false);
+            const uint32_t nc = scan_total(*this, lgflag.p, lgpos.p, n);
+            lgq.reserve(std::max<uint32_t>(nc, 1)); lgt.reserve(std::max<uint32_t>(nc, 1)); lgmap.reserve(std::max<uint32_t>(nc, 1));
+            A.lg_alns.reserve(std::max<uint32_t>(nc, 1));
+            hipLaunchKernelGGL(len_gate_gather_kernel, grid_for(n), dim3(256), 0, s, n, lgflag.p, lgpos.p, dq, dt, lgq.p, lgt.p, lgmap.p);
+            if (nc) UC_HIP(hipMemsetAsync(A.lg_alns.p, 0, (size_t)nc * sizeof(uc_aln), s));
+            UC_HIP(hipMemsetAsync(d_alns.p + b, 0, (size_t)n * sizeof(uc_aln), s));
+            dq = lgq.p; dt = lgt.p; alns_b = A.lg_alns.p; n = nc;
+        }
         if (n) {
             s0.reserve(n); qe0.reserve(n); te0.reserve(n); gflag.reserve(n); gpos.reserve(n);
-            const uint32_t *dq = d_hq.p + b, *dt = d_ht.p + b;
             const int tab = p.sw_pk ? 1 : 0;
             // the directed pair list the gates work on: sorted (query, target) + position in the hit list
             const uint32_t *Lsq = nullptr, *Lst = nullptr, *Lidx = nullptr;
@@ -1120,7 +1161,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                                    q2.p, t2.p, qe2.p, te2.p, link.p);
                 if (p.sw_pk || dedup) fix_ambiguous_ends(*this, n2, q2.p, t2.p, qe2.p, te2.p, link.p, s0.p, qe0.p, te0.p, work, tmp);
             }
-            hipLaunchKernelGGL(aln_basic_kernel, grid_for(n), dim3(256), 0, s, n, Lidx, s0.p, s1p, qe0.p, te0.p, gflag.p, d_alns.p + b);
+            hipLaunchKernelGGL(aln_basic_kernel, grid_for(n), dim3(256), 0, s, n, Lidx, s0.p, s1p, qe0.p, te0.p, gflag.p, alns_b);
             if (n2) {
                 // start pass; results end up in the natural order of the gate-passer list (iota2 stands for the plan order)
                 iota2.reserve(n2); s2s.reserve(n2); q2os.reserve(n2); t2os.reserve(n2);
@@ -1175,7 +1216,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                     stats.cells_start += hc;
                 }
                 hipLaunchKernelGGL(finalize_kernel, grid_for(n2), dim3(256), 0, s, n2, iota2.p, link.p, Lidx, q2.p, t2.p, s2.p,
-                                   q2o.p, t2o.p, ddb.len, p.cov, p.cov_mode, d_alns.p + b, eflag.p, mism.p);
+                                   q2o.p, t2o.p, ddb.len, p.cov, p.cov_mode, alns_b, eflag.p, mism.p);
                 scan_u32(*this, tmp, eflag.p, epos.p, n2, false);
                 uint32_t ne = scan_total(*this, eflag.p, epos.p, n2);
                 if ((p.min_seq_id > 0.0f || p.want_tb) && ne) {
@@ -1198,7 +1239,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                         q3.reserve(nt); t3.reserve(nt); src3.reserve(nt); qs3.reserve(nt); qe3.reserve(nt); ts3.reserve(nt); te3.reserve(nt);
                         pack3.reserve(nt); gaps3.reserve(nt); sc3.reserve(nt);
                         hipLaunchKernelGGL(tb_gather_kernel, grid_for(n2), dim3(256), 0, s, n2, flag, tpos.p, iota2.p, link.p, Lidx, q2.p,
-                                           t2.p, d_alns.p + b, q3.p, t3.p, qs3.p, qe3.p, ts3.p, te3.p, src3.p, sc3.p);
+                                           t2.p, alns_b, q3.p, t3.p, qs3.p, qe3.p, ts3.p, te3.p, src3.p, sc3.p);
                         static const uint32_t tb_gaps[4] = {0u, 0u, 1u, 0u};
                         uint64_t launches = 0;
                         int passes = 1;
@@ -1246,7 +1287,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                         stats.cells_run += passes * P3.cells;
                         stats.n_sw_runs += (uint64_t)passes * P3.n;
                         hipLaunchKernelGGL(tb_apply_kernel, grid_for(nt), dim3(256), 0, s, nt, P3.idx.p, src3.p, pack3.p,
-                                           p.want_tb ? gaps3.p : (const int32_t *)nullptr, iota2.p, link.p, Lidx, p.min_seq_id, d_alns.p + b,
+                                           p.want_tb ? gaps3.p : (const int32_t *)nullptr, iota2.p, link.p, Lidx, p.min_seq_id, alns_b,
                                            eflag.p, ttie.p);
                     };
                     // the walk over H bytes needs neighbouring cells within 127 of each other: largest substitution score + gap open
@@ -1263,10 +1304,10 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                     auto run_tb = [&](const uint32_t *flag) {
                         if (!p.sw_pk || !tb_bytes_ok) { tb_batch(flag, false); return; }
                         tlo.reserve(n2); thi.reserve(n2); tchunk.reserve(n2); tcpos.reserve(n2);
-                        hipLaunchKernelGGL(tb_split_kernel, grid_for(n2), dim3(256), 0, s, n2, flag, link.p, Lidx, d_alns.p + b, SW_PK_OVF_HOST, tlo.p, thi.p);
+                        hipLaunchKernelGGL(tb_split_kernel, grid_for(n2), dim3(256), 0, s, n2, flag, link.p, Lidx, alns_b, SW_PK_OVF_HOST, tlo.p, thi.p);
                         tb_batch(thi.p, false);                               // scores beyond the packed range: int32 MODE 3
                         UC_HIP(hipMemsetAsync(d_cells.p, 0, 8, s));
-                        hipLaunchKernelGGL(tb_estimate_kernel, grid_for(n2), dim3(256), 0, s, n2, tlo.p, q2.p, link.p, Lidx, d_alns.p + b, ddb.len, d_cells.p);
+                        hipLaunchKernelGGL(tb_estimate_kernel, grid_for(n2), dim3(256), 0, s, n2, tlo.p, q2.p, link.p, Lidx, alns_b, ddb.len, d_cells.p);
                         scan_u32(*this, tmp, tlo.p, tcpos.p, n2, false);
                         const uint32_t nlo = scan_total(*this, tlo.p, tcpos.p, n2);
                         unsigned long long est = 0;
@@ -1294,10 +1335,10 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                     };
                     if (dedup) {
                         hipLaunchKernelGGL(tbm_flag_kernel, grid_for(n2), dim3(256), 0, s, n2, eflag.p, link.p, Lidx, mirror.p, gflag.p, gpos.p,
-                                           d_alns.p + b, trun.p, tpart.p);
+                                           alns_b, trun.p, tpart.p);
                         run_tb(trun.p);
                         hipLaunchKernelGGL(tbm_resolve_kernel, grid_for(n2), dim3(256), 0, s, n2, tpart.p, ttie.p, link.p, Lidx, p.min_seq_id,
-                                           d_alns.p + b, eflag.p, trun.p);
+                                           alns_b, eflag.p, trun.p);
                         run_tb(trun.p);   // mirrors whose representative had a gap-direction tie on its traceback
                     } else {
                         UC_HIP(hipMemcpyAsync(trun.p, eflag.p, (size_t)n2 * 4, hipMemcpyDeviceToDevice, s));
@@ -1327,6 +1368,10 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
             if (bad) fail(UC_ERR_GENERIC, "start pass score differs from the forward score for %u pairs", bad);
             stats.n_gapped_alignments += n;
             stats.n_start_alignments += n2;
+            if (alns_b != d_alns.p + b) {
+                hipLaunchKernelGGL(len_gate_putback_kernel, grid_for(n), dim3(256), 0, s, n, A.lg_map.p, (const uc_aln *)alns_b, d_alns.p + b);
+                UC_HIP(hipStreamSynchronize(s));
+            }
         }
         qa = qb;
     }

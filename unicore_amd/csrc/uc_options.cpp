@@ -118,7 +118,7 @@ int option_arity(const std::string &f) {
         "--gap-open", "--gap-extend", "--spaced-kmer-pattern", "--rev-correction", "--linclust", "--kmer-per-seq", "--sym-dedup",
         "--sw-kernel", "--evalue-lambda", "--evalue-k", "--mat3di", "--mat-aa", "--cluster-mode", "--cluster-steps",
         "--alignment-type", "--alignment-mode", "--threads", "-v", "--remove-tmp-files", "--db-load-mode", "--compressed",
-        "--gpus", "--target-shards", "--mat-bit-factor-3di", "--mat-bit-factor-aa", "--comp-bias-corr", "--comp-bias-corr-scale", "--min-score-table"};
+        "--gpus", "--target-shards", "--mat-bit-factor-3di", "--mat-bit-factor-aa", "--comp-bias-corr", "--comp-bias-corr-scale", "--min-score-table", "--length-gate"};
     for (const char *v : valued) if (f == v) return 1;
     if (f == "--single-step-clustering") return 2;
     return -1;
@@ -164,6 +164,7 @@ void parse_cluster_options(const std::string &opts, Params &p) {
         else if (f == "--comp-bias-corr") { p.comp_bias = to_int(f, value()) != 0; }
         else if (f == "--comp-bias-corr-scale") { const double v = to_double(f, value()); if (v < 0 || v > 8) fail(UC_ERR_ARGS, "--comp-bias-corr-scale must be in [0,8]"); p.comp_bias_milli = (int)std::lround(v * 1000.0); }
         else if (f == "--min-score-table") { p.min_score_table_path = value(); }
+        else if (f == "--length-gate") { p.len_gate = to_int(f, value()) != 0; }
         else if (f == "--cluster-mode") { p.cluster_mode = to_int(f, value()); if (p.cluster_mode != 0) fail(UC_ERR_ARGS, "--cluster-mode %d unsupported (only 0 = greedy set cover)", p.cluster_mode); }
         else if (f == "--single-step-clustering") { p.single_step = opt_bool(); p.single_step_given = true; }
         else if (f == "--cluster-steps") { p.cluster_steps = to_int(f, value()); p.cluster_steps_given = true; }

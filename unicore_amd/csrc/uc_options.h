@@ -48,6 +48,7 @@ struct Params {
     int comp_bias_milli = 1000;             // --comp-bias-corr-scale F, in thousandths (exact integer arithmetic on both sides)
     std::string min_score_table_path;       // --min-score-table FILE: one integer per sequence replaces the Karlin-Altschul threshold (plain step only)
     std::vector<int32_t> min_score_table;
+    int len_gate = 0;                       // --length-gate 1 (rule UC-1/L, optional): pairs whose lengths alone rule the coverage threshold out are not aligned
     // clustering
     int cluster_mode = 0;
     int cluster_steps = 1;      // > 1: cascade (E8) — rounds on representatives with rising sensitivity, merged at the end
