@@ -724,6 +724,17 @@ def main():
         U.lib().uc_release_scratch()
         subs["c5-mini"] = c5_mini(args)
         out["configs"] = subs
+    if world == 1 and args.config == "c2" and not custom and not args.no_extra_legs:
+        # optional rule UC-1/L (default OFF): the headline workload with MMseqs2's length gate in front of the gapped stage -
+        # what the step costs if Foldseek's aligner skips the pairs whose lengths alone rule the coverage threshold out (believed, EXT-UNVERIFIED).
+        # value counts the pairs that WERE aligned, not the listed ones.
+        U.lib().uc_release_scratch()
+        p2 = CONFIGS["c2"]
+        og, _, _, _ = run_config(p2[0], p2[1], p2[2], p2[3], p2[4] + " --length-gate 1", p2[5], True, max(1, min(args.steps, 3)), 1)
+        out["optional_rules"] = {"UC-1/L": {"options": p2[4] + " --length-gate 1", "default": "off", "ms_per_step": og["ms_per_step"], "value": og["value"], "unit": "alignments/s",
+                                            "alignments_per_step": og["config"]["alignments_per_step"], "listed_pairs_per_step": out["config"]["alignments_per_step"],
+                                            "clusters": og["config"]["clusters"], "sw_kernel_ms_per_step": og["roofline"]["kernel_ms_per_step"],
+                                            "cells_run_per_step": og["roofline"]["cells_run_per_step"]}}
     if world > 1 and args.config == "c2" and not custom and not args.no_sub_records:
         # the configuration BASELINE names for the 8-GPU node (configs[2]: 500 proteomes, target DB sharded across the ranks): ONE timed pass
         # after one warm-up pass with all N ranks; the headline above stays configs[1] so that the N = 1 point of a scaling run agrees with BENCH

@@ -510,14 +510,15 @@ uint64_t cluster_step(Engine &E, Comm &C, int target_shards, uint32_t *assign) {
         prefilter_cell(E, C.world, target_shards, C.rank);
         E.stats.phase_seconds[0] += tp.seconds();
     }
-    uint64_t n_aln = E.n_hits;
-    if (C.world > 1 || C.uses_rccl) n_aln = exchange_hits(E, C);
+    if (C.world > 1 || C.uses_rccl) (void)exchange_hits(E, C);
+    const uint64_t aln_before = E.stats.n_gapped_alignments;
     {
         Turn turn(C, &E);
         Timer ta;
         E.align(0, n);
         E.stats.phase_seconds[5] += ta.seconds();
     }
+    const uint64_t n_aln = E.stats.n_gapped_alignments - aln_before;   // pairs this rank aligned: its installed lists minus what an optional length gate (UC-1/L) ruled out
     if (C.world == 1 && !C.uses_rccl) {   // one rank: the graph is built straight from the device-resident edge list
         if (!assign && n) fail(UC_ERR_ARGS, "cluster_step: rank 0 needs an assignment buffer");
         Timer tc;
