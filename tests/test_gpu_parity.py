@@ -390,7 +390,7 @@ def ref_pairs(cnt, hits):
     return _REF_PAIRS[key]
 
 
-@pytest.mark.parametrize("opts", ["-c 0.8", "-c 0.3 -e 1e-3 --max-seqs 12 --cov-mode 2"])
+@pytest.mark.parametrize("opts", ["-c 0.8", "-c 0.3 -e 1e-3 --max-seqs 12 --cov-mode 2", "-c 0.7 --cov-mode 1 --length-gate 1"])      # last: rule UC-1/L on the search path
 def test_search_m8_bytes(O, tmp_path, opts):
     """uc_search + uc_convertalis (query DB vs target DB, same kernels, traceback statistics for
     every accepted pair incl. the gap count) == the oracle's search + BLAST-tab writer, byte for byte"""
