@@ -239,12 +239,23 @@ def main():
     tmp = os.path.join(work, "tmp")
     v = subprocess.run([a.foldseek, "version"], capture_output=True, text=True).stdout.strip()
     print("foldseek %s (%s)" % (v, a.foldseek))
-    subprocess.check_call([a.foldseek, "cluster", a.db, os.path.join(work, "out_cluster"), tmp] + a.options.split() +
+    # flags of this repository's optional rules steer the ORACLE side only: Foldseek does not know them
+    own = {"--mat-bit-factor-3di", "--mat-bit-factor-aa", "--min-score-table", "--length-gate"}
+    tok, theirs_opts, i = a.options.split(), [], 0
+    while i < len(tok):
+        if tok[i] in own: i += 2; continue
+        theirs_opts.append(tok[i]); i += 1
+    subprocess.check_call([a.foldseek, "cluster", a.db, os.path.join(work, "out_cluster"), tmp] + theirs_opts +
                           ["--single-step-clustering", "-v", "3", "--remove-tmp-files", "0"])
     theirs = load_tmp(tmp)
     ours = oracle_single_step(a.db, a.options)
     stage = compare(ours, theirs)
     print("first diverging stage: %s" % (["E2-E4 prefilter", "E5-E6 alignment", "E7 set cover"][stage] if stage >= 0 else "none — identical at every stage"))
+    # the optional rules (all default off) that move each stage: try them one at a time through --options
+    hints = {0: "stage 1 rules: --mat-bit-factor-3di 2.1 --mat-bit-factor-aa 1.4 (UC-1/M), --comp-bias-corr 1 (UC-1/B)",
+             1: "stage 2 rules: --length-gate 1 (UC-1/L: pairs missing on Foldseek's side whose lengths rule the coverage out), --min-score-table FILE (UC-1/E)"}
+    if stage in hints:
+        print("switchable " + hints[stage])
     if not a.keep:
         shutil.rmtree(work, ignore_errors=True)
     return 0 if stage < 0 else 1
