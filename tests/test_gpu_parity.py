@@ -853,6 +853,7 @@ def test_random_option_sets_against_the_oracle(O, seed):
     eng = []
     if rng.random() < 0.3: eng.append("--sym-dedup 0")
     if rng.random() < 0.3: eng.append("--sw-kernel i32")
+    if rng.random() < 0.35: opts.append("--length-gate 1")     # optional rule UC-1/L (drawn last: the other draws of a seed are what they were)
     ostr = " ".join(opts)
     off, c3, ca = util.flat(s3, sa)
     e = U.Engine(ostr + " " + " ".join(eng), verbosity=1)

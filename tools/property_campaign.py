@@ -44,6 +44,7 @@ for seed in range(first, first + nw):
         steps, lin, m = int(rng.integers(1, 4)), int(rng.integers(0, 2)), int(rng.choice([3, 5, 20, 40]))
         base = "-c %.1f --cov-mode %d" % (rng.choice([0.5, 0.8, 0.9]), rng.integers(0, 3))
         if rng.random() < 0.3: base += " --min-seq-id %.1f" % rng.choice([0.3, 0.5])
+        if rng.random() < 0.3: base += " --length-gate 1"      # optional rule UC-1/L through every round of the workflow
         opts = base + " --linclust %d --cluster-steps %d" % (lin, steps) + (" --kmer-per-seq %d" % m if lin else "")
         if steps == 1 and not lin: opts = base + " --single-step-clustering"
         st = U.cluster(db, os.path.join(d, "c_cluster"), os.path.join(d, "tmp"), opts, threads=4)
