@@ -25,7 +25,12 @@ CONFIGS = {
     # configs[3]'s options at 200 proteomes (636 k sequences, 190 M residues, ~2.2e12 k-mer hits: dozens of density-cut target chunks, the
     # similar k-mers enumerated once per query part and cached — DESIGN.md 4.3 item 7); r2 could not run this size inside a test budget
     "c4-200": dict(proteomes=200, seed=0x5EED0004, opts="-c 0.8 --min-seq-id 0.3 -s 7.5", min_aln=150_000_000, sample=500, block=1000),
+    # optional rule UC-1/L (length gate before the gapped stage, default off) at size: configs[3]'s options on 50 proteomes in the suite,
+    # configs[2] behind UC_TEST_AT_SIZE_EXTRA=1 (builder-run, log under profiles/)
+    "c4-lite-gate": dict(proteomes=50, seed=0x5EED0004, opts="-c 0.8 --min-seq-id 0.3 -s 7.5 --length-gate 1", min_aln=5_000_000, sample=2000, block=4000),
+    "c3-gate": dict(proteomes=500, seed=0x5EED0003, opts="-c 0.8 --length-gate 1", min_aln=200_000_000, sample=2000, block=1500),
 }
+EXTRA = ["c3-gate"] if os.environ.get("UC_TEST_AT_SIZE_EXTRA") else []
 
 
 @pytest.fixture(scope="module")
@@ -34,7 +39,7 @@ def O():
     return oracle_py
 
 
-@pytest.mark.parametrize("name", ["c3", "c4-lite", "c4-200"])
+@pytest.mark.parametrize("name", ["c3", "c4-lite", "c4-200", "c4-lite-gate"] + EXTRA)
 def test_config_at_size(name, O, tmp_path_factory):
     import unicore_amd as U
     cfg = CONFIGS[name]
@@ -49,7 +54,8 @@ def test_config_at_size(name, O, tmp_path_factory):
     e.prefilter()
     e.align()
     st = e.stats()
-    assert st["n_gapped_alignments"] >= cfg["min_aln"] and st["n_gapped_alignments"] == e.hits_size()
+    gate = "--length-gate 1" in opts          # gated pairs stay in the hit lists but are not alignments
+    assert st["n_gapped_alignments"] >= cfg["min_aln"] and (st["n_gapped_alignments"] < e.hits_size() if gate else st["n_gapped_alignments"] == e.hits_size())
     edges = e.edges()
     assign = e.setcover(edges)
     n_clusters = int((assign == np.arange(n)).sum())
