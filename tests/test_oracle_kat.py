@@ -439,7 +439,13 @@ ix = O.build_index(odb, p)
 n, _, _, cnt, hits, alns = O.simd_sample_run(odb, ix, p, np.arange(odb.n, dtype=np.uint32), threads=2, records=True)
 O.free_index(ix)
 O.write_tsv(%r, odb, r["assign"])
-print("RESULT", int(r["counts"]["n_alignments"]), int(r["counts"]["n_clusters"]), int(w["counts"]["n_clusters"]), n, int(alns["accepted"].sum()))
+pg = util.oracle_params(O, "-c 0.8 --length-gate 1 --min-seq-id 0.3")      # optional rule UC-1/L through both legs
+rg = O.cluster(odb, pg, threads=2)
+ix = O.build_index(odb, pg)
+ng, _, _, _, _, ag = O.simd_sample_run(odb, ix, pg, np.arange(odb.n, dtype=np.uint32), threads=2, records=True)
+O.free_index(ix)
+print("RESULT", int(r["counts"]["n_alignments"]), int(r["counts"]["n_clusters"]), int(w["counts"]["n_clusters"]), n, int(alns["accepted"].sum()),
+      int(rg["counts"]["n_alignments"]), int(rg["counts"]["n_clusters"]), ng, int(ag["accepted"].sum()))
 """ % (ROOT, os.path.join(ROOT, "tests"), str(tmp_path / "a.tsv"))
     outs = []
     for lib_env in ({"UC_ORACLE_LIB": so, "LD_PRELOAD": subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip(),
