@@ -670,14 +670,6 @@ static void build_plan(Engine &E, SwPlan &P, DevBuf<char> &tmp, uint32_t n, cons
         if (E.device < 0 || E.device >= 64 || !uploaded[E.device]) {
             ClassTable t[3];
             memcpy(t, h_tab, sizeof t);
-            if (const char *e = getenv("UC_SW_TCAP")) {   // tuning aid: pairs per task of table 1 for G = 16, G = 32, G = 64 (R <= 24), G = 64 (R > 24)
-                unsigned v[4] = {0, 0, 0, 0};
-                if (sscanf(e, "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]) == 4)
-                    for (int c = 0; c < t[1].n; c++) {
-                        const unsigned x = t[1].G[c] == 16 ? v[0] : t[1].G[c] == 32 ? v[1] : t[1].R[c] <= 24 ? v[2] : v[3];
-                        if (x) t[1].tcap[c] = x;
-                    }
-            }
             UC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), t, sizeof t));
             if (E.device >= 0 && E.device < 64) uploaded[E.device] = true;
         }
@@ -1546,7 +1538,7 @@ void Engine::set_cover_graph(uint32_t n, const uint32_t *h_edges, const uint32_t
         hipLaunchKernelGGL(edge_adj_kernel, grid_for(m), dim3(256), 0, stream, m, key2.p, flag.p, pos.p, ukey.p, d_adj.p);
         hipLaunchKernelGGL(edge_off_kernel, grid_for((uint64_t)n + 1), dim3(256), 0, stream, n, ukey.p, (uint64_t)mu, d_off.p);
         UC_HIP(hipGetLastError());
-        const bool timing = getenv("UC_SETCOVER_TIMING") != nullptr;
+        const bool timing = getenv("UC_TIMING") != nullptr;
         if (timing) { UC_HIP(hipStreamSynchronize(stream)); fprintf(stderr, "set_cover_device: graph on the GPU %.2f ms\n", t_graph.seconds() * 1e3); }
         // the greedy cover itself, on the device too (parallel rounds, see above): neither the adjacency (2 x edges x 4 bytes) nor the serial
         // host sweep — rank 0's Amdahl term of an N-GPU pass — is left; only the assignment comes back

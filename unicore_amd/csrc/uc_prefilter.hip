@@ -1410,7 +1410,7 @@ void Engine::prefilter_impl(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uin
     // attracts, i.e. on the sensitivity (-s 7.5 gives ~30x the hits of the default 4): prefilter_one measures the density
     // (k-mer hits per query residue) of its first batch and gives up before expanding anything if the chunk is too dense;
     // the range is then re-cut into proportionally smaller chunks (one wasted enumeration pass).
-    const double DENSITY_LIMIT = getenv("UC_DENSITY_LIMIT") ? atof(getenv("UC_DENSITY_LIMIT")) : 400.0;   // hits per query residue and chunk (C2 whole DB at -s 4: 124)
+    const double DENSITY_LIMIT = 400.0;   // hits per query residue and chunk (C2 whole DB at -s 4: 124)
     for (int attempt = 0;; attempt++) {
         std::vector<std::pair<uint32_t, uint32_t>> chunks;
         for (uint32_t b = tbegin; b < tend;) {

@@ -77,7 +77,7 @@ static void greedy_cover(uint32_t n, const uint64_t *off, const uint32_t *adj, c
 }
 
 void set_cover(uint32_t n, const uint32_t *edges, uint64_t n_edges, uint32_t *assign) {
-    const bool timing = getenv("UC_SETCOVER_TIMING") != nullptr;
+    const bool timing = getenv("UC_TIMING") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;

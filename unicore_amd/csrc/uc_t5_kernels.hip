@@ -445,8 +445,7 @@ static void t5_gemm256x_launch(const void *A, const void *W, void *out, int M, i
         cus[dev] = hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount >= 8 ? pr.multiProcessorCount : 256;
         once[dev] = true;
     }
-    static const int gxm_env = getenv("UC_T5_GXM") ? atoi(getenv("UC_T5_GXM")) : 0;
-    const int gxm = gxm_env > 0 ? gxm_env : 2;
+    const int gxm = 2;     // M-tiles per XCD group (swept in r03: profiles/r03_t5_gxm*.log)
     const int nn = N / HBN_, nm = (M + HBM_ - 1) / HBM_, n_local = ((nm + 7) / 8 + gxm - 1) / gxm * gxm * nn;
     const int slots = std::min(n_local, std::max(1, cus[dev] / 8));
     hipLaunchKernelGGL(t5_gemm256x_kernel<EPI>, dim3((unsigned)(8 * slots)), dim3(512), LDS, s, (const _Float16 *)A, (const _Float16 *)W, out, M, N, K, gxm, slots);
