@@ -150,6 +150,9 @@ AT_SIZE = {
     # BASELINE configs[3] at its NOMINAL size.  One pass takes minutes; the oracle side (four sub-database indexes over up to 1.9 G residues and
     # 4 x 300 sampled queries) a few more.
     "c4": dict(proteomes=2000, seed=0x5EED0004, opts="-c 0.8 --min-seq-id 0.3 -s 7.5", s=7.5, per_round=300, min_aln=400_000_000),
+    # optional rule UC-1/L (length gate, default off) through every round at configs[2] size, against tests/golden/c3-gate_workflow_sha.json
+    # (the CPU oracle's workflow with the rule on, end to end); behind UC_TEST_AT_SIZE_EXTRA=1 - builder-run, log under profiles/
+    "c3-gate": dict(proteomes=500, seed=0x5EED0003, opts="-c 0.8 --length-gate 1", s=4.0, per_round=500, min_aln=20_000_000),
 }
 
 
@@ -163,12 +166,15 @@ def test_default_workflow_at_size(name, O, tmp_path_factory):
     if name == "c4" and os.environ.get("UC_TEST_NOMINAL_C4") != "1":
         pytest.skip("the nominal 2000-proteome case takes ~15 min (5 min on the GPU, the rest in the CPU oracle's four sub-database passes): "
                     "set UC_TEST_NOMINAL_C4=1; the builder's run is committed as profiles/r04/test_workflow_c4_nominal.log")
+    if name == "c3-gate" and not os.environ.get("UC_TEST_AT_SIZE_EXTRA"):
+        pytest.skip("set UC_TEST_AT_SIZE_EXTRA=1 (the builder's run: profiles/r04/gpu_test_workflow_c3_gate.log)")
     d = tmp_path_factory.mktemp("wf_" + name.replace("-", "_"))
     db = util.gen_synth_db(str(d / "db"), cfg["proteomes"], cfg["seed"], 6000, 1.0)
     out = str(d / "clust")
     st, recs = run_with_round_samples(U, db, out + "_cluster", str(d / "tmp"), cfg["opts"], cfg["per_round"], 20260929)
     n = st["n_seqs"]
-    assert st["n_gapped_alignments"] >= cfg["min_aln"] and st["n_gapped_alignments"] == sum(r["n_pairs"] for r in recs)
+    listed = sum(r["n_pairs"] for r in recs)      # under the length gate (UC-1/L) the listed pairs that are ruled out are no alignments
+    assert st["n_gapped_alignments"] >= cfg["min_aln"] and (st["n_gapped_alignments"] < listed if "--length-gate 1" in cfg["opts"] else st["n_gapped_alignments"] == listed)
     sizes = [len(r["ids"]) for r in recs]
     assert sizes[0] == n and all(a >= b for a, b in zip(sizes, sizes[1:])) and sizes[1] < n
     assert 0 < st["n_clusters"] <= sizes[-1]

@@ -24,7 +24,20 @@ CONFIGS = {  # == bench.py CONFIGS / tests/test_configs_gpu.py / tests/test_work
     "c3": (500, 6000, 1.0, 0x5EED0003, "-c 0.8", 4.0),
     "c4-200": (200, 6000, 1.0, 0x5EED0004, "-c 0.8 --min-seq-id 0.3 -s 7.5", 7.5),
     "c4-500": (500, 6000, 1.0, 0x5EED0004, "-c 0.8 --min-seq-id 0.3 -s 7.5", 7.5),
+    "c3-gate": (500, 6000, 1.0, 0x5EED0003, "-c 0.8 --length-gate 1", 4.0),      # optional rule UC-1/L on (default off)
+    "c2-gate": (50, 6000, 1.0, 0x5EED0002, "-c 0.8 --length-gate 1", 4.0),
 }
+
+
+def covered(p, lq, lt):
+    """rule UC-1/L as the C side evaluates it (float32 division): which pairs the length gate lets through; all of them when the rule is off"""
+    lq, lt = np.broadcast_arrays(np.asarray(lq, np.int64), np.asarray(lt, np.int64))
+    if not p.len_gate or not p.cov > 0:
+        return np.ones(lq.shape, bool)
+    a, b, c = lq.astype(np.float32), lt.astype(np.float32), np.float32(p.cov)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r1, r2 = a / b >= c, b / a >= c
+    return ((r1 & r2) if p.cov_mode == 0 else r1 if p.cov_mode == 1 else r2) & (lq > 0) & (lt > 0)
 
 
 def run_chunked(odb, p, threads, chunk, work, log=None):
@@ -60,9 +73,10 @@ def run_chunked(odb, p, threads, chunk, work, log=None):
             qq = np.broadcast_to(q[:, None], acc.shape)
             e = np.stack([qq[acc], hits["t"][acc]], axis=1).astype(np.uint32)      # (q asc, list order) == uco_cluster's edge order
             cn = dict(pc)
-            cn["n_alignments"] = int(cnt.sum()); cn["n_edges"] = int(len(e))
-            cn["cells_fwd"] = int((lq * lt).sum())
-            cn["cells_rev"] = int((lq * lt * (valid & (alns["score"] >= ms))).sum()) if p.rev_correction else 0
+            cov = valid & covered(p, lq, lens[hits["t"]])          # gated pairs (rule UC-1/L) are no alignments and run no cells
+            cn["n_alignments"] = int(cov.sum()); cn["n_edges"] = int(len(e))
+            cn["cells_fwd"] = int((lq * lt * cov).sum())
+            cn["cells_rev"] = int((lq * lt * (cov & (alns["score"] >= ms))).sum()) if p.rev_correction else 0
             cn["cells_start"] = int((((alns["qend"].astype(np.int64) + 1) * (alns["tend"].astype(np.int64) + 1)) * (valid & (alns["pass_evalue"] == 1))).sum())
             assert npairs == cn["n_alignments"]
             if ck:
@@ -102,8 +116,9 @@ def run_workflow(odb, p, target_s, steps, m, threads, chunk, work, log=None):
             lq, lt = lens[pairs[:, 0]], lens[pairs[:, 1]]
             ms = np.array([O.lib().uco_min_score(p, int(l), int(off[-1])) for l in np.unique(lq)], np.int64)
             msq = ms[np.searchsorted(np.unique(lq), lq)]
-            c = dict(n_prefilter_hits=len(pairs), n_alignments=len(pairs), n_edges=int((al["accepted"] == 1).sum()),
-                     cells_fwd=int((lq * lt).sum()), cells_rev=int((lq * lt * (al["score"] >= msq)).sum()) if p.rev_correction else 0,
+            cov = covered(p, lq, lt)
+            c = dict(n_prefilter_hits=len(pairs), n_alignments=int(cov.sum()), n_edges=int((al["accepted"] == 1).sum()),
+                     cells_fwd=int((lq * lt * cov).sum()), cells_rev=int((lq * lt * (cov & (al["score"] >= msq))).sum()) if p.rev_correction else 0,
                      cells_start=int(((al["qend"].astype(np.int64) + 1) * (al["tend"].astype(np.int64) + 1) * (al["pass_evalue"] == 1)).sum()))
             sa_ = O.setcover(sub.n, pairs[al["accepted"] == 1]).astype(np.int64)
             if log: log("pre-step: %d sequences, %d pairs, %d accepted" % (sub.n, len(pairs), c["n_edges"]))
@@ -130,18 +145,19 @@ def selfcheck():
     """the chunked driver == uco_cluster (assignment and all counters) on a family database"""
     s3, sa = util.family_db(11, n_fam=40, members=6, extra=(700, 900))
     odb = O.OracleDb(s3=s3, sa=sa)
-    p = util.oracle_params(O, "-c 0.8")
-    ref = O.cluster(odb, p, threads=4, dumps=False)
-    assign, tot, _ = run_chunked(odb, p, 4, 37, None)
-    assert np.array_equal(assign, ref["assign"])
-    for k, v in ref["counts"].items():
-        assert int(v) == tot[k], (k, int(v), tot[k])
+    for opts in ("-c 0.8", "-c 0.8 --length-gate 1", "-c 0.7 --cov-mode 2 --length-gate 1"):       # the last two: optional rule UC-1/L
+        p = util.oracle_params(O, opts)
+        ref = O.cluster(odb, p, threads=4, dumps=False)
+        assign, tot, _ = run_chunked(odb, p, 4, 37, None)
+        assert np.array_equal(assign, ref["assign"])
+        for k, v in ref["counts"].items():
+            assert int(v) == tot[k], (opts, k, int(v), tot[k])
     # ... and the workflow driver == uco_cluster_workflow on a synthetic proteome set
     import tempfile
     d = tempfile.mkdtemp(prefix="uc_oas_")
     db = util.gen_synth_db(os.path.join(d, "db"), 6, 0x5EED0004, 40, 0.6)
     odb = O.OracleDb(db)
-    for opts, s_ in (("-c 0.8", 4.0), ("-c 0.8 --min-seq-id 0.3 -s 7.5", 7.5)):
+    for opts, s_ in (("-c 0.8", 4.0), ("-c 0.8 --min-seq-id 0.3 -s 7.5", 7.5), ("-c 0.8 --length-gate 1", 4.0)):
         p = util.oracle_params(O, opts)
         ref = O.cluster_workflow(odb, p, O.cascade_thresholds(p, s_, 3), linclust_m=20, threads=4)
         assign, tot, sizes = run_workflow(odb, p, s_, 3, 20, 4, 50, None)
