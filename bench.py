@@ -29,8 +29,9 @@ N > 1   : one process per GPU (torch.distributed.run).  The data path is inside 
           `configs.c3`: ONE warm pass of configs[2] — the configuration BASELINE names for the 8-GPU node — over all N ranks, with
           per-phase maxima over ranks, rccl_ranks and exchange bytes.
 also (N = 1, default config): `configs` — sub-records measured in the same run: c3 (BASELINE configs[2] = north_star's quoted
-          1-GPU target size, 500 proteomes: ONE timed pass after one warm-up pass, with its own roofline block and CPU baseline sample) and c5-mini
-          (the ProstT5 encoder's MFMA fraction on one synthetic proteome); `value_one_shot_processes` — what an unmodified
+          1-GPU target size, 500 proteomes: ONE timed pass after one warm-up pass, with its own roofline block and CPU baseline sample), c5-mini
+          (the ProstT5 encoder's MFMA fraction on one synthetic proteome) and c4 (BASELINE configs[3] at its NOMINAL 2000 proteomes: one
+          uc_cluster call through the default workflow with its rooflines, rounds and round-by-round CPU leg; --no-c4 skips it); `value_one_shot_processes` — what an unmodified
           Unicore experiences: the two spawns of cluster.rs:45-64 (`foldseek cluster` + `foldseek createtsv` through the shim),
           wall from process start to clust.tsv.
 
@@ -388,8 +389,8 @@ def cpu_baseline_workflow(prefix, options, rounds, total_alignments, seconds_per
             "rounds": per_round}
 
 
-def bench_workflow(args, proteomes, families, len_scale, seed, options, label, custom):
-    """`--workflow default`: one step = one `uc_cluster(db, options)` call — the call of cluster.rs:45-49, which forwards the option string
+def bench_workflow(args, proteomes, families, len_scale, seed, options, label, custom, steps=None, warmup=None, cpu_seconds=None):
+    """-> the line as a dict.  `--workflow default`: one step = one `uc_cluster(db, options)` call — the call of cluster.rs:45-49, which forwards the option string
     WITHOUT --single-step-clustering — i.e. the linear-time pre-step + the 3-step cascade, one C entry point, from the DB files (page cache
     warm) to the cluster DB.  `value` excludes the host-side read + encode of the DB files (uc_stats.stage_seconds[load]; the contract's
     'inputs resident'); `value_disk_to_cluster_db` includes it.  One GPU (the N-GPU form of the workflow runs inside uc_cluster with --gpus N)."""
@@ -416,14 +417,16 @@ def bench_workflow(args, proteomes, families, len_scale, seed, options, label, c
         finally:
             U.set_round_hook(None)
         return st, time.perf_counter() - stamp[0]
-    for _ in range(args.warmup):
+    n_steps = args.steps if steps is None else steps
+    n_warm = args.warmup if warmup is None else warmup
+    for _ in range(n_warm):
         one(False)
     walls, loads, sts = [], [], []
-    for k in range(args.steps):
-        st, w = one(k == args.steps - 1)
+    for k in range(n_steps):
+        st, w = one(k == n_steps - 1)
         walls.append(w); loads.append(st["stage_seconds"][0]); sts.append(st)
     st = sts[-1]
-    steps_ = max(args.steps, 1)
+    steps_ = max(n_steps, 1)
     n_aln = sum(x["n_gapped_alignments"] for x in sts)
     dt, dl = sum(walls), sum(loads)
     sw_s = sum(x["sw_kernel_ms"] for x in sts) / 1e3
@@ -441,7 +444,7 @@ def bench_workflow(args, proteomes, families, len_scale, seed, options, label, c
                    "s_until_gapped_stage_done": r["t_since_call_s"] - prev})
         prev = r["t_since_call_s"]
     out = {
-        "metric": "3Di alignments/sec (cluster path)", "value": n_aln / (dt - dl), "unit": "alignments/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "metric": "3Di alignments/sec (cluster path)", "value": n_aln / (dt - dl), "unit": "alignments/s", "n_gpus": 1, "steps": n_steps, "warmup": n_warm,
         "ms_per_step": 1e3 * (dt - dl) / steps_, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
         "config": {"workload": "%s: %d synthetic proteomes, %d seqs, %d residues, options '%s' as cluster.rs:45-49 forwards them (no --single-step-clustering): DEFAULT workflow = "
                                "linear-time pre-step + 3-step cascade, gen_synth seed %#x, synthetic stand-in 3Di matrix" % (label if not custom else "custom size", proteomes,
@@ -472,8 +475,9 @@ def bench_workflow(args, proteomes, families, len_scale, seed, options, label, c
     }
     U.lib().uc_release_scratch()
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_workflow(prefix, options, rounds, st["n_gapped_alignments"], seconds_per_round=max(2.0, args.cpu_seconds / 2.5))
-    print(json.dumps(out))
+        out["cpu_baseline"] = cpu_baseline_workflow(prefix, options, rounds, st["n_gapped_alignments"],
+                                                    seconds_per_round=max(2.0, (args.cpu_seconds if cpu_seconds is None else cpu_seconds) / 2.5))
+    return out
 
 
 def main():
@@ -492,12 +496,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the disk-to-TSV and default-workflow legs")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--no-sub-records", action="store_true", help="skip the c3 / c5-mini sub-records and the one-shot-process leg of the default line")
+    ap.add_argument("--no-sub-records", action="store_true", help="skip the c3 / c5-mini / c4 sub-records and the one-shot-process leg of the default line")
+    ap.add_argument("--no-c4", action="store_true", help="skip the nominal configs[3] sub-record (2000 proteomes: ~6 min incl. database generation and its CPU leg)")
     ap.add_argument("--workflow", choices=["plain", "default"], help="plain = the all-vs-all step (--single-step-clustering semantics; default for c2/c3/c4-lite); "
                     "default = what cluster.rs:45-49 triggers: pre-step + 3-step cascade through one uc_cluster call (default for c4)")
     args = ap.parse_args()
     if args.config == "c5":
         return bench_c5(args)
+    for kv in filter(None, os.environ.get("UC_BENCH_PROTEOMES", "").split(",")):      # test hook, e.g. "c2=5,c3=5": the named configs at a toy size
+        k, v = kv.split("=")
+        CONFIGS[k] = (int(v),) + CONFIGS[k][1:]
     proteomes, families, len_scale, seed, options, label = CONFIGS[args.config]
     custom = any(v is not None for v in (args.proteomes, args.families, args.len_scale, args.options))
     proteomes = args.proteomes if args.proteomes is not None else proteomes
@@ -507,12 +515,17 @@ def main():
     if (args.workflow or ("default" if args.config == "c4" else "plain")) == "default":
         if args.gpus != 1:
             raise SystemExit("--workflow default is a single-process line (uc_cluster spreads over GPUs itself with '--gpus N' in --options)")
-        return bench_workflow(args, proteomes, families, len_scale, seed, options, label, custom)
+        print(json.dumps(bench_workflow(args, proteomes, families, len_scale, seed, options, label, custom)))
+        return
 
     import torch
     import unicore_amd as U
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # the N > 1 code path = everything `multi` switches on: RCCL communicator, gloo control plane, max/sum over ranks, the configs[2] leg over all
+    # ranks, the phase maxima.  UC_BENCH_FORCE_MULTI=1 takes it with ONE rank (a real ncclCommInitRank of world 1 under torch.distributed.run): the
+    # single-GPU box proves the line's N > 1 keys before the 8-GPU node needs them (tests/test_multi_gpu.py)
+    multi = world > 1 or os.environ.get("UC_BENCH_FORCE_MULTI") == "1"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -533,7 +546,7 @@ def main():
     comm = None
     dist = None
     rccl_ranks = 0
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         dist.init_process_group("gloo")                     # control plane only: RCCL id, barriers, max of the timing
         uid = [U.Comm.unique_id() if rank == 0 else None]
@@ -542,7 +555,7 @@ def main():
         rccl_ranks = comm.info()[0]                          # what RCCL itself says (ncclCommCount)
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -574,7 +587,7 @@ def main():
         st = eng.stats()
         eng.close()
         xbytes = 0
-        if world > 1:
+        if multi:
             v = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(v, op=dist.ReduceOp.MAX)
             dt = float(v.item())
@@ -598,7 +611,7 @@ def main():
         swt, pft = pmc_json("sw_traffic.json"), pmc_json("prefilter_traffic.json")
         is_c2 = not custom and label == CONFIGS["c2"][5]                       # the PMC files were collected on configs[1]
         n_streams = int(os.environ.get("UC_STREAMS", "8"))
-        Q, T = (world // (args.target_shards or world), args.target_shards or world) if world > 1 else (1, 1)
+        Q, T = (world // (args.target_shards or world), args.target_shards or world) if multi else (1, 1)
         out = {
             "metric": "3Di alignments/sec (cluster path)",
             "value": n_aln / dt, "unit": "alignments/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -609,7 +622,7 @@ def main():
                        "alignments_per_step": n_aln // steps_, "clusters": int((assign == np.arange(n)).sum()) if assign is not None else None,
                        "parallelism": ("%d query groups x %d target shards; exchange 1: shard lists to the query's home rank (ragged all-to-all, grouped ncclSend/ncclRecv "
                                        "from the C library), merge + top-M of 1/N of the queries per rank; exchange 2: surviving pairs to their owner rank; "
-                                       "edges to rank 0" % (Q, T)) if world > 1 else "single GPU"},
+                                       "edges to rank 0" % (Q, T)) if multi else "single GPU"},
             "rccl_ranks": rccl_ranks,
             "value_definition": "DB resident in HBM at the start of the timed region; see value_disk_to_tsv for SURVEY.md 8(d)'s disk -> clust.tsv wall",
             # dominant kernel: the gapped SW (all classes and passes)
@@ -644,7 +657,7 @@ def main():
                                    "traffic_per_step": pft["bytes_per_step"] if (pft and is_c2) else None,
                                    "traffic_source": pft["source"] if (pft and is_c2) else None},
             "roofline_end_to_end": {"bound": "hbm", "algorithmic_bytes_per_step": all_bytes / steps_,
-                                    "bytes_per_alignment": all_bytes / max(n_aln, 1) if world == 1 else None,
+                                    "bytes_per_alignment": all_bytes / max(n_aln, 1) if not multi else None,
                                     "achieved": all_bytes / dt / 1e9, "peak": HBM_COPY_GBS, "unit": "GB/s", "frac": all_bytes / dt / 1e9 / HBM_COPY_GBS,
                                     "note": "SURVEY.md 8(d): sum of per-stage algorithmic bytes / (wall x 6.29 TB/s); rank 0's bytes when N > 1"},
             "algorithmic_bytes_per_step": {k: v / steps_ for k, v in ab.items()},
@@ -657,14 +670,14 @@ def main():
                                                                    "n_gapped_alignments", "n_start_alignments", "n_pk_reruns")},
             "edges_last_step": st["n_edges"],
         }
-        if world > 1:
+        if multi:
             out["phases_max_over_ranks_s_per_step"] = {k: v / steps_ for k, v in zip(U.PHASES, st["phase_seconds"])}
         return out, prefix, n, workdir
 
     out, prefix, n, workdir = run_config(proteomes, families, len_scale, seed, options, label, custom, args.steps, args.warmup)
 
     if rank == 0:
-        if world == 1 and not args.no_extra_legs:
+        if not multi and not args.no_extra_legs:
             # uc_cluster + uc_createtsv, DB on disk (page cache warm) -> clust.tsv
             outp = os.path.join(workdir, "bench_clust")
             walls = []
@@ -691,12 +704,12 @@ def main():
             if not args.no_sub_records:
                 U.lib().uc_release_scratch()     # this process's parked work buffers (tens of GB) go back first: the spawned processes allocate their own
                 out["value_one_shot_processes"] = one_shot_processes(prefix, workdir, options, s1["n_gapped_alignments"], s2["n_gapped_alignments"])
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             cb = cpu_baseline(prefix, options, n, args.cpu_seconds)
             best = max(cb, key=lambda d: d["value"])
             out["cpu_baseline"] = best                       # the faster CPU leg is THE baseline ...
             out["cpu_baselines"] = cb                        # ... both are reported
-    if world == 1 and args.config == "c2" and not custom and not args.no_sub_records and not args.no_extra_legs:
+    if not multi and args.config == "c2" and not custom and not args.no_sub_records and not args.no_extra_legs:
         U.lib().uc_release_scratch()
         subs = {}
         # north_star's quoted 1-GPU target size (BASELINE configs[2] on one GPU): ONE timed pass after one untimed pass (a cold pass spends
@@ -723,8 +736,17 @@ def main():
         subs["c3"] = o3
         U.lib().uc_release_scratch()
         subs["c5-mini"] = c5_mini(args)
+        if not args.no_c4:
+            # BASELINE configs[3] at its NOMINAL size (2000 proteomes, 6.36 M sequences, "-c 0.8 --min-seq-id 0.3 -s 7.5"): ONE uc_cluster call through the
+            # default workflow (what cluster.rs:35,45-49 forwards), from the DB files; its own rooflines, per-round records and the round-by-round CPU leg
+            U.lib().uc_release_scratch()
+            p4 = CONFIGS["c4"]
+            o4 = bench_workflow(args, p4[0], p4[1], p4[2], p4[3], p4[4], p4[5], False, steps=1, warmup=0, cpu_seconds=min(args.cpu_seconds, 10.0))
+            for k in ("metric", "unit", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "value_definition", "n_gpus"):
+                o4.pop(k, None)
+            subs["c4"] = o4
         out["configs"] = subs
-    if world == 1 and args.config == "c2" and not custom and not args.no_extra_legs:
+    if not multi and args.config == "c2" and not custom and not args.no_extra_legs:
         # optional rule UC-1/L (default OFF): the headline workload with MMseqs2's length gate in front of the gapped stage -
         # what the step costs if Foldseek's aligner skips the pairs whose lengths alone rule the coverage threshold out (believed, EXT-UNVERIFIED).
         # value counts the pairs that WERE aligned, not the listed ones.
@@ -735,7 +757,7 @@ def main():
                                             "alignments_per_step": og["config"]["alignments_per_step"], "listed_pairs_per_step": out["config"]["alignments_per_step"],
                                             "clusters": og["config"]["clusters"], "sw_kernel_ms_per_step": og["roofline"]["kernel_ms_per_step"],
                                             "cells_run_per_step": og["roofline"]["cells_run_per_step"]}}
-    if world > 1 and args.config == "c2" and not custom and not args.no_sub_records:
+    if multi and args.config == "c2" and not custom and not args.no_sub_records:
         # the configuration BASELINE names for the 8-GPU node (configs[2]: 500 proteomes, target DB sharded across the ranks): ONE timed pass
         # after one warm-up pass with all N ranks; the headline above stays configs[1] so that the N = 1 point of a scaling run agrees with BENCH
         U.lib().uc_release_scratch()
@@ -747,7 +769,7 @@ def main():
             out["configs"] = {"c3": o3}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.barrier()
         comm.close()
         dist.destroy_process_group()

@@ -46,7 +46,7 @@ typedef struct uc_opts {
 /* ABI revision of this header: bumped whenever a struct below grows or an entry point changes meaning.  uc_stats is written in full by
  * uc_cluster / uc_search / uc_engine_stats and carries no size field of its own, so a caller built against an older header must check
  * uc_abi_version() == UC_ABI_VERSION (or uc_stats_size() == sizeof(uc_stats)) before passing one in. */
-#define UC_ABI_VERSION 4
+#define UC_ABI_VERSION 5
 uint32_t uc_abi_version(void);
 size_t uc_stats_size(void);
 
@@ -84,6 +84,11 @@ typedef struct uc_stats {
      * [6] edge gather to rank 0, [7] rank 0's serial tail (graph + greedy cover) */
     double phase_seconds[UC_NPHASE];
     uint32_t nccl_ranks, reserved0;                      /* ncclCommCount of the run's communicator (0 = no RCCL: one GPU or virtual ranks) */
+    /* phase [3] taken apart (ABI 5): [0] stable partition of the merged pairs by owner rank (device sort), [1] exchange of the per-peer counts
+     * (a small all-gather: it ends when the SLOWEST rank has finished its partition), [2] waiting at the rendezvous of the data exchange
+     * (in-process ranks: the barriers around the device copies; RCCL ranks: 0 - the wait is inside the stream synchronisation of [3]),
+     * [3] the data movement itself (grouped ncclSend / ncclRecv + stream synchronisation, or the device copies of in-process ranks) */
+    double exchange2_seconds[4];
 } uc_stats;
 
 /* ---- the three calls of cluster.rs ------------------------------------------------------------ */

@@ -20,6 +20,8 @@ import util
 pytestmark = pytest.mark.gpu
 
 CONFIGS = {
+    # BASELINE configs[1] (bench.py's headline workload) once through the same checks, for its whole-file golden
+    "c2": dict(proteomes=50, seed=0x5EED0002, opts="-c 0.8", min_aln=10_000_000, sample=500, block=2000),
     "c3": dict(proteomes=500, seed=0x5EED0003, opts="-c 0.8", min_aln=300_000_000, sample=2000, block=1500),
     "c4-lite": dict(proteomes=50, seed=0x5EED0004, opts="-c 0.8 --min-seq-id 0.3 -s 7.5", min_aln=30_000_000, sample=2000, block=4000),
     # configs[3]'s options at 200 proteomes (636 k sequences, 190 M residues, ~2.2e12 k-mer hits: dozens of density-cut target chunks, the
@@ -31,6 +33,10 @@ CONFIGS = {
     "c3-gate": dict(proteomes=500, seed=0x5EED0003, opts="-c 0.8 --length-gate 1", min_aln=200_000_000, sample=2000, block=1500),
 }
 EXTRA = ["c3-gate"] if os.environ.get("UC_TEST_AT_SIZE_EXTRA") else []
+# names whose WHOLE clust.tsv, accepted-pair set and stage counters are pinned by the CPU oracle run end to end in the build container
+# (tools/oracle_at_size.py -> tests/golden/<name>_sha.json); a golden named here and missing FAILS the test.  The others (configs[3]'s deep
+# prefilter as a plain all-vs-all step: hours of CPU at 200 proteomes) are pinned by the oracle's query samples below only - stated, not silent.
+GOLDEN = {"c2": True, "c3": True, "c4-lite": False, "c4-200": False, "c4-lite-gate": False, "c3-gate": False}
 
 
 @pytest.fixture(scope="module")
@@ -39,7 +45,7 @@ def O():
     return oracle_py
 
 
-@pytest.mark.parametrize("name", ["c3", "c4-lite", "c4-200", "c4-lite-gate"] + EXTRA)
+@pytest.mark.parametrize("name", ["c2", "c3", "c4-lite", "c4-200", "c4-lite-gate"] + EXTRA)
 def test_config_at_size(name, O, tmp_path_factory):
     import unicore_amd as U
     cfg = CONFIGS[name]
@@ -138,7 +144,8 @@ def test_config_at_size(name, O, tmp_path_factory):
     # (tools/oracle_at_size.py -> tests/golden/<name>_sha.json; ~5 h of CPU for configs[2]): north_star's "byte-identical clust.tsv on 500
     # proteomes at 1 GPU" as a whole-file statement, not a query sample
     gold = os.path.join(util.ROOT, "tests", "golden", "%s_sha.json" % name)
-    if os.path.exists(gold):
+    assert not GOLDEN[name] or os.path.exists(gold), "%s is missing (tools/oracle_at_size.py --config %s writes it)" % (gold, name)
+    if GOLDEN[name]:
         import hashlib
         import json
         g = json.load(open(gold))
@@ -151,8 +158,6 @@ def test_config_at_size(name, O, tmp_path_factory):
         assert len(edges) == g["counts"]["n_edges"] and n_clusters == g["counts"]["n_clusters"]
         key = np.sort(edges[:, 0].astype(np.uint64) << np.uint64(32) | edges[:, 1].astype(np.uint64))
         assert hashlib.sha256(key.tobytes()).hexdigest() == g["counts"]["edge_set_sha256"], "the set of accepted pairs differs from the oracle's"
-    else:
-        assert name != "c3" or os.environ.get("UC_ALLOW_MISSING_C3_GOLDEN") == "1", "tests/golden/c3_sha.json is missing (tools/oracle_at_size.py writes it)"
     e.close()
     U.lib().uc_release_scratch()
 

@@ -35,9 +35,7 @@ def run_with_round_samples(U, db, out, tmp, opts, per_round, seed, threads=16):
 
     def hook(rnd, ids, kthr, view):
         try:
-            m = len(ids)
-            rng = np.random.default_rng(seed + 7 * (rnd + 1))
-            qs = np.arange(m) if per_round is None or per_round >= m else np.sort(rng.choice(m, per_round, replace=False))
+            qs = sample_queries(len(ids), rnd, per_round, seed)
             got = []
             for q in qs:
                 cnt, hits = view.hits_range(int(q), int(q) + 1)
@@ -58,59 +56,116 @@ def run_with_round_samples(U, db, out, tmp, opts, per_round, seed, threads=16):
     return st, recs
 
 
-def check_rounds(O, odb, base_opts, recs, steps=3, m=20, target_s=4.0):
-    """every sampled query of every round == the oracle on that round's sub-database; returns the number of records compared"""
+def sample_queries(m, rnd, per_round, seed):
+    """the round-local queries a test looks at: all of them, or `per_round` drawn from a generator seeded by (seed, round)"""
+    if per_round is None or per_round >= m:
+        return np.arange(m)
+    return np.sort(np.random.default_rng(seed + 7 * (rnd + 1)).choice(m, per_round, replace=False))
+
+
+HIT_FIELDS = ("t", "score", "diag")
+ALN_FIELDS = ("score", "score_rev", "corrected", "pass_evalue", "accepted", "qstart", "qend", "tstart", "tend", "aln_len", "idents")
+
+
+def oracle_round(O, odb, base_opts, rnd, ids, kmer_thr, qs, m=20):
+    """the CPU oracle on ONE round's sub-database for the round-local queries `qs` -> dict of flat arrays (the layout of
+    tests/golden/c4_rounds.npz, written by tools/c4_round_fixture.py): n_pairs (pre-step only, else -1), cnt[len(qs)] and, concatenated in
+    query order, hit_<field> / aln_<field> of every listed pair"""
+    sub = odb.subset(ids)
+    p = util.oracle_params(O, base_opts)
+    out = {"n_pairs": -1}
+    hit = {f: [] for f in HIT_FIELDS}
+    aln = {f: [] for f in ALN_FIELDS}
+    cnt = []
+    if rnd < 0:
+        pairs = O.linclust_pairs(sub, p, m)
+        out["n_pairs"] = len(pairs)
+        lo = np.searchsorted(pairs[:, 0], qs, "left"); hi = np.searchsorted(pairs[:, 0], qs, "right")
+        for k, q in enumerate(qs):
+            exp = pairs[lo[k]:hi[k], 1]
+            cnt.append(len(exp))
+            ms = O.min_score(sub, p, int(q))
+            hit["t"].append(exp.astype(np.uint32)); hit["score"].append(np.zeros(len(exp), np.int32)); hit["diag"].append(np.zeros(len(exp), np.int32))
+            refs = [O.align_pair(sub, p, int(q), int(t), ms) for t in exp]
+            for f in ALN_FIELDS:
+                aln[f].append(np.array([r[f] for r in refs], np.int32))
+    else:
+        p.kmer_thr = kmer_thr
+        ix = O.build_index(sub, p)
+        _, _, _, ocnt, ohits, oalns = O.simd_sample_run(sub, ix, p, np.asarray(qs, np.uint32), threads=0, records=True)
+        O.free_index(ix)
+        for k in range(len(qs)):
+            c = int(ocnt[k])
+            cnt.append(c)
+            for f in HIT_FIELDS:
+                hit[f].append(np.asarray(ohits[k, :c][f]))
+            for f in ALN_FIELDS:
+                aln[f].append(np.asarray(oalns[k, :c][f]).astype(np.int32))
+    out["cnt"] = np.array(cnt, np.int64)
+    for f in HIT_FIELDS:
+        out["hit_" + f] = np.concatenate(hit[f]) if hit[f] else np.zeros(0, np.int32)
+    for f in ALN_FIELDS:
+        out["aln_" + f] = np.concatenate(aln[f]) if aln[f] else np.zeros(0, np.int32)
+    del sub
+    return out
+
+
+def compare_round(r, ref, min_seq_id):
+    """the records the workflow observer collected in round r == the oracle's (`ref`: oracle_round's dict, computed now or read from a fixture);
+    returns the number of records compared"""
+    rnd = r["round"]
+    if rnd < 0:
+        assert r["n_pairs"] == int(ref["n_pairs"]), ("pre-step pairs", r["n_pairs"], int(ref["n_pairs"]))
+    assert len(r["samples"]) == len(ref["cnt"])
+    off = np.concatenate([[0], np.cumsum(ref["cnt"])]).astype(np.int64)
+    for k, (q, hits, al) in enumerate(r["samples"]):
+        a, b = int(off[k]), int(off[k + 1])
+        assert len(hits) == b - a, ("round", rnd, q, len(hits), b - a)
+        assert np.array_equal(hits["target"], ref["hit_t"][a:b]), ("round", rnd, q, "targets")
+        if rnd >= 0:
+            assert np.array_equal(hits["score"], ref["hit_score"][a:b]) and np.array_equal(hits["diag"], ref["hit_diag"][a:b]), ("round", rnd, q)
+        for f in ("score", "score_rev", "corrected", "pass_evalue", "accepted"):
+            assert np.array_equal(al[f], ref["aln_" + f][a:b]), ("round", rnd, q, f)
+        if rnd >= 0:
+            pe = ref["aln_pass_evalue"][a:b] == 1
+            for f in ("qstart", "qend", "tstart", "tend"):
+                assert np.array_equal(al[f][pe], ref["aln_" + f][a:b][pe]), ("round", rnd, q, f)
+            if min_seq_id > 0:
+                cov = ref["aln_aln_len"][a:b] > 0
+                for f in ("aln_len", "idents"):
+                    assert np.array_equal(al[f][cov], ref["aln_" + f][a:b][cov]), ("round", rnd, q, f)
+    return int(off[-1])
+
+
+def check_rounds(O, odb, base_opts, recs, steps=3, m=20, target_s=4.0, fixture=None):
+    """every sampled query of every round == the oracle on that round's sub-database; returns the number of records compared.
+    `fixture` (a loaded tests/golden/<name>_rounds.npz): the oracle side was computed in the build container by tools/c4_round_fixture.py
+    on the SAME round sets (their sha256 is asserted) and the same query sample - the GPU box then only compares."""
+    import hashlib
     p0 = util.oracle_params(O, base_opts)
     thr = O.cascade_thresholds(p0, target_s, steps)
     assert [r["round"] for r in recs] == [-1] + list(range(steps))
-    assert np.array_equal(recs[0]["ids"], np.arange(odb.n))
+    n = odb.n if odb is not None else int(fixture["sequences"])
+    assert np.array_equal(recs[0]["ids"], np.arange(n))
     compared = 0
     prev = None
-    for r in recs:
+    for k, r in enumerate(recs):
         ids = r["ids"]
         if prev is not None:
             assert len(ids) <= len(prev) and np.all(np.diff(ids.astype(np.int64)) > 0) and np.isin(ids, prev).all()   # representatives of the round before
         prev = ids
-        sub = odb.subset(ids)
-        p = util.oracle_params(O, base_opts)
         if r["round"] >= 0:
             assert r["kmer_thr"] == thr[r["round"]], (r["round"], r["kmer_thr"], thr)     # the sensitivity schedule, restated by the test
-            p.kmer_thr = thr[r["round"]]
         qs = np.array([s[0] for s in r["samples"]], np.uint32)
-        if r["round"] < 0:
-            pairs = O.linclust_pairs(sub, p, m)
-            assert r["n_pairs"] == len(pairs)
-            lo = np.searchsorted(pairs[:, 0], qs, "left"); hi = np.searchsorted(pairs[:, 0], qs, "right")
-            for k, (q, hits, al) in enumerate(r["samples"]):
-                exp = pairs[lo[k]:hi[k], 1]
-                assert np.array_equal(hits["target"], exp), ("pre-step members", q)
-                ms = O.min_score(sub, p, q)
-                for h in range(len(exp)):
-                    ref = O.align_pair(sub, p, q, int(exp[h]), ms)
-                    for f in ("score", "score_rev", "corrected", "pass_evalue", "accepted"):
-                        assert al[f][h] == ref[f], ("pre-step", q, int(exp[h]), f)
-                    compared += 1
+        if fixture is not None:
+            assert hashlib.sha256(np.ascontiguousarray(ids, np.uint32).tobytes()).hexdigest() == str(fixture["r%d_ids_sha256" % k]), \
+                "round %d runs on a different sequence set than the fixture's" % r["round"]
+            assert int(fixture["r%d_kmer_thr" % k]) == (r["kmer_thr"] if r["round"] >= 0 else int(fixture["r%d_kmer_thr" % k]))
+            assert np.array_equal(qs, fixture["r%d_queries" % k])
+            ref = {key[len("r%d_" % k):]: fixture[key] for key in fixture.files if key.startswith("r%d_" % k)}
         else:
-            ix = O.build_index(sub, p)
-            _, _, _, ocnt, ohits, oalns = O.simd_sample_run(sub, ix, p, qs, threads=0, records=True)
-            O.free_index(ix)
-            for k, (q, hits, al) in enumerate(r["samples"]):
-                c = int(ocnt[k])
-                assert len(hits) == c, ("round", r["round"], q, len(hits), c)
-                assert np.array_equal(hits["target"], ohits[k, :c]["t"]) and np.array_equal(hits["score"], ohits[k, :c]["score"]) \
-                    and np.array_equal(hits["diag"], ohits[k, :c]["diag"]), ("round", r["round"], q)
-                ref = oalns[k, :c]
-                for f in ("score", "score_rev", "corrected", "pass_evalue", "accepted"):
-                    assert np.array_equal(al[f], ref[f]), ("round", r["round"], q, f)
-                pe = ref["pass_evalue"] == 1
-                for f in ("qstart", "qend", "tstart", "tend"):
-                    assert np.array_equal(al[f][pe], ref[f][pe]), ("round", r["round"], q, f)
-                if p.min_seq_id > 0:
-                    cov = ref["aln_len"] > 0
-                    for f in ("aln_len", "idents"):
-                        assert np.array_equal(al[f][cov], ref[f][cov]), ("round", r["round"], q, f)
-                compared += c
-        del sub
+            ref = oracle_round(O, odb, base_opts, r["round"], ids, r["kmer_thr"], qs, m)
+        compared += compare_round(r, ref, p0.min_seq_id)
     return compared
 
 
@@ -147,12 +202,26 @@ AT_SIZE = {
     "c3": dict(proteomes=500, seed=0x5EED0003, opts="-c 0.8", s=4.0, per_round=500, min_aln=50_000_000),
     "c4-200": dict(proteomes=200, seed=0x5EED0004, opts="-c 0.8 --min-seq-id 0.3 -s 7.5", s=7.5, per_round=500, min_aln=20_000_000),
     "c4-500": dict(proteomes=500, seed=0x5EED0004, opts="-c 0.8 --min-seq-id 0.3 -s 7.5", s=7.5, per_round=500, min_aln=100_000_000),
-    # BASELINE configs[3] at its NOMINAL size.  One pass takes minutes; the oracle side (four sub-database indexes over up to 1.9 G residues and
-    # 4 x 300 sampled queries) a few more.
-    "c4": dict(proteomes=2000, seed=0x5EED0004, opts="-c 0.8 --min-seq-id 0.3 -s 7.5", s=7.5, per_round=300, min_aln=400_000_000),
+    # BASELINE configs[3] at its NOMINAL size.  One pass takes ~4 minutes on the GPU; the oracle side (four sub-database indexes over up to 1.9 G
+    # residues and 4 x 200 sampled queries, minutes more) is a committed fixture computed in the build container: tests/golden/c4_rounds.npz
+    "c4": dict(proteomes=2000, seed=0x5EED0004, opts="-c 0.8 --min-seq-id 0.3 -s 7.5", s=7.5, per_round=200, min_aln=400_000_000),
     # optional rule UC-1/L (length gate, default off) through every round at configs[2] size, against tests/golden/c3-gate_workflow_sha.json
     # (the CPU oracle's workflow with the rule on, end to end); behind UC_TEST_AT_SIZE_EXTRA=1 - builder-run, log under profiles/
     "c3-gate": dict(proteomes=500, seed=0x5EED0003, opts="-c 0.8 --length-gate 1", s=4.0, per_round=500, min_aln=20_000_000),
+}
+
+
+SAMPLE_SEED = 20260929
+# every at-size name states what pins it: a whole-file golden of the CPU oracle's workflow run end to end in the build container
+# (tools/oracle_at_size.py --workflow -> tests/golden/<name>_workflow_sha.json) and / or per-round oracle records - computed on the GPU box's
+# host ("live") or committed (tests/golden/<name>_rounds.npz, tools/c4_round_fixture.py).  A fixture that is named here and missing FAILS the test.
+PINS = {
+    "c2": dict(golden=True, rounds="live"),
+    "c3": dict(golden=True, rounds="live"),
+    "c4-200": dict(golden=False, rounds="live"),      # whole-file golden: c4-500 carries configs[3]'s options end to end
+    "c4-500": dict(golden=True, rounds="live"),
+    "c4": dict(golden=False, rounds="fixture"),       # nominal size: the oracle end to end would take ~14 h on the build container's 8 cores
+    "c3-gate": dict(golden=True, rounds="live"),
 }
 
 
@@ -160,18 +229,23 @@ AT_SIZE = {
 def test_default_workflow_at_size(name, O, tmp_path_factory):
     """the call of cluster.rs:45-49 at BASELINE's sizes: uc_cluster(db, "<options>") with no single-step flag -> pre-step + 3-step cascade;
     (a) a random query sample of EACH round equals the CPU oracle on that round's sub-database (hit lists, scores, gates, coordinates,
-    traceback statistics); (b) the TSV satisfies the consumer contract of profile.rs; (c) the rounds shrink and the counters add up."""
+    traceback statistics); (b) the TSV satisfies the consumer contract of profile.rs; (c) the rounds shrink and the counters add up;
+    (d) where PINS says so, the WHOLE clust.tsv, the round sizes and the summed stage counters equal the CPU oracle's end-to-end run."""
+    import hashlib
+    import json
     import unicore_amd as U
     cfg = AT_SIZE[name]
-    if name == "c4" and os.environ.get("UC_TEST_NOMINAL_C4") != "1":
-        pytest.skip("the nominal 2000-proteome case takes ~15 min (5 min on the GPU, the rest in the CPU oracle's four sub-database passes): "
-                    "set UC_TEST_NOMINAL_C4=1; the builder's run is committed as profiles/r04/test_workflow_c4_nominal.log")
+    pin = PINS[name]
     if name == "c3-gate" and not os.environ.get("UC_TEST_AT_SIZE_EXTRA"):
         pytest.skip("set UC_TEST_AT_SIZE_EXTRA=1 (the builder's run: profiles/r04/gpu_test_workflow_c3_gate.log)")
+    gold = os.path.join(util.ROOT, "tests", "golden", "%s_workflow_sha.json" % name)
+    fix = os.path.join(util.ROOT, "tests", "golden", "%s_rounds.npz" % name)
+    assert not pin["golden"] or os.path.exists(gold), "%s is missing (tools/oracle_at_size.py --config %s --workflow writes it)" % (gold, name)
+    assert pin["rounds"] != "fixture" or os.path.exists(fix), "%s is missing (tools/c4_round_fixture.py writes it)" % fix
     d = tmp_path_factory.mktemp("wf_" + name.replace("-", "_"))
     db = util.gen_synth_db(str(d / "db"), cfg["proteomes"], cfg["seed"], 6000, 1.0)
     out = str(d / "clust")
-    st, recs = run_with_round_samples(U, db, out + "_cluster", str(d / "tmp"), cfg["opts"], cfg["per_round"], 20260929)
+    st, recs = run_with_round_samples(U, db, out + "_cluster", str(d / "tmp"), cfg["opts"], cfg["per_round"], SAMPLE_SEED)
     n = st["n_seqs"]
     listed = sum(r["n_pairs"] for r in recs)      # under the length gate (UC-1/L) the listed pairs that are ruled out are no alignments
     assert st["n_gapped_alignments"] >= cfg["min_aln"] and (st["n_gapped_alignments"] < listed if "--length-gate 1" in cfg["opts"] else st["n_gapped_alignments"] == listed)
@@ -184,20 +258,23 @@ def test_default_workflow_at_size(name, O, tmp_path_factory):
     rows = util.tsv_invariants(out + ".tsv", names)
     assert len(rows) == n and len({r[0] for r in rows}) == st["n_clusters"]
     del rows, names
-    # the WHOLE clust.tsv, the round sizes and the summed stage counters against the CPU oracle's workflow run end to end at this size in the build
-    # container (tools/oracle_at_size.py --workflow -> tests/golden/<name>_workflow_sha.json), where that run exists
-    gold = os.path.join(util.ROOT, "tests", "golden", "%s_workflow_sha.json" % name)
-    if os.path.exists(gold):
-        import hashlib
-        import json
+    data = open(out + ".tsv", "rb").read()
+    if pin["golden"]:
         g = json.load(open(gold))
-        data = open(out + ".tsv", "rb").read()
         assert g["sequences"] == n and g["round_sizes"] == sizes
         assert len(data) == g["tsv_bytes"] and hashlib.sha256(data).hexdigest() == g["tsv_sha256"], "workflow clust.tsv differs from the CPU oracle's at full size"
         for a, b in (("n_sim_kmers", "n_sim_kmers"), ("n_kmer_hits", "n_kmer_hits"), ("n_candidates", "n_candidates"), ("n_gapped_alignments", "n_alignments"),
                      ("cells_fwd", "cells_fwd"), ("cells_rev", "cells_rev"), ("cells_start", "cells_start"), ("n_clusters", "n_clusters")):
             assert st[a] == g["counts"][b], (a, st[a], g["counts"][b])
-    odb = O.OracleDb(db)
-    assert odb.n == n
-    compared = check_rounds(O, odb, cfg["opts"], recs, target_s=cfg["s"])
+    if pin["rounds"] == "fixture":
+        f = np.load(fix)
+        assert int(f["sequences"]) == n and [int(x) for x in f["round_sizes"]] == sizes and int(f["per_round"]) == cfg["per_round"] and int(f["sample_seed"]) == SAMPLE_SEED
+        compared = check_rounds(O, None, cfg["opts"], recs, target_s=cfg["s"], fixture=f)
+        # the TSV of the run the round sets were taken from (a regression pin of the HIP path against itself, NOT an oracle statement: the oracle side of
+        # this size is the per-round records above)
+        assert hashlib.sha256(data).hexdigest() == str(f["hip_tsv_sha256"]) and st["n_clusters"] == int(f["hip_clusters"])
+    else:
+        odb = O.OracleDb(db)
+        assert odb.n == n
+        compared = check_rounds(O, odb, cfg["opts"], recs, target_s=cfg["s"])
     assert compared > 20 * cfg["per_round"]

@@ -73,6 +73,12 @@ out = {
     "config": "%s: %d proteomes, %d sequences, options '%s'" % (label, proteomes, st1["n_seqs"], opts), "ranks": N,
     "one_gpu_pass_s": one_gpu, "one_gpu_wall_s_disk_to_cluster_db": wall1, "one_gpu_stage_seconds": dict(zip(U.STAGES, st1["stage_seconds"])),
     "slowest_rank_phase_s": ph, "exchange_bytes_received_per_rank": per_rank_rx,
+    # phase "exchange_pairs_to_owner" of its slowest rank taken apart (uc_stats.exchange2_seconds, VERDICT r04 item 6 ii): the device partition is real
+    # work of the rank; the count exchange and the rendezvous END when the slowest peer arrives - in this emulation that includes the other virtual
+    # ranks' partition TURNS on the one device (an artefact); the movement is device copies here, xGMI transfers on a node
+    "exchange_pairs_to_owner_split_s": dict(zip(("partition_by_owner_device_sort", "count_exchange_incl_waiting_for_the_slowest_rank",
+                                                 "rendezvous_wait", "data_movement"), stn["exchange2_seconds"])),
+    "emulated_critical_path_without_exchange2_waits_s": measured - stn["exchange2_seconds"][1] - stn["exchange2_seconds"][2],
     "exchange_model": {"links": N - 1, "GBps_per_link": LINK / 1e9, "assumed_efficiency": EFF, "seconds": x_model},
     "emulated_critical_path_s": critical, "emulated_critical_path_measured_phases_only_s": measured,
     "ideal_s": one_gpu / N, "emulated_speedup": one_gpu / critical if critical > 0 else None,

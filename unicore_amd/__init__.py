@@ -33,7 +33,7 @@ class UcStats(C.Structure):
         ("prefilter_kernel_ms", C.c_double), ("n_filtered_hits", C.c_uint64), ("n_sw_runs", C.c_uint64),
         ("cells_run", C.c_uint64), ("exchange_seconds", C.c_double), ("exchange_bytes", C.c_uint64),
         ("n_gpus", C.c_uint32), ("target_shards", C.c_uint32), ("phase_seconds", C.c_double * 8),
-        ("nccl_ranks", C.c_uint32), ("reserved0", C.c_uint32)]
+        ("nccl_ranks", C.c_uint32), ("reserved0", C.c_uint32), ("exchange2_seconds", C.c_double * 4)]
 
     def as_dict(self):
         d = {}
@@ -62,7 +62,7 @@ SYMBOLS = (
     "uc_engine_stats", "uc_engine_reset_stats", "uc_setcover", "uc_write_cluster_db",
     "uc_engine_ungapped_batch", "uc_engine_sw_batch", "uc_abi_version", "uc_stats_size", "uc_set_round_hook",
 )
-ABI_VERSION = 4      # == UC_ABI_VERSION of include/unicore_cluster.h this binding mirrors
+ABI_VERSION = 5      # == UC_ABI_VERSION of include/unicore_cluster.h this binding mirrors
 ROUND_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32), C.c_int32, C.c_void_p)
 
 _lib = None

@@ -368,6 +368,7 @@ void merge_stats(uc_stats &d, const uc_stats &s) {
     d.sw_kernel_ms = std::max(d.sw_kernel_ms, s.sw_kernel_ms);
     d.prefilter_kernel_ms = std::max(d.prefilter_kernel_ms, s.prefilter_kernel_ms);
     d.exchange_seconds = std::max(d.exchange_seconds, s.exchange_seconds);
+    if (s.phase_seconds[3] > d.phase_seconds[3]) memcpy(d.exchange2_seconds, s.exchange2_seconds, sizeof d.exchange2_seconds);   // the split of the slowest rank's phase 3
     for (int k = 0; k < UC_NPHASE; k++) d.phase_seconds[k] = std::max(d.phase_seconds[k], s.phase_seconds[k]);
 }
 

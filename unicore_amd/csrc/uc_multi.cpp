@@ -6,8 +6,10 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #define UC_NCCL(call)                                                                                          \
     do {                                                                                                       \
@@ -55,7 +57,14 @@ void Comm::abort() {
     aborted.store(true);
     // whoever takes the handle out aborts it, exactly once; no lock: the thread that owns this communicator may be blocked inside
     // ncclGroupEnd / a first-use connect waiting for the very peer that is calling us
-    if (ncclComm *h = nccl.exchange(nullptr)) (void)ncclCommAbort(h);
+    ncclComm *h = nccl.exchange(nullptr);
+    if (!h) return;
+    // ncclCommAbort reclaims the communicator: a thread that read the handle before the exchange above and is still inside its RCCL call
+    // (nccl_enqueue counts itself in BEFORE it reads the handle, so it is visible here) must be out first.  An enqueue is host-side work
+    // that returns in microseconds - unless it is blocked in a first-use connect on the dying peer: after the grace period the abort goes
+    // ahead, because it is then the only thing that gets that thread out.
+    for (int ms = 0; ms < 2000 && in_flight.load() > 0; ms++) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    (void)ncclCommAbort(h);
 }
 
 namespace {
@@ -79,6 +88,11 @@ bool inject_failure(int rank, int stage) {
 // surface as an error of this rank, which is what the caller wants to hear
 template <class F>
 void nccl_enqueue(Comm &C, F &&f) {
+    struct InFlight {      // counted in before the handle is read, out when the call (and its GroupScope) has been left, also by an exception
+        std::atomic<int> &n;
+        explicit InFlight(std::atomic<int> &c) : n(c) { n.fetch_add(1); }
+        ~InFlight() { n.fetch_sub(1); }
+    } guard(C.in_flight);
     ncclComm *h = C.nccl.load();
     if (C.aborted.load() || !h) fail(UC_ERR_DEVICE, "RCCL communicator of rank %d was aborted (another GPU rank of this run failed)", C.rank);
     f(h);
@@ -332,17 +346,22 @@ void Comm::all_gather_u64s(Engine &E, const uint64_t *v, int k, uint64_t *out) {
 // point-to-point sends / receives (over xGMI every pair of GPUs has its own link: the transfers of a rank run side by side);
 // virtual ranks: device copies from the peers' published buffers.
 void Comm::all_to_all_dev(Engine &E, int na, const void *const *send, const uint64_t *send_off, const uint64_t *send_cnt,
-                          void *const *recv, const uint64_t *recv_off, const uint64_t *recv_cnt) {
+                          void *const *recv, const uint64_t *recv_off, const uint64_t *recv_cnt, double *t_wait, double *t_move) {
     const int me = rank;
+    Timer tw;
+    auto waited = [&] { if (t_wait) *t_wait += tw.seconds(); tw = Timer(); };
+    auto moved = [&] { if (t_move) *t_move += tw.seconds(); tw = Timer(); };
     if (send_cnt[me] != recv_cnt[me]) fail(UC_ERR_GENERIC, "all_to_all_dev: inconsistent self segment");
     if (world == 1 && !uses_rccl) {
         for (int k = 0; k < na && send_cnt[0]; k++)
             UC_HIP(hipMemcpyAsync((char *)recv[k] + 4 * recv_off[0], (const char *)send[k] + 4 * send_off[0], 4 * send_cnt[0], hipMemcpyDeviceToDevice, E.stream));
         UC_HIP(hipStreamSynchronize(E.stream));
+        moved();
         return;
     }
     if (uses_rccl) {
         if (grp) grp->barrier();   // a rank that failed earlier must not leave its peers inside the exchange
+        waited();
         nccl_enqueue(*this, [&](ncclComm *h) {
             GroupScope g;
             for (int p = 0; p < world; p++) {
@@ -359,7 +378,9 @@ void Comm::all_to_all_dev(Engine &E, int na, const void *const *send, const uint
         for (int k = 0; k < na && send_cnt[me]; k++)
             UC_HIP(hipMemcpyAsync((char *)recv[k] + 4 * recv_off[me], (const char *)send[k] + 4 * send_off[me], 4 * send_cnt[me], hipMemcpyDeviceToDevice, E.stream));
         UC_HIP(hipStreamSynchronize(E.stream));
+        moved();
         if (grp) grp->barrier();   // ... and one that failed DURING it (its handler aborts every communicator) is reported as such
+        waited();
         return;
     }
     // in-process ranks without RCCL (several engines on ONE device): publish the send side, copy from the peers
@@ -367,6 +388,7 @@ void Comm::all_to_all_dev(Engine &E, int na, const void *const *send, const uint
     UC_HIP(hipStreamSynchronize(E.stream));   // the send buffers are complete
     grp->ptr[(size_t)me] = &pub;
     grp->barrier();
+    waited();
     for (int p = 0; p < world; p++) {
         if (!recv_cnt[p]) continue;
         const Pub &pp = *(const Pub *)grp->ptr[(size_t)p];
@@ -374,7 +396,9 @@ void Comm::all_to_all_dev(Engine &E, int na, const void *const *send, const uint
             UC_HIP(hipMemcpyAsync((char *)recv[k] + 4 * recv_off[p], (const char *)pp.send[k] + 4 * pp.off[(size_t)me], 4 * recv_cnt[p], hipMemcpyDefault, E.stream));
     }
     UC_HIP(hipStreamSynchronize(E.stream));
+    moved();
     grp->barrier();   // peers may reuse their send buffers only now
+    waited();
 }
 
 // The exchange of the sharded pass, two phases (r4; it replaced "all-gather the union, sort it on every rank, keep 1/N"):
@@ -479,16 +503,20 @@ uint64_t exchange_hits(Engine &E, Comm &C) {
     uint64_t o = 0;
     for (int p = 0; p < W; p++) { soff[(size_t)p] = o; o += scnt[(size_t)p]; }
     C.all_gather_u64s(E, scnt.data(), W, mat.data());
+    const double t_counts = t3.seconds();
+    double t_wait = 0, t_move = 0;
     uint64_t R2 = 0;
     for (int r = 0; r < W; r++) { rcnt[(size_t)r] = mat[(size_t)r * W + me]; roff[(size_t)r] = R2; R2 += rcnt[(size_t)r]; }
     S.all.reserve(4 * std::max<uint64_t>(R2, 1));
     {
         const void *snd[4] = {S.pad.p, S.pad.p + K, S.pad.p + 2 * K, S.pad.p + 3 * K};
         void *rcv[4] = {S.all.p, S.all.p + R2, S.all.p + 2 * R2, S.all.p + 3 * R2};
-        C.all_to_all_dev(E, 4, snd, soff.data(), scnt.data(), rcv, roff.data(), rcnt.data());
+        C.all_to_all_dev(E, 4, snd, soff.data(), scnt.data(), rcv, roff.data(), rcnt.data(), &t_wait, &t_move);
     }
     E.stats.exchange_bytes += 16 * (R2 - rcnt[(size_t)me]);
     E.stats.phase_seconds[3] += t3.seconds() + t_part;
+    E.stats.exchange2_seconds[0] += t_part; E.stats.exchange2_seconds[1] += t_counts;
+    E.stats.exchange2_seconds[2] += t_wait; E.stats.exchange2_seconds[3] += t_move;
     uint64_t kept;
     {
         Turn turn(C, &E);

@@ -54,6 +54,7 @@ struct Comm {
     std::atomic<ncclComm *> nccl{nullptr};
     std::unique_ptr<CommScratch> scratch;
     std::atomic<bool> aborted{false};
+    std::atomic<int> in_flight{0};   // threads inside an RCCL call on `nccl` (nccl_enqueue); abort() lets them leave before it reclaims the handle
     bool uses_rccl = false;          // the communicator was created over RCCL (stays true after an abort took the handle)
     Comm();
     ~Comm();
@@ -61,14 +62,17 @@ struct Comm {
     Comm &operator=(const Comm &) = delete;
 
     // failure path: ncclCommAbort, so that a peer blocked inside a collective of this communicator returns (its next barrier
-    // then throws); the handle is gone afterwards.  Safe to call from any thread, once or more; never waits for another thread.
+    // then throws); the handle is gone afterwards.  Safe to call from any thread, once or more.  Takes no lock; the reclamation of the handle
+    // is DEFERRED until the threads that entered an RCCL call with it have left (in_flight == 0) - bounded: after a grace period an enqueue
+    // that is still inside is blocked on the dying peer, and ncclCommAbort is the only call that gets it out.
     void abort();
     void barrier(Engine &E);
     void all_gather_u64(Engine &E, uint64_t v, uint64_t *out /* world */);
     void all_gather_u64s(Engine &E, const uint64_t *v, int k, uint64_t *out /* world x k */);
     // ragged all-to-all of `na` parallel arrays of 4-byte elements (offsets and counts in elements, per peer)
+    // t_wait / t_move (nullable) accumulate the seconds spent waiting for the peers' rendezvous and in the data movement itself
     void all_to_all_dev(Engine &E, int na, const void *const *send, const uint64_t *send_off, const uint64_t *send_cnt,
-                        void *const *recv, const uint64_t *recv_off, const uint64_t *recv_cnt);
+                        void *const *recv, const uint64_t *recv_off, const uint64_t *recv_cnt, double *t_wait = nullptr, double *t_move = nullptr);
     // recv holds world x bytes; send/recv are device buffers of E's device
     void all_gather_dev(Engine &E, const void *send, void *recv, size_t bytes);
     void broadcast_dev(Engine &E, void *buf, size_t bytes, int root);
