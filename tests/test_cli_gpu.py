@@ -149,18 +149,17 @@ def test_uc_cluster_virtual_gpus_shard_by_shard_exchange(synth_db, tmp_path):
 @pytest.mark.parametrize("opts", ["-c 0.8 --single-step-clustering", "-c 0.8 --single-step-clustering -s 7.5"])
 def test_prefilter_execution_variants_give_identical_tsv(synth_db, opts, tmp_path):
     """E2 runs the similar-k-mer enumeration once per DISTINCT query k-mer and plans its batches from exact per-query totals.
-    Neither the cut into query super-batches (forced here by a tiny run-list budget) nor the older per-position path
-    (UC_SIM_PER_POSITION=1) may change a byte of the result or any of the prefilter counts."""
+    The cut into query super-batches (forced here by a tiny run-list budget) may not change a byte of the result or any of the prefilter counts."""
     ref, st1 = _tsv(synth_db, tmp_path, "v0", opts, 1)
     keys = ("n_sim_kmers", "n_kmer_hits", "n_filtered_hits", "n_candidates", "n_prefilter_hits", "n_gapped_alignments", "n_clusters")
     # ... nor may the cut of the targets into index chunks — by default walked as the UPPER TRIANGLE of the chunk x chunk grid, the pairs the other
     # way round mirrored from the symmetric hit relation (fewer keys reach the sort, every other count is the algorithm's), with
-    # UC_PREFILTER_SYMMETRIC=0 as the full grid — or the way the kernels' code objects reach the device (helper-thread preload / HIP's lazy loading)
+    # UC_PREFILTER_SYMMETRIC=0 as the full grid
     small = {"UC_PREFILTER_CHUNK_RES": "20000"}
     tiny = {"UC_PREFILTER_CHUNK_RES": "6000"}
-    for tag, env in (("v1", {"UC_DRUN_MAX": "20000"}), ("v2", {"UC_DRUN_MAX": "3000"}), ("v3", {"UC_SIM_PER_POSITION": "1"}),
+    for tag, env in (("v1", {"UC_DRUN_MAX": "20000"}), ("v2", {"UC_DRUN_MAX": "3000"}),
                      ("v4", small), ("v5", tiny), ("v6", dict(small, UC_PREFILTER_SYMMETRIC="0")), ("v7", dict(small, UC_DRUN_MAX="20000")),
-                     ("v8", dict(tiny, UC_PREFILTER_WIDE="1")), ("v12", {"UC_PRELOAD": "0"})):
+                     ("v8", dict(tiny, UC_PREFILTER_WIDE="1"))):
         got, st = _tsv(synth_db, tmp_path, tag, opts, 1, env=env)
         assert got == ref, (tag, opts)
         kk = [k for k in keys if not (tag in ("v4", "v5", "v7", "v8") and k == "n_filtered_hits")]      # the triangle walk expands (and sorts) fewer keys

@@ -800,6 +800,72 @@ def test_traceback_bytes_in_several_batches(O, small):
     assert (al["aln_len"] > 0).sum() > 50
 
 
+def zigzag_db(seed, n_pairs=24):
+    """pairs whose optimal alignment leaves the corridor between its start and end diagonals: q = A X B, t = A Y B with unrelated X, Y (8-40
+    residues) - a gap out and a gap back; plus single-gap and shifted variants, on top of a family database"""
+    rng = np.random.default_rng(seed)
+    s3, sa = util.family_db(seed, n_fam=8, members=5, extra=(700, 1100))
+    def rnd(L): return rng.integers(0, 20, L, dtype=np.uint8), rng.integers(0, 20, L, dtype=np.uint8)
+    for k in range(n_pairs):
+        L1, L2, lx, ly = int(rng.integers(40, 200)), int(rng.integers(40, 400)), int(rng.integers(8, 40)), int(rng.integers(8, 40))
+        a3, aa = rnd(L1); b3, ba = rnd(L2); x3, xa = rnd(lx); y3, ya = rnd(ly)
+        if k % 3 == 2: y3, ya = y3[:0], ya[:0]                                     # one gap only: stays inside the corridor
+        pre = rnd(int(rng.integers(0, 30))) if k % 4 == 1 else rnd(0)              # a shifted start diagonal
+        s3.append(np.concatenate([a3, x3, b3])); sa.append(np.concatenate([aa, xa, ba]))
+        s3.append(np.concatenate([pre[0], a3, y3, b3])); sa.append(np.concatenate([pre[1], aa, ya, ba]))
+    return s3, sa
+
+
+@pytest.mark.parametrize("opts", ["-c 0.5 --min-seq-id 0.3", "-c 0.3 --cov-mode 1 --min-seq-id 0.2 --gap-open 6 --gap-extend 1 -e 10"])
+def test_traceback_band_and_its_fallback(O, opts, capfd):
+    """r05: MODE 7 stores the H bytes of a diagonal band of the box (tb_band_of, uc_device.h) and the walk gives up on a pair whose traceback
+    leaves it; such pairs are redone with the whole box stored.  On a database with zig-zag pairs (a gap out of the corridor and a gap back):
+    whatever the half-width - 0 (whole box, the r04 layout), 1, 4 (the zig-zags leave the band: the fallback does their work), the default -
+    the records are the same bytes, and the traceback statistics are the scalar oracle's."""
+    import unicore_amd as U
+    s3, sa = zigzag_db(77)
+    off, c3, ca = util.flat(s3, sa)
+    res, redone = {}, {}
+    for w in ("0", "1", "4", None):
+        if w is not None:
+            os.environ["UC_TB_BAND"] = w
+        os.environ["UC_TIMING"] = "1"
+        try:
+            e = U.Engine(opts, verbosity=1)
+            e.set_db(off, c3, ca)
+            e.prefilter()
+            capfd.readouterr()
+            e.align()
+            err = capfd.readouterr().err
+            res[w] = e.alns().tobytes()
+            if w is None:
+                cnt, hits = e.hits()
+            e.close()
+        finally:
+            os.environ.pop("UC_TB_BAND", None)
+            os.environ.pop("UC_TIMING", None)
+        # "sw pass mode 7: N pairs, ..., band W, B batch(es)" lines of tb_batch: a band-0 line in a run whose band is W > 0 is the fallback at work
+        m7 = [l for l in err.splitlines() if "sw pass mode 7:" in l]
+        bands = [int(l.split("band ")[1].split(",")[0]) for l in m7]
+        redone[w] = sum(int(l.split("mode 7: ")[1].split(" pairs")[0]) for l in m7 if "band 0," in l) if bands and max(bands) > 0 else 0
+    assert res["0"] == res["1"] == res["4"] == res[None]
+    assert redone["1"] >= 10 and redone["4"] >= 3 and redone["0"] == 0, redone           # the zig-zag pairs went through the fallback
+    al = np.frombuffer(res[None], U.ALN_DTYPE)
+    assert (al["aln_len"] > 0).sum() > 100
+    odb = O.OracleDb(s3=s3, sa=sa)
+    p = util.oracle_params(O, opts)
+    o = np.concatenate([[0], np.cumsum(cnt)])
+    checked = 0
+    for q in range(len(cnt)):
+        ms = O.min_score(odb, p, q)
+        for k in range(int(o[q]), int(o[q + 1])):
+            if al["aln_len"][k] > 0:
+                ref = O.align_pair(odb, p, q, int(hits["target"][k]), ms)
+                assert (ref["aln_len"], ref["idents"]) == (al["aln_len"][k], al["idents"][k]), (q, k)
+                checked += 1
+    assert checked > 100
+
+
 @pytest.mark.parametrize("opts,steps,m", [("-c 0.8 --linclust 1 --cluster-steps 1", 1, 20), ("-c 0.8 --linclust 1 --cluster-steps 3", 3, 20),
                                           ("-c 0.5 --linclust 1 --kmer-per-seq 5 --cluster-steps 2", 2, 5),
                                           ("-c 0.8 --length-gate 1 --linclust 1 --cluster-steps 3", 3, 20)])      # rule UC-1/L through every round

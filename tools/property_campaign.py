@@ -18,7 +18,6 @@ bad, t0 = [], time.time()
 for seed in range(first, first + n):
     env = {}
     if seed % 3 == 1: env = {"UC_DRUN_MAX": str(500 + 37 * (seed % 50))}
-    if seed % 3 == 2 and seed % 2 == 0: env = {"UC_SIM_PER_POSITION": "1"}
     if seed % 4 == 3: env = dict(env, UC_PREFILTER_CHUNK_RES=str(1500 + 113 * (seed % 40)))      # r04: several index chunks -> the symmetric (upper-triangle) walk + the single merge
     os.environ.update(env)
     try:

@@ -31,7 +31,7 @@ static unsigned long long tb_budget_bytes(size_t already_held) {
     size_t free_b = 0, total_b = 0;
     unsigned long long cap = 144ull << 30;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-        cap = std::min<unsigned long long>(cap, (unsigned long long)((free_b + already_held) * 0.6));
+        cap = std::min<unsigned long long>(cap, (unsigned long long)((free_b + already_held) * 0.55));
     return std::max<unsigned long long>(cap, 256ull << 20);
 }
 
@@ -396,6 +396,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(uint32_t n2, const uint32
 }
 
 // seq-id stage (only with --min-seq-id > 0): pairs that passed the coverage gate get their traceback statistics
+constexpr uint32_t TB_BAND_MISS = 0x7FFFFFFFu;     // "the walk left the stored band" (no traceback has length 0x7fff with 0xffff identities)
 __global__ void __launch_bounds__(256) tb_gather_kernel(uint32_t n2, const uint32_t *eflag, const uint32_t *epos, const uint32_t *idx2,
                                                         const uint32_t *link, const uint32_t *idx0, const uint32_t *sq2, const uint32_t *st2,
                                                         const uc_aln *alns, uint32_t *q3, uint32_t *t3, int32_t *qs3, int32_t *qe3,
@@ -411,11 +412,15 @@ __global__ void __launch_bounds__(256) tb_gather_kernel(uint32_t n2, const uint3
 }
 __global__ void __launch_bounds__(256) tb_apply_kernel(uint32_t n3, const uint32_t *idx3, const uint32_t *src3, const int32_t *pack,
                                                        const int32_t *gaps, const uint32_t *idx2, const uint32_t *link, const uint32_t *idx0,
-                                                       float min_seq_id, uc_aln *alns, uint32_t *eflag, uint32_t *tie) {
+                                                       float min_seq_id, uc_aln *alns, uint32_t *eflag, uint32_t *tie, uint32_t *miss) {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n3; i += gridDim.x * 256) {
         const uint32_t i2 = src3[idx3[i]];
         uc_aln &a = alns[idx0[link[idx2[i2]]]];
         const uint32_t pk = (uint32_t)pack[i];
+        if (miss) {                                          // banded MODE 7: the walk left the stored band - the record is not touched, the pair is redone
+            miss[i2] = pk == TB_BAND_MISS;
+            if (pk == TB_BAND_MISS) continue;
+        }
         a.aln_len = (int32_t)((pk >> 16) & 0x7fffu);
         a.idents = (int32_t)(pk & 0xffffu);
         if (tie) tie[i2] = pk >> 31;
@@ -430,10 +435,10 @@ __global__ void __launch_bounds__(256) tb_apply_kernel(uint32_t n3, const uint32
 }
 
 // ---- traceback bytes (packed MODE 7) + walk --------------------------------------------------------------------
-// bytes of pair p's matrix: (longer box of its slot + G + 2) steps x G lanes x RB row bytes; the slot partner is the
-// neighbour inside the workgroup task (pairs 2i, 2i+1 of the task), see sw_pk_kernel::start_slot
+// bytes of pair p's matrix: (longer box of its slot + G + 4) steps x NL lanes (those inside the pair's band, tb_band_of) x RB row bytes; the
+// slot partner is the neighbour inside the workgroup task (pairs 2i, 2i+1 of the task), see sw_pk_kernel::start_slot
 __global__ void __launch_bounds__(256) tb_size_kernel(uint32_t n_pk, const uint64_t *key, const uint32_t *segstart, const int32_t *ste,
-                                                      const int32_t *sts, int tab, unsigned long long *size) {
+                                                      const int32_t *sts, const int32_t *sqs, const int32_t *sqe, int band, int tab, unsigned long long *size) {
     for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < n_pk; p += gridDim.x * 256) {
         const int cls = (int)(key[p] >> 40);
         const uint32_t tcap = task_cap(cls, tab), seg = segstart[p];
@@ -442,7 +447,8 @@ __global__ void __launch_bounds__(256) tb_size_kernel(uint32_t n_pk, const uint6
         if (pp < n_pk && segstart[pp] == seg && (pp - seg) / tcap == (p - seg) / tcap && (key[pp] >> 16) == (key[p] >> 16))
             tl = max(tl, ste[pp] - sts[pp] + 1);
         const int G = c_tab[tab].G[cls], R = c_tab[tab].R[cls], RB = 4 * ((R + 3) / 4);
-        size[p] = (unsigned long long)(tl + G + 2) * (unsigned long long)(G * RB);
+        const int nl = tb_band_of(sqs[p], sqe[p], ste[p] - sts[p] + 1, G, R, band).nl;     // lanes per step inside the pair's stored band
+        size[p] = (unsigned long long)(tl + G + 4) * (unsigned long long)(nl * RB);      // (the kernel's step count is rounded up to its loop trip of 2 or 4 steps)
     }
 }
 // one thread per pair walks its matrix of H bytes (packed MODE 7) from the end cell (oracle: traceback(), diag > F > E, a gap is left
@@ -453,38 +459,72 @@ __global__ void __launch_bounds__(256) tb_size_kernel(uint32_t n_pk, const uint6
 // of such values:  diagonal iff H(i,j) == H(i-1,j-1) + s(i,j);  H(i,j) == F(i,j) iff some k has H(i-k,j) - open - (k-1) ext == H(i,j),
 // and the search up the column ends at the first k with H(i-k,j) < H(i,j) + k ext (F <= H in every cell, so no gap that long or longer
 // can reach H(i,j));  inside a gap of value f the gap was opened from the neighbour iff H(neighbour) - open == f.  E likewise along the row.
-__global__ void __launch_bounds__(256) tb_walk_kernel(uint32_t n_pk, const DeviceDb db, const uint64_t *key, const uint32_t *st,
+__global__ void __launch_bounds__(256) tb_walk_kernel(uint32_t p_begin, uint32_t n_pk /* pairs [p_begin, n_pk) of the plan */, const DeviceDb db, const uint64_t *key, const uint32_t *st,
                                                       const int32_t *sqs, const int32_t *sqe, const int32_t *sts, const int32_t *ste,
-                                                      const int32_t *score, int open, int ext,
+                                                      const int32_t *score, int open, int ext, int band,
                                                       int tab, const uint8_t *tbm, const unsigned long long *tboff, int32_t *pack,
                                                       int32_t *gaps_out) {
     __shared__ int8_t s_S3[21 * 21], s_SA[21 * 21];
     for (int k = threadIdx.x; k < 21 * 21; k += 256) { s_S3[k] = db.S3[k]; s_SA[k] = db.SA[k]; }
     __syncthreads();
-    for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < n_pk; p += gridDim.x * 256) {
+    for (uint32_t p = p_begin + blockIdx.x * 256 + threadIdx.x; p < n_pk; p += gridDim.x * 256) {
         const int cls = (int)(key[p] >> 40);
         const uint32_t q = (uint32_t)(key[p] >> 16) & 0xFFFFFFu, t = st[p];
         const int G = c_tab[tab].G[cls], R = c_tab[tab].R[cls], RB = 4 * ((R + 3) / 4);
         const int qs = sqs[p], ts = sts[p];
+        const TbBand bd = tb_band_of(qs, sqe[p], ste[p] - ts + 1, G, R, band);
+        const bool full = bd.nl >= G;
+        const unsigned long long trow = (unsigned long long)(bd.nl * RB);
+        bool miss = false;           // the walk asked for a cell outside the stored band: the pair is redone with the whole box stored
         const uint8_t *m = tbm + tboff[p];
         const uint16_t *ql = db.lt + db.off[q], *tl = db.lt + db.off[t];   // 3Di | AA << 8 per residue
         // full H of cell (ii, jj), a neighbour of a cell (or gap state) whose value is within 127 of it: ref
         auto H_at = [&](int ii, int jj, int ref) -> int {
             if (ii < qs || jj < ts) return 0;
-            const int lane = ii / R;
-            const uint32_t b = m[(unsigned long long)(jj - ts + lane) * (unsigned long long)(G * RB) + (unsigned long long)lane * RB + (ii - lane * R)];
+            const int lane = ii / R, stp = jj - ts + lane;
+            if (!full && (stp < lane * (R + 1) - bd.dhi || stp > lane * (R + 1) + R - 1 - bd.dlo)) { miss = true; return ref; }
+            const uint32_t b = m[(unsigned long long)stp * trow + (unsigned long long)((lane % bd.nl) * RB + (ii - lane * R))];
             return ref + (int)(int8_t)(uint8_t)(b - (uint32_t)ref);
         };
         int i = sqe[p], j = ste[p], state = 0;
         int h = score[p];            // state 0: H(i,j);  states 1 / 2: the value of the gap state the walk is in
         uint32_t len = 0, id = 0, gaps = 0, tie = 0;
-        while (i >= qs && j >= ts) {
+        while (i >= qs && j >= ts && !miss) {
             if (state == 0) {
                 if (h <= 0) break;                                      // H == 0
-                const uint32_t lq = ql[i], lt = tl[j];
-                const int hd = H_at(i - 1, j - 1, h);
-                const int sc = (int)s_S3[(lq & 0xffu) * 21 + (lt & 0xffu)] + (int)s_SA[(lq >> 8) * 21 + (lt >> 8)];
-                if (h == hd + sc) { len++; id += (lq >> 8) == (lt >> 8); i--; j--; h = hd; continue; }
+                // A traceback is mostly diagonal steps, and a step's three loads (two residues, the byte of the diagonal neighbour) depend on the path
+                // taken so far, not on loaded values: the next SPEC diagonal steps are fetched together and then taken one by one from registers - one
+                // memory round trip per run of up to SPEC matches instead of one per step (r05: the walk, one thread per pair on the engine's stream
+                // behind every MODE 7 batch, had grown to a fifth of the pass).
+                constexpr int SPEC = 8;
+                uint32_t lqv[SPEC], ltv[SPEC], bv[SPEC];                // bv: the neighbour's byte; 0x100 = outside the box (H = 0), 0x200 = outside the band
+#pragma unroll
+                for (int k = 0; k < SPEC; k++) {
+                    const int ii = i - k, jj = j - k;
+                    const bool in = ii >= qs && jj >= ts;
+                    lqv[k] = in ? ql[ii] : 0u;
+                    ltv[k] = in ? tl[jj] : 0u;
+                    uint32_t b = 0x100u;
+                    if (in && ii - 1 >= qs && jj - 1 >= ts) {
+                        const int lane = (ii - 1) / R, stp = jj - 1 - ts + lane;
+                        if (!full && (stp < lane * (R + 1) - bd.dhi || stp > lane * (R + 1) + R - 1 - bd.dlo)) b = 0x200u;
+                        else b = m[(unsigned long long)stp * trow + (unsigned long long)((lane % bd.nl) * RB + (ii - 1 - lane * R))];
+                    }
+                    bv[k] = b;
+                }
+                bool off_diag = false;
+                uint32_t lq = 0, lt = 0;
+#pragma unroll
+                for (int k = 0; k < SPEC; k++) {
+                    if (off_diag || miss || i < qs || j < ts || h <= 0) continue;
+                    lq = lqv[k]; lt = ltv[k];
+                    if (bv[k] == 0x200u) { miss = true; continue; }
+                    const int hd = bv[k] == 0x100u ? 0 : h + (int)(int8_t)(uint8_t)(bv[k] - (uint32_t)h);
+                    const int sc = (int)s_S3[(lq & 0xffu) * 21 + (lt & 0xffu)] + (int)s_SA[(lq >> 8) * 21 + (lt >> 8)];
+                    if (h == hd + sc) { len++; id += (lq >> 8) == (lt >> 8); i--; j--; h = hd; }
+                    else off_diag = true;
+                }
+                if (!off_diag) continue;                                // the run ended on a diagonal step (or the walk is over): next run
                 bool fv = false, ev = false;
                 {
                     int hu = h;
@@ -523,9 +563,13 @@ __global__ void __launch_bounds__(256) tb_walk_kernel(uint32_t n_pk, const Devic
                 j--;
             }
         }
-        pack[p] = (int32_t)((len << 16) | id | (tie << 31));
+        pack[p] = miss ? (int32_t)TB_BAND_MISS : (int32_t)((len << 16) | id | (tie << 31));
         if (gaps_out) gaps_out[p] = (int32_t)gaps;
     }
+}
+// byte offset of the first matrix of every task of the traceback plan (the batches are cut at task boundaries)
+__global__ void __launch_bounds__(256) tb_taskoff_kernel(uint32_t ntasks, const SwTask *tasks, const unsigned long long *tboff, unsigned long long *out) {
+    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < ntasks; k += gridDim.x * 256) out[k] = tboff[tasks[k].begin];
 }
 // accepted pairs by forward score: the packed DP of MODE 7 is only valid below its score range
 __global__ void __launch_bounds__(256) tb_split_kernel(uint32_t n2, const uint32_t *flag, const uint32_t *link, const uint32_t *idx0,
@@ -535,24 +579,6 @@ __global__ void __launch_bounds__(256) tb_split_kernel(uint32_t n2, const uint32
         lo[i] = flag[i] && !big;
         hi[i] = big;
     }
-}
-// matrix bytes of the flagged pairs (chunking against the scratch budget): the box length from the alignment record, the
-// rows of the query's class; the slot partner may be a little longer, the caller adds a margin
-__global__ void __launch_bounds__(256) tb_estimate_kernel(uint32_t n2, const uint32_t *flag, const uint32_t *q2, const uint32_t *link,
-                                                          const uint32_t *idx0, const uc_aln *alns, const uint32_t *len,
-                                                          unsigned long long *out) {
-    unsigned long long b = 0;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256)
-        if (flag[i]) {
-            const int cls = class_of((int)len[q2[i]], 1);
-            if (cls < c_tab[1].n) {
-                const uc_aln a = alns[idx0[link[i]]];
-                const int G = c_tab[1].G[cls], R = c_tab[1].R[cls], RB = 4 * ((R + 3) / 4);
-                b += (unsigned long long)(a.tend - a.tstart + 1 + G + 2) * (unsigned long long)(G * RB);
-            }
-        }
-    for (int o = 32; o > 0; o >>= 1) b += __shfl_down(b, o, 64);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, b);
 }
 __global__ void __launch_bounds__(256) tb_chunk_kernel(uint32_t n2, const uint32_t *flag, const uint32_t *pos, uint32_t lo, uint32_t hi, uint32_t *out) {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) out[i] = (flag[i] && pos[i] >= lo && pos[i] < hi) ? 1u : 0u;
@@ -635,6 +661,7 @@ struct SwPlan {
     int tab = 0;
     uint8_t *tbm = nullptr;                      // packed mode 7: traceback-byte matrices and per-pair offsets
     const unsigned long long *tboff = nullptr;
+    int tb_band = 0;                             // ... and the half-width of the stored diagonal band (0 = the whole box)
 };
 
 static void scan_u32(Engine &E, DevBuf<char> &tmp, const uint32_t *in, uint32_t *out, uint32_t n, bool inclusive_max) {
@@ -662,7 +689,8 @@ static uint32_t scan_total(Engine &E, const uint32_t *flag, const uint32_t *pos,
 
 static void build_plan(Engine &E, SwPlan &P, DevBuf<char> &tmp, uint32_t n, const uint32_t *q, const uint32_t *t,
                        const int32_t *qe, const int32_t *te, int tab, const int32_t *qs = nullptr, const int32_t *ts = nullptr,
-                       const int32_t *aux = nullptr /* one value per pair carried into plan order (known scores) */) {
+                       const int32_t *aux = nullptr /* one value per pair carried into plan order (known scores) */,
+                       bool lpt = true /* false: tasks stay in pair order (the traceback plan is cut into byte-budgeted pair ranges) */) {
     {   // a __constant__ symbol exists once per DEVICE: upload the class tables to every device an engine plans on
         static std::mutex mu;
         static bool uploaded[64] = {};
@@ -705,11 +733,13 @@ static void build_plan(Engine &E, SwPlan &P, DevBuf<char> &tmp, uint32_t n, cons
     // longest-processing-time-first inside each class: the big tasks start first, the small ones fill the tail
     P.tasks_in.reserve(P.ntasks); P.tkey.reserve(P.ntasks); P.tkey2.reserve(P.ntasks); P.tidx.reserve(P.ntasks); P.tidx2.reserve(P.ntasks);
     hipLaunchKernelGGL(plan_taskcount_kernel, grid_for(P.ntasks), dim3(256), 0, s, P.ntasks, n, P.tasks.p, P.tcls.p, P.key2.p, P.tkey.p, P.tidx.p);
-    UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, P.tkey.p, P.tkey2.p, P.tidx.p, P.tidx2.p, (size_t)P.ntasks, 0u, 37u, s));
-    tmp.reserve(tb + 256);
-    UC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, P.tkey.p, P.tkey2.p, P.tidx.p, P.tidx2.p, (size_t)P.ntasks, 0u, 37u, s));
-    UC_HIP(hipMemcpyAsync(P.tasks_in.p, P.tasks.p, (size_t)P.ntasks * sizeof(SwTask), hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(plan_taskgather_kernel, grid_for(P.ntasks), dim3(256), 0, s, P.ntasks, P.tidx2.p, P.tasks_in.p, P.tasks.p);
+    if (lpt) {
+        UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, P.tkey.p, P.tkey2.p, P.tidx.p, P.tidx2.p, (size_t)P.ntasks, 0u, 37u, s));
+        tmp.reserve(tb + 256);
+        UC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, P.tkey.p, P.tkey2.p, P.tidx.p, P.tidx2.p, (size_t)P.ntasks, 0u, 37u, s));
+        UC_HIP(hipMemcpyAsync(P.tasks_in.p, P.tasks.p, (size_t)P.ntasks * sizeof(SwTask), hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(plan_taskgather_kernel, grid_for(P.ntasks), dim3(256), 0, s, P.ntasks, P.tidx2.p, P.tasks_in.p, P.tasks.p);
+    }
     hipLaunchKernelGGL(plan_bounds_kernel, dim3(1), dim3(64), 0, s, P.ntasks, P.tcls.p, n, P.key2.p, P.bounds.p);
     uint32_t hb[2 * NB];
     unsigned long long bytes[2] = {0, 0};
@@ -724,8 +754,9 @@ static void build_plan(Engine &E, SwPlan &P, DevBuf<char> &tmp, uint32_t n, cons
 }
 
 // one launch per populated class; outputs are in the plan's sorted order.  Returns the number of launches.
+// [t0, t1): only the tasks of that range of the plan's task list (the byte-budgeted batches of the traceback plan); skip_long: not the long-query launch
 static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t *oqe, int32_t *ote, DevBuf<int32_t> &work,
-                            const uint32_t *tb = nullptr, bool only_long = false) {
+                            const uint32_t *tb = nullptr, bool only_long = false, uint32_t t0 = 0, uint32_t t1 = 0xFFFFFFFFu, bool skip_long = false) {
     const ClassTable &tab = h_tab[P.tab];
     SwArgs a;
     a.db = E.ddb; a.tasks = P.tasks.p; a.pt = P.st.p; a.pqe = P.sqe.p; a.pte = P.ste.p;
@@ -735,7 +766,7 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
     a.pscore = P.has_aux ? P.saux.p : nullptr;
     const int imode = mode >= 4 ? mode - 4 : mode;   // the int32 and long-query kernels have no known-score variant (they are exact anyway)
     if ((mode == 4 || mode == 6) && !P.has_aux) fail(UC_ERR_GENERIC, "known-score pass without scores");
-    a.tbm = P.tbm; a.tboff = P.tboff;
+    a.tbm = P.tbm; a.tboff = P.tboff; a.tb_band = P.tb_band;
     uint64_t launches = 0;
     const uint32_t gb = P.pair_base[tab.n], ngen = P.n - gb;
     uint32_t long_stride = 0;                        // queries beyond the largest systolic class: row-blocked kernel (uc_sw_long.hip)
@@ -744,7 +775,7 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
     UC_HIP(hipEventRecord(E.ev_fork, E.stream));
     for (int i = 0; i < E.n_streams - 1; i++) UC_HIP(hipStreamWaitEvent(E.aux[i], E.ev_fork, 0));
     int slot = 0;
-    if (ngen) {                                      // the longest-running launch goes first
+    if (ngen && !skip_long) {                        // the longest-running launch goes first
         SwArgs al = a;
         al.tasks = P.tasks.p + P.task_base[tab.n];
         launch_sw_long(imode, al, P.task_base[tab.n + 1] - P.task_base[tab.n], gb, work.p, long_stride, E.stream);
@@ -753,10 +784,11 @@ static uint64_t launch_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t
         launches++;
     }
     for (int c = tab.n - 1; c >= 0 && !only_long; c--) {
-        const uint32_t nt = P.task_base[c + 1] - P.task_base[c];
-        if (!nt) continue;
+        const uint32_t c0 = std::max(P.task_base[c], t0), c1 = std::min(P.task_base[c + 1], t1);
+        if (c0 >= c1) continue;
+        const uint32_t nt = c1 - c0;
         SwArgs ac = a;
-        ac.tasks = P.tasks.p + P.task_base[c];
+        ac.tasks = P.tasks.p + c0;
         hipStream_t st = slot % E.n_streams == 0 ? E.stream : E.aux[slot % E.n_streams - 1];
         slot++;
         if (tab.pk[c]) launch_sw_pk_class(tab.G[c], tab.R[c], mode, ac, nt, st);
@@ -843,9 +875,10 @@ struct AlignScratch {
     RerunBufs rr_B, amb_B;
     SwPlan rr_P2, amb_P3;
     // traceback statistics (align: --min-seq-id / search)
-    DevBuf<uint32_t> tb_q3, tb_t3, tb_src3, tb_trun, tb_tpos, tb_tpart, tb_ttie, tb_tlo, tb_thi, tb_tchunk, tb_tcpos;
-    DevBuf<unsigned long long> tb_tbsize, tb_tboff;
+    DevBuf<uint32_t> tb_q3, tb_t3, tb_src3, tb_trun, tb_tpos, tb_tpart, tb_ttie, tb_tlo, tb_thi, tb_tmiss, tb_tchunk, tb_tcpos;
+    DevBuf<unsigned long long> tb_tbsize, tb_tboff, tb_toff;
     DevBuf<uint8_t> tb_tbm;
+    bool tb_tbm_live = false;        // inside the batch loop of a MODE 7 call: the one time the matrices may not be given back (release_tb_matrices)
     DevBuf<int32_t> tb_qs3, tb_qe3, tb_ts3, tb_te3, tb_pack3, tb_gaps3, tb_sc3;
     SwPlan tb_P3;
     // set-cover graph build + greedy cover (set_cover_graph)
@@ -901,6 +934,8 @@ static void run_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t *oqe, 
     E.stats.sw_algorithmic_bytes += P.alg_bytes;
     E.stats.cells_run += P.cells;
     E.stats.n_sw_runs += P.n;
+    const bool timing = getenv("UC_TIMING") != nullptr;
+    if (timing) fprintf(stderr, "unicore-cluster[timing]: sw pass mode %d: %u pairs, %llu cells, %.2f ms (%llu launches)\n", mode, P.n, (unsigned long long)P.cells, ms, (unsigned long long)launches);
 }
 
 // exact (qEnd, tEnd) by the int32 forward kernel for the gate-passing pairs the packed kernel left ambiguous
@@ -929,6 +964,14 @@ static void fix_ambiguous_ends(Engine &E, uint32_t n2, const uint32_t *q2, const
 }
 
 void free_align_scratch(AlignScratch *p) { delete p; }
+
+// memory pressure inside the gapped stage: the traceback-byte buffer (up to 144 GiB, kept between calls because fresh memory is slow) is dead weight
+// outside the batch loop of a MODE 7 call - the engine's out-of-memory handler gives it back before it gives up
+bool release_tb_matrices(AlignScratch *p) {
+    if (!p || p->tb_tbm_live || !p->tb_tbm.cap) return false;
+    p->tb_tbm.release();
+    return true;
+}
 
 // parked between engines like the prefilter's work buffers (uc_prefilter.hip)
 namespace {
@@ -1215,16 +1258,22 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                     // sequence-identity gate / BLAST-tab statistics: (alignment length, identities[, gaps]) of the traceback on
                     // the box, computed by the MODE 3 pass of the int32 kernel for the pairs that passed the coverage gate
                     DevBuf<uint32_t> &q3 = A.tb_q3, &t3 = A.tb_t3, &src3 = A.tb_src3, &trun = A.tb_trun, &tpos = A.tb_tpos, &tpart = A.tb_tpart,
-                                     &ttie = A.tb_ttie, &tlo = A.tb_tlo, &thi = A.tb_thi, &tchunk = A.tb_tchunk, &tcpos = A.tb_tcpos;
+                                     &ttie = A.tb_ttie, &tlo = A.tb_tlo, &thi = A.tb_thi, &tmiss = A.tb_tmiss, &tchunk = A.tb_tchunk, &tcpos = A.tb_tcpos;
                     DevBuf<unsigned long long> &tbsize = A.tb_tbsize, &tboff = A.tb_tboff;
                     DevBuf<uint8_t> &tbm = A.tb_tbm;
                     DevBuf<int32_t> &qs3 = A.tb_qs3, &qe3 = A.tb_qe3, &ts3 = A.tb_ts3, &te3 = A.tb_te3, &pack3 = A.tb_pack3, &gaps3 = A.tb_gaps3, &sc3 = A.tb_sc3;
                     SwPlan &P3 = A.tb_P3;
                     trun.reserve(n2); tpos.reserve(n2); tpart.reserve(n2); ttie.reserve(n2);
                     UC_HIP(hipMemsetAsync(ttie.p, 0, (size_t)n2 * 4, s));
-                    // one batch: gather the flagged entries, plan, run, apply.  pk: packed MODE 7 (decision bytes) + walk kernel;
-                    // otherwise the int32 kernel carries the statistics through the DP (MODE 3, one pass per statistic)
-                    auto tb_batch = [&](const uint32_t *flag, bool pk) {
+                    // the flagged entries: gather, plan, run, apply.  pk: packed MODE 7 (H bytes of the box's diagonal band, tb_band_of) + walk
+                    // kernel; otherwise the int32 kernel carries the statistics through the DP (MODE 3, one pass per statistic).
+                    //
+                    // r05, pk: ONE plan for all flagged pairs of the call, and the byte matrices are produced in batches cut ALONG that plan - a batch is
+                    // a range of its class-sorted task list that fits the matrix budget, i.e. thousands of tasks of one or two length classes per
+                    // launch.  (r04 cut the flagged LIST into batches and planned each: every batch then ran all 28 class kernels with a handful of
+                    // tasks each - 442 batches at nominal configs[3], MODE 7 at 1.5 T cells/s against 5 T for the other passes:
+                    // profiles/r05/sw_pass_timing_*.txt.)  band > 0: the walk marks the pairs whose path left the band in tmiss.
+                    auto tb_batch = [&](const uint32_t *flag, bool pk, int band) {
                         scan_u32(*this, tmp, flag, tpos.p, n2, false);
                         const uint32_t nt = scan_total(*this, flag, tpos.p, n2);
                         if (!nt) return;
@@ -1235,6 +1284,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                         static const uint32_t tb_gaps[4] = {0u, 0u, 1u, 0u};
                         uint64_t launches = 0;
                         int passes = 1;
+                        const bool timing = getenv("UC_TIMING") != nullptr;
                         if (!pk) {
                             build_plan(*this, P3, tmp, nt, q3.p, t3.p, qe3.p, te3.p, 2, qs3.p, ts3.p);
                             timed_ms_begin();
@@ -1245,34 +1295,70 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                             }
                             stats.sw_kernel_ms += timed_ms_end();
                         } else {
-                            build_plan(*this, P3, tmp, nt, q3.p, t3.p, qe3.p, te3.p, 1, qs3.p, ts3.p, sc3.p);
+                            build_plan(*this, P3, tmp, nt, q3.p, t3.p, qe3.p, te3.p, 1, qs3.p, ts3.p, sc3.p, /*lpt=*/false);
                             const uint32_t n_pk3 = P3.pair_base[h_tab[1].n];      // every systolic class of table 1 is packed
-                            tbsize.reserve((size_t)n_pk3 + 1); tboff.reserve((size_t)n_pk3 + 1);
+                            const uint32_t nt_pk = P3.task_base[h_tab[1].n];      // ... and their tasks come first, in pair order
+                            double tb_ms = 0;
                             unsigned long long total = 0;
+                            uint32_t nbatch = 0;
+                            if (P3.n > n_pk3) {                                   // long queries: int32 MODE 3 (no matrices)
+                                timed_ms_begin();
+                                launches += launch_plan(*this, P3, 7, pack3.p, nullptr, nullptr, work, nullptr, /*only_long=*/true);
+                                if (p.want_tb) launches += launch_plan(*this, P3, 3, gaps3.p, nullptr, nullptr, work, tb_gaps, /*only_long=*/true);
+                                tb_ms += timed_ms_end();
+                            }
                             if (n_pk3) {
+                                tbsize.reserve((size_t)n_pk3 + 1); tboff.reserve((size_t)n_pk3 + 1);
                                 hipLaunchKernelGGL(tb_size_kernel, grid_for(n_pk3), dim3(256), 0, s, n_pk3, P3.key2.p, P3.segstart.p, P3.ste.p,
-                                                   P3.sts.p, 1, tbsize.p);
+                                                   P3.sts.p, P3.sqs.p, P3.sqe.p, band, 1, tbsize.p);
                                 size_t tbb = 0;
                                 UC_HIP(rocprim::exclusive_scan(nullptr, tbb, tbsize.p, tboff.p, 0ull, (size_t)n_pk3, rocprim::plus<unsigned long long>(), s));
                                 tmp.reserve(tbb + 256);
                                 UC_HIP(rocprim::exclusive_scan(tmp.p, tbb, tbsize.p, tboff.p, 0ull, (size_t)n_pk3, rocprim::plus<unsigned long long>(), s));
+                                // where every task's matrices begin, and its first pair: the host cuts the batches at task boundaries
+                                DevBuf<unsigned long long> &toff = A.tb_toff;
+                                toff.reserve((size_t)nt_pk + 1);
+                                hipLaunchKernelGGL(tb_taskoff_kernel, grid_for(nt_pk), dim3(256), 0, s, nt_pk, P3.tasks.p, tboff.p, toff.p);
+                                std::vector<unsigned long long> h_toff((size_t)nt_pk + 1);
+                                std::vector<SwTask> h_task(nt_pk);
                                 unsigned long long lo_ = 0, ls_ = 0;
+                                UC_HIP(hipMemcpyAsync(h_toff.data(), toff.p, (size_t)nt_pk * 8, hipMemcpyDeviceToHost, s));
+                                UC_HIP(hipMemcpyAsync(h_task.data(), P3.tasks.p, (size_t)nt_pk * sizeof(SwTask), hipMemcpyDeviceToHost, s));
                                 UC_HIP(hipMemcpyAsync(&lo_, tboff.p + (n_pk3 - 1), 8, hipMemcpyDeviceToHost, s));
                                 UC_HIP(hipMemcpyAsync(&ls_, tbsize.p + (n_pk3 - 1), 8, hipMemcpyDeviceToHost, s));
                                 UC_HIP(hipStreamSynchronize(s));
                                 total = lo_ + ls_;
-                                tbm.reserve(total + 64);
+                                h_toff[nt_pk] = total;
+                                // Fresh device memory is not free: 25-60 ms per GiB on a box whose memory has been used before (tools/ubench/alloc_cost.hip,
+                                // profiles/r04/alloc_*.log), so a call whose matrices would fit a few times over takes a third of them at a time, at least
+                                // 16 GiB (about the buffer r04 took for an eighth of its whole-box matrices).  What the buffer already holds is free to use.
+                                unsigned long long budget = tb_budget_bytes(tbm.cap);
+                                if (!getenv("UC_TB_BUDGET_MB")) {
+                                    const unsigned long long want = std::max<unsigned long long>(16ull << 30, total / 3);
+                                    budget = std::min(budget, std::max<unsigned long long>(want, (unsigned long long)tbm.cap));
+                                }
+                                A.tb_tbm_live = true;
+                                struct Live { bool &f; ~Live() { f = false; } } live{A.tb_tbm_live};
+                                for (uint32_t t0 = 0; t0 < nt_pk;) {
+                                    uint32_t t1 = t0 + 1;                      // (a single task always runs, whatever the budget: tests force tiny budgets)
+                                    while (t1 < nt_pk && h_toff[t1 + 1] - h_toff[t0] <= budget) t1++;
+                                    const unsigned long long base = h_toff[t0], bytes = h_toff[t1] - base;
+                                    const uint32_t p0 = h_task[t0].begin, p1 = t1 < nt_pk ? h_task[t1].begin : n_pk3;
+                                    tbm.reserve_exact(bytes + 64);
+                                    P3.tbm = tbm.p - base; P3.tboff = tboff.p; P3.tb_band = band;      // (a pair's offset counts from the start of the WHOLE plan)
+                                    timed_ms_begin();
+                                    launches += launch_plan(*this, P3, 7, pack3.p, nullptr, nullptr, work, nullptr, false, t0, t1, /*skip_long=*/true);
+                                    hipLaunchKernelGGL(tb_walk_kernel, grid_for(p1 - p0), dim3(256), 0, s, p0, p1, ddb, P3.key2.p, P3.st.p, P3.sqs.p, P3.sqe.p,
+                                                       P3.sts.p, P3.ste.p, P3.saux.p, p.gap_open, p.gap_ext, band, 1, tbm.p - base, tboff.p, pack3.p, gaps3.p);
+                                    tb_ms += timed_ms_end();
+                                    nbatch++;
+                                    t0 = t1;
+                                }
+                                P3.tbm = nullptr; P3.tboff = nullptr; P3.tb_band = 0;
                             }
-                            P3.tbm = tbm.p; P3.tboff = tboff.p;
-                            timed_ms_begin();
-                            launches = launch_plan(*this, P3, 7, pack3.p, nullptr, nullptr, work);        // long queries: int32 MODE 3
-                            if (p.want_tb && P3.n > n_pk3)
-                                launches += launch_plan(*this, P3, 3, gaps3.p, nullptr, nullptr, work, tb_gaps, /*only_long=*/true);
-                            if (n_pk3)
-                                hipLaunchKernelGGL(tb_walk_kernel, grid_for(n_pk3), dim3(256), 0, s, n_pk3, ddb, P3.key2.p, P3.st.p, P3.sqs.p, P3.sqe.p,
-                                                   P3.sts.p, P3.ste.p, P3.saux.p, p.gap_open, p.gap_ext, 1, tbm.p, tboff.p, pack3.p, gaps3.p);
-                            stats.sw_kernel_ms += timed_ms_end();
-                            P3.tbm = nullptr; P3.tboff = nullptr;
+                            stats.sw_kernel_ms += tb_ms;
+                            if (timing) fprintf(stderr, "unicore-cluster[timing]: sw pass mode 7: %u pairs, %llu cells, %.2f ms (%llu launches), %llu matrix bytes, band %d, %u batch(es)\n",
+                                                P3.n, (unsigned long long)P3.cells, tb_ms, (unsigned long long)launches, total, band, nbatch);
                         }
                         stats.sw_kernel_launches += launches;
                         stats.sw_algorithmic_bytes += passes * P3.alg_bytes;
@@ -1280,7 +1366,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                         stats.n_sw_runs += (uint64_t)passes * P3.n;
                         hipLaunchKernelGGL(tb_apply_kernel, grid_for(nt), dim3(256), 0, s, nt, P3.idx.p, src3.p, pack3.p,
                                            p.want_tb ? gaps3.p : (const int32_t *)nullptr, iota2.p, link.p, Lidx, p.min_seq_id, alns_b,
-                                           eflag.p, ttie.p);
+                                           eflag.p, ttie.p, (pk && band > 0) ? tmiss.p : (uint32_t *)nullptr);
                     };
                     // the walk over H bytes needs neighbouring cells within 127 of each other: largest substitution score + gap open
                     // (uc_align.hip tb_walk_kernel); anything else takes the int32 pass
@@ -1293,37 +1379,30 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                         }
                         tb_bytes_ok = tb_bytes_ok && m3 + ma + p.gap_open <= 127 && n3 + na >= -127;
                     }
+                    // r05: MODE 7 stores a diagonal band of the box, not the box (tb_band_of); the few pairs whose traceback leaves the band are redone
+                    // with everything stored.  UC_TB_BAND = half-width W (default 48; 0 = always the whole box; the tests force 1 and 4)
+                    const int tb_band_w = getenv("UC_TB_BAND") ? std::max(0, atoi(getenv("UC_TB_BAND"))) : 48;
+                    // the plan of a MODE 7 call costs ~110 B per pair beside the matrices: the flagged list is worked off in segments of 32 M pairs (nominal
+                    // configs[3]: 170 M flagged pairs per 256 M-pair batch of the stage), each planned and cut into matrix batches on its own; a segment
+                    // still holds ~1.5 TB of matrices, i.e. dozens of one-class batches.  (Tests: a forced matrix budget also forces 1000-pair segments.)
+                    auto tb_pk = [&](const uint32_t *flag, int band) {
+                        const uint32_t seg = getenv("UC_TB_BUDGET_MB") ? 1000u : (32u << 20);
+                        scan_u32(*this, tmp, flag, tcpos.p, n2, false);
+                        const uint32_t nlo = scan_total(*this, flag, tcpos.p, n2);
+                        if (nlo <= seg) { if (nlo) tb_batch(flag, true, band); return; }
+                        for (uint32_t lo = 0; lo < nlo; lo += seg) {
+                            hipLaunchKernelGGL(tb_chunk_kernel, grid_for(n2), dim3(256), 0, s, n2, flag, tcpos.p, lo, std::min<uint32_t>(nlo, lo + seg), tchunk.p);
+                            tb_batch(tchunk.p, true, band);
+                        }
+                    };
                     auto run_tb = [&](const uint32_t *flag) {
-                        if (!p.sw_pk || !tb_bytes_ok) { tb_batch(flag, false); return; }
-                        tlo.reserve(n2); thi.reserve(n2); tchunk.reserve(n2); tcpos.reserve(n2);
+                        if (!p.sw_pk || !tb_bytes_ok) { tb_batch(flag, false, 0); return; }
+                        tlo.reserve(n2); thi.reserve(n2); tmiss.reserve(n2); tchunk.reserve(n2); tcpos.reserve(n2);
                         hipLaunchKernelGGL(tb_split_kernel, grid_for(n2), dim3(256), 0, s, n2, flag, link.p, Lidx, alns_b, SW_PK_OVF_HOST, tlo.p, thi.p);
-                        tb_batch(thi.p, false);                               // scores beyond the packed range: int32 MODE 3
-                        UC_HIP(hipMemsetAsync(d_cells.p, 0, 8, s));
-                        hipLaunchKernelGGL(tb_estimate_kernel, grid_for(n2), dim3(256), 0, s, n2, tlo.p, q2.p, link.p, Lidx, alns_b, ddb.len, d_cells.p);
-                        scan_u32(*this, tmp, tlo.p, tcpos.p, n2, false);
-                        const uint32_t nlo = scan_total(*this, tlo.p, tcpos.p, n2);
-                        unsigned long long est = 0;
-                        UC_HIP(hipMemcpy(&est, d_cells.p, 8, hipMemcpyDeviceToHost));
-                        unsigned long long budget = tb_budget_bytes(tbm.cap);
-                        est += est / 8;                                       // slot partners can be longer than the pair itself
-                        // Fresh device memory is not free: 25-60 ms per GiB on a box whose memory has been used before (tools/ubench/alloc_cost.hip,
-                        // profiles/r04/alloc_*.log; UC_ALLOC_LOG=1 prints what every allocation costs).  The pre-step of configs[3]'s options at 500
-                        // proteomes took ONE 126 GiB buffer for its 26 M boxes: 2.9 s of a 5.1 s stage.  Small batches cost more than the allocation
-                        // saves, though (36 GiB batches for 2.6 TB of matrices: SW kernels 9.3 -> 11.0 s, the tails of 28 class kernels per batch), so
-                        // only a call whose matrices would fit a few times over is cut down: an eighth of the (conservative: ~3x) estimate, at least
-                        // 16 GiB — three or four batches for the pre-step above, the free-memory budget as before for every cascade round of that
-                        // database.  What the buffer already holds is free to use.
-                        if (!getenv("UC_TB_BUDGET_MB")) {
-                            const unsigned long long want = std::max<unsigned long long>(16ull << 30, est / 8);
-                            budget = std::min(budget, std::max<unsigned long long>(want, (unsigned long long)tbm.cap));
-                        }
-                        const uint32_t nchunk = (uint32_t)std::max<unsigned long long>(1, (est + budget - 1) / budget);
-                        const uint32_t per = (nlo + nchunk - 1) / std::max<uint32_t>(nchunk, 1);
-                        for (uint32_t c = 0; c < nchunk && nlo; c++) {
-                            if (nchunk == 1) { tb_batch(tlo.p, true); break; }
-                            hipLaunchKernelGGL(tb_chunk_kernel, grid_for(n2), dim3(256), 0, s, n2, tlo.p, tcpos.p, c * per, std::min<uint32_t>(nlo, (c + 1) * per), tchunk.p);
-                            tb_batch(tchunk.p, true);
-                        }
+                        tb_batch(thi.p, false, 0);                            // scores beyond the packed range: int32 MODE 3
+                        if (tb_band_w > 0) UC_HIP(hipMemsetAsync(tmiss.p, 0, (size_t)n2 * 4, s));
+                        tb_pk(tlo.p, tb_band_w);
+                        if (tb_band_w > 0) tb_pk(tmiss.p, 0);                 // tracebacks that left their band: the whole box
                     };
                     if (dedup) {
                         hipLaunchKernelGGL(tbm_flag_kernel, grid_for(n2), dim3(256), 0, s, n2, eflag.p, link.p, Lidx, mirror.p, gflag.p, gpos.p,

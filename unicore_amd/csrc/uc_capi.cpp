@@ -456,9 +456,9 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
         }
         const int pre = p.linclust ? 1 : 0;     // E8a: one linear-time pre-clustering round in front of the cascade rounds
         // the kernels' code objects are uploaded on a helper thread beside engine construction, database upload and prefilter (uc_sw.hip:preload_modules);
-        // UC_PRELOAD=0 leaves it to HIP's lazy loading.  (The future's destructor joins the thread on every way out of this function.)
+        // (The future's destructor joins the thread on every way out of this function.)
         std::future<void> preload;
-        if (W == 1 && !(getenv("UC_PRELOAD") && atoi(getenv("UC_PRELOAD")) == 0)) {
+        if (W == 1) {
             const int d0 = devices[0];
             const bool lc = pre != 0, st = stamp;
             preload = std::async(std::launch::async, [d0, lc, st]() {

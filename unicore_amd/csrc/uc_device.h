@@ -50,6 +50,7 @@ struct SwArgs {
     const int32_t *pqs = nullptr, *pts = nullptr;   // mode 3 only: box starts
     uint8_t *tbm = nullptr;                         // packed mode 7: traceback-byte matrices ...
     const unsigned long long *tboff = nullptr;      // ... and the byte offset of every pair's matrix
+    int tb_band = 0;                                // packed mode 7: half-width W of the stored diagonal band (0 = whole box), see tb_band_of()
     const int32_t *pscore = nullptr;                // packed modes 4/6: the known optimum score per pair
     int32_t *oscore, *oqe, *ote;
     int open, ext;
@@ -59,6 +60,26 @@ struct SwArgs {
 };
 
 constexpr int SW_MAX_ROWS = 2048;   // largest single-strip class (G=64, R=32)
+
+// ---- packed MODE 7: which bytes of a box are stored --------------------------------------------------------------------------------------------
+// The traceback of a box [qs..qe] x [0..tl) (columns relative to tStart) runs from (qe, tl-1) to (qs, 0): its diagonal i - c moves from qe - (tl-1)
+// to qs, and an optimal path strays from the corridor between the two only by paying for it twice (a gap out and a gap back).  MODE 7 therefore stores the
+// H bytes of the diagonals [dlo, dhi] = [min - W, max + W] only - r04 stored the whole box, 1 byte per cell, and ran at 1.5 T cells/s against the
+// forward pass's 5.1 T because of those stores (profiles/r05/sw_pass_timing_c4_p500.txt).  Granularity = what a lane produces per step: lane g owns query
+// rows [g R, g R + R) and is at column st - g in step st, so it touches the band in the steps [sa, sb] = [g (R+1) - dhi, g (R+1) + R - 1 - dlo]; at any step
+// the lanes inside the band are consecutive and at most NL = (dhi - dlo + R - 1) / (R + 1) + 1 of them, so a step's row of the matrix is NL x RB bytes and
+// lane g's slot in it is g % NL.  NL >= G (short queries, W = 0) means "everything": slot g, every step.  The walk (tb_walk_kernel) uses the same
+// numbers; a read outside the band makes it give up on the pair, which is then redone with the whole box stored.
+struct TbBand { int nl, dlo, dhi; };
+__host__ __device__ inline TbBand tb_band_of(int qs, int qe, int tl, int G, int R, int W) {
+    TbBand b;
+    const int d0 = qs, d1 = qe - (tl - 1);
+    b.dlo = (d0 < d1 ? d0 : d1) - W;
+    b.dhi = (d0 < d1 ? d1 : d0) + W;
+    const int nl = (b.dhi - b.dlo + R - 1) / (R + 1) + 1;
+    b.nl = (W <= 0 || nl >= G) ? G : nl;
+    return b;
+}
 
 // host launchers (uc_sw.hip / uc_prefilter.hip)
 void launch_sw_class(int G, int R, int mode, const SwArgs &a, uint32_t n_tasks, hipStream_t s);

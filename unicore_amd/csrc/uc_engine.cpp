@@ -195,6 +195,7 @@ bool Engine::relieve_pressure(int stage) {
     (void)hipMemGetInfo(&f0, &tot);
     bool freed = false;
     if (stage != 1 && aln) { free_align_scratch(aln); aln = nullptr; freed = true; }
+    if (stage == 1 && aln && release_tb_matrices(aln)) freed = true;      // the gapped stage's own traceback-byte buffer, when no batch loop is using it
     if (stage != 0 && pre) { free_prefilter_scratch(pre); pre = nullptr; freed = true; }
     if (PrefilterScratch *x = take_parked_prefilter_scratch(device)) { free_prefilter_scratch(x); freed = true; }
     if (AlignScratch *x = take_parked_align_scratch(device)) { free_align_scratch(x); freed = true; }

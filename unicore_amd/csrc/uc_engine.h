@@ -30,20 +30,11 @@ namespace uc {
 struct OomRelief { bool (*fn)(void *) = nullptr; void *ctx = nullptr; };
 inline OomRelief &oom_relief_slot() { static thread_local OomRelief r; return r; }
 inline hipError_t malloc_with_relief(void **p, size_t bytes) {
-    static const bool log = getenv("UC_ALLOC_LOG") != nullptr;   // what every allocation of 64 MiB and more costs (fresh device memory: ~60 ms per GiB on this box)
-    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(p, bytes);
     if (e == hipErrorOutOfMemory) {
         const OomRelief r = oom_relief_slot();
         (void)hipGetLastError();
         if (r.fn && r.fn(r.ctx)) e = hipMalloc(p, bytes);
-    }
-    if (log && bytes >= (64u << 20)) {
-        static std::atomic<uint64_t> tot_us{0}, tot_mib{0};
-        const uint64_t us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
-        tot_us += us; tot_mib += bytes >> 20;
-        fprintf(stderr, "unicore-cluster[alloc]: %8.1f MiB in %8.2f ms (running total %.1f GiB, %.1f ms)\n", (double)bytes / (1 << 20), us / 1e3, tot_mib.load() / 1024.0,
-                tot_us.load() / 1e3);
     }
     return e;
 }
@@ -68,6 +59,12 @@ struct DevBuf {   // plain owning device allocation (hipMalloc), grows geometric
         size_t want = n + n / 8 + 64;
         UC_HIP(malloc_with_relief((void **)&p, want * sizeof(T)));
         cap = want;
+    }
+    void reserve_exact(size_t n) {   // no growth margin (the traceback-byte buffer is sized against what is free)
+        if (n <= cap) return;
+        release();
+        UC_HIP(malloc_with_relief((void **)&p, n * sizeof(T)));
+        cap = n;
     }
     // keeps the first `used` elements.  The copy runs ON `s`, behind whatever that stream still has in flight for the old
     // buffer (a null-stream hipMemcpy does not order itself against a hipStreamNonBlocking stream), and is complete on return.
@@ -110,6 +107,7 @@ PrefilterScratch *take_prefilter_scratch(int device);
 PrefilterScratch *take_parked_prefilter_scratch(int device);
 struct AlignScratch;                                      // uc_align.hip
 void free_align_scratch(AlignScratch *p);
+bool release_tb_matrices(AlignScratch *p);   // the traceback-byte buffer, unless a MODE 7 batch loop is using it right now (uc_align.hip)
 void park_align_scratch(AlignScratch *p, int device);
 AlignScratch *take_align_scratch(int device);
 AlignScratch *take_parked_align_scratch(int device);

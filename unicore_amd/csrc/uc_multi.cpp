@@ -303,7 +303,7 @@ void prefilter_cell(Engine &E, int world, int target_shards, int rank) {
     grid_shape(world, target_shards, &Q, &T);
     const GridCell g = grid_cell(E.h_len, world, target_shards, rank);
     const char *off = getenv("UC_PREFILTER_SYMMETRIC");
-    const bool sym = T == world && world > 1 && E.p.mat_symmetric && !(off && atoi(off) == 0) && !getenv("UC_SIM_PER_POSITION");
+    const bool sym = T == world && world > 1 && E.p.mat_symmetric && !(off && atoi(off) == 0);
     if (!sym) { E.prefilter(g.tb, g.te, g.qb, g.qe); return; }
     const auto shards = shard_ranges(E.h_len, world);
     std::vector<std::pair<uint32_t, uint32_t>> others;

@@ -617,13 +617,9 @@ template <bool C>
 __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t qbegin, uint32_t p0, const uint32_t *rpidx,
                                                     const uint64_t *rval, const uint64_t *qr, const uint32_t *order, const void *ent, KeyFmt fmt,
                                                     unsigned long long *region_cursor, void *region_v, uint64_t region_cap,
-                                                    uint64_t *qbase, uint32_t *qsurv, unsigned long long *prof /* UC_FILTER_PROF: cycles per phase */) {
+                                                    uint64_t *qbase, uint32_t *qsurv) {
     using TD = typename TdType<C>::type;
-    struct __attribute__((aligned(4))) TD4 { TD v[KPT]; };
-    unsigned long long t_prev = prof ? wall_clock64() : 0;
-    auto lap = [&](int k) {
-        if (prof && threadIdx.x == 0) { const unsigned long long t = wall_clock64(); atomicAdd(prof + k, t - t_prev); t_prev = t; }
-    };        // KPT keys of one thread: dword-aligned vector access
+    struct __attribute__((aligned(4))) TD4 { TD v[KPT]; };        // KPT keys of one thread: dword-aligned vector access
     TD *region = (TD *)region_v;
     extern __shared__ __attribute__((aligned(16))) uint32_t f_lds[];
     constexpr int BW = 1 << (FB_LOG2 - 5);          // words per bitmap
@@ -762,11 +758,9 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
     const uint64_t base = s_misc[2];
     uint32_t *cur = (uint32_t *)&s_misc[3];
     uint32_t total = 0;
-    lap(0);                                  // clear + region reservation
     prefetch_tile(r0);
     for (uint64_t tile = r0; tile < r1; tile += TR) {
         load_tile(tile);
-        lap(1);                              // tile loads + scan
         prefetch_tile(tile + TR);
         const uint32_t T = s_pref[TR];
         using ET = typename std::conditional<C, uint32_t, uint64_t>::type;
@@ -802,7 +796,6 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
         }
         total += T;
         __syncthreads();
-        lap(2);                              // expansion + marks + key stream
     }
     __threadfence_block();
     __syncthreads();
@@ -858,7 +851,6 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
     // keys go back to the head of the query's region.
     __threadfence_block();
     __syncthreads();
-    lap(3);                                  // sweep 2
     const uint32_t n1 = *cur;
     for (int w = tid; w < 2 * BW; w += FT) f_lds[w] = 0;
     uint32_t *cur2 = cur + 1;
@@ -896,7 +888,6 @@ __global__ void __launch_bounds__(FT) filter_kernel(const DeviceDb db, uint32_t 
         }
     }
     __syncthreads();
-    lap(4);                                  // level 2
     if (tid == 0) { qbase[qi] = base; qsurv[qi] = *cur2; }
 }
 
@@ -1284,12 +1275,12 @@ struct WidenU32 {
 // work buffers of the prefilter, kept by the engine between calls (hipMalloc / hipFree of multi-GB buffers on every
 // call cost tens of ms per step and, now and then, seconds)
 struct PrefilterScratch {
-    DevBuf<unsigned long long> d_counters, d_prof;
+    DevBuf<unsigned long long> d_counters;
     DevBuf<char> d_temp;
     DevBuf<uint32_t> d_koff, k_in, k_out, d_ent32, v_in32, d_okey, d_okey2, d_oidx, d_order;
     DevBuf<uint64_t> d_ent, v_in;
-    DevBuf<uint32_t> d_cnt, d_flag, d_cq, d_ct, d_rpidx, d_rpidx2, d_qsurv;
-    DevBuf<uint64_t> d_keys, d_keys2, d_pos, d_skey, d_skey2, d_rval, d_rval2, d_qbase, d_soff, d_qr;
+    DevBuf<uint32_t> d_cnt, d_flag, d_cq, d_ct, d_rpidx2, d_qsurv;
+    DevBuf<uint64_t> d_keys, d_keys2, d_pos, d_skey, d_skey2, d_rval2, d_qbase, d_soff, d_qr;
     DevBuf<int32_t> d_cd, d_cd2, d_score;
     // distinct-k-mer enumeration (E2)
     DevBuf<uint8_t> d_kflag, d_wflag;
@@ -1299,9 +1290,9 @@ struct PrefilterScratch {
     DevBuf<uint32_t> d_kbits;       // presence bitmap of the chunk's k-mers
     // every buffer (for the size bookkeeping below)
     template <class F> void each(F f) {
-        f(d_counters); f(d_prof); f(d_temp); f(d_koff); f(k_in); f(k_out); f(d_ent32); f(v_in32); f(d_okey); f(d_okey2); f(d_oidx); f(d_order);
-        f(d_ent); f(v_in); f(d_cnt); f(d_flag); f(d_cq); f(d_ct); f(d_rpidx); f(d_rpidx2); f(d_qsurv); f(d_keys); f(d_keys2); f(d_pos); f(d_skey);
-        f(d_skey2); f(d_rval); f(d_rval2); f(d_qbase); f(d_soff); f(d_qr); f(d_cd); f(d_cd2); f(d_score); f(d_kflag); f(d_wflag); f(d_qk); f(d_kid); f(d_dk);
+        f(d_counters); f(d_temp); f(d_koff); f(k_in); f(k_out); f(d_ent32); f(v_in32); f(d_okey); f(d_okey2); f(d_oidx); f(d_order);
+        f(d_ent); f(v_in); f(d_cnt); f(d_flag); f(d_cq); f(d_ct); f(d_rpidx2); f(d_qsurv); f(d_keys); f(d_keys2); f(d_pos); f(d_skey);
+        f(d_skey2); f(d_rval2); f(d_qbase); f(d_soff); f(d_qr); f(d_cd); f(d_cd2); f(d_score); f(d_kflag); f(d_wflag); f(d_qk); f(d_kid); f(d_dk);
         f(d_nsimk); f(d_drk); f(d_drk2); f(d_roff); f(d_nr); f(d_src); f(d_ph); f(d_drv); f(d_drv2); f(d_cumh); f(d_cumr); f(d_qh); f(d_qrn); f(d_rec); f(d_kbits);
     }
     size_t bytes() {
@@ -1428,7 +1419,7 @@ void Engine::prefilter_impl(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uin
         // yield the candidates of the pairs the other way round (diag_select_kernel), i.e. what the skipped passes (query in c, target chunk
         // behind it) would have found: ~(1 + 1/C) / 2 of the k-mer hits are expanded.  The lists of a pass come back ungrouped and are merged
         // like the chunk lists always were (lossless: per-pass top-M of disjoint candidate sets).  UC_PREFILTER_SYMMETRIC=0: every pass matches all queries.
-        const bool triangle = chunks.size() > 1 && tbegin == qbegin && tend == qend && p.mat_symmetric && !getenv("UC_SIM_PER_POSITION") &&
+        const bool triangle = chunks.size() > 1 && tbegin == qbegin && tend == qend && p.mat_symmetric &&
                               !(getenv("UC_PREFILTER_SYMMETRIC") && atoi(getenv("UC_PREFILTER_SYMMETRIC")) == 0);
         if (chunks.size() <= 1) {
             // (mirror_all — prefilter_cells only: every query lies outside the shard and yields the pair the other way round as well; the lists come
@@ -1575,20 +1566,18 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
     stats.stage_seconds[UC_ST_INDEX] += t_index.seconds();
 
     // ------------------------------------------------------------ E2-E4 over query batches
-    const bool distinct_mode = !getenv("UC_SIM_PER_POSITION");   // the r2 path (DFS per query position + sort of all runs by position), kept for A/B runs
     // keys per batch (the filter's regions hold < 2^32 keys).  1.5 G keys = 12 GiB of regions: a one-shot `foldseek cluster` process
     // pays for every byte it allocates (34 GiB of regions at 3.75 G keys: 5.2 s from process start to clust.tsv at configs[1]
     // instead of 1.25 s), and a resident engine loses nothing measurable (681 vs 681 ms per step; UC_HIT_CAP overrides)
-    const uint64_t HIT_CAP = getenv("UC_HIT_CAP") ? std::max<uint64_t>(1u << 20, strtoull(getenv("UC_HIT_CAP"), nullptr, 10)) : distinct_mode ? (3ull << 29) : (1ull << 31);
+    const uint64_t HIT_CAP = getenv("UC_HIT_CAP") ? std::max<uint64_t>(1u << 20, strtoull(getenv("UC_HIT_CAP"), nullptr, 10)) : (3ull << 29);
     // ... unless the chunk has so many hits that the batches would run into the hundreds (2.5 M sequences: 1.5e12 hits): then the
     // per-batch costs outweigh the allocation and the regions take 3.75 G keys (30 GiB)
     const uint64_t HIT_CAP_BIG = getenv("UC_HIT_CAP") ? HIT_CAP : (15ull << 28);
     uint64_t hit_cap = HIT_CAP;
     const uint64_t RUN_MAX = 1ull << 29;       // runs per batch (6 GiB + 6 GiB sort double buffer)
-    double hits_per_res = 64.0;                // adaptive estimates
     uint64_t run_cap = 1ull << 20;
-    DevBuf<uint32_t> &d_cnt = S.d_cnt, &d_flag = S.d_flag, &d_cq = S.d_cq, &d_ct = S.d_ct, &d_rpidx = S.d_rpidx, &d_rpidx2 = S.d_rpidx2, &d_qsurv = S.d_qsurv;
-    DevBuf<uint64_t> &d_keys = S.d_keys, &d_keys2 = S.d_keys2, &d_pos = S.d_pos, &d_skey = S.d_skey, &d_skey2 = S.d_skey2, &d_rval = S.d_rval, &d_rval2 = S.d_rval2,
+    DevBuf<uint32_t> &d_cnt = S.d_cnt, &d_flag = S.d_flag, &d_cq = S.d_cq, &d_ct = S.d_ct, &d_rpidx2 = S.d_rpidx2, &d_qsurv = S.d_qsurv;
+    DevBuf<uint64_t> &d_keys = S.d_keys, &d_keys2 = S.d_keys2, &d_pos = S.d_pos, &d_skey = S.d_skey, &d_skey2 = S.d_skey2, &d_rval2 = S.d_rval2,
                      &d_qbase = S.d_qbase, &d_soff = S.d_soff;
     DevBuf<int32_t> &d_cd = S.d_cd, &d_cd2 = S.d_cd2, &d_score = S.d_score;
     uint64_t n_hits_total = 0, n_cand_total = 0, cand_cap = 0;
@@ -1695,7 +1684,7 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
         UC_HIP(hipStreamSynchronize(stream));
         plan_sims = c0;
         for (uint32_t i = 0; i < nqa; i++) plan_hits += h_qh[i];
-        hit_cap = distinct_mode && plan_hits > 16 * HIT_CAP ? HIT_CAP_BIG : HIT_CAP;
+        hit_cap = plan_hits > 16 * HIT_CAP ? HIT_CAP_BIG : HIT_CAP;
         gpu_ms += timed_ms_end();
         t_kmer += t_p.seconds();
         if (sa == first_query) {
@@ -1710,7 +1699,7 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
 
     uint32_t sb_begin = qbegin;
     for (uint32_t qa = qbegin; qa < qend;) {
-        if (distinct_mode && qa >= sb_end) {
+        if (qa >= sb_end) {
             for (;;) {
                 const uint32_t left = qend - qa;
                 const uint32_t sb = sb_frac >= 1.0 ? qend : qa + std::max<uint32_t>(1, std::min<uint32_t>(left, (uint32_t)(left * sb_frac)));
@@ -1733,9 +1722,9 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
         Timer t_b;
         timed_ms_begin();
         uint32_t qb = qa;
-        uint64_t total_hits = 0, n_runs = 0, sims_this_batch = 0, mirror_hits = 0;
+        uint64_t total_hits = 0, n_runs = 0, mirror_hits = 0;
         uint32_t qp0 = 0, qp1 = 0, nq_res = 0;
-        if (distinct_mode) {
+        {
             // exact plan: as many queries as fit the key and run buffers (a single query may exceed them and takes the wide path)
             while (qb < sb_end && qb - qa < (1u << 23) - 1) {
                 const uint64_t h = h_qh[qb - sb_begin], r = h_qr[qb - sb_begin];
@@ -1752,60 +1741,8 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
             if (n_runs)
                 hipLaunchKernelGGL(position_expand_kernel, grid_for(nq_res), dim3(256), 0, stream, qp0 - P0, qp1 - P0, S.d_nr.p, S.d_src.p, S.d_cumr.p, S.d_drv2.p,
                                    d_rpidx2.p, d_rval2.p);
-        } else {
-        // choose batch [qa, qb) by estimated hits
-        {
-            const double budget = (double)HIT_CAP * 0.5;
-            uint64_t res = 0;
-            while (qb < qend && qb - qa < (1u << 23) - 1) {
-                res += h_len[qb];
-                if (qb > qa && (double)res * hits_per_res > budget) break;
-                qb++;
-            }
-        }
-        for (;;) {   // pass 1: runs + exact hit count; shrink the batch / grow the run list if it does not fit
-            qp0 = h_poff[qa]; qp1 = h_poff[qb]; nq_res = qp1 - qp0;
-            const bool single = qb - qa == 1;
-            run_cap = std::min<uint64_t>(RUN_MAX, std::max<uint64_t>(run_cap, (uint64_t)nq_res * 16));
-            d_rpidx.reserve(run_cap); d_rval.reserve(run_cap);
-            UC_HIP(hipMemsetAsync(d_counters.p + 3, 0, 32, stream));   // run cursor, batch hits, key cursor, candidate cursor
-            UC_HIP(hipMemsetAsync(d_counters.p, 0, 8, stream));
-            const RunList rl{d_rpidx.p, d_rval.p, run_cap};
-            hipLaunchKernelGGL(sim_runs_kernel, sim_grid(nq_res), dim3(256), 0, stream, ddb, cfg, qa, qb, qp0, qp1, d_koff.p, rl, d_counters.p,
-                               (const uint32_t *)nullptr, (uint32_t *)nullptr, 1u);
-            unsigned long long c5[5];
-            UC_HIP(hipMemcpyAsync(c5, d_counters.p, 40, hipMemcpyDeviceToHost, stream));
-            UC_HIP(hipStreamSynchronize(stream));
-            n_runs = c5[3];
-            total_hits = c5[4];
-            if (total_hits > HIT_CAP && !single) { qb = qa + std::max<uint32_t>(1, (qb - qa) / 2); continue; }
-            if (n_runs > run_cap) {
-                if (run_cap < RUN_MAX || single) {
-                    if (n_runs > (1ull << 32)) fail(UC_ERR_GENERIC, "query %u alone produces %llu index ranges", qa, (unsigned long long)n_runs);
-                    run_cap = single ? n_runs : std::min<uint64_t>(RUN_MAX, std::max<uint64_t>(n_runs, run_cap * 2));
-                    if (n_runs > run_cap) qb = qa + std::max<uint32_t>(1, (qb - qa) / 2);
-                    continue;
-                }
-                qb = qa + std::max<uint32_t>(1, (qb - qa) / 2);
-                continue;
-            }
-            sims_this_batch = count_sims ? c5[0] : 0;
-            if (count_sims) stats.n_sim_kmers += c5[0];
-            break;
-        }
-        }
-        if (!distinct_mode && density_out && qa == qbegin) *density_out = (double)total_hits / std::max<uint32_t>(1, nq_res);
-        if (!distinct_mode && density_limit > 0 && qa == qbegin && p.min_diag_hits >= 2 && tend - tbegin > 1 &&
-            (double)total_hits / std::max<uint32_t>(1, nq_res) > density_limit) {
-            // undo what this abandoned attempt counted
-            if (count_sims) stats.n_sim_kmers -= std::min<uint64_t>(stats.n_sim_kmers, sims_this_batch);
-            stats.n_index_entries -= n_entries;
-            stats.algorithmic_bytes[UC_ST_INDEX] -= 6ull * n_entries + 8ull * KSPACE;
-            stats.prefilter_kernel_ms += gpu_ms + timed_ms_end();
-            return false;
         }
         if (total_hits > (1ull << 34)) fail(UC_ERR_GENERIC, "query %u alone produces %llu k-mer hits", qa, (unsigned long long)total_hits);
-        hits_per_res = std::max(1.0, (double)total_hits / std::max<uint32_t>(1, nq_res)) * 1.25;
         n_hits_total += total_hits + mirror_hits;
         uint64_t n_cand = 0;
         if (total_hits) {
@@ -1821,19 +1758,12 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
                 unsigned pbits = 1;
                 while ((1ull << pbits) < nq_res) pbits++;
                 d_rpidx2.reserve(run_cap); d_rval2.reserve(run_cap);
-                if (!distinct_mode) {   // distinct mode laid the runs out by position already
-                    UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, d_rpidx.p, d_rpidx2.p, d_rval.p, d_rval2.p, (size_t)n_runs, 0u, pbits, stream));
-                    temp_reserve(tb);
-                    UC_HIP(rocprim::radix_sort_pairs(d_temp.p, tb, d_rpidx.p, d_rpidx2.p, d_rval.p, d_rval2.p, (size_t)n_runs, 0u, pbits, stream));
-                }
                 d_qbase.reserve(nq); d_qsurv.reserve(nq); d_soff.reserve((size_t)nq + 1);
                 // the query regions hold (target, diagonal) keys: u32 in compact mode (half of the u64 buffer stays unused),
                 // every region rounded up to KPT keys
                 const uint64_t region_cap = total_hits + (uint64_t)KPT * nq;
                 d_keys.reserve(fmt.compact ? region_cap : 2 * region_cap);       // regions + survivor area of the same size
                 S.d_qr.reserve((size_t)nq + 1);
-                unsigned long long *prof_p = nullptr;
-                if (getenv("UC_FILTER_PROF")) { S.d_prof.reserve(8); prof_p = S.d_prof.p; UC_HIP(hipMemsetAsync(prof_p, 0, 64, stream)); }
                 hipLaunchKernelGGL(run_range_kernel, grid_for((uint64_t)nq + 1), dim3(256), 0, stream, ddb, qa, nq, qp0, d_rpidx2.p, n_runs, S.d_qr.p);
                 S.d_okey.reserve(nq); S.d_okey2.reserve(nq); S.d_oidx.reserve(nq); S.d_order.reserve(nq);
                 hipLaunchKernelGGL(run_order_key_kernel, grid_for(nq), dim3(256), 0, stream, nq, S.d_qr.p, S.d_okey.p, S.d_oidx.p);
@@ -1845,17 +1775,10 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
                         static PerDeviceOnce once[2];
                         once[fmt.compact ? 1 : 0]([&] { UC_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter_lds(FILTER_RPT))); });
                         hipLaunchKernelGGL(kern, dim3(nq), dim3(FT), filter_lds(FILTER_RPT), stream, ddb, qa, qp0, d_rpidx2.p, d_rval2.p, S.d_qr.p, S.d_order.p, ent_p, fmt,
-                                           d_counters.p + 5, (void *)d_keys.p, region_cap, d_qbase.p, d_qsurv.p, prof_p);
+                                           d_counters.p + 5, (void *)d_keys.p, region_cap, d_qbase.p, d_qsurv.p);
                     };
                     if (fmt.compact) launch(filter_kernel<true>);
                     else launch(filter_kernel<false>);
-                }
-                if (prof_p) {
-                    unsigned long long hp[8];
-                    UC_HIP(hipMemcpyAsync(hp, prof_p, 64, hipMemcpyDeviceToHost, stream));
-                    UC_HIP(hipStreamSynchronize(stream));
-                    fprintf(stderr, "filter phases (sum over %u workgroups, 100 MHz ticks): clear+reserve %llu, tile loads %llu, expand %llu, sweep2 %llu, level2 %llu\n",
-                            nq, hp[0], hp[1], hp[2], hp[3], hp[4]);
                 }
                 auto sin = rocprim::make_transform_iterator(d_qsurv.p, WidenU32());
                 UC_HIP(rocprim::exclusive_scan(nullptr, tb, sin, d_soff.p, (uint64_t)0, (size_t)nq, rocprim::plus<uint64_t>(), stream));
@@ -1883,7 +1806,7 @@ bool Engine::prefilter_one(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint
             } else {
                 d_keys.reserve(total_hits);
                 d_keys2.reserve(total_hits);
-                const RunList rl{distinct_mode ? d_rpidx2.p : d_rpidx.p, distinct_mode ? d_rval2.p : d_rval.p, run_cap};
+                const RunList rl{d_rpidx2.p, d_rval2.p, run_cap};
                 hipLaunchKernelGGL(expand_kernel, grid_for(n_runs), dim3(256), 0, stream, ddb, qa, qb, qp0, rl, n_runs, ent_p, fmt,
                                    d_counters.p + 5, d_keys.p, total_hits);
                 UC_HIP(rocprim::radix_sort_keys(nullptr, tb, d_keys.p, d_keys2.p, (size_t)total_hits, 0u, kbits, stream));

@@ -62,8 +62,8 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
     // column, and only at such steps (a rare, wave-level branch) the lane looks at its rows: first optimal row, and
     // whether a single row holds all optimal cells (the condition under which a mutual hit may share the result).
     // MODE 7 = traceback bytes: the forward DP on the box [qs..qe] x [ts..te] of an accepted pair; instead of tracking an
-    // end position every cell stores ONE byte, H mod 256, into a per-pair matrix in HBM, laid out by anti-diagonal step so
-    // that a lane group stores G*RB contiguous bytes per step.  No decision is computed here (r04: six compare bits per
+    // end position every cell of the diagonal band the traceback can reach (tb_band_of, uc_device.h; r05) stores ONE byte, H mod 256,
+    // into a per-pair matrix in HBM, laid out by anti-diagonal step so that the lanes inside the band store NL*RB contiguous bytes per step.  No decision is computed here (r04: six compare bits per
     // cell had cost 16 of the pass's 27 VALU instructions per row and step; a byte of H costs the byte shuffle only).  A
     // second kernel (tb_walk_kernel, uc_align.hip) walks every pair's matrix from the end cell, whose H it knows (the
     // score): neighbouring cells differ by less than 128, so every H it needs is exact again, and every decision of the
@@ -116,6 +116,8 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
     [[maybe_unused]] uint32_t knownA = 0, knownB = 0;
     uint32_t gA = 0, gB = 0, toffA = 0, toffB = 0;
     [[maybe_unused]] unsigned long long tbA = 0, tbB = 0;
+    [[maybe_unused]] int tsaA = 0, tsbA = 0, tsaB = 0, tsbB = 0;        // MODE 7: the steps in which this lane is inside the pair's stored band
+    [[maybe_unused]] uint32_t trowA = 0, trowB = 0, tslotA = 0, tslotB = 0;   // ... bytes per step of the pair's matrix, this lane's byte offset in a step
     int tlenA = 0, tlenB = 0, rowoffA = 0, rowoffB = 0;
     bool vB = false, active = false;
     int lst = 0, nst = 0;
@@ -196,6 +198,15 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
             tlenB = vB ? a.pte[gB] - a.pts[gB] + 1 : 0;
             tbA = a.tboff[gA]; tbB = a.tboff[gB];
             const int qsA = a.pqs[gA], qeA = a.pqe[gA], qsB = a.pqs[gB], qeB = a.pqe[gB];
+            {   // the stored band of either pair (tb_band_of, uc_device.h)
+                constexpr int RBc = 4 * RW;
+                const TbBand bA = tb_band_of(qsA, qeA, tlenA, G, R, a.tb_band), bB = tb_band_of(qsB, qeB, vB ? tlenB : 1, G, R, a.tb_band);
+                const bool fullA = bA.nl >= G, fullB = bB.nl >= G;
+                tsaA = fullA ? 0 : g * (R + 1) - bA.dhi; tsbA = fullA ? 0x7fffffff : g * (R + 1) + R - 1 - bA.dlo;
+                tsaB = fullB ? 0 : g * (R + 1) - bB.dhi; tsbB = fullB ? 0x7fffffff : g * (R + 1) + R - 1 - bB.dlo;
+                trowA = (uint32_t)(bA.nl * RBc); trowB = (uint32_t)(bB.nl * RBc);
+                tslotA = (uint32_t)((g % bA.nl) * RBc); tslotB = (uint32_t)((g % bB.nl) * RBc);
+            }
 #pragma unroll
             for (int k = 0; k < RW; k++) {
                 uint32_t ma = 0, mb = 0;
@@ -288,7 +299,6 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
             if (r & 1) colmax = pk_max3(colmax, H[r - 1], h);   // two rows per instruction (R is even)
         }
         if constexpr (TBB) {   // bytes of 4 rows -> one dword per pair; step-major matrix: G*RB contiguous bytes per group and step
-            constexpr int RB = 4 * RW;
             uint32_t wa[RW], wb[RW];
 #pragma unroll
             for (int k = 0; k < RW; k++) {
@@ -301,8 +311,9 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
             }
             // every lane writes its RB bytes with as few (dword-aligned) wide stores as possible: the lanes of a group cover
             // G*RB contiguous bytes, so the stores of a step fill whole lines; streaming (written once, read sparsely)
-            uint8_t *dA = a.tbm + tbA + (unsigned long long)st * (G * RB) + (unsigned long long)g * RB;
-            uint8_t *dB = a.tbm + tbB + (unsigned long long)st * (G * RB) + (unsigned long long)g * RB;
+            // (a step's row holds the lanes inside the pair's band only: trow = NL * RB bytes, this lane at tslot)
+            uint8_t *dA = a.tbm + tbA + (unsigned long long)st * trowA + tslotA;
+            uint8_t *dB = a.tbm + tbB + (unsigned long long)st * trowB + tslotB;
             auto put = [&](uint8_t *d, const uint32_t *w) __attribute__((always_inline)) {
                 int k = 0;
 #pragma unroll
@@ -318,8 +329,8 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
 #pragma unroll
                 for (; k < RW; k++) *(uint32_t *)(d + 4 * k) = w[k];
             };
-            put(dA, wa);
-            if (vB) put(dB, wb);
+            if (st >= tsaA && st <= tsbA) put(dA, wa);
+            if (vB && st >= tsaB && st <= tsbB) put(dB, wb);
         }
         if constexpr (TRACK && !KNOWN) {
             const uint32_t cmA = colmax & 0xffffu, cmB = colmax >> 16;

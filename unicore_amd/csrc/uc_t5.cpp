@@ -366,18 +366,12 @@ void T5Model::encode_batch(const std::vector<const std::string *> &seqs, std::ve
 
     UC_HIP(hipEventRecord(ev[0], stream));
     t5_embed(d_tok, emb, hidden, T, D, cfg.vocab, stream);
-    int run_layers = cfg.n_layers, dbg_part = 3;
-    if (const char *e = getenv("UC_T5_DEBUG_LAYERS")) run_layers = std::min(cfg.n_layers, atoi(e));     // bisecting aid: stop after k blocks
-    if (const char *e = getenv("UC_T5_DEBUG_PART")) dbg_part = atoi(e);                                   // bit 0: attention half, bit 1: FFN half
-    for (int li = 0; li < run_layers; li++) {
+    for (int li = 0; li < cfg.n_layers; li++) {
         const Layer &L = layers[(size_t)li];
-        if (!(dbg_part & 1)) goto ffn_half;
         t5_rmsnorm(hidden, L.attn_norm, xn, T, D, cfg.eps, stream);
         t5_gemm(0, xn, L.wqkv, qkv, T, 3 * HD, D, stream);
         t5_attention(qkv, d_tiles, (int)tiles.size(), bias_tab, bias_span, H, ao, stream);
         t5_gemm(2, ao, L.wo, hidden, T, D, HD, stream);
-    ffn_half:
-        if (!(dbg_part & 2)) continue;
         t5_rmsnorm(hidden, L.ffn_norm, xn, T, D, cfg.eps, stream);
         t5_gemm(1, xn, L.wi, ff, T, F, D, stream);
         t5_gemm(2, ff, L.wo2, hidden, T, D, F, stream);
