@@ -89,6 +89,9 @@ typedef struct uc_stats {
      * (in-process ranks: the barriers around the device copies; RCCL ranks: 0 - the wait is inside the stream synchronisation of [3]),
      * [3] the data movement itself (grouped ncclSend / ncclRecv + stream synchronisation, or the device copies of in-process ranks) */
     double exchange2_seconds[4];
+    /* (ABI 5) DP cells of the traceback boxes [qStart..qEnd] x [tStart..tEnd] of every pair whose statistics were asked for (--min-seq-id, search):
+     * the fourth pass of the spec; cells_fwd + cells_rev + cells_start + cells_tb is what cells_run has to be read against */
+    uint64_t cells_tb;
 } uc_stats;
 
 /* ---- the three calls of cluster.rs ------------------------------------------------------------ */

@@ -33,7 +33,7 @@ class UcStats(C.Structure):
         ("prefilter_kernel_ms", C.c_double), ("n_filtered_hits", C.c_uint64), ("n_sw_runs", C.c_uint64),
         ("cells_run", C.c_uint64), ("exchange_seconds", C.c_double), ("exchange_bytes", C.c_uint64),
         ("n_gpus", C.c_uint32), ("target_shards", C.c_uint32), ("phase_seconds", C.c_double * 8),
-        ("nccl_ranks", C.c_uint32), ("reserved0", C.c_uint32), ("exchange2_seconds", C.c_double * 4)]
+        ("nccl_ranks", C.c_uint32), ("reserved0", C.c_uint32), ("exchange2_seconds", C.c_double * 4), ("cells_tb", C.c_uint64)]
 
     def as_dict(self):
         d = {}

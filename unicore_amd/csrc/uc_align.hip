@@ -347,6 +347,18 @@ __global__ void __launch_bounds__(256) len_gate_gather_kernel(uint32_t n, const 
 __global__ void __launch_bounds__(256) len_gate_putback_kernel(uint32_t nc, const uint32_t *map, const uc_aln *src, uc_aln *dst) {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nc; i += gridDim.x * 256) dst[map[i]] = src[i];
 }
+// algorithmic cells of the traceback pass: the box of every entry whose statistics are asked for
+__global__ void __launch_bounds__(256) cells_tb_kernel(uint32_t n2, const uint32_t *eflag, const uint32_t *link, const uint32_t *idx0, const uc_aln *alns,
+                                                       unsigned long long *out) {
+    unsigned long long c = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256)
+        if (eflag[i]) {
+            const uc_aln a = alns[idx0[link[i]]];
+            c += (unsigned long long)(a.qend - a.qstart + 1) * (unsigned long long)(a.tend - a.tstart + 1);
+        }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
 // algorithmic cells of the start pass: (qEnd+1) x (tEnd+1) per gate passer
 __global__ void __launch_bounds__(256) cells_box_kernel(uint32_t n, const int32_t *qe, const int32_t *te, unsigned long long *out) {
     unsigned long long c = 0;
@@ -1265,6 +1277,14 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                     SwPlan &P3 = A.tb_P3;
                     trun.reserve(n2); tpos.reserve(n2); tpart.reserve(n2); ttie.reserve(n2);
                     UC_HIP(hipMemsetAsync(ttie.p, 0, (size_t)n2 * 4, s));
+                    {
+                        unsigned long long hc = 0;
+                        UC_HIP(hipMemsetAsync(d_cells.p, 0, 8, s));
+                        hipLaunchKernelGGL(cells_tb_kernel, grid_for(n2), dim3(256), 0, s, n2, eflag.p, link.p, Lidx, alns_b, d_cells.p);
+                        UC_HIP(hipMemcpyAsync(&hc, d_cells.p, 8, hipMemcpyDeviceToHost, s));
+                        UC_HIP(hipStreamSynchronize(s));
+                        stats.cells_tb += hc;
+                    }
                     // the flagged entries: gather, plan, run, apply.  pk: packed MODE 7 (H bytes of the box's diagonal band, tb_band_of) + walk
                     // kernel; otherwise the int32 kernel carries the statistics through the DP (MODE 3, one pass per statistic).
                     //
@@ -1629,6 +1649,7 @@ void Engine::set_cover_graph(uint32_t n, const uint32_t *h_edges, const uint32_t
         const uint32_t h_ctr[4] = {n, 0, 0, 0};
         UC_HIP(hipMemcpyAsync(ctr.p, h_ctr, 16, hipMemcpyHostToDevice, stream));
         uint32_t left = n, rounds = 0;
+        bool host_tail = false;
         uint32_t *cur = w0.p, *nxt = w1.p;
         while (left) {
             const dim3 gw((uint32_t)std::min<uint64_t>(((uint64_t)left + 3) / 4, 1u << 16));
@@ -1645,11 +1666,33 @@ void Engine::set_cover_graph(uint32_t n, const uint32_t *h_edges, const uint32_t
             left = h[3];
             std::swap(cur, nxt);
             rounds++;
+            // Family graphs finish in a handful of rounds; a chain-like remainder (equal counts, ids ascending along a path) gives ONE pick per round -
+            // n / 3 rounds of six launches and a host synchronisation each.  When the rounds stop paying, the rest - the greedy cover of
+            // the subgraph the unassigned nodes induce, which is all the sequential rule still looks at - is finished by the host cover.
+            if (left && rounds >= 32 && h[1] < 64) { host_tail = true; break; }
         }
         UC_HIP(hipMemcpyAsync(assign, d_assign.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
         UC_HIP(hipStreamSynchronize(stream));
         UC_HIP(hipGetLastError());
-        if (timing) fprintf(stderr, "set_cover_device: greedy cover on the GPU %.2f ms in %u rounds\n", t_greedy.seconds() * 1e3, rounds);
+        if (host_tail) {
+            std::vector<uint64_t> off((size_t)n + 1);
+            std::vector<uint32_t> adj(mu);
+            UC_HIP(hipMemcpy(off.data(), d_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
+            if (mu) UC_HIP(hipMemcpy(adj.data(), d_adj.p, (size_t)mu * 4, hipMemcpyDeviceToHost));
+            std::vector<uint32_t> sub((size_t)n, SC_NONE), back;
+            for (uint32_t v = 0; v < n; v++) if (assign[v] == SC_NONE) { sub[v] = (uint32_t)back.size(); back.push_back(v); }      // ids keep their order: so do the ties
+            std::vector<uint32_t> e2;
+            for (uint32_t v : back)
+                for (uint64_t k = off[v]; k < off[(size_t)v + 1]; k++) {
+                    const uint32_t w = adj[k];
+                    if (w > v && assign[w] == SC_NONE) { e2.push_back(sub[v]); e2.push_back(sub[w]); }
+                }
+            std::vector<uint32_t> a2(back.size());
+            set_cover((uint32_t)back.size(), e2.data(), e2.size() / 2, a2.data());
+            for (size_t i = 0; i < back.size(); i++) assign[back[i]] = back[a2[i]];
+        }
+        if (timing) fprintf(stderr, "set_cover_device: greedy cover on the GPU %.2f ms in %u rounds%s\n", t_greedy.seconds() * 1e3, rounds,
+                            host_tail ? ", the chain-like rest on the host" : "");
         return;
     }
     for (uint32_t i = 0; i < n; i++) assign[i] = i;      // no edges: every node is its own representative

@@ -358,7 +358,7 @@ void merge_stats(uc_stats &d, const uc_stats &s) {
     d.n_index_entries += s.n_index_entries; d.n_sim_kmers += s.n_sim_kmers; d.n_kmer_hits += s.n_kmer_hits;
     d.n_candidates += s.n_candidates; d.n_prefilter_hits += s.n_prefilter_hits; d.n_gapped_alignments += s.n_gapped_alignments;
     d.n_start_alignments += s.n_start_alignments; d.n_pk_reruns += s.n_pk_reruns;
-    d.cells_fwd += s.cells_fwd; d.cells_rev += s.cells_rev; d.cells_start += s.cells_start;
+    d.cells_fwd += s.cells_fwd; d.cells_rev += s.cells_rev; d.cells_start += s.cells_start; d.cells_tb += s.cells_tb;
     d.sw_kernel_launches += s.sw_kernel_launches; d.sw_algorithmic_bytes += s.sw_algorithmic_bytes;
     d.n_filtered_hits += s.n_filtered_hits; d.n_sw_runs += s.n_sw_runs; d.cells_run += s.cells_run; d.exchange_bytes += s.exchange_bytes;
     for (int k = 0; k < UC_NSTAGE; k++) {
