@@ -104,10 +104,13 @@ __global__ void __launch_bounds__(256) kmer_bits_kernel(const uint32_t *koff, ui
 }
 
 // ---------------------------------------------------------------- E2: similar k-mers
+constexpr int SIM_NEED_MAX = 49;   // substitution scores lie in [-48, 48] (checked by the host): a needed score beyond either end selects all / no letters
 struct SimTables {           // LDS: per query letter a, target letters sorted by score descending
     int8_t sc[KA][KA];
     uint8_t ord[KA][KA];
     int8_t rowmax[KA];
+    uint8_t lcnt[KA][2 * SIM_NEED_MAX + 1];    // [a][need + SIM_NEED_MAX]: how many letters b have S(a, b) >= need (they are the first lcnt of the sorted row) ...
+    uint32_t pmask[KA][KA + 1];                // ... and [a][n]: the first n letters of a's sorted row as a bit mask (r05: the DFS's last level in ONE step)
 };
 
 __device__ void build_sim_tables(SimTables &t, const int8_t *S3) {
@@ -125,6 +128,19 @@ __device__ void build_sim_tables(SimTables &t, const int8_t *S3) {
         }
         for (int b = 0; b < KA; b++) { t.sc[a][b] = sc[b]; t.ord[a][b] = ord[b]; }
         t.rowmax[a] = sc[0];
+    }
+    for (int i = threadIdx.x; i < KA * (2 * SIM_NEED_MAX + 1); i += blockDim.x) {
+        const int a = i / (2 * SIM_NEED_MAX + 1), need = i % (2 * SIM_NEED_MAX + 1) - SIM_NEED_MAX;
+        int n = 0;
+        for (int b = 0; b < KA; b++) n += S3[a * 21 + b] >= need ? 1 : 0;
+        t.lcnt[a][i % (2 * SIM_NEED_MAX + 1)] = (uint8_t)n;
+    }
+    __syncthreads();                            // (ord is read below)
+    for (int i = threadIdx.x; i < KA * (KA + 1); i += blockDim.x) {
+        const int a = i / (KA + 1), n = i % (KA + 1);
+        uint32_t m = 0;
+        for (int j = 0; j < n; j++) m |= 1u << t.ord[a][j];
+        t.pmask[a][n] = m;
     }
 }
 
@@ -167,7 +183,7 @@ struct RunList {
 constexpr int LEAFQ = 256;          // leaf queue entries per wave
 constexpr int POSQ = 128;           // decoded positions per wave (ring)
 constexpr int SIM_MIN_WAVE_POS = 256;   // fewer positions per wave than this: fewer workgroups
-constexpr int SIM_MAX_BLOCKS = 1280;     // 256 CUs x 5 resident workgroups (29 KB of LDS each)
+constexpr int SIM_MAX_BLOCKS = 1024;     // 256 CUs x 4 resident workgroups (37 KB of LDS each)
 
 __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCfg cfg, uint32_t qbegin, uint32_t qend,
                                                             uint32_t p0, uint32_t p1, const uint32_t *koff, RunList out,
@@ -181,18 +197,20 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
     __shared__ uint32_t s_n[4];
     __shared__ uint64_t s_val[4][RUN_STAGE];
     __shared__ uint32_t s_pi[4][RUN_STAGE];
-    __shared__ uint32_t s_qv[4][LEAFQ], s_qp[4][LEAFQ];
+    __shared__ uint32_t s_qv[4][LEAFQ], s_qp[4][LEAFQ], s_qm[4][LEAFQ];
     __shared__ uint32_t s_pc[4][POSQ], s_pp[4][POSQ];
     __shared__ uint64_t s_pr[4][POSQ];
     build_sim_tables(tab, db.S3);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x < K) { uint32_t m = 1; for (int i = 0; i < (int)threadIdx.x; i++) m *= KA; s_mul[threadIdx.x] = m; }
+    // level L of the DFS decides k-mer position K - 1 - L, so the LAST level is the least significant digit of the k-mer value: the (up to 20) similar
+    // k-mers under one five-letter prefix are consecutive values - one or two words of the presence bitmap, neighbouring entries of the offset table
+    if (threadIdx.x < K) { uint32_t m = 1; for (int i = 0; i < K - 1 - (int)threadIdx.x; i++) m *= KA; s_mul[threadIdx.x] = m; }
     if (lane == 0) s_n[wv] = 0;
     __syncthreads();
     volatile uint32_t *vn = &s_n[wv];
     volatile uint64_t *vval = s_val[wv];
     volatile uint32_t *vpi = s_pi[wv];
-    volatile uint32_t *qv = s_qv[wv], *qp = s_qp[wv];
+    volatile uint32_t *qv = s_qv[wv], *qp = s_qp[wv], *qm = s_qm[wv];
     volatile uint32_t *pc = s_pc[wv], *pp = s_pp[wv];
     volatile uint64_t *pr = s_pr[wv];
     const int thr = cfg.thr;
@@ -216,28 +234,40 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
         __builtin_amdgcn_wave_barrier();
     };
     unsigned long long nhit = 0;
-    // look the queued leaves up, 64 at a time (whole wave), and stage the non-empty index ranges
+    // A queued leaf GROUP is a five-letter prefix (its value with the last digit 0) and the mask of the last letters that keep the k-mer similar.  64 groups at a
+    // time (whole wave): the group's 20 presence bits are one or two words of the bitmap; only the k-mers that occur in the index are looked up in the offset
+    // table (neighbouring entries), and the non-empty index ranges are staged.  (r04 probed the bitmap and the table once per similar k-mer, 3.2e10 times per
+    // configs[3] @ 500 call, the last level one DFS step per letter.)
     auto drain_leaves = [&](uint32_t qn) {
         for (uint32_t b = 0; b < qn; b += 64) {
             const uint32_t i = b + lane;
-            uint32_t e0 = 0, n = 0, pi = 0;
+            uint32_t m = 0, v0 = 0, pi = 0;
             if (i < qn) {
-                const uint32_t v = qv[i];
-                pi = qp[i];
-                if (!kbits || ((kbits[v >> 5] >> (v & 31)) & 1u)) {
+                v0 = qv[i]; pi = qp[i]; m = qm[i];
+                if (kbits) {
+                    const uint32_t w = v0 >> 5, sh = v0 & 31;
+                    const uint64_t two = (uint64_t)kbits[w] | ((uint64_t)(sh > 32 - KA ? kbits[w + 1] : 0u) << 32);
+                    m &= (uint32_t)(two >> sh);
+                }
+            }
+            while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
+                uint32_t e0 = 0, n = 0;
+                if (m) {
+                    const uint32_t v = v0 + (uint32_t)__builtin_ctz(m);
+                    m &= m - 1;
                     e0 = koff[v];
                     n = koff[v + 1] - e0;
                 }
-            }
-            nhit += n;
-            const uint64_t m = __builtin_amdgcn_ballot_w64(n != 0);
-            if (m) {
-                if (*vn + 64 > RUN_STAGE) flush_runs();
-                const uint32_t slot = *vn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (n) { vval[slot] = ((uint64_t)n << 32) | e0; vpi[slot] = pi; }
-                __builtin_amdgcn_wave_barrier();
-                if (lane == 0) *vn = *vn + (uint32_t)__popcll(m);
-                __builtin_amdgcn_wave_barrier();
+                nhit += n;
+                const uint64_t bm = __builtin_amdgcn_ballot_w64(n != 0);
+                if (bm) {
+                    if (*vn + 64 > RUN_STAGE) flush_runs();
+                    const uint32_t slot = *vn + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
+                    if (n) { vval[slot] = ((uint64_t)n << 32) | e0; vpi[slot] = pi; }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) *vn = *vn + (uint32_t)__popcll(bm);
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
     };
@@ -285,10 +315,10 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
                     if (valid) {
                         int rest = 0;
 #pragma unroll
-                        for (int m = K - 1; m >= 0; m--) {
-                            rp |= (uint64_t)(uint32_t)(rest + 64) << (8 * m);       // field m holds rest[m + 1]
-                            rest += tab.rowmax[c[m]];
-                            cp |= c[m] << (5 * m);
+                        for (int L_ = K - 1; L_ >= 0; L_--) {                         // level L_ decides position K - 1 - L_
+                            rp |= (uint64_t)(uint32_t)(rest + 64) << (8 * L_);      // field L_ holds the best score the levels behind L_ can still add
+                            rest += tab.rowmax[c[K - 1 - L_]];
+                            cp |= c[K - 1 - L_] << (5 * L_);
                         }
                         ok = rest >= thr;
                     }
@@ -325,7 +355,7 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
             // ---- one DFS node per lane, branch-free: probe (L, k[L]); descend, emit a leaf, or step back to level L-1 ----
             // (three divergent paths would run one after the other in nearly every step; selects cost fewer issue slots)
             bool leaf = false;
-            uint32_t leafv = 0;
+            uint32_t leafv = 0, leafm = 0;
             {
                 const int Lm = L > 0 ? L - 1 : 0;
                 const uint32_t a = (cpack >> (5 * L)) & 31u, k = (kpack >> (5 * L)) & 31u;
@@ -338,24 +368,29 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
                 const int cand = scur + sc1;
                 const bool act = !idle;
                 const bool ok = act && k < (uint32_t)KA && cand + restn >= thr;
-                const bool push = ok && L < K - 1, pop = act && !ok && L > 0;
-                leaf = ok && L == K - 1;
+                const bool push = ok && L < K - 2, pop = act && !ok && L > 0;
+                leaf = ok && L == K - 2;                                        // the last level is taken in one step: every letter that keeps cand + S >= thr
                 leafv = vcur + o1 * mulL;
-                lc += leaf ? 1u : 0u;
+                {
+                    const int need = min(max(thr - cand, -SIM_NEED_MAX), SIM_NEED_MAX);
+                    const uint32_t al = (cpack >> (5 * (K - 1))) & 31u;
+                    leafm = leaf ? tab.pmask[al][tab.lcnt[al][need + SIM_NEED_MAX]] : 0u;
+                }
+                lc += (uint32_t)__popc(leafm);
                 idle = idle || (act && !ok && L == 0);
                 scur = push ? cand : (pop ? scur - sc2 : scur);
                 vcur = push ? leafv : (pop ? vcur - o2 * mulM : vcur);
-                const uint32_t kp_leaf = kpack + (1u << (5 * (K - 1)));
-                const uint32_t kp_push = kpack & ~(31u << (5 * (L + 1)));       // L + 1 <= 5 when push
+                const uint32_t kp_leaf = kpack + (1u << (5 * (K - 2)));
+                const uint32_t kp_push = kpack & ~(31u << (5 * (L + 1)));       // L + 1 <= K - 2 when push
                 const uint32_t kp_pop = kpack + (1u << (5 * Lm));
                 kpack = leaf ? kp_leaf : (push ? kp_push : (pop ? kp_pop : kpack));
                 L = push ? L + 1 : (pop ? L - 1 : L);
             }
             const uint64_t lm = __builtin_amdgcn_ballot_w64(leaf);
             if (lm) {
-                if (leaf) { const uint32_t slot = qn + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull)); qv[slot] = leafv; qp[slot] = pidx; }
+                if (leaf) { const uint32_t slot = qn + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull)); qv[slot] = leafv; qp[slot] = pidx; qm[slot] = leafm; }
                 qn += (uint32_t)__popcll(lm);
-                nsim += (lane == 0) ? (unsigned long long)__popcll(lm) : 0ull;
+                nsim += (unsigned long long)__popc(leafm);
                 if (qn > LEAFQ - 64) { __builtin_amdgcn_wave_barrier(); drain_leaves(qn); qn = 0; }
             }
         }
