@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """tools/property_campaign.py <first_seed> <n_seeds> — the property test of tests/test_gpu_parity.py (random small databases x
 random option strings against the oracle: hit lists, every alignment field, set cover) for seeds beyond the 16 of the suite;
-every third seed also forces the prefilter's super-batch cut (UC_DRUN_MAX) or the per-position path, every fourth tiny index chunks
-(the upper-triangle walk of the chunk grid).  Run on the GPU box after
+every third seed also forces the prefilter's super-batch cut (UC_DRUN_MAX), every fourth tiny index chunks (the upper-triangle walk of
+the chunk grid), every fifth a narrow traceback band (UC_TB_BAND 1 / 2 / 4 / 8: the whole-box fallback) and every seventh a 1 MB matrix
+budget (one task per batch, 1000-pair plan segments).  Run on the GPU box after
 kernel changes; the result line goes into DESIGN.md 2."""
 import os, sys, time, traceback
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,6 +20,8 @@ for seed in range(first, first + n):
     env = {}
     if seed % 3 == 1: env = {"UC_DRUN_MAX": str(500 + 37 * (seed % 50))}
     if seed % 4 == 3: env = dict(env, UC_PREFILTER_CHUNK_RES=str(1500 + 113 * (seed % 40)))      # r04: several index chunks -> the symmetric (upper-triangle) walk + the single merge
+    if seed % 5 == 2: env = dict(env, UC_TB_BAND=str((1, 2, 4, 8)[seed % 4]))                    # r05: narrow traceback bands -> the whole-box fallback
+    if seed % 7 == 4: env = dict(env, UC_TB_BUDGET_MB="1")                                       # r05: many matrix batches, plan segments
     os.environ.update(env)
     try:
         fn(O, seed)
