@@ -218,7 +218,7 @@ SAMPLE_SEED = 20260929
 PINS = {
     "c2": dict(golden=True, rounds="live"),
     "c3": dict(golden=True, rounds="live"),
-    "c4-200": dict(golden=False, rounds="live"),      # whole-file golden: c4-500 carries configs[3]'s options end to end
+    "c4-200": dict(golden=True, rounds="live"),
     "c4-500": dict(golden=True, rounds="live"),
     "c4": dict(golden=False, rounds="fixture"),       # nominal size: the oracle end to end would take ~14 h on the build container's 8 cores
     "c3-gate": dict(golden=True, rounds="live"),
