@@ -250,23 +250,33 @@ __global__ void __launch_bounds__(256) sim_runs_kernel(const DeviceDb db, KmerCf
                     m &= (uint32_t)(two >> sh);
                 }
             }
+            // FOUR k-mers of a group per round trip: the kernel's waves spend two thirds of their cycles waiting (PMC, profiles/r05/sim_runs_filter_pmc.txt),
+            // mostly for these dependent offset-table loads - eight of them in flight per lane instead of two
             while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
-                uint32_t e0 = 0, n = 0;
-                if (m) {
-                    const uint32_t v = v0 + (uint32_t)__builtin_ctz(m);
-                    m &= m - 1;
-                    e0 = koff[v];
-                    n = koff[v + 1] - e0;
+                uint32_t e0[4], n[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    e0[u] = 0; n[u] = 0;
+                    if (m) {
+                        const uint32_t v = v0 + (uint32_t)__builtin_ctz(m);
+                        m &= m - 1;
+                        e0[u] = koff[v];
+                        n[u] = koff[v + 1];
+                    }
                 }
-                nhit += n;
-                const uint64_t bm = __builtin_amdgcn_ballot_w64(n != 0);
-                if (bm) {
-                    if (*vn + 64 > RUN_STAGE) flush_runs();
-                    const uint32_t slot = *vn + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
-                    if (n) { vval[slot] = ((uint64_t)n << 32) | e0; vpi[slot] = pi; }
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == 0) *vn = *vn + (uint32_t)__popcll(bm);
-                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t nn = n[u] - e0[u];           // (both 0 for a lane without a k-mer in this slot)
+                    nhit += nn;
+                    const uint64_t bm = __builtin_amdgcn_ballot_w64(nn != 0);
+                    if (bm) {
+                        if (*vn + 64 > RUN_STAGE) flush_runs();
+                        const uint32_t slot = *vn + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
+                        if (nn) { vval[slot] = ((uint64_t)nn << 32) | e0[u]; vpi[slot] = pi; }
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane == 0) *vn = *vn + (uint32_t)__popcll(bm);
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
             }
         }
