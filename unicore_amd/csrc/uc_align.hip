@@ -674,6 +674,13 @@ struct SwPlan {
     uint8_t *tbm = nullptr;                      // packed mode 7: traceback-byte matrices and per-pair offsets
     const unsigned long long *tboff = nullptr;
     int tb_band = 0;                             // ... and the half-width of the stored diagonal band (0 = the whole box)
+    // the plan's device arrays back to the allocator (a plan that has run is dead weight: ~70 B per pair; the next build_plan reserves again)
+    void release() {
+        key.release(); key2.release(); idx_in.release(); idx.release(); sq.release(); st.release(); head.release(); segstart.release(); flag.release(); tpos.release();
+        tcls.release(); bounds.release(); sqe.release(); ste.release(); sqs.release(); sts.release(); saux.release(); tasks.release(); tasks_in.release();
+        tkey.release(); tkey2.release(); tidx.release(); tidx2.release(); bytes.release();
+        n = ntasks = 0;
+    }
 };
 
 static void scan_u32(Engine &E, DevBuf<char> &tmp, const uint32_t *in, uint32_t *out, uint32_t n, bool inclusive_max) {
@@ -1275,6 +1282,13 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                     DevBuf<uint8_t> &tbm = A.tb_tbm;
                     DevBuf<int32_t> &qs3 = A.tb_qs3, &qe3 = A.tb_qe3, &ts3 = A.tb_ts3, &te3 = A.tb_te3, &pack3 = A.tb_pack3, &gaps3 = A.tb_gaps3, &sc3 = A.tb_sc3;
                     SwPlan &P3 = A.tb_P3;
+                    // the plans of the passes behind us are dead (their results have been scattered): at sizes where the matrix budget is what is left of the
+                    // device (nominal configs[3]: ~35 GB of plan arrays beside ~57 GiB of matrices per batch) they go back before the matrices are sized
+                    if (n2 >= (8u << 20)) {
+                        UC_HIP(hipStreamSynchronize(s));
+                        P1.release(); P2.release(); P2b.release(); A.rr_P2.release(); A.amb_P3.release();
+                        if (dedup) P0.release();                   // (without sharing, Lsq / Lst / Lidx ARE P0's arrays)
+                    }
                     trun.reserve(n2); tpos.reserve(n2); tpart.reserve(n2); ttie.reserve(n2);
                     UC_HIP(hipMemsetAsync(ttie.p, 0, (size_t)n2 * 4, s));
                     {
