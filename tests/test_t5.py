@@ -366,3 +366,15 @@ def test_createdb_writes_the_database_the_cluster_path_reads(tmp_path):
     names = [h.split()[0] for h, _ in recs]
     rows = util.tsv_invariants(out + ".tsv", names)
     assert len(rows) == len(recs)
+    # the reading of the ProstT5 head that predicted the track travels with the database ...
+    assert open(db + "_ss.source").read() == "prostt5_head eos_in_head=1 uzob_to_x=0\n"
+    # ... and a search across two databases built under different readings says so (and runs)
+    db2 = str(tmp_path / "proteome_db_p3d")
+    r = subprocess.run([shim, "createdb", str(fa), db2, "--prostt5-model", str(mdir), "--threads", "4"], capture_output=True, text=True,
+                       env=dict(os.environ, UC_T5_EOS_IN_HEAD="0", UC_T5_KEEP_UZOB="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(db2 + "_ss.source").read() == "prostt5_head eos_in_head=0 uzob_to_x=1\n"
+    for q, want in ((db, False), (db2, True)):
+        r = subprocess.run([shim, "search", "--threads", "4", "-v", "2", q, db, str(tmp_path / "aln"), str(tmp_path / "tmp")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert ("different ProstT5 head conventions" in r.stdout + r.stderr) == want, (r.stdout + r.stderr)[-600:]

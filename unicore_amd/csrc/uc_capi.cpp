@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <future>
 #include <memory>
 #include <mutex>
@@ -712,6 +713,13 @@ int uc_search(const char *query_db, const char *target_db, const char *out_aln_d
         HostDb T, Q;
         read_seq_db(target_db, T, false);
         read_seq_db(query_db, Q, false);
+        {   // 3Di tracks predicted under different readings of the ProstT5 head (uc_createdb records its reading in <db>_ss.source) are not comparable at the sequence ends
+            auto source_of = [](const std::string &db) { std::ifstream f(db + "_ss.source"); std::string l; if (f) std::getline(f, l); return l; };
+            const std::string st = source_of(target_db), sq = source_of(query_db);
+            if (!st.empty() && !sq.empty() && st != sq)
+                logf(2, "unicore-search: WARNING: the 3Di tracks of the two databases were predicted under different ProstT5 head conventions (%s: '%s'; %s: '%s')\n",
+                     target_db, st.c_str(), query_db, sq.c_str());
+        }
         const uint32_t nt = T.n, nq = Q.n, n = nt + nq;
         if ((uint64_t)nt + nq >= (1u << 24)) fail(UC_ERR_ARGS, "this build supports < 2^24 sequences (query + target)");
         // one loaded set: targets first, then queries; only [0, nt) is indexed, only [nt, n) are queries

@@ -480,6 +480,12 @@ void t5_createdb(const std::vector<std::string> &fasta_paths, const std::string 
     }
     write_db_files(out_db, seqs, 0);
     write_db_files(out_db + "_ss", ss, 0);
+    {   // which reading of the ProstT5 head produced this 3Di track (both are EXT-UNVERIFIED against Foldseek): databases built under different
+        // readings differ in the last ~3 states of every protein and in U/Z/O/B positions - uc_search warns when it is given two that disagree
+        std::ofstream sc(out_db + "_ss.source");
+        sc << "prostt5_head eos_in_head=" << model.cfg.eos_in_head << " uzob_to_x=" << model.cfg.uzob_to_x << "\n";
+        if (!sc) fail(UC_ERR_IO, "cannot write %s_ss.source", out_db.c_str());
+    }
     write_db_files(out_db + "_h", headers, 12);
     std::ofstream lk(out_db + ".lookup");
     for (size_t i = 0; i < headers.size(); i++) lk << i << '\t' << headers[i].substr(0, headers[i].find_first_of(" \t")) << "\t0\n";
