@@ -22,6 +22,7 @@ from oracle import oracle_py as O
 CONFIGS = {  # == bench.py CONFIGS / tests/test_configs_gpu.py / tests/test_workflow_gpu.py (name: proteomes, families, scale, seed, options, target sensitivity)
     "c2": (50, 6000, 1.0, 0x5EED0002, "-c 0.8", 4.0),
     "c3": (500, 6000, 1.0, 0x5EED0003, "-c 0.8", 4.0),
+    "c4-lite": (50, 6000, 1.0, 0x5EED0004, "-c 0.8 --min-seq-id 0.3 -s 7.5", 7.5),      # configs[3]'s options, PLAIN step, 50 proteomes
     "c4-200": (200, 6000, 1.0, 0x5EED0004, "-c 0.8 --min-seq-id 0.3 -s 7.5", 7.5),
     "c4-500": (500, 6000, 1.0, 0x5EED0004, "-c 0.8 --min-seq-id 0.3 -s 7.5", 7.5),
     "c3-gate": (500, 6000, 1.0, 0x5EED0003, "-c 0.8 --length-gate 1", 4.0),      # optional rule UC-1/L on (default off)
