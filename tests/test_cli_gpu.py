@@ -88,6 +88,25 @@ def test_unicore_cluster_options_string_and_quiet(tmp_path):
     assert open(str(tmp_path / "cluster.chk")).read() == "1"
 
 
+def test_out_of_memory_relief_and_retry(tmp_path):
+    """uc_engine.h malloc_with_relief / Engine::relieve_pressure: a device allocation that fails with out-of-memory inside a stage makes the
+    engine give back what that stage is not using (the other stage's work buffers, parked buffers) and is tried once more.  The failure is
+    injected (UC_TEST_OOM_AT=k: the k-th allocation under a registered handler reports out-of-memory once) at allocations spread over the
+    default workflow - uploads, prefilter, gapped stage, later rounds where both stages hold scratch - and the result may not change a byte."""
+    db, gold_default, _ = CASES["c1"]
+    fired, stages = 0, set()
+    for k in (1, 2, 3, 5, 8, 13, 21, 34, 55, 89):
+        out = str(tmp_path / ("k%d" % k) / "clust")
+        r = run([EXE, "cluster", db, out, str(tmp_path / "tmp"), "--threads", "4"], env=dict(os.environ, UC_TEST_OOM_AT=str(k)))
+        assert open(out + ".tsv", "rb").read() == open(gold_default, "rb").read(), k
+        msg = [l for l in (r.stdout + r.stderr).splitlines() if "device memory ran out in the" in l]
+        assert len(msg) <= 1, msg
+        if msg:
+            fired += 1
+            stages.add(msg[0].split("ran out in the ")[1].split(";")[0])
+    assert fired >= 6 and len(stages) >= 2, (fired, stages)      # the handler ran in most runs and for more than one stage
+
+
 def test_unicore_search_success_path(tmp_path):
     """modules::search::run (search.rs:8-84) through bin/unicore: OUT.m8 equals the committed golden, search.chk == "1" """
     db = CASES["db"][0]
