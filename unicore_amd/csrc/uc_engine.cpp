@@ -194,9 +194,10 @@ bool Engine::relieve_pressure(int stage) {
     size_t f0 = 0, f1 = 0, tot = 0;
     (void)hipMemGetInfo(&f0, &tot);
     bool freed = false;
-    if (stage != 1 && aln) { free_align_scratch(aln); aln = nullptr; freed = true; }
+    // a scratch set goes only when no frame of its own stage is open on this engine - the innermost scope decides what is asked for, every open one what is pinned
+    if (stage != 1 && !stage_frames[1] && aln) { free_align_scratch(aln); aln = nullptr; freed = true; }
     if (stage == 1 && aln && release_tb_matrices(aln)) freed = true;      // the gapped stage's own traceback-byte buffer, when no batch loop is using it
-    if (stage != 0 && pre) { free_prefilter_scratch(pre); pre = nullptr; freed = true; }
+    if (stage != 0 && !stage_frames[0] && pre) { free_prefilter_scratch(pre); pre = nullptr; freed = true; }
     if (PrefilterScratch *x = take_parked_prefilter_scratch(device)) { free_prefilter_scratch(x); freed = true; }
     if (AlignScratch *x = take_parked_align_scratch(device)) { free_align_scratch(x); freed = true; }
     (void)hipMemGetInfo(&f1, &tot);

@@ -193,13 +193,15 @@ struct Engine {
     // out-of-memory handler of a stage (see OomRelief): stage 0 = the prefilter is at work (gives back the gapped stage's scratch), 1 = the gapped
     // stage / set cover is at work (gives back the prefilter's), 2 = neither (database upload: both); parked sets of the device go in every case
     bool relieve_pressure(int stage);
+    int stage_frames[3] = {0, 0, 0};                       // open PressureScopes per stage: a stage's scratch is pinned while one of its frames is on the stack (nested scopes)
     struct PressureScope {
         OomRelief saved;
         struct Ctx { Engine *e; int stage; } ctx;
         PressureScope(Engine &E, int stage) : saved(oom_relief_slot()), ctx{&E, stage} {
+            E.stage_frames[stage]++;
             oom_relief_slot() = OomRelief{[](void *c) { return ((Ctx *)c)->e->relieve_pressure(((Ctx *)c)->stage); }, &ctx};
         }
-        ~PressureScope() { oom_relief_slot() = saved; }
+        ~PressureScope() { oom_relief_slot() = saved; ctx.e->stage_frames[ctx.stage]--; }
         PressureScope(const PressureScope &) = delete;
         PressureScope &operator=(const PressureScope &) = delete;
     };

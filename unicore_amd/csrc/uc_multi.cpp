@@ -203,6 +203,7 @@ void Comm::broadcast_dev(Engine &E, void *buf, size_t bytes, int root) {
 }
 
 uint64_t Comm::gather_edges_dev(Engine &E, const uint32_t **dev_out) {
+    Engine::PressureScope ps(E, 1);      // e_send / e_recv (2 x all ranks' edges on rank 0) may ask for the prefilter's work buffers and the traceback bytes back
     CommScratch &S = *scratch;
     if (dev_out) *dev_out = nullptr;
     // this rank's list as a device array (align() leaves it on the device; a list that only exists on the host is staged once)
