@@ -36,8 +36,8 @@ typedef struct uc_opts {
     int32_t threads;             /* host threads, >=1 (cluster.rs:46 "--threads") */
     int32_t verbosity;           /* 0..3, Foldseek scale after the 4->3,3->2 mapping of cluster.rs:18 */
     int32_t device;              /* HIP device ordinal of a single-GPU run / of an engine, -1 = current */
-    int32_t num_gpus;            /* uc_cluster only: GPUs the run is spread over: 0 = all visible, 1 = `device`,
-                                    N = devices 0..N-1; "--gpus N" inside cluster_options overrides it */
+    int32_t num_gpus;            /* uc_cluster, uc_createdb: GPUs the run is spread over: 0 = all visible, 1 = `device`,
+                                    N = devices 0..N-1; "--gpus N" inside cluster_options overrides it (uc_cluster) */
     const char *cluster_options; /* may be NULL == "" */
     const char *data_dir;        /* directory holding mat3di.out / blosum62.out; NULL = <lib dir>/data.  Without a real
                                     mat3di.out the call fails unless UC_ALLOW_SYNTHETIC=1 opts into the seeded stand-in */
@@ -46,7 +46,7 @@ typedef struct uc_opts {
 /* ABI revision of this header: bumped whenever a struct below grows or an entry point changes meaning.  uc_stats is written in full by
  * uc_cluster / uc_search / uc_engine_stats and carries no size field of its own, so a caller built against an older header must check
  * uc_abi_version() == UC_ABI_VERSION (or uc_stats_size() == sizeof(uc_stats)) before passing one in. */
-#define UC_ABI_VERSION 5
+#define UC_ABI_VERSION 6
 uint32_t uc_abi_version(void);
 size_t uc_stats_size(void);
 
@@ -129,7 +129,11 @@ int uc_convertalis(const char *query_db, const char *target_db, const char *aln_
 typedef struct uc_t5_stats {
     uint64_t n_seqs, n_tokens;       /* tokens = residues + 2 per sequence (<AA2fold> ... </s>) */
     double flops;                    /* algorithmic FLOPs of the linear layers + attention */
-    double gpu_ms;                   /* HIP-event time of the encoder passes */
+    double gpu_ms;                   /* HIP-event time of the encoder passes (several replicas: the SLOWEST replica's - they run side by side) */
+    /* (ABI 6) uc_createdb on N GPUs: one encoder replica per GPU, sequences sharded over them, no collective (uc_opts.num_gpus as for uc_cluster) */
+    uint32_t n_replicas, reserved0;
+    double gpu_ms_sum;               /* sum over the replicas (== gpu_ms for one) */
+    uint64_t tokens_min_replica, tokens_max_replica;   /* balance of the dynamic dealing */
 } uc_t5_stats;
 int uc_createdb(const char *const *fasta_paths, int n_fasta, const char *out_db, const char *model, const uc_opts *o, uc_t5_stats *stats_out);
 /* the encoder alone (no disk round trip: the codes go straight into uc_engine_set_db): */

@@ -378,3 +378,78 @@ def test_createdb_writes_the_database_the_cluster_path_reads(tmp_path):
         r = subprocess.run([shim, "search", "--threads", "4", "-v", "2", q, db, str(tmp_path / "aln"), str(tmp_path / "tmp")], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         assert ("different ProstT5 head conventions" in r.stdout + r.stderr) == want, (r.stdout + r.stderr)[-600:]
+
+
+def _ndev():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+def _createdb_case(tmp_path, n_seqs=40, seed=31):
+    cfg, path = _tiny(tmp_path)
+    rng = np.random.default_rng(seed)
+    recs = [("unicore_%010x entry %d" % (k + 1, k), "".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWY"), int(rng.integers(30, 260))))) for k in range(n_seqs)]
+    fa = tmp_path / "in.fasta"
+    fa.write_text("".join(">%s\n%s\n" % r for r in recs))
+    return path, str(fa), recs
+
+
+DB_FILES = ("", "_ss", "_h", ".index", "_ss.index", "_h.index", ".dbtype", "_ss.dbtype", "_h.dbtype", ".lookup", "_ss.source")
+
+
+@pytest.mark.gpu
+def test_createdb_on_n_encoder_replicas_writes_the_same_database(tmp_path, monkeypatch):
+    """createdb on N GPUs (BASELINE configs[4] on the 8-GPU node; the reference's ONE `foldseek createdb` call, createdb.rs:157-166): one encoder
+    replica per GPU, the sequences sharded over them by a dynamic deal of the length-sorted batch plan, no collective.  On the single-GPU box the
+    replicas share the device (UC_VIRTUAL_GPUS=1, as for uc_cluster's virtual ranks): every file of the database is byte-identical to the one
+    replica's, whatever N and whatever the dealing was; without the switch, asking for more GPUs than are visible is an error, not a silent fallback."""
+    import unicore_amd as U
+    model, fa, recs = _createdb_case(tmp_path)
+    monkeypatch.setenv("UC_T5_BATCH_TOKENS", "700")          # ~12 batches: something to deal out
+    ref = str(tmp_path / "db1")
+    st1 = U.createdb(fa, ref, model, num_gpus=1)
+    assert st1["n_replicas"] == 1 and st1["n_seqs"] == len(recs) and st1["tokens_min_replica"] == st1["tokens_max_replica"] == st1["n_tokens"]
+    want = {s: open(ref + s, "rb").read() for s in DB_FILES}
+    assert want["_ss"] and len(want["_ss"]) == len(want[""])
+    nd = _ndev()
+    if nd < 4:
+        with pytest.raises(U.UcError) as ei:
+            U.createdb(fa, str(tmp_path / "dbx"), model, num_gpus=4)
+        assert ei.value.code == 4 and "GPUs requested" in str(ei.value)
+    monkeypatch.setenv("UC_VIRTUAL_GPUS", "1")
+    for n in (2, 3, 5):
+        out = str(tmp_path / ("db%d" % n))
+        st = U.createdb(fa, out, model, num_gpus=n)
+        assert st["n_replicas"] == n and st["n_seqs"] == len(recs) and st["n_tokens"] == st1["n_tokens"] and abs(st["flops"] - st1["flops"]) <= 1e-9 * st1["flops"]
+        assert st["tokens_max_replica"] <= st["n_tokens"] and st["gpu_ms"] <= st["gpu_ms_sum"] + 1e-9
+        for s in DB_FILES:
+            assert open(out + s, "rb").read() == want[s], (n, s)
+    # the shim's spelling: `--gpus N` next to the reference's own arguments
+    shim = os.path.join(ROOT, "bin", "foldseek")
+    out = str(tmp_path / "db_shim")
+    r = subprocess.run([shim, "createdb", fa, out, "--prostt5-model", model, "--threads", "4", "--gpu", "1", "--gpus", "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "3 replica(s)" in r.stdout + r.stderr
+    for s in DB_FILES:
+        assert open(out + s, "rb").read() == want[s], ("shim", s)
+    # a replica that fails takes the call down with its message (here: every replica - the model file is gone)
+    with pytest.raises(U.UcError):
+        U.createdb(fa, str(tmp_path / "dby"), str(tmp_path / "no_such.gguf"), num_gpus=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_ndev() < 2, reason="needs >= 2 visible GPUs (one encoder replica per GPU); replicas sharing one GPU are covered by the test above")
+def test_createdb_on_all_visible_gpus(tmp_path, monkeypatch):
+    """the same on REAL devices: num_gpus = 0 (all visible) == one replica, file for file"""
+    import unicore_amd as U
+    model, fa, recs = _createdb_case(tmp_path, n_seqs=120)
+    monkeypatch.setenv("UC_T5_BATCH_TOKENS", "700")
+    ref, out = str(tmp_path / "db1"), str(tmp_path / "dbN")
+    U.createdb(fa, ref, model, num_gpus=1)
+    st = U.createdb(fa, out, model, num_gpus=0)
+    assert st["n_replicas"] == _ndev()
+    for s in DB_FILES:
+        assert open(out + s, "rb").read() == open(ref + s, "rb").read(), s

@@ -25,6 +25,7 @@ CONFIGS = {  # == bench.py CONFIGS / tests/test_configs_gpu.py / tests/test_work
     "c4-lite": (50, 6000, 1.0, 0x5EED0004, "-c 0.8 --min-seq-id 0.3 -s 7.5", 7.5),      # configs[3]'s options, PLAIN step, 50 proteomes
     "c4-200": (200, 6000, 1.0, 0x5EED0004, "-c 0.8 --min-seq-id 0.3 -s 7.5", 7.5),
     "c4-500": (500, 6000, 1.0, 0x5EED0004, "-c 0.8 --min-seq-id 0.3 -s 7.5", 7.5),
+    "c4-1000": (1000, 6000, 1.0, 0x5EED0004, "-c 0.8 --min-seq-id 0.3 -s 7.5", 7.5),   # r06: the largest size whose end-to-end CPU run fits a round (nominal 2000: ~100 core-hours)
     "c3-gate": (500, 6000, 1.0, 0x5EED0003, "-c 0.8 --length-gate 1", 4.0),      # optional rule UC-1/L on (default off)
     "c2-gate": (50, 6000, 1.0, 0x5EED0002, "-c 0.8 --length-gate 1", 4.0),
 }

@@ -44,7 +44,9 @@ class UcStats(C.Structure):
 
 
 class UcT5Stats(C.Structure):
-    _fields_ = [("n_seqs", C.c_uint64), ("n_tokens", C.c_uint64), ("flops", C.c_double), ("gpu_ms", C.c_double)]
+    _fields_ = [("n_seqs", C.c_uint64), ("n_tokens", C.c_uint64), ("flops", C.c_double), ("gpu_ms", C.c_double),
+                ("n_replicas", C.c_uint32), ("reserved0", C.c_uint32), ("gpu_ms_sum", C.c_double),
+                ("tokens_min_replica", C.c_uint64), ("tokens_max_replica", C.c_uint64)]
 
 
 HIT_DTYPE = np.dtype([("target", "<u4"), ("score", "<i4"), ("diag", "<i4")])
@@ -62,7 +64,7 @@ SYMBOLS = (
     "uc_engine_stats", "uc_engine_reset_stats", "uc_setcover", "uc_write_cluster_db",
     "uc_engine_ungapped_batch", "uc_engine_sw_batch", "uc_abi_version", "uc_stats_size", "uc_set_round_hook",
 )
-ABI_VERSION = 5      # == UC_ABI_VERSION of include/unicore_cluster.h this binding mirrors
+ABI_VERSION = 6      # == UC_ABI_VERSION of include/unicore_cluster.h this binding mirrors
 ROUND_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32), C.c_int32, C.c_void_p)
 
 _lib = None
@@ -219,12 +221,13 @@ def hits_merge(n_seqs, max_seqs, parts):
     return oc, oh[: on.value].copy()
 
 
-def createdb(fasta_paths, out_db, model, verbosity=1, device=-1):
-    """== `foldseek createdb <fasta...> <db> --prostt5-model <model>` (createdb.rs:157-166): ProstT5 AA -> 3Di on the GPU"""
+def createdb(fasta_paths, out_db, model, verbosity=1, device=-1, num_gpus=1):
+    """== `foldseek createdb <fasta...> <db> --prostt5-model <model>` (createdb.rs:157-166): ProstT5 AA -> 3Di on the GPU(s);
+    num_gpus: one encoder replica per GPU, sequences sharded over them (0 = all visible GPUs)"""
     if isinstance(fasta_paths, str):
         fasta_paths = [fasta_paths]
     arr = (C.c_char_p * len(fasta_paths))(*[p.encode() for p in fasta_paths])
-    o, st = make_opts("", 1, verbosity, device), UcT5Stats()
+    o, st = make_opts("", 1, verbosity, device, None, num_gpus), UcT5Stats()
     _check(lib().uc_createdb(arr, len(fasta_paths), out_db.encode(), model.encode(), C.byref(o), C.byref(st)))
     return {k: getattr(st, k) for k, _ in UcT5Stats._fields_}
 

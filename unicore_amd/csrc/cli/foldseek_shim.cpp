@@ -62,16 +62,17 @@ int main(int argc, char **argv) {
         else opts += (opts.empty() ? "" : " ") + a + (has_val ? " " + val : "");
     }
     if (cmd == "createdb") {
-        // createdb <fasta> [<fasta> ...] <db> --prostt5-model <dir> [--gpu 0|1] [--threads T] [-v V]        createdb.rs:157-166
+        // createdb <fasta> [<fasta> ...] <db> --prostt5-model <dir> [--gpu 0|1] [--gpus N] [--threads T] [-v V]        createdb.rs:157-166
         std::vector<std::string> cpos;
         std::string model;
-        int cverb = 3;
+        int cverb = 3, cgpus = 0;      // all visible GPUs: one encoder replica each, sequences sharded over them (`--gpus N` narrows it, as for cluster)
         for (int i = 2; i < argc; i++) {
             const std::string a = argv[i];
-            if ((a == "--prostt5-model" || a == "--gpu" || a == "--threads" || a == "-v") && i + 1 < argc) {
+            if ((a == "--prostt5-model" || a == "--gpu" || a == "--gpus" || a == "--threads" || a == "-v") && i + 1 < argc) {
                 const char *v = argv[++i];
                 if (a == "--prostt5-model") model = v;
                 else if (a == "-v") cverb = atoi(v);
+                else if (a == "--gpus") cgpus = atoi(v);
             } else if (a.size() > 1 && a[0] == '-') { fprintf(stderr, "Error: createdb: option %s is not provided by this engine\n", a.c_str()); return 2; }
             else cpos.push_back(a);
         }
@@ -80,7 +81,7 @@ int main(int argc, char **argv) {
         for (size_t i = 0; i + 1 < cpos.size(); i++) fp.push_back(cpos[i].c_str());
         uc_opts co;
         memset(&co, 0, sizeof co);
-        co.struct_size = sizeof co; co.threads = 1; co.verbosity = cverb; co.device = -1; co.num_gpus = 1;
+        co.struct_size = sizeof co; co.threads = 1; co.verbosity = cverb; co.device = -1; co.num_gpus = cgpus;
         int rc = uc_createdb(fp.data(), (int)fp.size(), cpos.back().c_str(), model.c_str(), &co, nullptr);
         if (rc) return die(rc);
         leave(0);

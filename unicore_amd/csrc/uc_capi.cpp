@@ -796,9 +796,36 @@ int uc_createdb(const char *const *fasta_paths, int n_fasta, const char *out_db,
         if (n_fasta < 1) fail(UC_ERR_ARGS, "createdb: no input files");
         std::vector<std::string> fp;
         for (int i = 0; i < n_fasta; i++) { require(fasta_paths[i], "fasta path"); fp.push_back(fasta_paths[i]); }
+        // devices: the convention of uc_cluster (uc_opts.num_gpus: 0 = all visible, 1 = `device`, N = devices 0..N-1; more than are visible only with
+        // UC_VIRTUAL_GPUS=1: several replicas per device, the single-GPU box's test of this path).  The encoder shards by sequence, "replicas only".
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) fail(UC_ERR_DEVICE, "no HIP device available; the ProstT5 encoder has no CPU fallback");
+        const int want = o ? o->num_gpus : 1;
+        if (want < 0 || want > 64) fail(UC_ERR_ARGS, "createdb: num_gpus must be in [0,64] (0 = all visible)");
+        const int W = want == 0 ? ndev : want;
+        std::vector<int> devices;
+        if (W == 1) {
+            int d = o ? o->device : -1;
+            if (d < 0) UC_HIP(hipGetDevice(&d));
+            devices.push_back(d);
+        } else {
+            if (W > ndev) {
+                const char *v = getenv("UC_VIRTUAL_GPUS");
+                if (!v || strcmp(v, "1") != 0) fail(UC_ERR_DEVICE, "%d GPUs requested but only %d visible", W, ndev);
+            }
+            for (int r = 0; r < W; r++) devices.push_back(r % ndev);
+        }
         T5Stats st;
-        t5_createdb(fp, out_db, model, o ? o->device : -1, o ? o->verbosity : 3, &st);
-        if (stats_out) { stats_out->n_seqs = st.n_seqs; stats_out->n_tokens = st.n_tokens; stats_out->flops = st.flops; stats_out->gpu_ms = st.total_ms; }
+        std::vector<T5Stats> per;
+        t5_createdb(fp, out_db, model, devices, o ? o->verbosity : 3, &st, &per);
+        if (stats_out) {
+            stats_out->n_seqs = st.n_seqs; stats_out->n_tokens = st.n_tokens; stats_out->flops = st.flops; stats_out->gpu_ms = st.total_ms;
+            stats_out->n_replicas = (uint32_t)per.size(); stats_out->reserved0 = 0;
+            stats_out->gpu_ms_sum = 0;
+            uint64_t lo = UINT64_MAX, hi = 0;
+            for (const T5Stats &x : per) { stats_out->gpu_ms_sum += x.total_ms; lo = std::min<uint64_t>(lo, x.n_tokens); hi = std::max<uint64_t>(hi, x.n_tokens); }
+            stats_out->tokens_min_replica = per.empty() ? 0 : lo; stats_out->tokens_max_replica = hi;
+        }
     });
 }
 
@@ -841,6 +868,7 @@ int uc_t5_get_stats(const uc_t5 *m, uc_t5_stats *out) {
     return guard([&] {
         require(m, "model"); require(out, "out");
         out->n_seqs = m->m.stats.n_seqs; out->n_tokens = m->m.stats.n_tokens; out->flops = m->m.stats.flops; out->gpu_ms = m->m.stats.total_ms;
+        out->n_replicas = 1; out->reserved0 = 0; out->gpu_ms_sum = m->m.stats.total_ms; out->tokens_min_replica = out->tokens_max_replica = m->m.stats.n_tokens;
     });
 }
 

@@ -31,12 +31,26 @@ Engine::Engine(const Params &pp, int dev) : p(pp) {
     if (dev >= ndev) fail(UC_ERR_DEVICE, "device %d requested but only %d visible", dev, ndev);
     device = dev;
     UC_HIP(hipSetDevice(device));
-    UC_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    // UC_STREAM_PRIORITY=high|low (read per engine; tools/overlap_probe.py only): the co-residency probe of r06 gives the prefilter engine's streams
+    // priority over the gapped stage's to see whether the dispatcher then lets the two stages share the chip (profiles/r06/overlap_*.json: it does not)
+    int prio = 0;
+    bool have_prio = false;
+    if (const char *sp = getenv("UC_STREAM_PRIORITY")) {
+        int lo = 0, hi = 0;      // numerically lower = higher priority
+        UC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        if (!strcmp(sp, "high")) { prio = hi; have_prio = true; }
+        else if (!strcmp(sp, "low")) { prio = lo; have_prio = true; }
+    }
+    auto make_stream = [&](hipStream_t *st) {
+        if (have_prio) UC_HIP(hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio));
+        else UC_HIP(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    };
+    make_stream(&stream);
     UC_HIP(hipEventCreate(&ev0));
     UC_HIP(hipEventCreate(&ev1));
     UC_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     for (int i = 0; i < N_AUX; i++) {      // (creating these on a helper thread beside the upload bought nothing: tools/cold_stamps.sh, r4)
-        UC_HIP(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
+        make_stream(&aux[i]);
         UC_HIP(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
     }
     if (const char *ns = getenv("UC_STREAMS")) n_streams = std::max(1, std::min(N_AUX + 1, atoi(ns)));

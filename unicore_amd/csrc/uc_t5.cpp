@@ -11,7 +11,9 @@
 #include <cmath>
 #include <cstring>
 #include <fstream>
+#include <atomic>
 #include <numeric>
+#include <thread>
 
 #include "uc_common.h"
 #include "uc_options.h"
@@ -401,31 +403,98 @@ void T5Model::encode_batch(const std::vector<const std::string *> &seqs, std::ve
     }
 }
 
-void T5Model::encode(const std::vector<std::string> &seqs, std::vector<std::vector<uint8_t>> &out_codes, std::vector<std::vector<float>> *out_logits) {
+// batches of similar lengths (sorted, longest first), bounded by tokens: activations are ~(14 d_model + 2 d_ff) bytes per token.  The plan depends on the
+// sequence lengths only; a sequence's codes do not depend on the batch it is encoded in (tests/test_configs_gpu.py), so the plan may be worked off by
+// any number of model replicas in any order (t5_encode_replicated)
+std::vector<std::vector<uint32_t>> t5_plan_batches(const std::vector<std::string> &seqs) {
     const size_t n = seqs.size();
-    out_codes.assign(n, {});
-    if (out_logits) out_logits->assign(n, {});
-    // batches of similar lengths (sorted), bounded by tokens: activations are ~(14 d_model + 2 d_ff) bytes per token
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return seqs[a].size() > seqs[b].size(); });
     size_t tok_budget = 65536;
     if (const char *e = getenv("UC_T5_BATCH_TOKENS")) tok_budget = std::max<size_t>(64, strtoull(e, nullptr, 10));
-    std::vector<std::vector<uint8_t>> tmp_codes;
-    std::vector<std::vector<float>> tmp_logits;
+    std::vector<std::vector<uint32_t>> plan;
     for (size_t i = 0; i < n;) {
-        std::vector<const std::string *> batch;
         std::vector<uint32_t> ids;
         size_t t = 0;
-        while (i < n && (batch.empty() || t + seqs[order[i]].size() + 2 <= tok_budget)) { t += seqs[order[i]].size() + 2; batch.push_back(&seqs[order[i]]); ids.push_back(order[i]); i++; }
-        tmp_codes.assign(batch.size(), {});
-        if (out_logits) tmp_logits.assign(batch.size(), {});
-        encode_batch(batch, tmp_codes, 0, out_logits ? &tmp_logits : nullptr);
-        for (size_t k = 0; k < ids.size(); k++) {
-            out_codes[ids[k]] = std::move(tmp_codes[k]);
-            if (out_logits) (*out_logits)[ids[k]] = std::move(tmp_logits[k]);
-        }
+        while (i < n && (ids.empty() || t + seqs[order[i]].size() + 2 <= tok_budget)) { t += seqs[order[i]].size() + 2; ids.push_back(order[i]); i++; }
+        plan.push_back(std::move(ids));
     }
+    return plan;
+}
+
+void T5Model::encode_ids(const std::vector<std::string> &seqs, const std::vector<uint32_t> &ids, std::vector<std::vector<uint8_t>> &out_codes,
+                         std::vector<std::vector<float>> *out_logits) {
+    std::vector<const std::string *> batch;
+    for (uint32_t i : ids) batch.push_back(&seqs[i]);
+    std::vector<std::vector<uint8_t>> tmp_codes(batch.size());
+    std::vector<std::vector<float>> tmp_logits;
+    if (out_logits) tmp_logits.assign(batch.size(), {});
+    encode_batch(batch, tmp_codes, 0, out_logits ? &tmp_logits : nullptr);
+    for (size_t k = 0; k < ids.size(); k++) {
+        out_codes[ids[k]] = std::move(tmp_codes[k]);
+        if (out_logits) (*out_logits)[ids[k]] = std::move(tmp_logits[k]);
+    }
+}
+
+void T5Model::encode(const std::vector<std::string> &seqs, std::vector<std::vector<uint8_t>> &out_codes, std::vector<std::vector<float>> *out_logits) {
+    out_codes.assign(seqs.size(), {});
+    if (out_logits) out_logits->assign(seqs.size(), {});
+    for (const std::vector<uint32_t> &ids : t5_plan_batches(seqs)) encode_ids(seqs, ids, out_codes, out_logits);
+}
+
+// createdb on N GPUs (BASELINE configs[4] on the 8-GPU node; the reference's call is ONE `foldseek createdb`, createdb.rs:157-166): the encoder shards by
+// sequence with no exchange at all - "replicas only".  One host thread + one model replica per entry of `devices` (a device may be named more than once:
+// several replicas on one GPU, the single-GPU box's test of this path); the length-sorted batch plan is dealt out dynamically, longest batches first (a
+// batch's cost grows with the square of its lengths, so a static round-robin would leave the replica that drew the long batches behind); every replica
+// writes the codes of its sequences into their slots of `out_codes`, so the output is in input order whatever the dealing was.
+void t5_encode_replicated(const std::vector<std::string> &seqs, const std::string &gguf, const std::vector<int> &devices,
+                          std::vector<std::vector<uint8_t>> &out_codes, T5Config *cfg_out, T5Stats *stats_out, std::vector<T5Stats> *per_replica) {
+    if (devices.empty()) fail(UC_ERR_ARGS, "createdb: no device");
+    out_codes.assign(seqs.size(), {});
+    const std::vector<std::vector<uint32_t>> plan = t5_plan_batches(seqs);
+    const size_t R = devices.size();
+    std::vector<T5Stats> rs(R);
+    std::vector<T5Config> cfgs(R);
+    std::vector<std::string> errs(R);
+    std::vector<int> codes_of(R, 0);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> failed{false};
+    auto work = [&](size_t r) {
+        try {
+            T5Model model;
+            model.load(gguf, devices[r]);                      // hipSetDevice is per host thread
+            cfgs[r] = model.cfg;
+            for (;;) {
+                if (failed.load()) break;
+                const size_t b = next.fetch_add(1);
+                if (b >= plan.size()) break;
+                model.encode_ids(seqs, plan[b], out_codes, nullptr);
+            }
+            rs[r] = model.stats;
+        } catch (const Error &f) {
+            failed.store(true); errs[r] = f.what(); codes_of[r] = f.code;
+        } catch (const std::exception &e) {
+            failed.store(true); errs[r] = e.what(); codes_of[r] = UC_ERR_GENERIC;
+        }
+    };
+    if (R == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t r = 0; r < R; r++) th.emplace_back(work, r);
+        for (std::thread &t : th) t.join();
+    }
+    for (size_t r = 0; r < R; r++)
+        if (!errs[r].empty()) fail(codes_of[r], "createdb: encoder replica %zu (device %d): %s", r, devices[r], errs[r].c_str());
+    T5Stats tot;
+    for (const T5Stats &x : rs) {
+        tot.n_seqs += x.n_seqs; tot.n_tokens += x.n_tokens; tot.flops += x.flops;
+        tot.gemm_ms += x.gemm_ms; tot.attn_ms += x.attn_ms; tot.other_ms += x.other_ms;
+        tot.total_ms = std::max(tot.total_ms, x.total_ms);      // the replicas run side by side: the job's GPU time is the slowest replica's
+    }
+    if (cfg_out) *cfg_out = cfgs[0];
+    if (stats_out) *stats_out = tot;
+    if (per_replica) *per_replica = rs;
 }
 
 // ---------------------------------------------------------------------------------------------- createdb
@@ -446,7 +515,8 @@ void write_db_files(const std::string &prefix, const std::vector<std::string> &e
 }
 }  // namespace
 
-void t5_createdb(const std::vector<std::string> &fasta_paths, const std::string &out_db, const std::string &model_path, int device, int verbosity, T5Stats *stats_out) {
+void t5_createdb(const std::vector<std::string> &fasta_paths, const std::string &out_db, const std::string &model_path, const std::vector<int> &devices, int verbosity,
+                 T5Stats *stats_out, std::vector<T5Stats> *per_replica) {
     g_verbosity = verbosity;
     std::vector<std::string> headers, seqs;
     for (const std::string &fp : fasta_paths) {
@@ -465,13 +535,13 @@ void t5_createdb(const std::vector<std::string> &fasta_paths, const std::string 
     std::string gguf = model_path;
     struct stat st;
     if (stat(gguf.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) gguf += "/prostt5-f16.gguf";      // createdb.rs:148
-    T5Model model;
-    model.load(gguf, device);
     std::vector<std::vector<uint8_t>> codes;
     Timer tm;
-    model.encode(seqs, codes);
-    logf(3, "ProstT5 encoder: %zu sequences, %llu tokens in %.2f s (%.1f TFLOP/s on the GPU timeline)\n", seqs.size(), (unsigned long long)model.stats.n_tokens,
-         tm.seconds(), model.stats.total_ms > 0 ? model.stats.flops / (model.stats.total_ms * 1e-3) / 1e12 : 0.0);
+    T5Config cfg;
+    T5Stats est;
+    t5_encode_replicated(seqs, gguf, devices, codes, &cfg, &est, per_replica);
+    logf(3, "ProstT5 encoder: %zu sequences, %llu tokens in %.2f s on %zu replica(s) (weights loaded per replica; %.1f TFLOP/s over all replicas on the GPU timeline)\n",
+         seqs.size(), (unsigned long long)est.n_tokens, tm.seconds(), devices.size(), est.total_ms > 0 ? est.flops / (est.total_ms * 1e-3) / 1e12 : 0.0);
     static const char LET[] = "ACDEFGHIKLMNPQRSTVWYX";
     std::vector<std::string> ss(seqs.size());
     for (size_t i = 0; i < seqs.size(); i++) {
@@ -483,14 +553,14 @@ void t5_createdb(const std::vector<std::string> &fasta_paths, const std::string 
     {   // which reading of the ProstT5 head produced this 3Di track (both are EXT-UNVERIFIED against Foldseek): databases built under different
         // readings differ in the last ~3 states of every protein and in U/Z/O/B positions - uc_search warns when it is given two that disagree
         std::ofstream sc(out_db + "_ss.source");
-        sc << "prostt5_head eos_in_head=" << model.cfg.eos_in_head << " uzob_to_x=" << model.cfg.uzob_to_x << "\n";
+        sc << "prostt5_head eos_in_head=" << cfg.eos_in_head << " uzob_to_x=" << cfg.uzob_to_x << "\n";
         if (!sc) fail(UC_ERR_IO, "cannot write %s_ss.source", out_db.c_str());
     }
     write_db_files(out_db + "_h", headers, 12);
     std::ofstream lk(out_db + ".lookup");
     for (size_t i = 0; i < headers.size(); i++) lk << i << '\t' << headers[i].substr(0, headers[i].find_first_of(" \t")) << "\t0\n";
     if (!lk) fail(UC_ERR_IO, "cannot write %s.lookup", out_db.c_str());
-    if (stats_out) *stats_out = model.stats;
+    if (stats_out) *stats_out = est;
 }
 
 }  // namespace uc

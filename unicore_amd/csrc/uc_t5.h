@@ -97,12 +97,19 @@ struct T5Model {
     void load(const std::string &gguf_path, int device);
     // encode a batch: seqs[i] = residue letters; out_codes[i] = 3Di states 0..19 per residue; optional logits (n_out per residue)
     void encode(const std::vector<std::string> &seqs, std::vector<std::vector<uint8_t>> &out_codes, std::vector<std::vector<float>> *out_logits = nullptr);
+    // one batch of the plan: the sequences seqs[ids[k]] -> out_codes[ids[k]] (the slots of other sequences are not touched)
+    void encode_ids(const std::vector<std::string> &seqs, const std::vector<uint32_t> &ids, std::vector<std::vector<uint8_t>> &out_codes,
+                    std::vector<std::vector<float>> *out_logits);
     void encode_batch(const std::vector<const std::string *> &seqs, std::vector<std::vector<uint8_t>> &out_codes, size_t out_base,
                       std::vector<std::vector<float>> *out_logits);
 };
 
 // `foldseek createdb <fasta...> <out_db> --prostt5-model <dir>`: FASTA -> <db>, <db>_h, <db>_ss (predicted 3Di), .index, .dbtype, .lookup
-void t5_createdb(const std::vector<std::string> &fasta_paths, const std::string &out_db, const std::string &model_path, int device, int verbosity,
-                 T5Stats *stats_out);
+// `devices`: one encoder replica (host thread + weights + activations) per entry; the sequences are sharded over the replicas, no collective (uc_t5.cpp)
+void t5_createdb(const std::vector<std::string> &fasta_paths, const std::string &out_db, const std::string &model_path, const std::vector<int> &devices, int verbosity,
+                 T5Stats *stats_out, std::vector<T5Stats> *per_replica = nullptr);
+std::vector<std::vector<uint32_t>> t5_plan_batches(const std::vector<std::string> &seqs);      // length-sorted, token-bounded batches (ids into seqs), longest first
+void t5_encode_replicated(const std::vector<std::string> &seqs, const std::string &gguf, const std::vector<int> &devices,
+                          std::vector<std::vector<uint8_t>> &out_codes, T5Config *cfg_out, T5Stats *stats_out, std::vector<T5Stats> *per_replica);
 
 }  // namespace uc
