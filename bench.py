@@ -241,86 +241,140 @@ def c5_mini(args):
     fl, ms = s1["flops"] - s0["flops"], s1["gpu_ms"] - s0["gpu_ms"]
     tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     res = sum(len(x) for x in aa)
-    return {"config": {"workload": "BASELINE configs[4]'s encoder stage on 1 synthetic proteome: %d sequences, %d residues; ProtT5-XL geometry, 24 blocks, seeded random-init f16 weights" % (len(aa), res)},
+    return {"note": "ONE proteome: configs[4] at its nominal 500 proteomes is ~1,190 s of encoder on one GPU at this rate (profiles/r05/c5_p500_check.json, builder-run) and fits "
+                    "neither driver step; on N GPUs uc_createdb runs one encoder replica per GPU (sequences sharded, no collective): ~150 s expected at N = 8",
+            "config": {"workload": "BASELINE configs[4]'s encoder stage on 1 synthetic proteome: %d sequences, %d residues; ProtT5-XL geometry, 24 blocks, seeded random-init f16 weights" % (len(aa), res)},
             "encoder_residues_per_s": res / dt, "wall_s": dt,
             "roofline": {"bound": "mfma", "kernel": "t5_gemm256_kernel + t5_attention_kernel (f16 v_mfma_f32_16x16x32_f16, fp32 accumulate)", "achieved": tf, "peak": 2500.0,
                          "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None, "algorithmic_flops": fl, "gpu_ms": ms,
                          "note": "algorithmic FLOPs = linear layers (2 x tokens x weights) + attention (4 L^2 x 4096 per sequence and block) / HIP-event time of the encoder passes"}}
 
 
-def bench_c5(args):
+def bench_c5(args, world=1, rank=0, local_rank=0, multi=False):
     """BASELINE configs[4]: createdb's ProstT5 AA -> 3Di encoder (hand-written f16 MFMA kernels) fused ahead of the cluster
     path, no disk round trip: AA residues -> uc_t5_encode -> 3Di codes -> uc_engine_set_db -> uc_engine_cluster_step.
     ProtT5-XL geometry (24 blocks, 1024 / 32 x 128 / 16384) with seeded random-init weights (the real prostt5-f16.gguf
-    cannot be shipped; same loader).  One step = the whole chain on `--proteomes` synthetic proteomes (default 5)."""
+    cannot be shipped; same loader).  One step = the whole chain on `--proteomes` synthetic proteomes (default 5).
+    N > 1 (r06; one process per GPU): the encoder shards by sequence - rank r encodes every N-th sequence of the length-sorted order ("replicas only",
+    no data-path collective in the encoder: the codes are gathered over the gloo control plane, as a file system would carry them between `unicore
+    createdb` and `unicore cluster`) - then every rank holds the whole 3Di database and the cluster step runs sharded over RCCL as for --config c2."""
     import torch
     import unicore_amd as U
     from oracle import prostt5_ref as R
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    dist = comm = None
+    rccl_ranks = 0
+    if multi:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        uid = [U.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = U.Comm(uid[0], rank, world, device=local_rank)
+        rccl_ranks = comm.info()[0]
+
+    def barrier():
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     proteomes = args.proteomes if args.proteomes is not None else 5
     seed = 0x5EED0005
     workdir = os.path.join(args.workdir, "p%d_f6000_s1_%x" % (proteomes, seed))
-    prefix = gen_db(workdir, proteomes, 6000, 1.0, seed)
+    gguf = os.path.join(args.workdir, "prostt5_synth_24.gguf")
+    if rank == 0:
+        gen_db(workdir, proteomes, 6000, 1.0, seed)
+        if not os.path.exists(gguf):
+            R.write_synthetic_gguf(gguf + ".tmp", R.default_config(), seed=seed)
+            os.replace(gguf + ".tmp", gguf)
+    barrier()
+    prefix = os.path.join(workdir, "db")
     aa = [e.decode() for e in open(prefix, "rb").read().split(b"\n\0")[:-1]]
     n, residues = len(aa), sum(len(x) for x in aa)
-    gguf = os.path.join(args.workdir, "prostt5_synth_24.gguf")
-    if not os.path.exists(gguf):
-        R.write_synthetic_gguf(gguf + ".tmp", R.default_config(), seed=seed)
-        os.replace(gguf + ".tmp", gguf)
-    enc = U.T5Encoder(gguf)
+    enc = U.T5Encoder(gguf, device=local_rank)
     options = args.options if args.options is not None else "-c 0.8"
-    eng = U.Engine(options, threads=os.cpu_count() or 1, verbosity=1)
+    eng = U.Engine(options, threads=max(1, (os.cpu_count() or 1) // world), verbosity=1, device=local_rank)
     lut = np.full(256, 20, np.uint8)
     for i, c in enumerate("ACDEFGHIKLMNPQRSTVWY"):
         lut[ord(c)] = i
     sa = lut[np.frombuffer("".join(aa).encode(), np.uint8)]
+    lens = np.array([len(x) for x in aa], np.int64)
     off = np.zeros(n + 1, np.uint64)
-    off[1:] = np.cumsum([len(x) for x in aa])
-    t_enc = t_clu = 0.0
+    off[1:] = np.cumsum(lens)
+    order = np.argsort(-lens, kind="stable")
+    mine = order[rank::world]                              # every N-th sequence of the length-sorted order: equal residue counts AND equal length mixes per rank
+    t_enc = t_gather = t_clu = 0.0
     n_aln = 0
     assign = None
 
     def step(timed):
-        nonlocal t_enc, t_clu, n_aln, assign
+        nonlocal t_enc, t_gather, t_clu, n_aln, assign
         t0 = time.perf_counter()
-        codes = enc.encode(aa)
+        codes = enc.encode([aa[i] for i in mine])
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        eng.set_db(off, np.concatenate(codes), sa)
-        assign, a = eng.cluster_step()
-        torch.cuda.synchronize()
+        s3 = np.empty(residues, np.uint8)
+        if multi:
+            parts = [None] * world
+            dist.all_gather_object(parts, np.concatenate(codes) if len(codes) else np.zeros(0, np.uint8))
+            for r in range(world):
+                ids = order[r::world]
+                o = 0
+                for i in ids:
+                    s3[int(off[i]):int(off[i + 1])] = parts[r][o:o + lens[i]]
+                    o += lens[i]
+        else:
+            for k, i in enumerate(mine):
+                s3[int(off[i]):int(off[i + 1])] = codes[k]
         t2 = time.perf_counter()
+        eng.set_db(off, s3, sa)
+        assign, a = eng.cluster_step(comm, args.target_shards) if multi else eng.cluster_step()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
         if timed:
-            t_enc += t1 - t0; t_clu += t2 - t1; n_aln += a
+            t_enc += t1 - t0; t_gather += t2 - t1; t_clu += t3 - t2; n_aln += a
     for _ in range(args.warmup):
         step(False)
     s0 = enc.stats()
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
-    torch.cuda.synchronize()
+    barrier()
     dt = time.perf_counter() - t0
     s1 = enc.stats()
     steps = max(args.steps, 1)
     fl, ms = s1["flops"] - s0["flops"], s1["gpu_ms"] - s0["gpu_ms"]
-    tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    print(json.dumps({
-        "metric": "3Di alignments/sec (createdb ProstT5 AA->3Di encoder + cluster path, end to end)", "value": n_aln / dt, "unit": "alignments/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f16 (MFMA, fp32 accumulate) + u16 (packed DP)", "data": "synthetic (sequences and random-init weights)",
-        "config": {"workload": "BASELINE configs[4] chain at %d synthetic proteomes: %d sequences, %d residues; ProtT5-XL-geometry encoder (24 blocks, d_model 1024, "
-                               "32 x 128 heads, d_ff 16384, 3Di CNN head) with seeded random-init f16 weights -> 3Di codes -> cluster '%s' (plain all-vs-all step); "
-                               "no disk round trip" % (proteomes, n, residues, options),
-                   "alignments_per_step": n_aln // steps, "clusters": int((assign == np.arange(n)).sum()) if assign is not None else None},
-        "stages_s_per_step": {"prostt5_encode": t_enc / steps, "set_db_and_cluster": t_clu / steps},
-        "encoder_residues_per_s": residues * steps / t_enc if t_enc > 0 else 0.0,
-        "roofline": {"bound": "mfma", "kernel": "t5_gemm_kernel + t5_attention_kernel (f16 v_mfma_f32_16x16x32_f16, fp32 accumulate)", "achieved": tf, "peak": 2500.0,
-                     "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None,
-                     "algorithmic_flops_per_step": fl / steps, "gpu_ms_per_step": ms / steps,
-                     "note": "algorithmic FLOPs = linear layers (2 x tokens x weights) + attention (4 L^2 x 4096 per sequence and block) / HIP-event time of the encoder passes"},
-    }))
+    if multi:
+        v = torch.tensor([dt, t_enc, t_gather, t_clu, ms], dtype=torch.float64)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        dt, t_enc, t_gather, t_clu, ms = [float(x) for x in v]
+        c = torch.tensor([float(n_aln), fl], dtype=torch.float64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        n_aln, fl = int(c[0].item()), float(c[1].item())
+    tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0            # all replicas together: summed FLOPs over the slowest replica's GPU time
+    if rank == 0:
+        print(json.dumps({
+            "metric": "3Di alignments/sec (createdb ProstT5 AA->3Di encoder + cluster path, end to end)", "value": n_aln / dt, "unit": "alignments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f16 (MFMA, fp32 accumulate) + u16 (packed DP)", "data": "synthetic (sequences and random-init weights)",
+            "config": {"workload": "BASELINE configs[4] chain at %d synthetic proteomes: %d sequences, %d residues; ProtT5-XL-geometry encoder (24 blocks, d_model 1024, "
+                                   "32 x 128 heads, d_ff 16384, 3Di CNN head) with seeded random-init f16 weights -> 3Di codes -> cluster '%s' (plain all-vs-all step); "
+                                   "no disk round trip" % (proteomes, n, residues, options),
+                       "alignments_per_step": n_aln // steps, "clusters": int((assign == np.arange(n)).sum()) if assign is not None else None,
+                       "parallelism": ("%d encoder replicas (one per GPU, every N-th sequence of the length-sorted order, no data-path collective), then the cluster step "
+                                       "sharded over RCCL" % world) if multi else "single GPU"},
+            "rccl_ranks": rccl_ranks,
+            "stages_s_per_step": {"prostt5_encode": t_enc / steps, "gather_codes": t_gather / steps, "set_db_and_cluster": t_clu / steps},
+            "encoder_residues_per_s": residues * steps / t_enc if t_enc > 0 else 0.0,
+            "roofline": {"bound": "mfma", "kernel": "t5_gemm_kernel + t5_attention_kernel (f16 v_mfma_f32_16x16x32_f16, fp32 accumulate)", "achieved": tf, "peak": 2500.0 * world,
+                         "unit": "TFLOP/s", "frac": tf / (2500.0 * world), "traffic": None,
+                         "algorithmic_flops_per_step": fl / steps, "gpu_ms_per_step": ms / steps,
+                         "note": "algorithmic FLOPs = linear layers (2 x tokens x weights) + attention (4 L^2 x 4096 per sequence and block), summed over the replicas / HIP-event "
+                                 "time of the slowest replica's encoder passes; peak = 2.5 PFLOP/s dense f16 per GPU"},
+        }))
+    if multi:
+        dist.barrier()
+        comm.close()
+        dist.destroy_process_group()
 
 
 def cpu_baseline_workflow(prefix, options, rounds, total_alignments, seconds_per_round=8.0):
@@ -480,6 +534,130 @@ def bench_workflow(args, proteomes, families, len_scale, seed, options, label, c
     return out
 
 
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _slim_roof(r):
+    return _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "valu_frac", "valu_frac_of_guide_nominal_peak", "valu_gcups", "kernel_ms_per_step",
+                     "avg_launch_ms", "launches", "algorithmic_bytes_per_launch", "algorithmic_bytes_per_step", "cells_run_per_step", "cells_algorithmic_per_step",
+                     "achieved_tflops", "algorithmic_flops", "gpu_ms", "traffic_per_step", "frac_of_measured_copy_bw"))
+
+
+def _slim_cpu(c):
+    o = _pick(c, ("value", "unit", "cores", "kind", "estimated_workflow_wall_s", "gapped_gcups_all_threads", "effective_cores"))
+    if isinstance(c, dict) and "sample" in c:
+        o["sample"] = c["sample"][:160]
+    return o
+
+
+def _slim_record(o):
+    """a sub-record (or the headline) without its prose and per-round arrays: what a reader of the driver's 10 kB tail needs"""
+    if not isinstance(o, dict) or "error" in o:
+        return o
+    r = _pick(o, ("value", "n_gpus", "rccl_ranks", "phases_max_over_ranks_s_per_step", "exchange_bytes_per_step_all_ranks", "ms_per_step", "steps", "warmup", "wall_s_per_step", "load_s_per_step", "value_disk_to_cluster_db", "encoder_residues_per_s", "wall_s",
+                  "prefilter_kernel_ms_per_step", "sw_kernel_ms_per_step", "stages_s_per_step", "note"))
+    if "config" in o:
+        r["config"] = dict(_pick(o["config"], ("alignments_per_step", "clusters", "workflow")), workload=str(o["config"].get("workload", ""))[:110])
+    if "roofline" in o:
+        r["roofline"] = _pick(o["roofline"], ("bound", "achieved", "peak", "unit", "frac", "valu_frac", "kernel_ms_per_step", "launches", "cells_run_per_step", "gpu_ms"))
+    if "roofline_prefilter" in o:
+        r["roofline_prefilter"] = _pick(o["roofline_prefilter"], ("achieved", "frac", "kernel_ms_per_step", "algorithmic_bytes_per_step"))
+    if "cpu_baseline" in o:
+        r["cpu_baseline"] = _slim_cpu(o["cpu_baseline"])
+    if "workflow_default" in o:
+        r["workflow_default"] = _pick(o["workflow_default"], ("wall_s", "wall_s_best", "alignments", "clusters", "value"))
+    if "rounds_last_step" in o:
+        r["rounds"] = [[x["round"], x["sequences"], x["pairs_aligned"], round(x["s_until_gapped_stage_done"], 2)] for x in o["rounds_last_step"]]
+        r["rounds_columns"] = "round (-1 = pre-step), sequences, pairs aligned, seconds"
+    return r
+
+
+def slim_line(out, args):
+    """The ONE line the driver records (BENCH_r05.json kept a 10 kB tail of a 20 kB line and lost configs.c3.value).  The figures a
+    reader needs sit at the TOP LEVEL and early; the full record (formulas, launch notes, per-round CPU arrays, both CPU legs) goes to a side file whose
+    path the line carries.  --full-line prints the full record instead."""
+    if out is None or args.full_line:
+        return out
+    detail = None
+    for d in ((args.detail_dir,) if getattr(args, "detail_dir", None) else (os.path.join(ROOT, "gpurun_out"), args.workdir)):
+        try:
+            os.makedirs(d, exist_ok=True)
+            detail = os.path.join(d, "bench_detail_%s_n%d.json" % (args.config, out.get("n_gpus", 1)))
+            json.dump(out, open(detail, "w"), indent=1, default=lambda x: x.tolist() if hasattr(x, "tolist") else str(x))
+            break
+        except OSError:
+            detail = None
+    head = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    line = dict(head)
+    cfg = out.get("config", {})
+    line["config"] = dict(_pick(cfg, ("alignments_per_step", "clusters", "workflow")), workload=str(cfg.get("workload", ""))[:260], parallelism=str(cfg.get("parallelism", ""))[:200])
+    line["value_definition"] = "value = alignments / wall of the timed steps with the DB resident in HBM (the bench contract); value_disk_to_tsv_aln_s = SURVEY.md 8(d)'s disk -> clust.tsv wall"
+    top = {}
+    v = out.get("value_disk_to_tsv")
+    if isinstance(v, dict):
+        top["value_disk_to_tsv_aln_s"] = v.get("value"); top["disk_to_tsv_wall_s"] = v.get("wall_s_best"); top["disk_to_tsv_same_clusters"] = v.get("same_clusters_as_steps")
+    v = out.get("workflow_default")
+    if isinstance(v, dict):
+        top["workflow_default_wall_s"] = v.get("wall_s_best"); top["workflow_default_aln_s"] = v.get("value")
+    v = out.get("value_one_shot_processes")
+    if isinstance(v, dict):
+        top["value_one_shot_aln_s"] = v.get("plain_step", {}).get("value"); top["one_shot_wall_s"] = v.get("plain_step", {}).get("wall_s_best")
+        top["one_shot_default_workflow_wall_s"] = v.get("default_workflow", {}).get("wall_s_best")
+    subs = out.get("configs", {}) or {}
+    c3 = subs.get("c3")
+    if isinstance(c3, dict) and "error" not in c3:
+        top["c3_value"] = c3.get("value"); top["c3_ms_per_step"] = c3.get("ms_per_step")
+        cb = c3.get("cpu_baseline", {})
+        top["c3_cpu_value"] = cb.get("value"); top["c3_cpu_cores"] = cb.get("cores")
+        top["c3_cpu_ratio"] = (c3["value"] / cb["value"]) if cb.get("value") else None
+        top["c3_sw_kernel_s"] = c3.get("sw_kernel_ms_per_step", 0) / 1e3; top["c3_prefilter_kernel_s"] = c3.get("prefilter_kernel_ms_per_step", 0) / 1e3
+        top["c3_valu_frac"] = c3.get("roofline", {}).get("valu_frac"); top["c3_prefilter_frac"] = c3.get("roofline_prefilter", {}).get("frac")
+        top["c3_workflow_default_wall_s"] = c3.get("workflow_default", {}).get("wall_s")
+    c4 = subs.get("c4")
+    if isinstance(c4, dict) and "error" not in c4:
+        top["c4_value"] = c4.get("value"); top["c4_wall_s"] = c4.get("wall_s_per_step"); top["c4_alignments"] = c4.get("config", {}).get("alignments_per_step")
+        top["c4_sw_kernel_s"] = c4.get("sw_kernel_ms_per_step", 0) / 1e3; top["c4_prefilter_kernel_s"] = c4.get("prefilter_kernel_ms_per_step", 0) / 1e3
+        top["c4_valu_frac"] = c4.get("roofline", {}).get("valu_frac"); top["c4_prefilter_frac"] = c4.get("roofline_prefilter", {}).get("frac")
+        cb = c4.get("cpu_baseline", {})
+        top["c4_cpu_value"] = cb.get("value"); top["c4_cpu_ratio"] = (c4["value"] / cb["value"]) if cb.get("value") else None
+    c5 = subs.get("c5-mini")
+    if isinstance(c5, dict) and "error" not in c5:
+        top["c5_mini_tflops"] = c5.get("roofline", {}).get("achieved"); top["c5_mini_mfma_frac"] = c5.get("roofline", {}).get("frac")
+    line.update({k: v for k, v in top.items() if v is not None})
+    for k in ("roofline", "roofline_prefilter"):
+        if k in out:
+            line[k] = _slim_roof(out[k])
+    if "roofline_end_to_end" in out:
+        line["roofline_end_to_end"] = _pick(out["roofline_end_to_end"], ("bound", "achieved", "peak", "unit", "frac", "bytes_per_alignment"))
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = _slim_cpu(out["cpu_baseline"])
+    for k in ("stages_s_per_step", "prefilter_kernel_ms_per_step", "sw_kernel_ms_per_step", "rccl_ranks", "exchange_rank0_s_per_step", "exchange_bytes_per_step_all_ranks", "phases_max_over_ranks_s_per_step",
+              "wall_s_per_step", "load_s_per_step", "value_disk_to_cluster_db", "encoder_residues_per_s"):
+        if k in out:
+            line[k] = out[k]
+    if "rounds_last_step" in out:
+        line.update(_pick(_slim_record(out), ("rounds", "rounds_columns")))
+    if subs:
+        line["configs"] = {k: _slim_record(v) for k, v in subs.items()}
+        errs = {k: v["error"] for k, v in subs.items() if isinstance(v, dict) and "error" in v}
+        if errs:
+            line["errors"] = errs
+    if "optional_rules" in out:
+        line["optional_rules"] = out["optional_rules"]
+    line["detail_file"] = detail
+
+    def sig(x):      # six significant digits are more than any of these measurements carry; the full precision is in the detail file
+        if isinstance(x, float):
+            return float("%.6g" % x)
+        if isinstance(x, dict):
+            return {k: sig(v) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return [sig(v) for v in x]
+        return x
+    return sig(line)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -498,24 +676,25 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-sub-records", action="store_true", help="skip the c3 / c5-mini / c4 sub-records and the one-shot-process leg of the default line")
     ap.add_argument("--no-c4", action="store_true", help="skip the nominal configs[3] sub-record (2000 proteomes: ~6 min incl. database generation and its CPU leg)")
+    ap.add_argument("--optional-rules", action="store_true", help="add the timed leg of the optional rule UC-1/L (length gate, default off) to the default line")
+    ap.add_argument("--detail-dir", help="where the full record of the run goes (default: gpurun_out/ of the repository, else --workdir)")
+    ap.add_argument("--full-line", action="store_true", help="print the full record (every sub-record with its prose, ~20 kB) instead of the slim line + detail file")
     ap.add_argument("--workflow", choices=["plain", "default"], help="plain = the all-vs-all step (--single-step-clustering semantics; default for c2/c3/c4-lite); "
                     "default = what cluster.rs:45-49 triggers: pre-step + 3-step cascade through one uc_cluster call (default for c4)")
     args = ap.parse_args()
-    if args.config == "c5":
-        return bench_c5(args)
     for kv in filter(None, os.environ.get("UC_BENCH_PROTEOMES", "").split(",")):      # test hook, e.g. "c2=5,c3=5": the named configs at a toy size
         k, v = kv.split("=")
         CONFIGS[k] = (int(v),) + CONFIGS[k][1:]
-    proteomes, families, len_scale, seed, options, label = CONFIGS[args.config]
+    proteomes, families, len_scale, seed, options, label = CONFIGS[args.config] if args.config != "c5" else (5, 6000, 1.0, 0x5EED0005, "-c 0.8", "BASELINE configs[4]")
     custom = any(v is not None for v in (args.proteomes, args.families, args.len_scale, args.options))
     proteomes = args.proteomes if args.proteomes is not None else proteomes
     families = args.families if args.families is not None else families
     len_scale = args.len_scale if args.len_scale is not None else len_scale
     options = args.options if args.options is not None else options
-    if (args.workflow or ("default" if args.config == "c4" else "plain")) == "default":
+    if args.config != "c5" and (args.workflow or ("default" if args.config == "c4" else "plain")) == "default":
         if args.gpus != 1:
             raise SystemExit("--workflow default is a single-process line (uc_cluster spreads over GPUs itself with '--gpus N' in --options)")
-        print(json.dumps(bench_workflow(args, proteomes, families, len_scale, seed, options, label, custom)))
+        print(json.dumps(slim_line(bench_workflow(args, proteomes, families, len_scale, seed, options, label, custom), args)))
         return
 
     import torch
@@ -543,6 +722,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
+    if args.config == "c5":
+        return bench_c5(args, world, rank, local_rank, multi)
     comm = None
     dist = None
     rccl_ranks = 0
@@ -710,46 +891,61 @@ def main():
             out["cpu_baseline"] = best                       # the faster CPU leg is THE baseline ...
             out["cpu_baselines"] = cb                        # ... both are reported
     if not multi and args.config == "c2" and not custom and not args.no_sub_records and not args.no_extra_legs:
-        U.lib().uc_release_scratch()
+        # every sub-record is guarded on its own: an exception, an out-of-memory or a missing tool in one leg leaves {"error": ...} in its
+        # place and the headline, the other records and the line itself stand
         subs = {}
-        # north_star's quoted 1-GPU target size (BASELINE configs[2] on one GPU): ONE timed pass after one untimed pass (a cold pass spends
-        # ~6 s of its 46 s in first-touch hipMalloc of ~150 GB of work buffers), its own roofline blocks and CPU sample
-        p3 = CONFIGS["c3"]
-        o3, prefix3, n3, _ = run_config(p3[0], p3[1], p3[2], p3[3], p3[4], p3[5], False, 1, 1)
-        for k in ("metric", "unit", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "value_definition", "rccl_ranks"):
-            o3.pop(k, None)
-        if not args.no_cpu_baseline:
-            cb3 = cpu_baseline(prefix3, p3[4], n3, min(args.cpu_seconds, 12.0))
-            o3["cpu_baseline"] = max(cb3, key=lambda d: d["value"])
-        # ... and the same database through the DEFAULT workflow (what cluster.rs:45-49 triggers), disk -> clust.tsv, second of two calls
-        U.lib().uc_release_scratch()
-        outp3 = os.path.join(os.path.dirname(prefix3), "bench_clust")
-        for _ in range(2):
-            t1 = time.perf_counter()
-            s3 = U.cluster(prefix3, outp3 + "_cluster", os.path.join(os.path.dirname(prefix3), "tmp"), p3[4], threads=threads)
-            U.createtsv(prefix3, outp3 + "_cluster", outp3 + ".tsv")
-            w3 = time.perf_counter() - t1
-        U.rmdb(outp3 + "_cluster")
-        o3["workflow_default"] = {"what": "uc_cluster('%s') + uc_createtsv: pre-step + 3-step cascade, disk -> clust.tsv, warm call" % p3[4], "wall_s": w3,
-                                  "alignments": s3["n_gapped_alignments"], "clusters": s3["n_clusters"], "value": s3["n_gapped_alignments"] / w3, "unit": "alignments/s",
-                                  "sw_kernel_ms": s3["sw_kernel_ms"], "prefilter_kernel_ms": s3["prefilter_kernel_ms"]}
-        subs["c3"] = o3
-        U.lib().uc_release_scratch()
-        subs["c5-mini"] = c5_mini(args)
-        if not args.no_c4:
+
+        def guarded(name, fn):
+            try:
+                U.lib().uc_release_scratch()
+                subs[name] = fn()
+            except BaseException as e:          # noqa: BLE001 (SystemExit of a nested leg included: the line must still be printed)
+                if isinstance(e, KeyboardInterrupt):
+                    raise
+                subs[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+        def leg_c3():
+            # north_star's quoted 1-GPU target size (BASELINE configs[2] on one GPU): ONE timed pass after one untimed pass (a cold pass spends
+            # ~6 s of its 46 s in first-touch hipMalloc of ~150 GB of work buffers), its own roofline blocks and CPU sample
+            p3 = CONFIGS["c3"]
+            o3, prefix3, n3, _ = run_config(p3[0], p3[1], p3[2], p3[3], p3[4], p3[5], False, 1, 1)
+            for k in ("metric", "unit", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "value_definition", "rccl_ranks"):
+                o3.pop(k, None)
+            if not args.no_cpu_baseline:
+                cb3 = cpu_baseline(prefix3, p3[4], n3, min(args.cpu_seconds, 12.0))
+                o3["cpu_baseline"] = max(cb3, key=lambda d: d["value"])
+            # ... and the same database through the DEFAULT workflow (what cluster.rs:45-49 triggers), disk -> clust.tsv, second of two calls
+            U.lib().uc_release_scratch()
+            outp3 = os.path.join(os.path.dirname(prefix3), "bench_clust")
+            for _ in range(2):
+                t1 = time.perf_counter()
+                s3 = U.cluster(prefix3, outp3 + "_cluster", os.path.join(os.path.dirname(prefix3), "tmp"), p3[4], threads=threads)
+                U.createtsv(prefix3, outp3 + "_cluster", outp3 + ".tsv")
+                w3 = time.perf_counter() - t1
+            U.rmdb(outp3 + "_cluster")
+            o3["workflow_default"] = {"what": "uc_cluster('%s') + uc_createtsv: pre-step + 3-step cascade, disk -> clust.tsv, warm call" % p3[4], "wall_s": w3,
+                                      "alignments": s3["n_gapped_alignments"], "clusters": s3["n_clusters"], "value": s3["n_gapped_alignments"] / w3, "unit": "alignments/s",
+                                      "sw_kernel_ms": s3["sw_kernel_ms"], "prefilter_kernel_ms": s3["prefilter_kernel_ms"]}
+            return o3
+
+        def leg_c4():
             # BASELINE configs[3] at its NOMINAL size (2000 proteomes, 6.36 M sequences, "-c 0.8 --min-seq-id 0.3 -s 7.5"): ONE uc_cluster call through the
             # default workflow (what cluster.rs:35,45-49 forwards), from the DB files; its own rooflines, per-round records and the round-by-round CPU leg
-            U.lib().uc_release_scratch()
             p4 = CONFIGS["c4"]
             o4 = bench_workflow(args, p4[0], p4[1], p4[2], p4[3], p4[4], p4[5], False, steps=1, warmup=0, cpu_seconds=min(args.cpu_seconds, 10.0))
             for k in ("metric", "unit", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "value_definition", "n_gpus"):
                 o4.pop(k, None)
-            subs["c4"] = o4
+            return o4
+
+        guarded("c3", leg_c3)
+        guarded("c5-mini", lambda: c5_mini(args))
+        if not args.no_c4:
+            guarded("c4", leg_c4)
         out["configs"] = subs
-    if not multi and args.config == "c2" and not custom and not args.no_extra_legs:
-        # optional rule UC-1/L (default OFF): the headline workload with MMseqs2's length gate in front of the gapped stage -
-        # what the step costs if Foldseek's aligner skips the pairs whose lengths alone rule the coverage threshold out (believed, EXT-UNVERIFIED).
-        # value counts the pairs that WERE aligned, not the listed ones.
+    if not multi and args.config == "c2" and not custom and not args.no_extra_legs and args.optional_rules:
+        # optional rule UC-1/L (default OFF; opt-in leg since r06: --optional-rules): the headline workload with MMseqs2's length gate in
+        # front of the gapped stage - what the step costs if Foldseek's aligner skips the pairs whose lengths alone rule the coverage threshold out (believed,
+        # EXT-UNVERIFIED).  value counts the pairs that WERE aligned, not the listed ones.
         U.lib().uc_release_scratch()
         p2 = CONFIGS["c2"]
         og, _, _, _ = run_config(p2[0], p2[1], p2[2], p2[3], p2[4] + " --length-gate 1", p2[5], True, max(1, min(args.steps, 3)), 1)
@@ -768,7 +964,7 @@ def main():
                 o3.pop(k, None)
             out["configs"] = {"c3": o3}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(slim_line(out, args)))
     if multi:
         dist.barrier()
         comm.close()

@@ -719,11 +719,25 @@ def test_bench_line_contract(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--proteomes", "3", "--families", "60", "--steps", "2", "--warmup", "1",
-                        "--cpu-seconds", "1", "--workdir", str(tmp_path)], capture_output=True, text=True, timeout=600)
+                        "--cpu-seconds", "1", "--workdir", str(tmp_path), "--detail-dir", str(tmp_path / "detail")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    d = json.loads(lines[0])
+    slim = json.loads(lines[0])
+    # r06: the line is the SLIM record (< 8 kB: the driver keeps a 10 kB tail) with the figures a reader needs at the top level; the full record
+    # (formulas, notes, both CPU legs, counts) is the side file the line names - the recomputation checks below read that
+    assert len(lines[0]) < 8000
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "value_definition", "value_disk_to_tsv_aln_s", "disk_to_tsv_wall_s", "workflow_default_wall_s",
+              "value_one_shot_aln_s", "stages_s_per_step", "detail_file"):
+        assert k in slim, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "valu_frac"):
+        assert k in slim["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in slim["cpu_baseline"], k
+    assert "workload" in slim["config"] and "model" not in slim["config"]
+    d = json.load(open(slim["detail_file"]))
+    assert abs(slim["value"] - d["value"]) <= 1e-5 * d["value"] and abs(slim["value_disk_to_tsv_aln_s"] - d["value_disk_to_tsv"]["value"]) <= 1e-5 * d["value_disk_to_tsv"]["value"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -767,7 +781,7 @@ def test_bench_line_does_not_depend_on_the_step_count(tmp_path):
     res = []
     for steps in (1, 4):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--proteomes", "3", "--families", "60", "--steps", str(steps), "--warmup", "1",
-                            "--no-cpu-baseline", "--no-extra-legs", "--workdir", str(tmp_path)], capture_output=True, text=True, timeout=600)
+                            "--no-cpu-baseline", "--no-extra-legs", "--full-line", "--workdir", str(tmp_path)], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
     a, b = res

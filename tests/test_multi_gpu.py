@@ -169,3 +169,33 @@ def test_bench_n_gt_1_code_path_with_one_real_rccl_rank(tmp_path):
     c3 = line["configs"]["c3"]                                # the configs[2] leg of an N > 1 line
     assert c3["n_gpus"] == 1 and c3["rccl_ranks"] == 1 and c3["config"]["alignments_per_step"] > 0 and "phases_max_over_ranks_s_per_step" in c3
     assert "6 synthetic proteomes" in c3["config"]["workload"] and "5 synthetic proteomes" in line["config"]["workload"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_c5_n_gt_1_code_path_with_one_real_rccl_rank(tmp_path):
+    """`bench.py --config c5 --gpus N` (BASELINE configs[4] on N GPUs: one ProstT5 encoder replica per rank, every N-th sequence of the length-sorted order,
+    codes gathered over the control plane, then the RCCL-sharded cluster step) through its N > 1 code path with ONE rank, launched as the driver launches
+    N > 1; same alignments and clusters as the plain single-GPU form of the same workload (one synthetic proteome, the shared full-depth synthetic model)."""
+    import socket
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_t5_full_depth as F
+    gguf = F.ensure_gguf()
+    work = os.path.dirname(gguf)
+    assert os.path.basename(gguf) == "prostt5_synth_24.gguf"          # the file bench_c5 looks for in its --workdir
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, UC_ALLOW_SYNTHETIC="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "UC_BENCH_FORCE_MULTI"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--config", "c5", "--proteomes", "1", "--gpus", "1", "--steps", "1", "--warmup", "0", "--workdir", work]
+    r1 = subprocess.run([sys.executable] + tail, env=env, capture_output=True, text=True, timeout=800)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port)] + tail,
+                       env=dict(env, UC_BENCH_FORCE_MULTI="1"), capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and "encoder replicas" in line["config"]["parallelism"]
+    assert line["config"]["alignments_per_step"] == one["config"]["alignments_per_step"] > 0 and line["config"]["clusters"] == one["config"]["clusters"]
+    assert line["roofline"]["bound"] == "mfma" and 0.1 < line["roofline"]["frac"] < 1.0 and set(line["stages_s_per_step"]) == {"prostt5_encode", "gather_codes", "set_db_and_cluster"}

@@ -1284,7 +1284,10 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                     SwPlan &P3 = A.tb_P3;
                     // the plans of the passes behind us are dead (their results have been scattered): at sizes where the matrix budget is what is left of the
                     // device (nominal configs[3]: ~35 GB of plan arrays beside ~57 GiB of matrices per batch) they go back before the matrices are sized
-                    if (n2 >= (8u << 20)) {
+                    // (r06, ADVICE r05: only when memory IS short - re-allocating ~35 GB of plan arrays in the next 256 M-pair batch costs 1-2 s of fresh-memory time)
+                    size_t free_now = 0, total_now = 0;
+                    const bool mem_short = hipMemGetInfo(&free_now, &total_now) != hipSuccess || free_now < (160ull << 30);
+                    if (n2 >= (8u << 20) && mem_short) {
                         UC_HIP(hipStreamSynchronize(s));
                         P1.release(); P2.release(); P2b.release(); A.rr_P2.release(); A.amb_P3.release();
                         if (dedup) P0.release();                   // (without sharing, Lsq / Lst / Lidx ARE P0's arrays)
@@ -1603,6 +1606,24 @@ __global__ void __launch_bounds__(256) sc_compact_kernel(uint32_t *ctr, const ui
         if (assign[v] == SC_NONE) next[atomicAdd(&ctr[3], 1u)] = v;
     }
 }
+// the edges among the still-unassigned nodes of the work list (v < w once each): out == nullptr counts them, else appends them behind an atomic cursor
+__global__ void __launch_bounds__(256) sc_induced_kernel(uint32_t left, const uint32_t *work, const uint64_t *off, const uint32_t *adj, const uint32_t *assign,
+                                                         uint32_t *out, unsigned long long *cursor) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < left; i += gridDim.x * 256) {
+        const uint32_t v = work[i];
+        if (assign[v] != SC_NONE) continue;
+        uint32_t c = 0;
+        for (uint64_t k = off[v]; k < off[(size_t)v + 1]; k++) { const uint32_t w = adj[k]; c += (w > v && assign[w] == SC_NONE) ? 1u : 0u; }
+        if (!c) continue;
+        const unsigned long long base = atomicAdd(cursor, (unsigned long long)c);
+        if (!out) continue;
+        unsigned long long o = base;
+        for (uint64_t k = off[v]; k < off[(size_t)v + 1]; k++) {
+            const uint32_t w = adj[k];
+            if (w > v && assign[w] == SC_NONE) { out[2 * o] = v; out[2 * o + 1] = w; o++; }
+        }
+    }
+}
 __global__ void sc_next_round_kernel(uint32_t *ctr) { ctr[0] = ctr[3]; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; }
 
 void Engine::set_cover_own_edges(uint32_t n, uint32_t *assign) {
@@ -1689,18 +1710,28 @@ void Engine::set_cover_graph(uint32_t n, const uint32_t *h_edges, const uint32_t
         UC_HIP(hipStreamSynchronize(stream));
         UC_HIP(hipGetLastError());
         if (host_tail) {
-            std::vector<uint64_t> off((size_t)n + 1);
-            std::vector<uint32_t> adj(mu);
-            UC_HIP(hipMemcpy(off.data(), d_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
-            if (mu) UC_HIP(hipMemcpy(adj.data(), d_adj.p, (size_t)mu * 4, hipMemcpyDeviceToHost));
-            std::vector<uint32_t> sub((size_t)n, SC_NONE), back;
-            for (uint32_t v = 0; v < n; v++) if (assign[v] == SC_NONE) { sub[v] = (uint32_t)back.size(); back.push_back(v); }      // ids keep their order: so do the ties
-            std::vector<uint32_t> e2;
-            for (uint32_t v : back)
-                for (uint64_t k = off[v]; k < off[(size_t)v + 1]; k++) {
-                    const uint32_t w = adj[k];
-                    if (w > v && assign[w] == SC_NONE) { e2.push_back(sub[v]); e2.push_back(sub[w]); }
-                }
+            // r06: only the subgraph the `left` unassigned nodes induce goes to the host - their ids and the edges among them, gathered on the
+            // device (count pass, then an append pass; the order of the edge list does not matter to the cover) - not the whole adjacency (4 B x 10^9 entries
+            // over PCIe plus an O(n) scan at nominal sizes, however few nodes were left)
+            DevBuf<unsigned long long> ecnt;
+            ecnt.reserve(1);
+            UC_HIP(hipMemsetAsync(ecnt.p, 0, 8, stream));
+            hipLaunchKernelGGL(sc_induced_kernel, grid_for(left), dim3(256), 0, stream, left, (const uint32_t *)cur, d_off.p, d_adj.p, d_assign.p, (uint32_t *)nullptr, ecnt.p);
+            unsigned long long ne2 = 0;
+            UC_HIP(hipMemcpyAsync(&ne2, ecnt.p, 8, hipMemcpyDeviceToHost, stream));
+            UC_HIP(hipStreamSynchronize(stream));
+            DevBuf<uint32_t> de2;
+            de2.reserve(2 * std::max<unsigned long long>(ne2, 1));
+            UC_HIP(hipMemsetAsync(ecnt.p, 0, 8, stream));
+            if (ne2) hipLaunchKernelGGL(sc_induced_kernel, grid_for(left), dim3(256), 0, stream, left, (const uint32_t *)cur, d_off.p, d_adj.p, d_assign.p, de2.p, ecnt.p);
+            std::vector<uint32_t> back(left), e2(2 * (size_t)ne2);
+            UC_HIP(hipMemcpyAsync(back.data(), cur, (size_t)left * 4, hipMemcpyDeviceToHost, stream));
+            if (ne2) UC_HIP(hipMemcpyAsync(e2.data(), de2.p, 2 * (size_t)ne2 * 4, hipMemcpyDeviceToHost, stream));
+            UC_HIP(hipStreamSynchronize(stream));
+            UC_HIP(hipGetLastError());
+            std::sort(back.begin(), back.end());                                   // ids keep their order: so do the ties
+            auto sub = [&](uint32_t v) { return (uint32_t)(std::lower_bound(back.begin(), back.end(), v) - back.begin()); };
+            for (uint32_t &x : e2) x = sub(x);
             std::vector<uint32_t> a2(back.size());
             set_cover((uint32_t)back.size(), e2.data(), e2.size() / 2, a2.data());
             for (size_t i = 0; i < back.size(); i++) assign[back[i]] = back[a2[i]];

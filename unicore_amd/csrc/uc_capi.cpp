@@ -630,7 +630,7 @@ int uc_cluster(const char *db, const char *out_cluster_db, const char *tmp, cons
             std::vector<std::thread> th;
             // a rank on its way out fails the group (peers leave their next barrier with an error) and aborts every RCCL
             // communicator (peers blocked INSIDE a collective return from it)
-            auto bail = [&] { grp.fail_all(); for (auto &c : comms) c->abort(); };
+            auto bail = [&] { grp.fail_all(); std::vector<Comm *> cs; for (auto &c : comms) cs.push_back(c.get()); abort_all(cs); };
             for (int r = 0; r < W; r++)
                 th.emplace_back([&, r] {
                     try { rank_main(r); }

@@ -32,7 +32,13 @@ inline OomRelief &oom_relief_slot() { static thread_local OomRelief r; return r;
 // test hook (tests/test_gpu_parity.py::test_out_of_memory_relief): UC_TEST_OOM_AT=k makes the k-th allocation made under a registered handler
 // report out-of-memory once, so the relief-and-retry path runs without 288 GB having to be filled first
 inline bool oom_test_fires() {
-    static std::atomic<int> left([] { const char *s = getenv("UC_TEST_OOM_AT"); return s ? atoi(s) : 0; }());
+    static std::atomic<int> left([] {
+        const char *s = getenv("UC_TEST_OOM_AT");
+        const int k = s ? atoi(s) : 0;
+        if (k > 0) fprintf(stderr, "unicore-cluster: UC_TEST_OOM_AT=%d is set: allocation #%d made under an out-of-memory handler will be FAILED on purpose (test fault injection; "
+                                   "unset it for production runs)\n", k, k);      // said once, loudly: a stray variable must not go unnoticed
+        return k;
+    }());
     return left.load(std::memory_order_relaxed) > 0 && left.fetch_sub(1) == 1;
 }
 inline hipError_t malloc_with_relief(void **p, size_t bytes) {
@@ -212,6 +218,9 @@ struct Engine {
     void export_hits_dev(uint32_t *dq, uint32_t *dt, int32_t *ds, int32_t *dd) const;
     uint64_t import_hits_dev(uint64_t n, const uint32_t *dq, const uint32_t *dt, const int32_t *ds, const int32_t *dd,
                              uint32_t rank, uint32_t world);
+    // list 1 (already in key order: query, score desc, target asc) merged with list 2 (sorted here unless `sorted2`), truncated to max_seqs per query, installed
+    uint64_t merge_hits_dev(uint64_t n1, const uint32_t *q1, const uint32_t *t1, const int32_t *s1, const int32_t *d1,
+                            uint64_t n2, const uint32_t *q2, const uint32_t *t2, const int32_t *s2, const int32_t *d2, bool sorted2, uint32_t rank, uint32_t world);
     // the installed lists regrouped by owner rank of each pair (stable; counts[world] on the host) into caller-owned device arrays
     void partition_hits_by_owner(uint32_t world, uint32_t *dq, uint32_t *dt, int32_t *ds, int32_t *dd, uint64_t *counts);
     void get_alns(uint64_t begin, uint64_t n, uc_aln *out) const;

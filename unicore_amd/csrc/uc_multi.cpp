@@ -53,6 +53,15 @@ Comm::~Comm() {
     if (ncclComm *h = nccl.exchange(nullptr)) (void)ncclCommDestroy(h);
 }
 
+// How long an abort waits for the threads that are inside an RCCL call with the handle it is about to reclaim.  An enqueue is host-side work that
+// returns in microseconds, so in the common case the wait is over at once; what can still be inside after milliseconds is a thread blocked in a
+// first-use connect (ncclGroupEnd of the first exchange) on the very peer that is dying - nothing but the abort gets that thread out, so the wait must
+// be bounded.  2 s: three orders of magnitude above any healthy enqueue, and short against the run it ends (a failing N-rank call reports within
+// seconds).  When it expires the abort proceeds UNDER the live enqueue by design, and says so (verbosity >= 2).
+constexpr int ABORT_GRACE_MS = 2000;
+
+void Comm::mark_aborted() { aborted.store(true); }
+
 void Comm::abort() {
     aborted.store(true);
     // whoever takes the handle out aborts it, exactly once; no lock: the thread that owns this communicator may be blocked inside
@@ -60,11 +69,20 @@ void Comm::abort() {
     ncclComm *h = nccl.exchange(nullptr);
     if (!h) return;
     // ncclCommAbort reclaims the communicator: a thread that read the handle before the exchange above and is still inside its RCCL call
-    // (nccl_enqueue counts itself in BEFORE it reads the handle, so it is visible here) must be out first.  An enqueue is host-side work
-    // that returns in microseconds - unless it is blocked in a first-use connect on the dying peer: after the grace period the abort goes
-    // ahead, because it is then the only thing that gets that thread out.
-    for (int ms = 0; ms < 2000 && in_flight.load() > 0; ms++) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    // (nccl_enqueue / comm_info count themselves in BEFORE they read the handle, so they are visible here) must be out first
+    int ms = 0;
+    for (; ms < ABORT_GRACE_MS && in_flight.load() > 0; ms++) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    if (in_flight.load() > 0)
+        logf(2, "unicore-cluster: rank %d: %d thread(s) still inside an RCCL call after the %d ms abort grace (blocked on a dying peer): aborting the communicator under them\n",
+             rank, in_flight.load(), ABORT_GRACE_MS);
     (void)ncclCommAbort(h);
+}
+
+// the failure path of an N-rank run: every communicator is MARKED first (new enqueues fail at once, the ones inside start to drain everywhere at the
+// same time), then the bounded waits and aborts follow - the grace periods overlap instead of adding up to 2 N seconds
+void abort_all(const std::vector<Comm *> &comms) {
+    for (Comm *c : comms) if (c) c->mark_aborted();
+    for (Comm *c : comms) if (c) c->abort();
 }
 
 namespace {
@@ -86,13 +104,14 @@ bool inject_failure(int rank, int stage) {
 
 // RCCL enqueue: the handle is read once; an abort() that lands between the read and the call makes the call fail (or return early) — both
 // surface as an error of this rank, which is what the caller wants to hear
+struct InFlight {      // counted in before the handle is read, out when the call (and its GroupScope) has been left, also by an exception
+    std::atomic<int> &n;
+    explicit InFlight(std::atomic<int> &c) : n(c) { n.fetch_add(1); }
+    ~InFlight() { n.fetch_sub(1); }
+};
 template <class F>
 void nccl_enqueue(Comm &C, F &&f) {
-    struct InFlight {      // counted in before the handle is read, out when the call (and its GroupScope) has been left, also by an exception
-        std::atomic<int> &n;
-        explicit InFlight(std::atomic<int> &c) : n(c) { n.fetch_add(1); }
-        ~InFlight() { n.fetch_sub(1); }
-    } guard(C.in_flight);
+    InFlight guard(C.in_flight);
     ncclComm *h = C.nccl.load();
     if (C.aborted.load() || !h) fail(UC_ERR_DEVICE, "RCCL communicator of rank %d was aborted (another GPU rank of this run failed)", C.rank);
     f(h);
@@ -120,8 +139,9 @@ void comm_init_rank(Comm &C, const uint8_t id[128], int rank, int world, int dev
 }
 
 void comm_info(const Comm &C, int *count, int *rank, int *device) {
+    InFlight guard(const_cast<Comm &>(C).in_flight);      // the info calls read the handle too: an abort must not reclaim it under them
     ncclComm *h = C.nccl.load();
-    if (!h) fail(UC_ERR_ARGS, "communicator has no RCCL handle");
+    if (!h || C.aborted.load()) fail(UC_ERR_ARGS, "communicator has no RCCL handle");
     UC_NCCL(ncclCommCount(h, count));
     UC_NCCL(ncclCommUserRank(h, rank));
     UC_NCCL(ncclCommCuDevice(h, device));

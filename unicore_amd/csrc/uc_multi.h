@@ -66,6 +66,7 @@ struct Comm {
     // is DEFERRED until the threads that entered an RCCL call with it have left (in_flight == 0) - bounded: after a grace period an enqueue
     // that is still inside is blocked on the dying peer, and ncclCommAbort is the only call that gets it out.
     void abort();
+    void mark_aborted();             // first half of abort(): new enqueues fail from here on (abort_all marks every communicator before it waits on any)
     void barrier(Engine &E);
     void all_gather_u64(Engine &E, uint64_t v, uint64_t *out /* world */);
     void all_gather_u64s(Engine &E, const uint64_t *v, int k, uint64_t *out /* world x k */);
@@ -123,5 +124,6 @@ void comm_init_rank(Comm &C, const uint8_t id[128], int rank, int world, int dev
 // all communicators of an in-process group from ONE thread (ncclCommInitAll): either every rank gets its handle or the call
 // fails as a whole — no rank can be left waiting inside a collective init for a peer that died while building its engine
 void comm_init_all(const std::vector<Comm *> &comms, const std::vector<int> &devices);
+void abort_all(const std::vector<Comm *> &comms);     // failure path: mark every communicator, then the bounded waits + aborts (grace periods overlap)
 
 }  // namespace uc

@@ -1326,7 +1326,8 @@ struct PrefilterScratch {
     DevBuf<uint64_t> d_ent, v_in;
     DevBuf<uint32_t> d_cnt, d_flag, d_cq, d_ct, d_rpidx2, d_qsurv;
     DevBuf<uint64_t> d_keys, d_keys2, d_pos, d_skey, d_skey2, d_rval2, d_qbase, d_soff, d_qr;
-    DevBuf<int32_t> d_cd, d_cd2, d_score;
+    DevBuf<int32_t> d_cd, d_cd2, d_score, d_mval;      // d_mkey / d_mval: output of the sorted-run merge (merge_hits_dev)
+    DevBuf<uint64_t> d_mkey;
     // distinct-k-mer enumeration (E2)
     DevBuf<uint8_t> d_kflag, d_wflag;
     DevBuf<uint32_t> d_qk, d_kid, d_dk, d_nsimk, d_drk, d_drk2, d_roff, d_nr, d_src, d_ph;
@@ -1338,7 +1339,7 @@ struct PrefilterScratch {
         f(d_counters); f(d_temp); f(d_koff); f(k_in); f(k_out); f(d_ent32); f(v_in32); f(d_okey); f(d_okey2); f(d_oidx); f(d_order);
         f(d_ent); f(v_in); f(d_cnt); f(d_flag); f(d_cq); f(d_ct); f(d_rpidx2); f(d_qsurv); f(d_keys); f(d_keys2); f(d_pos); f(d_skey);
         f(d_skey2); f(d_rval2); f(d_qbase); f(d_soff); f(d_qr); f(d_cd); f(d_cd2); f(d_score); f(d_kflag); f(d_wflag); f(d_qk); f(d_kid); f(d_dk);
-        f(d_nsimk); f(d_drk); f(d_drk2); f(d_roff); f(d_nr); f(d_src); f(d_ph); f(d_drv); f(d_drv2); f(d_cumh); f(d_cumr); f(d_qh); f(d_qrn); f(d_rec); f(d_kbits);
+        f(d_nsimk); f(d_drk); f(d_drk2); f(d_roff); f(d_nr); f(d_src); f(d_ph); f(d_drv); f(d_drv2); f(d_cumh); f(d_cumr); f(d_qh); f(d_qrn); f(d_rec); f(d_kbits); f(d_mkey); f(d_mval);
     }
     size_t bytes() {
         size_t b = 0;
@@ -1488,27 +1489,18 @@ void Engine::prefilter_impl(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uin
                     aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd);
                     acc_n = n_hits;
                 } else if (n_hits) {       // (a mirrored pass always comes here: its lists are ungrouped)
-                    const uint64_t tot = acc_n + n_hits;
-                    tq.reserve(tot); tt.reserve(tot); ts.reserve(tot); td.reserve(tot);
-                    if (acc_n) {
-                        UC_HIP(hipMemcpyAsync(tq.p, aq.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
-                        UC_HIP(hipMemcpyAsync(tt.p, at.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
-                        UC_HIP(hipMemcpyAsync(ts.p, as.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
-                        UC_HIP(hipMemcpyAsync(td.p, ad.p, acc_n * 4, hipMemcpyDeviceToDevice, stream));
-                    }
-                    UC_HIP(hipMemcpyAsync(tq.p + acc_n, d_hq.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-                    UC_HIP(hipMemcpyAsync(tt.p + acc_n, d_ht.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-                    UC_HIP(hipMemcpyAsync(ts.p + acc_n, d_hs.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-                    UC_HIP(hipMemcpyAsync(td.p + acc_n, d_hd.p, n_hits * 4, hipMemcpyDeviceToDevice, stream));
-                    UC_HIP(hipStreamSynchronize(stream));
-                    acc_n = import_hits_dev(tot, tq.p, tt.p, ts.p, td.p, 0, 1);      // merge + truncate to max_seqs
+                    // the pass's lists leave the engine (swap, no copy), the merge installs accumulator + pass in their place.  The accumulator is in key
+                    // order, a plain pass's lists are too: only a mirrored pass's records are sorted before the two runs are merged (merge_hits_dev)
+                    const uint64_t n_pass = n_hits;
+                    tq.swap(d_hq); tt.swap(d_ht); ts.swap(d_hs); td.swap(d_hd);
+                    acc_n = merge_hits_dev(acc_n, aq.p, at.p, as.p, ad.p, n_pass, tq.p, tt.p, ts.p, td.p, /*sorted2=*/!mir, 0, 1);      // merge + truncate to max_seqs
                     if (c + 1 == chunks.size()) installed = true;
                     else { aq.swap(d_hq); at.swap(d_ht); as.swap(d_hs); ad.swap(d_hd); }
                 }
             }
             if (ok) {
                 // install the accumulated lists (also rebuilds the per-query counts) unless the last merge already did
-                if (!installed) import_hits_dev(acc_n, aq.p, at.p, as.p, ad.p, 0, 1);
+                if (!installed) merge_hits_dev(acc_n, aq.p, at.p, as.p, ad.p, 0, nullptr, nullptr, nullptr, nullptr, true, 0, 1);     // (in key order already: counts only)
                 stats.n_prefilter_hits += n_hits;
                 if (pre) pre->trim(scratch_trim_limit());
                 return;
@@ -1999,6 +1991,18 @@ void Engine::partition_hits_by_owner(uint32_t world, uint32_t *dq, uint32_t *dt,
 
 uint64_t Engine::import_hits_dev(uint64_t n_in, const uint32_t *dq, const uint32_t *dt, const int32_t *ds, const int32_t *dd,
                                  uint32_t rank, uint32_t world) {
+    return merge_hits_dev(0, nullptr, nullptr, nullptr, nullptr, n_in, dq, dt, ds, dd, false, rank, world);
+}
+
+// The union of two record lists, merged per query under the frozen order (score desc, target asc), truncated to max_seqs and installed.  List 1 is
+// ALREADY in key order (a running top-M accumulator, i.e. the output of an earlier merge or a grouped pass); list 2 is sorted here unless the caller says
+// it is in key order as well.  r06: the chunk loop of prefilter_impl used to radix-sort accumulator + chunk after every pass - at nominal configs[3] the
+// accumulator of up to max_seqs x queries records went through ~7 sort passes (~170 B of traffic per record) once per target chunk, 8.9 s of the call.
+// Now only the chunk's records are sorted and the two runs are merged (one read + one write of every record); the result is the stable sort's, record for record
+// (the passes' candidate sets are disjoint, so no two keys are equal; rocprim::merge takes list 1 first on ties, as the stable sort of the concatenation did).
+uint64_t Engine::merge_hits_dev(uint64_t n1, const uint32_t *q1, const uint32_t *t1, const int32_t *s1, const int32_t *d1,
+                                uint64_t n2, const uint32_t *q2, const uint32_t *t2, const int32_t *s2, const int32_t *d2, bool sorted2,
+                                uint32_t rank, uint32_t world) {
     PressureScope ps(*this, 0);
     if (!have_db) fail(UC_ERR_ARGS, "no database loaded");
     UC_HIP(hipSetDevice(device));
@@ -2009,6 +2013,7 @@ uint64_t Engine::import_hits_dev(uint64_t n_in, const uint32_t *dq, const uint32
     n_hits = 0;
     alns_valid = false;
     clear_edges();
+    const uint64_t n_in = n1 + n2;
     if (!n_in) return 0;
     Timer tm;
     timed_ms_begin();
@@ -2020,17 +2025,55 @@ uint64_t Engine::import_hits_dev(uint64_t n_in, const uint32_t *dq, const uint32
     DevBuf<uint32_t> &flag = pre->d_flag, &cnt = pre->d_cnt;
     DevBuf<uint32_t> bad;
     DevBuf<char> &tmp = pre->d_temp;
-    skey.reserve(n_in); skey2.reserve(n_in); cd2.reserve(n_in); flag.reserve(n_in); pos.reserve(n_in); bad.reserve(1);
+    // the merge path (rocprim::merge partitions with 32-bit indices) - UC_MERGE_SORTED=0 keeps the plain sort of everything for A/B runs
+    static const bool merge_ok = !(getenv("UC_MERGE_SORTED") && atoi(getenv("UC_MERGE_SORTED")) == 0);
+    const bool merging = n1 > 0 && n2 > 0 && merge_ok && n_in < (1ull << 32) - (1ull << 20);
+    const bool presorted = n1 > 0 && n2 == 0 && merge_ok;              // nothing to add: only truncation / ownership / counts
+    skey.reserve(n_in); flag.reserve(n_in); pos.reserve(n_in); bad.reserve(1);
     UC_HIP(hipMemsetAsync(bad.p, 0, 4, stream));
-    hipLaunchKernelGGL(merge_key_kernel, grid_for(n_in), dim3(256), 0, stream, n_in, dq, dt, ds, n, skey.p, bad.p);
+    if (n1) hipLaunchKernelGGL(merge_key_kernel, grid_for(n1), dim3(256), 0, stream, n1, q1, t1, s1, n, skey.p, bad.p);
+    if (n2) hipLaunchKernelGGL(merge_key_kernel, grid_for(n2), dim3(256), 0, stream, n2, q2, t2, s2, n, skey.p + n1, bad.p);
     size_t tb = 0;
     unsigned kb = 33;                              // [query | 255 - score : 8 | target : 24]: the query field ends at bit 32 + log2 n
     while (kb < 64 && (1ull << (kb - 32)) < n) kb++;
-    UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, skey.p, skey2.p, dd, cd2.p, (size_t)n_in, 0u, kb, stream));
-    tmp.reserve(tb + 256);
-    UC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, skey.p, skey2.p, dd, cd2.p, (size_t)n_in, 0u, kb, stream));
-    hipLaunchKernelGGL(rank_flag_kernel, grid_for(n_in), dim3(256), 0, stream, skey2.p, n_in, (uint32_t)p.max_seqs, flag.p);
-    if (world > 1) hipLaunchKernelGGL(owner_flag_kernel, grid_for(n_in), dim3(256), 0, stream, skey2.p, n_in, ddb.len, rank, world, flag.p);
+    const uint64_t *sk = nullptr;                  // the sorted keys and their diagonals
+    const int32_t *sd = nullptr;
+    if (presorted) { sk = skey.p; sd = d1; }
+    else if (merging) {
+        const uint64_t *k2 = skey.p + n1;
+        const int32_t *v2 = d2;
+        if (!sorted2) {
+            skey2.reserve(n2); cd2.reserve(n2);
+            UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, skey.p + n1, skey2.p, d2, cd2.p, (size_t)n2, 0u, kb, stream));
+            tmp.reserve(tb + 256);
+            UC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, skey.p + n1, skey2.p, d2, cd2.p, (size_t)n2, 0u, kb, stream));
+            k2 = skey2.p; v2 = cd2.p;
+        }
+        DevBuf<uint64_t> &mkey = pre->d_mkey;
+        DevBuf<int32_t> &mval = pre->d_mval;
+        mkey.reserve(n_in); mval.reserve(n_in);
+        UC_HIP(rocprim::merge(nullptr, tb, skey.p, k2, mkey.p, d1, v2, mval.p, (size_t)n1, (size_t)n2, rocprim::less<uint64_t>(), stream));
+        tmp.reserve(tb + 256);
+        UC_HIP(rocprim::merge(tmp.p, tb, skey.p, k2, mkey.p, d1, v2, mval.p, (size_t)n1, (size_t)n2, rocprim::less<uint64_t>(), stream));
+        sk = mkey.p; sd = mval.p;
+    } else {
+        // one list (or the A/B switch): the diagonals of the two inputs have to be one array for the pair sort
+        const int32_t *dd = n1 ? nullptr : d2;
+        skey2.reserve(n_in); cd2.reserve(n_in);
+        if (n1) {
+            DevBuf<int32_t> &mval = pre->d_mval;
+            mval.reserve(n_in);
+            UC_HIP(hipMemcpyAsync(mval.p, d1, n1 * 4, hipMemcpyDeviceToDevice, stream));
+            if (n2) UC_HIP(hipMemcpyAsync(mval.p + n1, d2, n2 * 4, hipMemcpyDeviceToDevice, stream));
+            dd = mval.p;
+        }
+        UC_HIP(rocprim::radix_sort_pairs(nullptr, tb, skey.p, skey2.p, dd, cd2.p, (size_t)n_in, 0u, kb, stream));
+        tmp.reserve(tb + 256);
+        UC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, skey.p, skey2.p, dd, cd2.p, (size_t)n_in, 0u, kb, stream));
+        sk = skey2.p; sd = cd2.p;
+    }
+    hipLaunchKernelGGL(rank_flag_kernel, grid_for(n_in), dim3(256), 0, stream, sk, n_in, (uint32_t)p.max_seqs, flag.p);
+    if (world > 1) hipLaunchKernelGGL(owner_flag_kernel, grid_for(n_in), dim3(256), 0, stream, sk, n_in, ddb.len, rank, world, flag.p);
     auto rin = rocprim::make_transform_iterator(flag.p, WidenU32());
     UC_HIP(rocprim::exclusive_scan(nullptr, tb, rin, pos.p, (uint64_t)0, (size_t)n_in, rocprim::plus<uint64_t>(), stream));
     tmp.reserve(tb + 256);
@@ -2043,8 +2086,17 @@ uint64_t Engine::import_hits_dev(uint64_t n_in, const uint32_t *dq, const uint32
     if (hbad) fail(UC_ERR_ARGS, "hits_import_dev: %u records with a sequence id or score out of range", hbad);
     const uint64_t keep = lp + lf;
     if (keep) {
+        // (list 1 or 2 may BE the engine's own arrays: the scatter reads only keys and the sorted diagonals, never q / t / s / d of the inputs - but the
+        // diagonals of a presorted or merged input are read from d1 / d2 themselves, so the output must not overwrite them in place)
+        const bool alias = (sd == d1 && d1 == d_hd.p) || (sd == d2 && d2 == d_hd.p);
+        if (alias) {
+            DevBuf<int32_t> &mval = pre->d_mval;
+            mval.reserve(n_in);
+            UC_HIP(hipMemcpyAsync(mval.p, sd, n_in * 4, hipMemcpyDeviceToDevice, stream));
+            sd = mval.p;
+        }
         d_hq.reserve(keep); d_ht.reserve(keep); d_hs.reserve(keep); d_hd.reserve(keep);
-        hipLaunchKernelGGL(hit_scatter_kernel, grid_for(n_in), dim3(256), 0, stream, skey2.p, cd2.p, n_in, flag.p, pos.p, d_hq.p, d_ht.p, d_hs.p, d_hd.p);
+        hipLaunchKernelGGL(hit_scatter_kernel, grid_for(n_in), dim3(256), 0, stream, sk, sd, n_in, flag.p, pos.p, d_hq.p, d_ht.p, d_hs.p, d_hd.p);
         n_hits = keep;
         cnt.reserve(n);
         hipLaunchKernelGGL(hit_count_kernel, grid_for(n), dim3(256), 0, stream, d_hq.p, n_hits, n, cnt.p);
