@@ -27,7 +27,7 @@ oracle/_asan/liboracle_asan.so: oracle/uc_oracle.c oracle/uc_simd.c oracle/uc_or
 tools: bin/gen_synth
 bin/gen_synth: tools/gen_synth.c
 	@mkdir -p bin
-	$(CC) -std=c11 -O2 -Wall -o $@ $< -lm
+	$(CC) -std=gnu11 -O2 -Wall -pthread -o $@ $< -lm
 
 # ---------------------------------------------------------------- product (C++17 host + HIP kernels, gfx950 only)
 CSRC    := unicore_amd/csrc

@@ -15,9 +15,29 @@ def ensure_tools():
     return gen
 
 
+DB_SUFFIXES = ("", "_ss", "_h", ".index", "_ss.index", "_h.index", ".dbtype", "_ss.dbtype", "_h.dbtype", ".lookup", ".map")
+_DB_CACHE = {}          # (proteomes, seed, families, scale) -> prefix of the copy generated first in this session
+
+
 def gen_synth_db(prefix, n_proteomes, seed, n_families, len_scale):
+    """the seeded synthetic proteome database at `prefix`.  At-size databases (>= 50 proteomes: 4-70 s of generation, up to 4.5 GB) are generated ONCE per test
+    session: test_configs_gpu.py and test_workflow_gpu.py ask for the same (proteomes, seed) several times, and every later request gets hard links to the
+    first copy's files (the files are never modified in place; a link to a removed directory's files stays valid)."""
+    key = (int(n_proteomes), int(seed), int(n_families), float(len_scale))
+    src = _DB_CACHE.get(key)
+    if src and all(os.path.exists(src + s) for s in DB_SUFFIXES):
+        try:
+            for s in DB_SUFFIXES:
+                if os.path.exists(prefix + s):
+                    os.remove(prefix + s)
+                os.link(src + s, prefix + s)
+            return prefix
+        except OSError:
+            pass                      # another file system: generate
     subprocess.check_call([ensure_tools(), prefix, str(n_proteomes), hex(seed), str(n_families), str(len_scale)],
                           stderr=subprocess.DEVNULL)
+    if n_proteomes >= 50:
+        _DB_CACHE[key] = prefix
     return prefix
 
 

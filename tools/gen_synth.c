@@ -149,6 +149,140 @@ static long nameset_get_or_put(nameset_t *s, uint64_t h, uint32_t v) {
     s->k[i] = h; s->v[i] = v; return -1;
 }
 
+/* ---- r06: the same bytes, generated on several threads ------------------------------------------------------------------------------
+ * Every (proteome, family) has its own RNG stream, so the members of different proteomes are independent - except for two things the
+ * sequential generator carried from proteome to proteome: (a) "the last first-copy member of family f" (the source of the 0.5 % exact
+ * duplicates; whether one exists also decides whether the duplicate draw is consumed at all) and (b) the name set that drops a protein
+ * already in the database.  (a) is a function of the per-(p, f) presence / duplicate draws alone: a cheap sequential PLAN pass replays
+ * just those draws and records, per (p, f), the number of copies, whether the first copy is a duplicate and of which earlier proteome's
+ * member (that member is regenerated from its own stream where it is needed).  Then the proteomes of a batch are generated in parallel
+ * into memory (letters, md5 names), and (b) + all file output stay sequential, in proteome order.  Checked byte for byte against the
+ * sequential generator of r01-r05 (all eleven files; 3 ... 200 proteomes, 40 / 60 / 6000 families, length scales 0.6 / 0.7 / 1, seven seeds
+ * incl. every seed the tests and the bench use); every committed golden under tests/golden/ that was computed on a generated database pins
+ * it as well (a changed byte changes their sha256).  UC_GEN_THREADS overrides the thread count (default: online CPUs, at most 16). */
+#include <pthread.h>
+#include <unistd.h>
+
+typedef struct {
+    uint8_t copies, dup, had_last;   /* first copy: exact duplicate of (src_p, f)'s first copy; had_last: a last member existed when (p, f) drew */
+    int32_t src_p;
+} pf_plan_t;
+
+typedef struct {                     /* one generated proteome, in member order */
+    int n_members;
+    int *len;                        /* per member */
+    char *aa, *ss;                   /* concatenated letters */
+    size_t *off;                     /* start of member i in aa / ss */
+    char (*name)[20];                /* "unicore_<10 hex>" */
+    uint64_t *h40;
+    size_t cap_members, cap_res;
+} proteome_t;
+
+typedef struct {
+    uint64_t seed; int F, lmin; double scale;
+    const gene_t *anc; const pf_plan_t *plan;   /* plan[p * F + f] */
+} gen_ctx_t;
+
+/* the first-copy member of (p, f), generated from its own stream exactly as the sequential generator did (not a duplicate itself) */
+static int gen_first_copy(const gen_ctx_t *cx, int p, int f, uint8_t *oa, uint8_t *os, rng_t *r_out) {
+    const pf_plan_t *pl = &cx->plan[(size_t)p * cx->F + f];
+    rng_t r = rng_key(cx->seed, 2, (uint64_t)p, (uint64_t)f);
+    (void)rng_u01(&r);                               /* presence (was < pf: the member exists) */
+    (void)rng_u01(&r);                               /* paralog draw */
+    if (pl->had_last) (void)rng_u01(&r);             /* duplicate draw (was >= 0.005) */
+    double r3 = 0.05 + 0.30 * rng_u01(&r), ra = 0.10 + 0.50 * rng_u01(&r);
+    int n = make_member(&cx->anc[f], &r, r3, ra, oa, os, cx->lmin);
+    if (r_out) *r_out = r;
+    return n;
+}
+
+static void prot_push(proteome_t *pr, const uint8_t *oa, const uint8_t *os, int n) {
+    if ((size_t)pr->n_members + 1 > pr->cap_members) {
+        pr->cap_members = pr->cap_members ? pr->cap_members * 2 : 4096;
+        pr->len = (int *)realloc(pr->len, pr->cap_members * sizeof(int));
+        pr->off = (size_t *)realloc(pr->off, pr->cap_members * sizeof(size_t));
+        pr->name = (char (*)[20])realloc(pr->name, pr->cap_members * 20);
+        pr->h40 = (uint64_t *)realloc(pr->h40, pr->cap_members * 8);
+    }
+    const size_t o = pr->n_members ? pr->off[pr->n_members - 1] + (size_t)pr->len[pr->n_members - 1] : 0;
+    if (o + (size_t)n > pr->cap_res) {
+        pr->cap_res = (o + (size_t)n) * 2 + 65536;
+        pr->aa = (char *)realloc(pr->aa, pr->cap_res); pr->ss = (char *)realloc(pr->ss, pr->cap_res);
+    }
+    for (int i = 0; i < n; i++) { pr->aa[o + i] = LET[oa[i]]; pr->ss[o + i] = LET[os[i]]; }
+    uint8_t dg[16]; md5((const uint8_t *)pr->aa + o, (size_t)n, dg);
+    snprintf(pr->name[pr->n_members], 20, "unicore_%02x%02x%02x%02x%02x", dg[0], dg[1], dg[2], dg[3], dg[4]);
+    pr->h40[pr->n_members] = ((uint64_t)dg[0] << 32) | ((uint64_t)dg[1] << 24) | ((uint64_t)dg[2] << 16) | ((uint64_t)dg[3] << 8) | dg[4];
+    pr->len[pr->n_members] = n; pr->off[pr->n_members] = o;
+    pr->n_members++;
+}
+
+static void gen_proteome(const gen_ctx_t *cx, int p, proteome_t *pr) {
+    uint8_t *oa = (uint8_t *)malloc(8192), *os = (uint8_t *)malloc(8192);
+    pr->n_members = 0;
+    for (int f = 0; f < cx->F; f++) {
+        const pf_plan_t *pl = &cx->plan[(size_t)p * cx->F + f];
+        if (!pl->copies) continue;
+        rng_t r;
+        int n;
+        if (pl->dup) {
+            n = gen_first_copy(cx, pl->src_p, f, oa, os, NULL);
+            r = rng_key(cx->seed, 2, (uint64_t)p, (uint64_t)f);
+            (void)rng_u01(&r); (void)rng_u01(&r); (void)rng_u01(&r);      /* presence, paralog, duplicate (< 0.005) */
+        } else {
+            n = gen_first_copy(cx, p, f, oa, os, &r);
+        }
+        prot_push(pr, oa, os, n);
+        if (pl->copies == 2) {                                             /* paralog: more diverged, the same stream goes on */
+            double r3 = 0.05 + 0.30 * rng_u01(&r), ra = 0.10 + 0.50 * rng_u01(&r);
+            r3 = r3 * 0.5 + 0.25; ra = ra * 0.5 + 0.40;
+            n = make_member(&cx->anc[f], &r, r3, ra, oa, os, cx->lmin);
+            prot_push(pr, oa, os, n);
+        }
+    }
+    const int nsingle = (int)(pr->n_members * 0.05 + 0.5);               /* proteome-private singletons */
+    for (int c = 0; c < nsingle; c++) {
+        gene_t g; rng_t rs = rng_key(cx->seed, 3, (uint64_t)p, (uint64_t)c);
+        make_ancestor(&g, &rs, cx->scale, cx->lmin);
+        prot_push(pr, g.aa, g.ss, g.len);
+        free(g.aa); free(g.ss);
+    }
+    free(oa); free(os);
+}
+
+typedef struct { const gen_ctx_t *cx; proteome_t *prots; int p0, np; volatile int *next; pthread_mutex_t *mu; } worker_t;
+static void *worker_main(void *arg) {
+    worker_t *w = (worker_t *)arg;
+    for (;;) {
+        pthread_mutex_lock(w->mu);
+        const int k = (*w->next)++;
+        pthread_mutex_unlock(w->mu);
+        if (k >= w->np) break;
+        gen_proteome(w->cx, w->p0 + k, &w->prots[k]);
+    }
+    return NULL;
+}
+
+/* buffered output with cheap integer formatting (five index / lookup lines per sequence: fprintf was a third of the run time) */
+typedef struct { FILE *fp; char *buf; size_t n, cap; } out_t;
+static void out_flush(out_t *o) { if (o->n) fwrite(o->buf, 1, o->n, o->fp); o->n = 0; }
+static void out_bytes(out_t *o, const char *s, size_t n) {
+    if (o->n + n > o->cap) { out_flush(o); if (n > o->cap) { fwrite(s, 1, n, o->fp); return; } }
+    memcpy(o->buf + o->n, s, n); o->n += n;
+}
+static void out_ch(out_t *o, char c) { out_bytes(o, &c, 1); }
+static void out_u64(out_t *o, unsigned long long v) {
+    char t[24]; int k = 24;
+    do { t[--k] = (char)('0' + v % 10); v /= 10; } while (v);
+    out_bytes(o, t + k, (size_t)(24 - k));
+}
+static void out_u5(out_t *o, unsigned v) {       /* %05d */
+    char t[16]; int k = 16;
+    do { t[--k] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (16 - k < 5) t[--k] = '0';
+    out_bytes(o, t + k, (size_t)(16 - k));
+}
+
 int main(int argc, char **argv) {
     if (argc < 4) { fprintf(stderr, "usage: %s <out_prefix> <n_proteomes> <seed> [n_families=6000] [len_scale=1.0]\n", argv[0]); return 2; }
     const char *out = argv[1];
@@ -167,87 +301,89 @@ int main(int argc, char **argv) {
         make_ancestor(&anc[f], &r, scale, lmin);
         pf[f] = f < ncore ? 0.95 : 0.05 + 0.55 * rng_u01(&r);
     }
+    /* plan pass: the presence / paralog / duplicate draws of every (p, f), in the sequential generator's order of events per family */
+    pf_plan_t *plan = (pf_plan_t *)calloc((size_t)P * F, sizeof(pf_plan_t));
+    for (int f = 0; f < F; f++) {
+        int has_last = 0, last_src = -1;
+        for (int p = 0; p < P; p++) {
+            pf_plan_t *pl = &plan[(size_t)p * F + f];
+            rng_t r = rng_key(seed, 2, (uint64_t)p, (uint64_t)f);
+            if (!(rng_u01(&r) < pf[f])) continue;
+            pl->copies = 1;
+            if (rng_u01(&r) < 0.05) pl->copies = 2;
+            pl->had_last = (uint8_t)has_last;
+            if (has_last && rng_u01(&r) < 0.005) { pl->dup = 1; pl->src_p = last_src; }
+            else { has_last = 1; last_src = p; }
+        }
+    }
 
     char path[4096];
     FILE *fa, *fs, *fh, *ia, *is, *ih, *lk, *mp;
 #define OPEN(fp, suffix) do { snprintf(path, sizeof path, "%s%s", out, suffix); fp = fopen(path, "wb"); if (!fp) { perror(path); return 3; } } while (0)
     OPEN(fa, ""); OPEN(fs, "_ss"); OPEN(fh, "_h"); OPEN(ia, ".index"); OPEN(is, "_ss.index"); OPEN(ih, "_h.index");
     OPEN(lk, ".lookup"); OPEN(mp, ".map");
+    out_t o_fa = {fa, 0, 0, 0}, o_fs = {fs, 0, 0, 0}, o_fh = {fh, 0, 0, 0}, o_ia = {ia, 0, 0, 0}, o_is = {is, 0, 0, 0}, o_ih = {ih, 0, 0, 0}, o_lk = {lk, 0, 0, 0}, o_mp = {mp, 0, 0, 0};
+    out_t *outs[8] = {&o_fa, &o_fs, &o_fh, &o_ia, &o_is, &o_ih, &o_lk, &o_mp};
+    for (int i = 0; i < 8; i++) { outs[i]->cap = (size_t)4 << 20; outs[i]->buf = (char *)malloc(outs[i]->cap); }
 
     nameset_t ns; ns.cap = 1; while (ns.cap < (size_t)P * (size_t)F * 2 + 1024) ns.cap <<= 1;
     ns.k = (uint64_t *)malloc(ns.cap * 8); ns.v = (uint32_t *)malloc(ns.cap * 4);
     memset(ns.k, 0xFF, ns.cap * 8);
 
-    uint8_t *oa = (uint8_t *)malloc(8192), *os = (uint8_t *)malloc(8192);
-    uint8_t *pa = (uint8_t *)malloc(8192), *ps = (uint8_t *)malloc(8192); /* previous-proteome member for dups */
+    int T = 1;
+    {
+        long nc = sysconf(_SC_NPROCESSORS_ONLN);
+        T = nc > 16 ? 16 : (nc < 1 ? 1 : (int)nc);
+        const char *e = getenv("UC_GEN_THREADS");
+        if (e && atoi(e) > 0) T = atoi(e);
+        if (T > P) T = P;
+    }
+    const int BATCH = 2 * T > 16 ? 2 * T : 16;             /* proteomes generated (in parallel) before their output is written (in order) */
+    proteome_t *prots = (proteome_t *)calloc((size_t)BATCH, sizeof(proteome_t));
+    gen_ctx_t cx = {seed, F, lmin, scale, anc, plan};
     uint32_t nkeys = 0; uint64_t offa = 0, offh = 0, nres = 0, nmap = 0;
-    /* last member of each family (for exact duplicates) */
-    uint8_t **lasta = (uint8_t **)calloc(F, sizeof(uint8_t *)), **lasts = (uint8_t **)calloc(F, sizeof(uint8_t *));
-    int *lastn = (int *)calloc(F, sizeof(int));
-    (void)pa; (void)ps;
 
-    for (int p = 0; p < P; p++) {
-        char species[64]; snprintf(species, sizeof species, "synth_%04d", p);
-        int gene_no = 0;
-        int nsingle = 0;
-        for (int f = 0; f < F + 1; f++) {
-            int copies = 0; int is_single = (f == F);
-            rng_t r = rng_key(seed, 2, (uint64_t)p, (uint64_t)f);
-            if (!is_single) {
-                if (rng_u01(&r) < pf[f]) { copies = 1; if (rng_u01(&r) < 0.05) copies = 2; }
-            } else {
-                copies = nsingle = (int)(gene_no * 0.05 + 0.5);
-            }
-            for (int c = 0; c < copies; c++) {
-                int n;
-                if (is_single) {
-                    gene_t g; rng_t rs = rng_key(seed, 3, (uint64_t)p, (uint64_t)c);
-                    make_ancestor(&g, &rs, scale, lmin);
-                    n = g.len; memcpy(oa, g.aa, n); memcpy(os, g.ss, n); free(g.aa); free(g.ss);
-                } else if (c == 0 && lastn[f] > 0 && rng_u01(&r) < 0.005) {
-                    n = lastn[f]; memcpy(oa, lasta[f], n); memcpy(os, lasts[f], n); /* exact duplicate */
-                } else {
-                    double r3 = 0.05 + 0.30 * rng_u01(&r), ra = 0.10 + 0.50 * rng_u01(&r);
-                    if (c == 1) { r3 = r3 * 0.5 + 0.25; ra = ra * 0.5 + 0.40; } /* paralog: more diverged */
-                    n = make_member(&anc[f], &r, r3, ra, oa, os, lmin);
-                    if (c == 0) {
-                        free(lasta[f]); free(lasts[f]);
-                        lasta[f] = (uint8_t *)malloc(n); lasts[f] = (uint8_t *)malloc(n);
-                        memcpy(lasta[f], oa, n); memcpy(lasts[f], os, n); lastn[f] = n;
-                    }
-                }
-                /* letters + md5 name */
-                static char aa_txt[8192], ss_txt[8192];
-                for (int i = 0; i < n; i++) { aa_txt[i] = LET[oa[i]]; ss_txt[i] = LET[os[i]]; }
-                uint8_t dg[16]; md5((const uint8_t *)aa_txt, (size_t)n, dg);
-                char name[32]; snprintf(name, sizeof name, "unicore_%02x%02x%02x%02x%02x", dg[0], dg[1], dg[2], dg[3], dg[4]);
-                uint64_t h40 = ((uint64_t)dg[0] << 32) | ((uint64_t)dg[1] << 24) | ((uint64_t)dg[2] << 16) | ((uint64_t)dg[3] << 8) | dg[4];
-                fprintf(mp, "%s\t%s\t%s_g%05d\n", name, species, species, gene_no); nmap++;
-                gene_no++;
-                if (nameset_get_or_put(&ns, h40, nkeys) >= 0) continue; /* identical protein already in DB (createdb.rs:107) */
-                fwrite(aa_txt, 1, n, fa); fputc('\n', fa); fputc(0, fa);
-                fwrite(ss_txt, 1, n, fs); fputc('\n', fs); fputc(0, fs);
-                fprintf(ia, "%u\t%llu\t%d\n", nkeys, (unsigned long long)offa, n + 2);
-                fprintf(is, "%u\t%llu\t%d\n", nkeys, (unsigned long long)offa, n + 2);
+    for (int p0 = 0; p0 < P; p0 += BATCH) {
+        const int np = P - p0 < BATCH ? P - p0 : BATCH;
+        volatile int next = 0;
+        pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+        worker_t w = {&cx, prots, p0, np, &next, &mu};
+        pthread_t th[64];
+        const int nt = T < np ? T : np;
+        for (int t = 1; t < nt; t++) pthread_create(&th[t], NULL, worker_main, &w);
+        worker_main(&w);
+        for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
+        for (int k = 0; k < np; k++) {
+            const proteome_t *pr = &prots[k];
+            char species[64]; const int sl = snprintf(species, sizeof species, "synth_%04d", p0 + k);
+            for (int m = 0; m < pr->n_members; m++) {
+                const char *name = pr->name[m];
+                const int hl = (int)strlen(name), n = pr->len[m];
+                /* "%s\t%s\t%s_g%05d\n" */
+                out_bytes(&o_mp, name, (size_t)hl); out_ch(&o_mp, '\t'); out_bytes(&o_mp, species, (size_t)sl); out_ch(&o_mp, '\t');
+                out_bytes(&o_mp, species, (size_t)sl); out_bytes(&o_mp, "_g", 2); out_u5(&o_mp, (unsigned)m); out_ch(&o_mp, '\n'); nmap++;
+                if (nameset_get_or_put(&ns, pr->h40[m], nkeys) >= 0) continue; /* identical protein already in DB (createdb.rs:107) */
+                out_bytes(&o_fa, pr->aa + pr->off[m], (size_t)n); out_bytes(&o_fa, "\n\0", 2);
+                out_bytes(&o_fs, pr->ss + pr->off[m], (size_t)n); out_bytes(&o_fs, "\n\0", 2);
+                out_u64(&o_ia, nkeys); out_ch(&o_ia, '\t'); out_u64(&o_ia, offa); out_ch(&o_ia, '\t'); out_u64(&o_ia, (unsigned long long)n + 2); out_ch(&o_ia, '\n');
+                out_u64(&o_is, nkeys); out_ch(&o_is, '\t'); out_u64(&o_is, offa); out_ch(&o_is, '\t'); out_u64(&o_is, (unsigned long long)n + 2); out_ch(&o_is, '\n');
                 offa += (uint64_t)n + 2;
-                int hl = (int)strlen(name);
-                fwrite(name, 1, hl, fh); fputc('\n', fh); fputc(0, fh);
-                fprintf(ih, "%u\t%llu\t%d\n", nkeys, (unsigned long long)offh, hl + 2);
+                out_bytes(&o_fh, name, (size_t)hl); out_bytes(&o_fh, "\n\0", 2);
+                out_u64(&o_ih, nkeys); out_ch(&o_ih, '\t'); out_u64(&o_ih, offh); out_ch(&o_ih, '\t'); out_u64(&o_ih, (unsigned long long)hl + 2); out_ch(&o_ih, '\n');
                 offh += (uint64_t)hl + 2;
-                fprintf(lk, "%u\t%s\t0\n", nkeys, name);
-                nkeys++; nres += n;
+                out_u64(&o_lk, nkeys); out_ch(&o_lk, '\t'); out_bytes(&o_lk, name, (size_t)hl); out_bytes(&o_lk, "\t0\n", 3);
+                nkeys++; nres += (uint64_t)n;
             }
         }
-        (void)nsingle;
     }
-    fclose(fa); fclose(fs); fclose(fh); fclose(ia); fclose(is); fclose(ih); fclose(lk); fclose(mp);
+    for (int i = 0; i < 8; i++) { out_flush(outs[i]); fclose(outs[i]->fp); }
     const int32_t dt_aa = 0, dt_h = 12;
     const char *sfx[3] = {".dbtype", "_ss.dbtype", "_h.dbtype"};
     for (int i = 0; i < 3; i++) {
         FILE *fp; OPEN(fp, sfx[i]);
         fwrite(i == 2 ? &dt_h : &dt_aa, 4, 1, fp); fclose(fp);
     }
-    fprintf(stderr, "gen_synth: %u sequences, %llu residues, %llu map lines -> %s\n", nkeys,
-            (unsigned long long)nres, (unsigned long long)nmap, out);
+    fprintf(stderr, "gen_synth: %u sequences, %llu residues, %llu map lines -> %s (%d threads)\n", nkeys,
+            (unsigned long long)nres, (unsigned long long)nmap, out, T);
     return 0;
 }

@@ -47,7 +47,7 @@ struct ClassTable {
 };
 // pairs per task: the long-query classes have few queries, so their pair lists are cut finer to keep every
 // CU busy (rebuilding the LDS profile per task is negligible against >= 16 long alignments)
-const ClassTable h_tab[3] = {
+const ClassTable h_tab[4] = {
     {16,
      {64, 128, 192, 256, 320, 384, 448, 512, 640, 768, 896, 1024, 1280, 1536, 1792, 2048},
      {16, 16, 16, 16, 16, 16, 16, 16, 32, 32, 32, 32, 64, 64, 64, 64},
@@ -68,8 +68,26 @@ const ClassTable h_tab[3] = {
      {4, 8, 12, 16, 12, 16, 12, 16, 20, 24, 28, 32},
      {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
      {256, 256, 256, 256, 64, 64, 24, 24, 24, 24, 24, 24}},
+    // Table 3 (r06): the packed kernel for SPARSE plans - the known-score passes that re-run a handful of pairs per query (MODE 4: ambiguous end rows;
+    // the second MODE 6 round: mirrors that could not take their partner's start).  With one or two pairs per query a task is ONE slot: in the classes of
+    // table 1 it keeps one lane group of its workgroup busy (G = 16: an eighth of the lanes) while every wave instruction is issued for all of them - those
+    // passes ran at 1.5-2.1 T cells/s against 5-6 T for the dense ones (profiles/r05/sw_pass_timing_c2_c3.txt).  Here every class spans the whole wave
+    // (G = 64, R = rows / 64): the one slot of a task uses all 64 lanes; the price is the longer pipeline fill (Lt + 63 steps) and fewer rows per step to
+    // amortise the per-step overhead, still ~2x fewer issued instructions per sparse pair.  R < 14: two-wave workgroups (sw_pk_kernel<64, R, 4|6, 2>).
+    {16,
+     {128, 256, 384, 512, 640, 768, 896, 1024, 1152, 1280, 1408, 1536, 1664, 1792, 1920, 2048},
+     {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64},
+     {2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32},
+     {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1},
+     {8, 8, 8, 8, 8, 8, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16}},
 };
-__device__ __constant__ ClassTable c_tab[3];
+__device__ __constant__ ClassTable c_tab[4];
+// which table a known-score pass of the packed path plans with: sparse (table 3) when the plan holds fewer than 2.5 pairs per query of the call
+// (UC_SW_SPARSE=0: always table 1, for A/B runs; results do not depend on the table - every class computes the exact DP)
+static int pk_known_tab(uint32_t n_pairs, uint32_t n_queries) {
+    static const bool on = !(getenv("UC_SW_SPARSE") && atoi(getenv("UC_SW_SPARSE")) == 0);
+    return on && (double)n_pairs < 2.5 * (double)n_queries ? 3 : 1;
+}
 
 __device__ __forceinline__ int class_of(int lq, int tab) {
     int c = 0;
@@ -715,7 +733,7 @@ static void build_plan(Engine &E, SwPlan &P, DevBuf<char> &tmp, uint32_t n, cons
         static bool uploaded[64] = {};
         std::lock_guard<std::mutex> g(mu);
         if (E.device < 0 || E.device >= 64 || !uploaded[E.device]) {
-            ClassTable t[3];
+            ClassTable t[4];
             memcpy(t, h_tab, sizeof t);
             UC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), t, sizeof t));
             if (E.device >= 0 && E.device < 64) uploaded[E.device] = true;
@@ -963,7 +981,7 @@ static void run_plan(Engine &E, SwPlan &P, int mode, int32_t *os, int32_t *oqe, 
 // MODE 4; int32 kernel for --sw-kernel i32 and for queries beyond the systolic classes)
 static void fix_ambiguous_ends(Engine &E, uint32_t n2, const uint32_t *q2, const uint32_t *t2, int32_t *qe2, int32_t *te2,
                                const uint32_t *link, const int32_t *s0, int32_t *qe0, int32_t *te0, DevBuf<int32_t> &work,
-                               DevBuf<char> &tmp) {
+                               DevBuf<char> &tmp, uint32_t n_queries) {
     RerunBufs &B = scratch_of(E).amb_B;
     SwPlan &P3 = scratch_of(E).amb_P3;
     hipStream_t s = E.stream;
@@ -976,7 +994,7 @@ static void fix_ambiguous_ends(Engine &E, uint32_t n2, const uint32_t *q2, const
     B.q2.reserve(n3); B.t2.reserve(n3); B.link.reserve(n3); B.s.reserve(n3); B.qe.reserve(n3); B.te.reserve(n3); B.sin.reserve(n3);
     hipLaunchKernelGGL(amb_gather_kernel, grid_for(n2), dim3(256), 0, s, n2, B.flag.p, B.pos.p, q2, t2, link, s0, B.q2.p, B.t2.p, B.link.p, B.sin.p);
     const bool pk = E.p.sw_pk != 0;
-    build_plan(E, P3, tmp, n3, B.q2.p, B.t2.p, nullptr, nullptr, pk ? 1 : 0, nullptr, nullptr, pk ? B.sin.p : nullptr);
+    build_plan(E, P3, tmp, n3, B.q2.p, B.t2.p, nullptr, nullptr, pk ? pk_known_tab(n3, n_queries) : 0, nullptr, nullptr, pk ? B.sin.p : nullptr);
     run_plan(E, P3, pk ? 4 : 0, B.s.p, B.qe.p, B.te.p, work, tmp);
     hipLaunchKernelGGL(amb_putback_kernel, grid_for(n3), dim3(256), 0, s, n3, P3.idx.p, B.link.p, link, B.qe.p, B.te.p, qe2, te2, qe0, te0);
     UC_HIP(hipGetLastError());
@@ -1213,7 +1231,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                 s2.reserve(n2); q2o.reserve(n2); t2o.reserve(n2); eflag.reserve(n2); epos.reserve(n2);
                 hipLaunchKernelGGL(gate_scatter_kernel, grid_for(n), dim3(256), 0, s, n, gflag.p, gpos.p, Lsq, Lst, qe0.p, te0.p,
                                    q2.p, t2.p, qe2.p, te2.p, link.p);
-                if (p.sw_pk || dedup) fix_ambiguous_ends(*this, n2, q2.p, t2.p, qe2.p, te2.p, link.p, s0.p, qe0.p, te0.p, work, tmp);
+                if (p.sw_pk || dedup) fix_ambiguous_ends(*this, n2, q2.p, t2.p, qe2.p, te2.p, link.p, s0.p, qe0.p, te0.p, work, tmp, qb - qa);
             }
             hipLaunchKernelGGL(aln_basic_kernel, grid_for(n), dim3(256), 0, s, n, Lidx, s0.p, s1p, qe0.p, te0.p, gflag.p, alns_b);
             if (n2) {
@@ -1251,7 +1269,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                                            q2a.p, t2a.p, qe2a.p, te2a.p, mapa.p);
                         sknown.reserve(n2b);
                         hipLaunchKernelGGL(sm_score_kernel, grid_for(n2b), dim3(256), 0, s, n2b, mapa.p, link.p, s0.p, sknown.p);
-                        build_plan(*this, P2b, tmp, n2b, q2a.p, t2a.p, qe2a.p, te2a.p, 1, nullptr, nullptr, sknown.p);
+                        build_plan(*this, P2b, tmp, n2b, q2a.p, t2a.p, qe2a.p, te2a.p, pk_known_tab(n2b, qb - qa), nullptr, nullptr, sknown.p);
                         run_plan(*this, P2b, 6, s2s.p, q2os.p, t2os.p, work, tmp);   // known-score start pass (packed MODE 6)
                         hipLaunchKernelGGL(sm_scatter_kernel, grid_for(n2b), dim3(256), 0, s, n2b, P2b.idx.p, mapa.p, s2s.p, q2os.p, t2os.p,
                                            s2.p, q2o.p, t2o.p, (uint32_t *)nullptr);

@@ -451,7 +451,8 @@ void launch_sw_pk_class_mode(int G, int R, const SwArgs &a, uint32_t n_tasks, hi
 #define UC_SW_CASE(GG, RR)                                                                              \
     if (G == GG && R == RR) {                                                                           \
         constexpr int BW = (((RR + 3) / 4) | 1);                                                        \
-        constexpr int NW = GG == 16 ? 2 : (GG == 32 ? 4 : 8);   /* small workgroups share one LDS profile */ \
+        /* small workgroups share one LDS profile; G = 64 with R < 14: the wave-wide classes of sparse known-score plans (table 3 of uc_align.hip) */ \
+        constexpr int NW = GG == 16 ? 2 : (GG == 32 ? 4 : (RR < 14 ? 2 : 8));                           \
         const size_t lds = (size_t)2 * SW_NLET * GG * BW * 4 + 16;                                      \
         static PerDeviceOnce once;                                                                      \
         if (lds > 64 * 1024)                                                                            \
@@ -466,6 +467,9 @@ void launch_sw_pk_class_mode(int G, int R, const SwArgs &a, uint32_t n_tasks, hi
     UC_SW_CASE(32, 14) UC_SW_CASE(32, 16) UC_SW_CASE(32, 18) UC_SW_CASE(32, 20) UC_SW_CASE(32, 22) UC_SW_CASE(32, 24)
     UC_SW_CASE(64, 14) UC_SW_CASE(64, 16) UC_SW_CASE(64, 18) UC_SW_CASE(64, 20) UC_SW_CASE(64, 22) UC_SW_CASE(64, 24)
     UC_SW_CASE(64, 26) UC_SW_CASE(64, 28) UC_SW_CASE(64, 30) UC_SW_CASE(64, 32)   // ~6R + 60 live registers: R = 32 still fits 256 VGPRs
+    if constexpr (MODE == 4 || MODE == 6) {   // sparse plans only exist for the known-score passes
+        UC_SW_CASE(64, 2) UC_SW_CASE(64, 4) UC_SW_CASE(64, 6) UC_SW_CASE(64, 8) UC_SW_CASE(64, 10) UC_SW_CASE(64, 12)
+    }
 #undef UC_SW_CASE
     fprintf(stderr, "unicore-cluster: no packed SW kernel for class (G=%d, R=%d)\n", G, R);
     abort();
