@@ -1328,6 +1328,8 @@ struct PrefilterScratch {
     DevBuf<uint64_t> d_keys, d_keys2, d_pos, d_skey, d_skey2, d_rval2, d_qbase, d_soff, d_qr;
     DevBuf<int32_t> d_cd, d_cd2, d_score, d_mval;      // d_mkey / d_mval: output of the sorted-run merge (merge_hits_dev)
     DevBuf<uint64_t> d_mkey;
+    DevBuf<uint32_t> acc_q, acc_t, pass_q, pass_t;     // chunk loop of prefilter_impl: running top-M accumulator and the pass's lists (swapped in and out of the engine)
+    DevBuf<int32_t> acc_s, acc_d, pass_s, pass_d;
     // distinct-k-mer enumeration (E2)
     DevBuf<uint8_t> d_kflag, d_wflag;
     DevBuf<uint32_t> d_qk, d_kid, d_dk, d_nsimk, d_drk, d_drk2, d_roff, d_nr, d_src, d_ph;
@@ -1339,7 +1341,7 @@ struct PrefilterScratch {
         f(d_counters); f(d_temp); f(d_koff); f(k_in); f(k_out); f(d_ent32); f(v_in32); f(d_okey); f(d_okey2); f(d_oidx); f(d_order);
         f(d_ent); f(v_in); f(d_cnt); f(d_flag); f(d_cq); f(d_ct); f(d_rpidx2); f(d_qsurv); f(d_keys); f(d_keys2); f(d_pos); f(d_skey);
         f(d_skey2); f(d_rval2); f(d_qbase); f(d_soff); f(d_qr); f(d_cd); f(d_cd2); f(d_score); f(d_kflag); f(d_wflag); f(d_qk); f(d_kid); f(d_dk);
-        f(d_nsimk); f(d_drk); f(d_drk2); f(d_roff); f(d_nr); f(d_src); f(d_ph); f(d_drv); f(d_drv2); f(d_cumh); f(d_cumr); f(d_qh); f(d_qrn); f(d_rec); f(d_kbits); f(d_mkey); f(d_mval);
+        f(d_nsimk); f(d_drk); f(d_drk2); f(d_roff); f(d_nr); f(d_src); f(d_ph); f(d_drv); f(d_drv2); f(d_cumh); f(d_cumr); f(d_qh); f(d_qrn); f(d_rec); f(d_kbits); f(d_mkey); f(d_mval); f(acc_q); f(acc_t); f(pass_q); f(pass_t); f(acc_s); f(acc_d); f(pass_s); f(pass_d);
     }
     size_t bytes() {
         size_t b = 0;
@@ -1350,6 +1352,7 @@ struct PrefilterScratch {
     // stage sizes its own batches by the memory that is FREE, so above `limit` the big buffers go back before it starts
     // (re-allocating them costs milliseconds per step at a scale where a step takes a minute; small databases keep everything).
     void trim(size_t limit) {
+        if (getenv("UC_TIMING")) fprintf(stderr, "unicore-cluster[timing]: prefilter scratch %.1f GiB, trim limit %.1f GiB%s\n", bytes() / 1073741824.0, limit / 1073741824.0, bytes() > limit ? ": buffers >= 1 GiB released" : "");
         if (bytes() <= limit) return;
         each([&](auto &x) { if (x.cap * sizeof(*x.p) >= ((size_t)1 << 30)) x.release(); });
     }
@@ -1390,10 +1393,15 @@ PrefilterScratch *take_prefilter_scratch(int device) {
 // the prefilter's work buffers stay allocated between steps (re-allocating the 34 GiB key regions alone costs a second per
 // step at configs[1]) unless they hold more than 40 % of the device memory: then the gapped stage, which sizes its batches by
 // the free memory, gets them back (2.5 M sequences: 170 GB)
-static size_t scratch_trim_limit() {
+// r06: the 40 % rule only where the gapped stage really sizes something by the free memory - the traceback-byte matrices of --min-seq-id / search (MODE 7).
+// Without them the gapped stage needs ~150 B per pair of a 256 M-pair batch and nothing else: the prefilter's buffers stay up to 65 % of the device, and if
+// that is ever too much the stage's out-of-memory handler gives them back (Engine::relieve_pressure).  Why it matters: releasing ~100 GB after every pass
+// means allocating them again in the next one, and on a box whose device memory has not been touched since it came up that costs seconds PER PASS for as long
+// as untouched memory is left (configs[2], first process on such a box: prefilter 9.2 s instead of 5.3 s per pass - profiles/r06/c3_first_process.txt).
+static size_t scratch_trim_limit(bool gapped_stage_sizes_by_free_memory) {
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess || tot == 0) return (size_t)96 << 30;
-    return (size_t)((double)tot * 0.4);
+    return (size_t)((double)tot * (gapped_stage_sizes_by_free_memory ? 0.4 : 0.65));
 }
 
 // E1-E4 for a target range.  Large ranges are processed as several index chunks whose per-query top-M lists are
@@ -1432,7 +1440,7 @@ void Engine::prefilter_cells(uint32_t tbegin, uint32_t tend, const std::vector<s
     }
     const uint64_t kept = import_hits_dev(cat_n, cq.p, ct.p, cs.p, cd.p, 0, 1);
     stats.n_prefilter_hits = before + kept;
-    if (pre) pre->trim(scratch_trim_limit());
+    if (pre) pre->trim(scratch_trim_limit(p.min_seq_id > 0.0f || p.want_tb));
 }
 
 void Engine::prefilter_impl(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend, bool mirror_all) {
@@ -1471,13 +1479,15 @@ void Engine::prefilter_impl(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uin
             // (mirror_all — prefilter_cells only: every query lies outside the shard and yields the pair the other way round as well; the lists come
             // back ungrouped and are merged by the caller)
             ok = prefilter_one(tbegin, tend, qbegin, qend, true, limit, &density, mirror_all ? qbegin : UINT32_MAX);
-            if (ok) { stats.n_prefilter_hits += n_hits; if (pre && !mirror_all) pre->trim(scratch_trim_limit()); return; }
+            if (ok) { stats.n_prefilter_hits += n_hits; if (pre && !mirror_all) pre->trim(scratch_trim_limit(p.min_seq_id > 0.0f || p.want_tb)); return; }
         } else {
             // (Measured and reverted in r04: concatenating the per-pass lists and merging ONCE at the end — 1.5-2 G records in one sort instead of a
             // running top-M accumulator of <= max_seqs x queries — made configs[2] SLOWER, 35.7 -> 39.3 s per pass: the single merge needs ~64 B per
             // record of work buffers at the moment the key regions are largest.  The accumulator is merged after every pass.)
-            DevBuf<uint32_t> aq, at, tq, tt;
-            DevBuf<int32_t> as, ad, ts, td;
+            // (r06: the accumulator / pass arrays live in the scratch set - up to 4 x 7 GB at configs[2] were allocated and freed by every call)
+            if (!pre) pre = take_prefilter_scratch(device);
+            DevBuf<uint32_t> &aq = pre->acc_q, &at = pre->acc_t, &tq = pre->pass_q, &tt = pre->pass_t;
+            DevBuf<int32_t> &as = pre->acc_s, &ad = pre->acc_d, &ts = pre->pass_s, &td = pre->pass_d;
             uint64_t acc_n = 0;
             bool installed = false;       // the last pass's merge leaves its result installed in the engine: no second merge of the accumulator
             for (size_t c = 0; c < chunks.size() && ok; c++) {
@@ -1502,7 +1512,7 @@ void Engine::prefilter_impl(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uin
                 // install the accumulated lists (also rebuilds the per-query counts) unless the last merge already did
                 if (!installed) merge_hits_dev(acc_n, aq.p, at.p, as.p, ad.p, 0, nullptr, nullptr, nullptr, nullptr, true, 0, 1);     // (in key order already: counts only)
                 stats.n_prefilter_hits += n_hits;
-                if (pre) pre->trim(scratch_trim_limit());
+                if (pre) pre->trim(scratch_trim_limit(p.min_seq_id > 0.0f || p.want_tb));
                 return;
             }
         }

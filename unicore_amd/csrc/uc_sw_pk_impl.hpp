@@ -87,6 +87,9 @@ __global__ void __launch_bounds__(NW * 64) sw_pk_kernel(const SwArgs a) {
     const uint32_t nslots = (task.count + 1) >> 1;
 
     // ---- query profile in LDS: bytes S3+64 and SA+64 (sum = s+128), PAD letters / rows = 0 ----
+    // (r06, measured and not kept: the two 21 x 21 matrices and the query letters staged in LDS first, the entries assembled from LDS bytes instead of eight
+    // dependent global round trips each - no change in any pass, the sparse ones included (mode 4 at configs[1]: 23.1 ms either way): the build is not
+    // what a task waits for.  profiles/r06/sparse_passes.txt)
     for (int idx = tid; idx < SW_NLET * G * RW; idx += NT) {
         const int c = idx / (G * RW), rem = idx % (G * RW), gg = rem / RW, k = rem % RW;
         uint32_t w3 = 0, wa = 0;
