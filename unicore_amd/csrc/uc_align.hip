@@ -24,12 +24,15 @@ namespace uc {
 
 constexpr int SW_PK_OVF_HOST = 0x7C00 - 256;   // == SW_PK_OVF of uc_sw_pk_impl.hpp
 
-// scratch for the traceback-byte matrices of one batch (MODE 7): up to 144 GiB of the 288 GB, never more than 60 % of what
-// is free right now (plus what the scratch buffer already holds); UC_TB_BUDGET_MB overrides (tests)
+// scratch for the traceback-byte matrices of one batch (MODE 7): up to 64 GiB (r06; 144 GiB until r05), never more than 55 % of what
+// is free right now (plus what the scratch buffer already holds); UC_TB_BUDGET_MB overrides (tests).  Why 64: taking device memory costs 25-40 ms per GiB
+// whenever the box's memory is not warm for this process (one 108 GiB buffer: 4.2 s of a 14 s call at 500 proteomes in the first process on a fresh box,
+// profiles/r06/c4_p500_alloc.txt), while the batches a smaller buffer adds cost a launch tail each (r05: halving the batches of nominal configs[3] cost 3 %
+// of the pass)
 static unsigned long long tb_budget_bytes(size_t already_held) {
     if (const char *e = getenv("UC_TB_BUDGET_MB")) return std::max<unsigned long long>(1, strtoull(e, nullptr, 10)) << 20;
     size_t free_b = 0, total_b = 0;
-    unsigned long long cap = 144ull << 30;
+    unsigned long long cap = 64ull << 30;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
         cap = std::min<unsigned long long>(cap, (unsigned long long)((free_b + already_held) * 0.55));
     return std::max<unsigned long long>(cap, 256ull << 20);
@@ -1391,15 +1394,29 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                                 if (!getenv("UC_TB_BUDGET_MB")) {
                                     const unsigned long long want = std::max<unsigned long long>(16ull << 30, total / 3);
                                     budget = std::min(budget, std::max<unsigned long long>(want, (unsigned long long)tbm.cap));
+                                    // a buffer of a useful size that is there already IS the budget: a segment whose batches would be a little larger than
+                                    // the last one's must not take a new block (r06)
+                                    if (tbm.cap >= ((size_t)8 << 30)) budget = (unsigned long long)tbm.cap - 64;
                                 }
                                 A.tb_tbm_live = true;
                                 struct Live { bool &f; ~Live() { f = false; } } live{A.tb_tbm_live};
+                                // the batches first, then ONE buffer for the largest of them (r06: every batch that was a little larger than the buffer the first
+                                // one had sized took a new ~30 GiB block - 12 allocations of 0.8 s each in a 14 s call at 500 proteomes on a box with untouched memory)
+                                std::vector<std::pair<uint32_t, uint32_t>> batches;
+                                unsigned long long max_bytes = 0;
                                 for (uint32_t t0 = 0; t0 < nt_pk;) {
                                     uint32_t t1 = t0 + 1;                      // (a single task always runs, whatever the budget: tests force tiny budgets)
                                     while (t1 < nt_pk && h_toff[t1 + 1] - h_toff[t0] <= budget) t1++;
+                                    batches.emplace_back(t0, t1);
+                                    max_bytes = std::max(max_bytes, h_toff[t1] - h_toff[t0]);
+                                    t0 = t1;
+                                }
+                                tbm.reserve_exact(std::max<unsigned long long>(max_bytes, std::min<unsigned long long>(total, budget)) + 64);
+                                for (const auto &bt : batches) {
+                                    const uint32_t t0 = bt.first, t1 = bt.second;
                                     const unsigned long long base = h_toff[t0], bytes = h_toff[t1] - base;
+                                    (void)bytes;
                                     const uint32_t p0 = h_task[t0].begin, p1 = t1 < nt_pk ? h_task[t1].begin : n_pk3;
-                                    tbm.reserve_exact(bytes + 64);
                                     P3.tbm = tbm.p - base; P3.tboff = tboff.p; P3.tb_band = band;      // (a pair's offset counts from the start of the WHOLE plan)
                                     timed_ms_begin();
                                     launches += launch_plan(*this, P3, 7, pack3.p, nullptr, nullptr, work, nullptr, false, t0, t1, /*skip_long=*/true);
@@ -1407,7 +1424,6 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                                                        P3.sts.p, P3.ste.p, P3.saux.p, p.gap_open, p.gap_ext, band, 1, tbm.p - base, tboff.p, pack3.p, gaps3.p);
                                     tb_ms += timed_ms_end();
                                     nbatch++;
-                                    t0 = t1;
                                 }
                                 P3.tbm = nullptr; P3.tboff = nullptr; P3.tb_band = 0;
                             }

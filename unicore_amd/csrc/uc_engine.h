@@ -41,9 +41,15 @@ inline bool oom_test_fires() {
     }());
     return left.load(std::memory_order_relaxed) > 0 && left.fetch_sub(1) == 1;
 }
+// UC_ALLOC_LOG=1 (profiling): every device allocation of 64 MiB and more with its host time, on stderr (tools/alloc_log.py sums them)
+inline bool alloc_log_on() { static const bool on = getenv("UC_ALLOC_LOG") != nullptr; return on; }
 inline hipError_t malloc_with_relief(void **p, size_t bytes) {
     const bool fake = oom_relief_slot().fn && oom_test_fires();
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = fake ? hipErrorOutOfMemory : hipMalloc(p, bytes);
+    if (alloc_log_on() && bytes >= ((size_t)64 << 20))
+        fprintf(stderr, "unicore-cluster[alloc]: %.3f GiB in %.2f ms%s\n", bytes / 1073741824.0,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), e == hipSuccess ? "" : " FAILED");
     if (e == hipErrorOutOfMemory) {
         const OomRelief r = oom_relief_slot();
         (void)hipGetLastError();
@@ -64,12 +70,24 @@ struct DevBuf {   // plain owning device allocation (hipMalloc), grows geometric
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() {
+        if (p) {
+            const auto t0 = std::chrono::steady_clock::now();
+            (void)hipFree(p);
+            if (alloc_log_on() && cap * sizeof(T) >= ((size_t)64 << 20))
+                fprintf(stderr, "unicore-cluster[alloc]: free %.3f GiB in %.2f ms\n", cap * sizeof(T) / 1073741824.0,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+        p = nullptr; cap = 0;
+    }
     void swap(DevBuf &o) { std::swap(p, o.p); std::swap(cap, o.cap); }
     void reserve(size_t n) {   // contents are NOT preserved
         if (n <= cap) return;
         release();
-        size_t want = n + n / 8 + 64;
+        // growth margin: a buffer that is re-sized batch after batch is allocated anew every time it grows, and device memory costs ~30 ms per GiB to take
+        // (UC_ALLOC_LOG at nominal configs[3]: 674 allocations, 1,239 GiB, 18 s of a 150 s call - profiles/r06/c4_nominal_alloc.txt).  Buffers below 4 GiB take
+        // half again as much (a third of the re-allocations for at most 2 GiB of slack each), the big ones stay at an eighth (memory is tight where they are big)
+        size_t want = n + (n * sizeof(T) < ((size_t)4 << 30) ? n / 2 : n / 8) + 64;
         UC_HIP(malloc_with_relief((void **)&p, want * sizeof(T)));
         cap = want;
     }
