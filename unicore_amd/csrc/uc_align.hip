@@ -1305,9 +1305,11 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                     SwPlan &P3 = A.tb_P3;
                     // the plans of the passes behind us are dead (their results have been scattered): at sizes where the matrix budget is what is left of the
                     // device (nominal configs[3]: ~35 GB of plan arrays beside ~57 GiB of matrices per batch) they go back before the matrices are sized
-                    // (r06, ADVICE r05: only when memory IS short - re-allocating ~35 GB of plan arrays in the next 256 M-pair batch costs 1-2 s of fresh-memory time)
+                    // (r06, ADVICE r05: only when memory IS short, i.e. when what is free would not give the matrix buffer its full budget (64 GiB = 55 % of 116 GiB) -
+                    // re-allocating ~35 GB of plan arrays in the next 256 M-pair batch costs 1-2 s, more than the few batches the room buys: UC_ALLOC_LOG at nominal
+                    // configs[3] showed 443 GiB of 1-2 GiB blocks, 10-12 s per call, profiles/r06/c4_nominal_alloc.txt)
                     size_t free_now = 0, total_now = 0;
-                    const bool mem_short = hipMemGetInfo(&free_now, &total_now) != hipSuccess || free_now < (160ull << 30);
+                    const bool mem_short = hipMemGetInfo(&free_now, &total_now) != hipSuccess || free_now + A.tb_tbm.cap < (120ull << 30);
                     if (n2 >= (8u << 20) && mem_short) {
                         UC_HIP(hipStreamSynchronize(s));
                         P1.release(); P2.release(); P2b.release(); A.rr_P2.release(); A.amb_P3.release();

@@ -215,6 +215,9 @@ bool Engine::relieve_pressure(int stage) {
     if (PrefilterScratch *x = take_parked_prefilter_scratch(device)) { free_prefilter_scratch(x); freed = true; }
     if (AlignScratch *x = take_parked_align_scratch(device)) { free_align_scratch(x); freed = true; }
     (void)hipMemGetInfo(&f1, &tot);
+    if (getenv("UC_TIMING") && g_verbosity < 2)
+        fprintf(stderr, "unicore-cluster[timing]: device memory ran out in the %s; %s work buffers released (%.1f -> %.1f GiB free)\n",
+                stage == 0 ? "prefilter" : stage == 1 ? "gapped stage" : "database upload", freed ? "the other stage's" : "no", (double)f0 / (1ull << 30), (double)f1 / (1ull << 30));
     logf(2, "unicore-cluster: device memory ran out in the %s; %s work buffers released (%.1f -> %.1f GiB free)\n",
          stage == 0 ? "prefilter" : stage == 1 ? "gapped stage" : "database upload", freed ? "the other stage's" : "no", (double)f0 / (1ull << 30), (double)f1 / (1ull << 30));
     return freed;
