@@ -205,6 +205,10 @@ AT_SIZE = {
     # BASELINE configs[3] at its NOMINAL size.  One pass takes ~4 minutes on the GPU; the oracle side (four sub-database indexes over up to 1.9 G
     # residues and 4 x 200 sampled queries, minutes more) is a committed fixture computed in the build container: tests/golden/c4_rounds.npz
     "c4": dict(proteomes=2000, seed=0x5EED0004, opts="-c 0.8 --min-seq-id 0.3 -s 7.5", s=7.5, per_round=200, min_aln=400_000_000),
+    # r06: the largest size whose END-TO-END CPU-oracle run fits a round of the build (tools/oracle_at_size.py --config c4-1000 --workflow: ~40 core-hours; the nominal
+    # 2000 would take ~100): configs[3]'s options on 1000 proteomes (3.18 M sequences, 961 M residues), whole clust.tsv + round sizes + every counter.  Behind
+    # UC_TEST_AT_SIZE_EXTRA=1 (a ~90 s case; builder-run log under profiles/r06/) so that the driver's suite stays inside its step
+    "c4-1000": dict(proteomes=1000, seed=0x5EED0004, opts="-c 0.8 --min-seq-id 0.3 -s 7.5", s=7.5, per_round=200, min_aln=200_000_000),
     # optional rule UC-1/L (length gate, default off) through every round at configs[2] size, against tests/golden/c3-gate_workflow_sha.json
     # (the CPU oracle's workflow with the rule on, end to end); behind UC_TEST_AT_SIZE_EXTRA=1 - builder-run, log under profiles/
     "c3-gate": dict(proteomes=500, seed=0x5EED0003, opts="-c 0.8 --length-gate 1", s=4.0, per_round=500, min_aln=20_000_000),
@@ -222,6 +226,7 @@ PINS = {
     "c4-500": dict(golden=True, rounds="live"),
     "c4": dict(golden=False, rounds="fixture"),       # nominal size: the oracle end to end would take ~14 h on the build container's 8 cores
     "c3-gate": dict(golden=True, rounds="live"),
+    "c4-1000": dict(golden=True, rounds="live"),
 }
 
 
@@ -238,6 +243,8 @@ def test_default_workflow_at_size(name, O, tmp_path_factory):
     pin = PINS[name]
     if name == "c3-gate" and not os.environ.get("UC_TEST_AT_SIZE_EXTRA"):
         pytest.skip("set UC_TEST_AT_SIZE_EXTRA=1 (the builder's run: profiles/r04/gpu_test_workflow_c3_gate.log)")
+    if name == "c4-1000" and not os.environ.get("UC_TEST_AT_SIZE_EXTRA"):
+        pytest.skip("set UC_TEST_AT_SIZE_EXTRA=1 (the builder's run: profiles/r06/gpu_test_workflow_c4_1000.log)")
     gold = os.path.join(util.ROOT, "tests", "golden", "%s_workflow_sha.json" % name)
     fix = os.path.join(util.ROOT, "tests", "golden", "%s_rounds.npz" % name)
     assert not pin["golden"] or os.path.exists(gold), "%s is missing (tools/oracle_at_size.py --config %s --workflow writes it)" % (gold, name)
