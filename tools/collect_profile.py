@@ -7,7 +7,7 @@ copies the judged summaries from gpurun_out/ into profiles/:
   <tag>_bench.json        the default bench line
   <tag>_serial_kernel_stats.csv / _serial_summary.txt   the UC_STREAMS=1 trace: per-kernel durations add up to the HIP-event time
   sw_traffic.json         FETCH_SIZE / WRITE_SIZE of the SW kernels: what bench.py reports as roofline.traffic
-  prefilter_traffic.json  the same for the E1-E4 kernels: roofline_prefilter.traffic_per_step"""
+  prefilter_traffic_handwritten.json  the same for the hand-written E1-E4 kernels only (roofline_prefilter.traffic_per_step comes from tools/prefilter_traffic_all.sh -> profiles/prefilter_traffic.json, sorts included)"""
 import collections, csv, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -76,7 +76,7 @@ if pt:
                "fetch_size_kib": pt.get("FETCH_SIZE"), "write_size_kib": pt.get("WRITE_SIZE"),
                "bytes_per_step": (pt.get("FETCH_SIZE", 0) + pt.get("WRITE_SIZE", 0)) * 1024.0,
                "note": "KiB units of rocprofv3; gfx950 caveat: FETCH_SIZE counts 1/2 of wide coalesced streams (MI355X_MICROARCH.md), gathers are counted in full"},
-              open(os.path.join(prof, "prefilter_traffic.json"), "w"), indent=1)
+              open(os.path.join(prof, "prefilter_traffic_handwritten.json"), "w"), indent=1)      # (r06: profiles/prefilter_traffic.json - what bench.py reads - is the ALL-dispatch figure of tools/prefilter_traffic_all.sh, rocPRIM sorts included)
 for extra in ("c3", "c4l", "c5"):
     b2 = os.path.join(ROOT, "gpurun_out", "bench_%s_%s.json" % (extra, tag))
     if os.path.exists(b2) and os.path.getsize(b2):

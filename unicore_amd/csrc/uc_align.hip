@@ -1520,6 +1520,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
         qa = qb;
     }
     alns_valid = true;
+    last_align_hits = qbegin == 0 && qend == hdb.n ? n_hits : 0;      // what the buffers of this set have just served (uc_prefilter.hip: scratch_release_target)
     stats.n_edges = edges_on_host ? edges.size() / 2 : n_edges_dev;
     stats.algorithmic_bytes[UC_ST_GAPPED] = stats.sw_algorithmic_bytes;
     stats.stage_seconds[UC_ST_GAPPED] += tm.seconds();

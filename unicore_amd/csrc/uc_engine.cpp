@@ -200,7 +200,7 @@ void Engine::drop_scratch() {
     // parked, not freed: the next virtual rank on this device takes the same buffers (one set per device), so no rank pays for
     // tens of GB of hipMalloc inside its timed phase
     if (pre) { park_prefilter_scratch(pre, device); pre = nullptr; }
-    if (aln) { park_align_scratch(aln, device); aln = nullptr; }
+    if (aln) { park_align_scratch(aln, device); aln = nullptr; last_align_hits = 0; }
 }
 
 bool Engine::relieve_pressure(int stage) {
@@ -209,7 +209,7 @@ bool Engine::relieve_pressure(int stage) {
     (void)hipMemGetInfo(&f0, &tot);
     bool freed = false;
     // a scratch set goes only when no frame of its own stage is open on this engine - the innermost scope decides what is asked for, every open one what is pinned
-    if (stage != 1 && !stage_frames[1] && aln) { free_align_scratch(aln); aln = nullptr; freed = true; }
+    if (stage != 1 && !stage_frames[1] && aln) { free_align_scratch(aln); aln = nullptr; last_align_hits = 0; freed = true; }
     if (stage == 1 && aln && release_tb_matrices(aln)) freed = true;      // the gapped stage's own traceback-byte buffer, when no batch loop is using it
     if (stage != 0 && !stage_frames[0] && pre) { free_prefilter_scratch(pre); pre = nullptr; freed = true; }
     if (PrefilterScratch *x = take_parked_prefilter_scratch(device)) { free_prefilter_scratch(x); freed = true; }

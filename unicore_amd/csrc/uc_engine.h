@@ -84,10 +84,10 @@ struct DevBuf {   // plain owning device allocation (hipMalloc), grows geometric
     void reserve(size_t n) {   // contents are NOT preserved
         if (n <= cap) return;
         release();
-        // growth margin: a buffer that is re-sized batch after batch is allocated anew every time it grows, and device memory costs ~30 ms per GiB to take
-        // (UC_ALLOC_LOG at nominal configs[3]: 674 allocations, 1,239 GiB, 18 s of a 150 s call - profiles/r06/c4_nominal_alloc.txt).  Buffers below 4 GiB take
-        // half again as much (a third of the re-allocations for at most 2 GiB of slack each), the big ones stay at an eighth (memory is tight where they are big)
-        size_t want = n + (n * sizeof(T) < ((size_t)4 << 30) ? n / 2 : n / 8) + 64;
+        // (r06, measured and not kept: half again as much for buffers below 4 GiB / below 1 GiB instead of an eighth - a third of the re-allocations of the 454 small
+        // buffers a nominal configs[3] call re-sizes, but 7-20 GiB more resident at configs[2], which is what tipped the gapped stage over the device's edge there:
+        // profiles/r06/c3_memory_edge.txt)
+        size_t want = n + n / 8 + 64;
         UC_HIP(malloc_with_relief((void **)&p, want * sizeof(T)));
         cap = want;
     }
@@ -213,6 +213,7 @@ struct Engine {
                        double *density_out = nullptr, uint32_t mirror_q0 = UINT32_MAX);   // one target chunk (mirror_q0: symmetric pass, uc_prefilter.hip)
     PrefilterScratch *pre = nullptr;                       // work buffers kept between prefilter calls
     AlignScratch *aln = nullptr;                           // ... and between align calls
+    uint64_t last_align_hits = 0;                          // listed pairs of the last align() whose buffers `aln` still holds (0 after the set was given back)
     void drop_scratch();                                   // parks both (results stay): virtual-rank emulation
     // out-of-memory handler of a stage (see OomRelief): stage 0 = the prefilter is at work (gives back the gapped stage's scratch), 1 = the gapped
     // stage / set cover is at work (gives back the prefilter's), 2 = neither (database upload: both); parked sets of the device go in every case

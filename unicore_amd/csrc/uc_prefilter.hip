@@ -1351,10 +1351,19 @@ struct PrefilterScratch {
     // Large databases grow this set to well over 100 GB (per-position arrays, run lists, 30 GiB of key regions); the gapped
     // stage sizes its own batches by the memory that is FREE, so above `limit` the big buffers go back before it starts
     // (re-allocating them costs milliseconds per step at a scale where a step takes a minute; small databases keep everything).
-    void trim(size_t limit) {
-        if (getenv("UC_TIMING")) fprintf(stderr, "unicore-cluster[timing]: prefilter scratch %.1f GiB, trim limit %.1f GiB%s\n", bytes() / 1073741824.0, limit / 1073741824.0, bytes() > limit ? ": buffers >= 1 GiB released" : "");
-        if (bytes() <= limit) return;
-        each([&](auto &x) { if (x.cap * sizeof(*x.p) >= ((size_t)1 << 30)) x.release(); });
+    void release_bytes(size_t target) {      // largest buffers first until `target` bytes are back (target >= bytes(): everything of 1 GiB and more, the r01-r05 trim)
+        if (getenv("UC_TIMING")) fprintf(stderr, "unicore-cluster[timing]: prefilter scratch %.1f GiB, %.1f GiB to give back before the gapped stage\n", bytes() / 1073741824.0, target / 1073741824.0);
+        if (!target) return;
+        if (target >= bytes()) { each([&](auto &x) { if (x.cap * sizeof(*x.p) >= ((size_t)1 << 30)) x.release(); }); return; }
+        size_t freed = 0;
+        while (freed < target) {
+            size_t best = 0;
+            each([&](auto &x) { best = std::max(best, x.cap * sizeof(*x.p)); });
+            if (best < ((size_t)256 << 20)) break;
+            bool done = false;
+            each([&](auto &x) { if (!done && x.cap * sizeof(*x.p) == best) { x.release(); done = true; } });
+            freed += best;
+        }
     }
 };
 void free_prefilter_scratch(PrefilterScratch *p) { delete p; }
@@ -1398,10 +1407,19 @@ PrefilterScratch *take_prefilter_scratch(int device) {
 // that is ever too much the stage's out-of-memory handler gives them back (Engine::relieve_pressure).  Why it matters: releasing ~100 GB after every pass
 // means allocating them again in the next one, and on a box whose device memory has not been touched since it came up that costs seconds PER PASS for as long
 // as untouched memory is left (configs[2], first process on such a box: prefilter 9.2 s instead of 5.3 s per pass - profiles/r06/c3_first_process.txt).
-static size_t scratch_trim_limit(bool gapped_stage_sizes_by_free_memory) {
+// -> bytes of the prefilter's buffers to give back before the gapped stage starts (0 = keep everything)
+static size_t scratch_release_target(bool gapped_stage_sizes_by_free_memory, uint64_t n_hits, size_t scratch_bytes, bool gapped_scratch_warm) {
     size_t fr = 0, tot = 0;
-    if (hipMemGetInfo(&fr, &tot) != hipSuccess || tot == 0) return (size_t)96 << 30;
-    return (size_t)((double)tot * (gapped_stage_sizes_by_free_memory ? 0.4 : 0.65));
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || tot == 0) return scratch_bytes > ((size_t)96 << 30) ? scratch_bytes : 0;
+    if (gapped_stage_sizes_by_free_memory) return scratch_bytes > (size_t)((double)tot * 0.4) ? scratch_bytes : 0;       // the 40 % rule of r01-r05: everything >= 1 GiB
+    // ... otherwise only what the gapped stage will not fit beside: its plans and pass arrays take up to ~600 B per pair of a 256 M-pair batch (measured at
+    // configs[2]: it ran out of memory beside 133 GiB of kept buffers with 126 GiB free) + 44 B of records per listed pair.  Kept buffers that the stage's
+    // out-of-memory handler has to take back after all cost more than releasing them here: the block allocated right behind a 130 GiB release waits seconds
+    // for it (configs[2]: 41.4 s per pass instead of 33.3, profiles/r06/c3_memory_edge.txt).  The largest buffers go first, only as many as needed.
+    // (warm: the gapped stage still holds the buffers of a call at least this large - repeated steps, the shrinking rounds of a cascade: only the margin)
+    const size_t need = gapped_scratch_warm ? ((size_t)8 << 30)
+                                            : (size_t)600 * (size_t)std::min<uint64_t>(n_hits, 256ull << 20) + (size_t)44 * (size_t)n_hits + ((size_t)8 << 30);
+    return fr >= need ? 0 : std::min(scratch_bytes, need - fr);
 }
 
 // E1-E4 for a target range.  Large ranges are processed as several index chunks whose per-query top-M lists are
@@ -1440,7 +1458,7 @@ void Engine::prefilter_cells(uint32_t tbegin, uint32_t tend, const std::vector<s
     }
     const uint64_t kept = import_hits_dev(cat_n, cq.p, ct.p, cs.p, cd.p, 0, 1);
     stats.n_prefilter_hits = before + kept;
-    if (pre) pre->trim(scratch_trim_limit(p.min_seq_id > 0.0f || p.want_tb));
+    if (pre) pre->release_bytes(scratch_release_target(p.min_seq_id > 0.0f || p.want_tb, n_hits, pre->bytes(), aln != nullptr && (double)last_align_hits >= 0.9 * (double)n_hits));
 }
 
 void Engine::prefilter_impl(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uint32_t qend, bool mirror_all) {
@@ -1479,7 +1497,7 @@ void Engine::prefilter_impl(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uin
             // (mirror_all — prefilter_cells only: every query lies outside the shard and yields the pair the other way round as well; the lists come
             // back ungrouped and are merged by the caller)
             ok = prefilter_one(tbegin, tend, qbegin, qend, true, limit, &density, mirror_all ? qbegin : UINT32_MAX);
-            if (ok) { stats.n_prefilter_hits += n_hits; if (pre && !mirror_all) pre->trim(scratch_trim_limit(p.min_seq_id > 0.0f || p.want_tb)); return; }
+            if (ok) { stats.n_prefilter_hits += n_hits; if (pre && !mirror_all) pre->release_bytes(scratch_release_target(p.min_seq_id > 0.0f || p.want_tb, n_hits, pre->bytes(), aln != nullptr && (double)last_align_hits >= 0.9 * (double)n_hits)); return; }
         } else {
             // (Measured and reverted in r04: concatenating the per-pass lists and merging ONCE at the end — 1.5-2 G records in one sort instead of a
             // running top-M accumulator of <= max_seqs x queries — made configs[2] SLOWER, 35.7 -> 39.3 s per pass: the single merge needs ~64 B per
@@ -1512,7 +1530,7 @@ void Engine::prefilter_impl(uint32_t tbegin, uint32_t tend, uint32_t qbegin, uin
                 // install the accumulated lists (also rebuilds the per-query counts) unless the last merge already did
                 if (!installed) merge_hits_dev(acc_n, aq.p, at.p, as.p, ad.p, 0, nullptr, nullptr, nullptr, nullptr, true, 0, 1);     // (in key order already: counts only)
                 stats.n_prefilter_hits += n_hits;
-                if (pre) pre->trim(scratch_trim_limit(p.min_seq_id > 0.0f || p.want_tb));
+                if (pre) pre->release_bytes(scratch_release_target(p.min_seq_id > 0.0f || p.want_tb, n_hits, pre->bytes(), aln != nullptr && (double)last_align_hits >= 0.9 * (double)n_hits));
                 return;
             }
         }
