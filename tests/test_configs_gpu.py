@@ -163,14 +163,15 @@ def test_config_at_size(name, O, tmp_path_factory):
     U.lib().uc_release_scratch()
 
 
-def test_c5_chain_at_50_proteomes(O, tmp_path_factory):
-    """BASELINE configs[4]'s chain at 50 synthetic proteomes (158 k sequences, 47 M residues): ProstT5 AA -> 3Di encoder
+def test_c5_chain_at_40_proteomes(O, tmp_path_factory):
+    """BASELINE configs[4]'s chain at 40 synthetic proteomes (127 k sequences, 38 M residues; r06: 50 until then - the encoder alone is 120 s of GPU time at 50,
+    the largest single item of the driver's GPU step; tools/c5_at_size.py runs the same checks at 50 ... 500): ProstT5 AA -> 3Di encoder
     (24 blocks, full geometry, seeded synthetic weights) -> uc_engine_set_db (no disk round trip) -> cluster step.
     (a) the 3Di states of a 10-sequence sample (r06: 20 until then; the fp32 restatement of 24 blocks takes ~2 s per sequence on the host) equal the fp32 restatement's (same tolerance as tests/test_t5.py) and do not
     depend on the batch they were encoded in; (b) hit lists and alignment records of 200 random queries equal the CPU
     oracle's on the encoder's 3Di track; (c) the cluster TSV satisfies the consumer contract of profile.rs.
     (tools/c5_at_size.py runs the same checks at the configuration's nominal 500 proteomes: profiles/r04/c5_p500_check.json)"""
-    c5_chain_checks(O, str(tmp_path_factory.mktemp("c5")), 50, 10, 200)
+    c5_chain_checks(O, str(tmp_path_factory.mktemp("c5")), 40, 10, 200)
 
 
 def c5_chain_checks(O, d, proteomes, n_state_sample, n_query_sample):

@@ -199,9 +199,9 @@ def test_round_hook_every_round_equals_the_oracle(O, tmp_path):
 
 AT_SIZE = {
     "c2": dict(proteomes=50, seed=0x5EED0002, opts="-c 0.8", s=4.0, per_round=300, min_aln=2_000_000),
-    "c3": dict(proteomes=500, seed=0x5EED0003, opts="-c 0.8", s=4.0, per_round=500, min_aln=50_000_000),
-    "c4-200": dict(proteomes=200, seed=0x5EED0004, opts="-c 0.8 --min-seq-id 0.3 -s 7.5", s=7.5, per_round=500, min_aln=20_000_000),
-    "c4-500": dict(proteomes=500, seed=0x5EED0004, opts="-c 0.8 --min-seq-id 0.3 -s 7.5", s=7.5, per_round=500, min_aln=100_000_000),
+    "c3": dict(proteomes=500, seed=0x5EED0003, opts="-c 0.8", s=4.0, per_round=300, min_aln=50_000_000),
+    "c4-200": dict(proteomes=200, seed=0x5EED0004, opts="-c 0.8 --min-seq-id 0.3 -s 7.5", s=7.5, per_round=300, min_aln=20_000_000),
+    "c4-500": dict(proteomes=500, seed=0x5EED0004, opts="-c 0.8 --min-seq-id 0.3 -s 7.5", s=7.5, per_round=300, min_aln=100_000_000),
     # BASELINE configs[3] at its NOMINAL size.  One pass takes ~4 minutes on the GPU; the oracle side (four sub-database indexes over up to 1.9 G
     # residues and 4 x 200 sampled queries, minutes more) is a committed fixture computed in the build container: tests/golden/c4_rounds.npz
     "c4": dict(proteomes=2000, seed=0x5EED0004, opts="-c 0.8 --min-seq-id 0.3 -s 7.5", s=7.5, per_round=200, min_aln=400_000_000),

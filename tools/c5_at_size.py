@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/c5_at_size.py [proteomes=500] — BASELINE configs[4]'s chain at its NOMINAL size behind the checks of
-tests/test_configs_gpu.py::test_c5_chain_at_50_proteomes: ProstT5 AA -> 3Di encoder over all sequences (~21 min of MFMA
+tests/test_configs_gpu.py::test_c5_chain_at_40_proteomes: ProstT5 AA -> 3Di encoder over all sequences (~21 min of MFMA
 work at 500 proteomes) -> uc_engine_set_db -> cluster step; 3Di states of 200 random sequences == the fp32 restatement, hit lists and
 alignment records of 300 random queries == the CPU oracle on the encoder's 3Di track at full database size, TSV invariants.
 Run on the GPU box; writes gpurun_out/c5_p<N>_check.json (copied to profiles/r04/)."""
