@@ -22,9 +22,6 @@ def kernel_body(asm, G, R, mode, NW):
             out.append(l.rstrip("\n"))
     if not out:
         raise SystemExit("kernel %s not found" % name)
-    meta = {}
-    for l in asm:
-        pass
     return name, out
 
 
@@ -96,9 +93,6 @@ def main():
         cells = 2 * R * steps
         valu = sum(v for k, v in cnt.items() if k.startswith("VALU"))
         print("## sw_pk_kernel<%d, %d, %d, %d>: longest branch-free run = %d DP step(s), %d instructions, %d VALU; %d cells per lane -> %.3f VALU instructions per cell" % (G, R, a.mode, NW, steps, len(run), valu, cells, valu / cells))
-        # registers
-        for l in asm:
-            pass
         for k, v in sorted(cnt.items(), key=lambda kv: (not kv[0].startswith("VALU"), -kv[1])):
             print("  %5d  %6.3f / cell   %s" % (v, v / cells, k))
         rec = (10 if a.mode == 0 else 9.5) * R * steps                      # per step and row: perm + add + sub + max3 + 3 sub + 2 max = 9, + colmax max3 every second row = 0.5, + rowbest max3 every second step = 0.5

@@ -1416,8 +1416,7 @@ void Engine::align(uint32_t qbegin, uint32_t qend) {
                                 tbm.reserve_exact(std::max<unsigned long long>(max_bytes, std::min<unsigned long long>(total, budget)) + 64);
                                 for (const auto &bt : batches) {
                                     const uint32_t t0 = bt.first, t1 = bt.second;
-                                    const unsigned long long base = h_toff[t0], bytes = h_toff[t1] - base;
-                                    (void)bytes;
+                                    const unsigned long long base = h_toff[t0];
                                     const uint32_t p0 = h_task[t0].begin, p1 = t1 < nt_pk ? h_task[t1].begin : n_pk3;
                                     P3.tbm = tbm.p - base; P3.tboff = tboff.p; P3.tb_band = band;      // (a pair's offset counts from the start of the WHOLE plan)
                                     timed_ms_begin();
