@@ -1352,7 +1352,12 @@ struct PrefilterScratch {
     // stage sizes its own batches by the memory that is FREE, so above `limit` the big buffers go back before it starts
     // (re-allocating them costs milliseconds per step at a scale where a step takes a minute; small databases keep everything).
     void release_bytes(size_t target) {      // largest buffers first until `target` bytes are back (target >= bytes(): everything of 1 GiB and more, the r01-r05 trim)
-        if (getenv("UC_TIMING")) fprintf(stderr, "unicore-cluster[timing]: prefilter scratch %.1f GiB, %.1f GiB to give back before the gapped stage\n", bytes() / 1073741824.0, target / 1073741824.0);
+        if (getenv("UC_TIMING")) {
+            fprintf(stderr, "unicore-cluster[timing]: prefilter scratch %.1f GiB, %.1f GiB to give back before the gapped stage; buffers >= 2 GiB (index in PrefilterScratch::each: GiB):", bytes() / 1073741824.0, target / 1073741824.0);
+            int i = 0;
+            each([&](auto &x) { const double g = x.cap * sizeof(*x.p) / 1073741824.0; if (g >= 2.0) fprintf(stderr, " %d:%.1f", i, g); i++; });
+            fprintf(stderr, "\n");
+        }
         if (!target) return;
         if (target >= bytes()) { each([&](auto &x) { if (x.cap * sizeof(*x.p) >= ((size_t)1 << 30)) x.release(); }); return; }
         size_t freed = 0;
