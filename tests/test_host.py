@@ -272,3 +272,54 @@ def test_gemm_supply_microbenchmark_generator_still_matches_the_kernel_text(tmp_
     src = src.replace('open(os.path.join(HERE, "gemm_supply.hip"), "w")', 'open(%r, "w")' % str(tmp_path / "gemm_supply.hip"))
     exec(compile(src, gen, "exec"), {"__name__": "gen"})
     assert open(tmp_path / "gemm_supply.hip").read() == committed
+
+
+def test_synthetic_generator_bytes_are_pinned_whatever_the_thread_count(tmp_path):
+    """tools/gen_synth.c runs on threads since r06; every golden under tests/golden/ that was computed on a generated database depends on its BYTES.  The eight
+    content files of two small databases, concatenated, hash to what the sequential generator of r01-r05 wrote (hashes taken with that binary), for 1, 3 and the
+    default number of threads."""
+    import hashlib
+    gen = util.ensure_tools()
+    want = {("3", "0x5EED0009", "60", "1.0"): "b7a0bbcd4d47a66caf0e0910e4608f102f7a8f521512b5a0efb5c5929f426f47",
+            ("6", "0x5EED0004", "40", "0.6"): "5d2a87494c4c1769e038220b66453369425a062501d18f3c1abbed3d3c8f5843"}
+    for args, sha in want.items():
+        for threads in ("1", "3", None):
+            prefix = str(tmp_path / ("db_%s_%s" % (args[0], threads)))
+            env = dict(os.environ)
+            env.pop("UC_GEN_THREADS", None)
+            if threads:
+                env["UC_GEN_THREADS"] = threads
+            subprocess.check_call([gen, prefix] + list(args), env=env, stderr=subprocess.DEVNULL)
+            h = hashlib.sha256()
+            for sfx in ("", "_ss", "_h", ".index", "_ss.index", "_h.index", ".lookup", ".map"):
+                h.update(open(prefix + sfx, "rb").read())
+            assert h.hexdigest() == sha, (args, threads)
+
+
+def test_bench_slim_line_of_a_committed_full_record():
+    """bench.py's ONE line: the slim form of the committed full record of the round's driver-form run stays below 8 kB, carries the contract
+    keys and the c3 / c4 figures at the top level, and loses nothing the headline needs (pure host logic: no GPU)."""
+    import importlib.util
+    import json
+    import types
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06", "r06f_bench_detail.json")))
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        line = b.slim_line(full, types.SimpleNamespace(full_line=False, workdir=d, detail_dir=d, config="c2"))
+        text = json.dumps(line)
+        assert len(text) < 8000
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+                  "cpu_baseline", "value_disk_to_tsv_aln_s", "value_one_shot_aln_s", "c3_value", "c3_ms_per_step", "c3_cpu_ratio", "c4_value", "c4_wall_s", "c5_mini_tflops", "detail_file"):
+            assert k in line, k
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "valu_frac"):
+            assert k in line["roofline"], k
+        assert abs(line["value"] - full["value"]) <= 1e-5 * full["value"] and abs(line["c3_value"] - full["configs"]["c3"]["value"]) <= 1e-5 * line["c3_value"]
+        assert set(line["configs"]) == {"c3", "c5-mini", "c4"} and "errors" not in line
+        assert json.load(open(line["detail_file"]))["value"] == full["value"]
+        # a failed sub-record stays visible, the headline stands
+        broken = dict(full, configs=dict(full["configs"], c4={"error": "RuntimeError: out of memory"}))
+        l2 = b.slim_line(broken, types.SimpleNamespace(full_line=False, workdir=d, detail_dir=d, config="c2"))
+        assert l2["errors"] == {"c4": "RuntimeError: out of memory"} and "c4_value" not in l2 and l2["value"] == line["value"] and "c3_value" in l2
