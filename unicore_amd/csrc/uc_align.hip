@@ -529,7 +529,7 @@ __global__ void __launch_bounds__(256) tb_walk_kernel(uint32_t p_begin, uint32_t
                 // taken so far, not on loaded values: the next SPEC diagonal steps are fetched together and then taken one by one from registers - one
                 // memory round trip per run of up to SPEC matches instead of one per step (r05: the walk, one thread per pair on the engine's stream
                 // behind every MODE 7 batch, had grown to a fifth of the pass).
-                constexpr int SPEC = 8;
+                constexpr int SPEC = 8;      // (r06: 16 measured - SW + traceback kernels of configs[3] options @ 500 8,090 -> 8,230 ms: longer runs are rarer than the registers and wasted fetches cost)
                 uint32_t lqv[SPEC], ltv[SPEC], bv[SPEC];                // bv: the neighbour's byte; 0x100 = outside the box (H = 0), 0x200 = outside the band
 #pragma unroll
                 for (int k = 0; k < SPEC; k++) {
