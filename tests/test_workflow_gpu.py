@@ -11,6 +11,7 @@ and alignment records of a random query sample, which are then recomputed by the
   c3      BASELINE configs[2]: 500 proteomes, "-c 0.8"
   c4-200  BASELINE configs[3]'s options "-c 0.8 --min-seq-id 0.3 -s 7.5" on 200 proteomes
   c4-500  ... on 500 proteomes (1.59 M sequences)
+  c4-1000 ... on 1000 proteomes (3.18 M sequences; r06: the largest whole-file CPU-oracle golden, opt-in: UC_TEST_AT_SIZE_EXTRA=1)
   c4      ... at the NOMINAL 2000 proteomes (6.3 M sequences, 1.9 G residues) — the configuration VERDICT r3 listed as never run"""
 import os
 
